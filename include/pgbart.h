@@ -1,0 +1,154 @@
+/*
+ * pgbart.h -- C ABI of the MI355X-native particle-Gibbs BART sampler.
+ *
+ * This is the drop-in boundary for the hot path of pymc-bart 0.13.1: the native
+ * sampler classes the reference imports from the external `bartrs` wheel
+ *     pymc_bart/pymc_bart.py:2   PySampler, PyBartSettings, TreeArrays, PosteriorSampler
+ *     tests/test_bart.py:4,231   bartrs.PGBART([rv], num_particles=...)
+ * The reference binds them through PyO3; a maintainer binds THIS library with the
+ * ctypes stubs shown in INTEGRATION.md (pymc_bart_amd/_abi.py is that stub).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  "dev" pointers are device
+ *     (HBM) addresses owned by the caller (torch tensors kept alive by Python);
+ *     "host" pointers are ordinary memory.  All scratch is owned by the handle.
+ *   - every function returns 0 on success or a negative PGB_E_* code; the message
+ *     is available from pgb_last_error() (thread-local).  No exception crosses.
+ *   - a handle is bound to one device and one HIP stream and is single-threaded.
+ *     Calls are stream-synchronous at return unless stated otherwise.
+ *   - numerics follow include/pgbart_spec.h: results are a pure function of
+ *     (settings, data, seed) and are bit-identical across conforming backends.
+ */
+#ifndef PGBART_H
+#define PGBART_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGB_OK 0
+#define PGB_E_INVALID -1  /* bad argument / call order        */
+#define PGB_E_DEVICE -2   /* HIP runtime error                */
+#define PGB_E_NOMEM -3    /* allocation failed                */
+#define PGB_E_STATE -4    /* sampler state machine stuck      */
+#define PGB_E_UNSUPPORTED -5
+
+typedef struct pgb_handle pgb_handle;
+
+/* Mirrors bartrs' PyBartSettings (pymc_bart/pymc_bart.py:2) + the BART op
+ * attributes the step method snapshots at construction (bart.py:141-158).     */
+typedef struct {
+  int64_t n;              /* rows of X                                          */
+  int32_t p;              /* columns of X                                       */
+  int32_t m;              /* number of trees                 (bart.py:119)      */
+  int32_t num_particles;  /* incl. the reference particle    (test_bart.py:231) */
+  int32_t n_outputs;      /* K: leaves are K-vectors         (test_bart.py:117) */
+  int32_t family;         /* PGB_FAMILY_*                                       */
+  int32_t batch_tune;     /* trees updated per step while tuning                */
+  int32_t batch_draw;     /* trees updated per step after tuning                */
+  int32_t range_exp;      /* fixed-point range: |sum_trees|,|y - mu| < 2^range_exp */
+  uint64_t seed;          /* Philox key                                         */
+  double init_sum;        /* initial sum_trees value = mean(Y)   (bart.py:148)  */
+  double init_leaf;       /* initial leaf value      = mean(Y)/m                */
+  double init_leaf_sd;    /* std(Y)/sqrt(m)  (3/sqrt(m) for 0/1 responses)      */
+  double prior_leaf[64];  /* P(node at depth d stays a leaf) = 1 - alpha(1+d)^-beta
+                             (bart.py:107-109); entries >= 1 stop growth        */
+} pgb_settings;
+
+/* Work counters, maintained identically by every backend. */
+typedef struct {
+  int64_t particle_steps; /* non-reference particles popped with a non-empty queue */
+  int64_t tree_updates;   /* trees re-sampled                                    */
+  int64_t rows_touched;   /* sum of leaf sizes over executed split partitions    */
+  int64_t rounds;         /* SMC rounds                                          */
+  int64_t saturations;    /* fixed-point saturation events (should stay 0)       */
+  int64_t slots;          /* backend-specific: kernel slots consumed             */
+} pgb_counters;
+
+/* SoA tree storage: the counterpart of bartrs' TreeArrays (pymc_bart/pymc_bart.py:2).
+ * Trees are concatenated; tree t owns nodes [node_off[t], node_off[t+1]).
+ * Node 0 of each tree is its root; children indices are tree-local; a leaf has
+ * left == right == -1.  `value` holds K doubles per node (leaves only).
+ * `count` is the number of training rows in the node ("nvalue" upstream) and is
+ * what prediction uses to average over an excluded / NaN split.               */
+typedef struct {
+  int32_t n_trees;
+  int32_t n_outputs;
+  int32_t total_nodes;
+  int32_t* tree_id;   /* [n_trees]      which of the m slots the tree occupies  */
+  int32_t* node_off;  /* [n_trees + 1]                                          */
+  int32_t* var;       /* [total_nodes]  split variable, -1 for a leaf           */
+  double* split;      /* [total_nodes]  split value                             */
+  int32_t* left;      /* [total_nodes]                                          */
+  int32_t* right;     /* [total_nodes]                                          */
+  int64_t* count;     /* [total_nodes]                                          */
+  double* value;      /* [total_nodes * n_outputs]                              */
+} pgb_tree_arrays;
+
+const char* pgb_last_error(void);
+const char* pgb_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
+
+/* Create a sampler.  `stream` is a hipStream_t (NULL = default stream); ignored by
+ * CPU backends.  Replaces PGBART.__init__ / PySampler construction.            */
+int pgb_create(const pgb_settings* settings, void* stream, pgb_handle** out);
+int pgb_destroy(pgb_handle* h);
+
+/* Snapshot the design matrix.  X is row-major n x p doubles with leading
+ * dimension ldx (as produced by bart.py:209-210 preprocess_xy), NaN = missing.
+ * The backend keeps its own device-resident copy (column-major) -- X need not
+ * stay alive.  rules[p] are PGB_RULE_*, split_prior[p] > 0 (bart.py:139: empty
+ * prior => all ones, done by the caller).                                      */
+int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
+                 const double* split_prior_host);
+
+/* Observed response of the likelihood, n doubles (class index for categorical). */
+int pgb_set_response(pgb_handle* h, const double* y_dev);
+
+/* Likelihood parameters at the current point of the other model variables
+ * (upstream evaluates model.datalogp; here a closed family).  NORMAL: {sigma}.  */
+int pgb_set_likelihood(pgb_handle* h, const double* params_host, int32_t n_params);
+
+/* One PGBART.astep: re-sample the next batch of trees.
+ *   sum_trees_dev_out  K*n doubles (layout [K][n]), may be NULL
+ *   vi_counts_host_out p int32: split-variable counts of the accepted trees of
+ *                      this step (zeros while tuning), may be NULL
+ *   counters_out       cumulative counters, may be NULL                          */
+int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi_counts_host_out,
+             pgb_counters* counters_out);
+
+/* Asynchronous variant for throughput runs: enqueue `n_steps` steps and return;
+ * pgb_sync waits for them and fills the counters.                               */
+int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps);
+int pgb_sync(pgb_handle* h, pgb_counters* counters_out);
+
+/* Tree export.  Call once with out->... pointers NULL to get sizes (n_trees,
+ * total_nodes filled), allocate, call again.  which = 0: the trees updated by the
+ * last step (a "batch"); which = 1: all m current trees (a "baseline forest").  */
+int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out);
+
+/* Current sampler scalars: leaf_sd[K], iter, lower cursor. */
+int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out);
+/* Current split-variable weights alpha_vec[p] (prior + tuning counts). */
+int pgb_get_split_weights(pgb_handle* h, double* alpha_vec_host_out);
+
+/* Prediction from stored trees (PosteriorSampler.sample_posterior, utils.py:66-69):
+ * out[d][k][row] = sum over the trees of forest d of the leaf value reached by
+ * X[row,:]; at a split on an excluded variable or a NaN value the result is the
+ * count-weighted mean of both subtrees.  `forest_tree_idx` is [n_forests][m]
+ * indices into `trees`.  X_dev row-major n_rows x p; out_dev n_forests*K*n_rows;
+ * rules_host[p] are the PGB_RULE_* of the columns.                              */
+int pgb_predict(const pgb_tree_arrays* trees_host, const int32_t* forest_tree_idx_host,
+                int32_t n_forests, int32_t m, const double* X_dev, int64_t n_rows, int32_t p,
+                int64_t ldx, const int32_t* rules_host, const int32_t* excluded_host,
+                int32_t n_excluded, double* out_dev, void* stream);
+
+/* Profiling aid for bench.py: when enabled, the backend brackets every launch of
+ * its dominant kernel with events on its stream and accumulates their duration. */
+int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGBART_H */

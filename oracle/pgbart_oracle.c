@@ -1,0 +1,665 @@
+/*
+ * pgbart_oracle.c -- CPU restatement of particle-Gibbs BART (PGBART.astep).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (pymc_bart_amd/) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / CPU baseline.
+ *
+ * PARITY UNPINNED against the reference binary: pymc-bart 0.13.1 delegates the
+ * sampler to the external Rust wheel `bartrs>=0.4.0` (requirements.txt:6,
+ * pymc_bart/pymc_bart.py:2, tests/test_bart.py:4); its source is not vendored and
+ * cannot be built or imported here (no Rust toolchain, no network), and the
+ * reference's tests pin no numeric outputs on this path.  This file
+ * therefore restates the published algorithm -- pymc-bart's pgbart.py / tree.py
+ * as they existed up to 0.12.x and as summarised in SURVEY.md Appendix A -- under
+ * the numeric contract of include/pgbart_spec.h, and is pinned by (i) the
+ * behavioural assertions of the reference's own tests (tests/test_oracle_*.py cite
+ * them) and (ii) the golden vectors of the one exactly-runnable piece, the
+ * variable-inclusion codec (utils.py:1368-1398, tests/golden/vi_codec.json).
+ *
+ * Implements the same C ABI as the HIP library (include/pgbart.h) with "device"
+ * pointers being ordinary host pointers.  It deliberately uses a DIFFERENT data
+ * structure from the HIP backend -- per-node sorted row-index segments in a shared
+ * arena (the upstream idx_data_points design) instead of per-particle leaf-label
+ * arrays -- so that agreement between the two is evidence, not tautology.  Only the
+ * numeric primitives of pgbart_spec.h (Philox, exp/log, fixed point) are shared.
+ *
+ * Where each step follows upstream ([U] = upstream recall):
+ *   astep batching ............. o_step()          [U] PGBART.astep
+ *   residual removal ........... o_tree_begin()    [U] sum_trees_noi = sum_trees - tree.predict
+ *   init_particles ............. o_tree_begin()    [U] PGBART.init_particles
+ *   sample_tree / grow_tree .... o_particle_step() [U] ParticleTree.sample_tree, grow_tree
+ *   draw_leaf_value ............ pgb_leaf_value    [U] draw_leaf_value ("constant" response)
+ *   update_weight .............. pgb_leaf_sse      [U] PGBART.update_weight (Normal family,
+ *                                                   evaluated from exact sufficient statistics)
+ *   normalize/resample ......... o_resample()      [U] normalize, systematic, inverse_cdf
+ *   get_particle_tree .......... o_tree_end()      [U] (one categorical draw from the weights)
+ *   tuning ..................... o_tree_end()      [U] alpha_vec counts, RunningSd (CHANGELOG.md:413)
+ *   prediction ................. pgb_predict       utils.py:60-71, CHANGELOG.md:410-411
+ * Deviations from upstream, all deliberate and documented in DESIGN.md:
+ *   - counter-based RNG instead of the NumPy stream;
+ *   - a fresh particle's weight is the likelihood of its stump (upstream leaves 0);
+ *   - the final particle is one categorical draw (same distribution as upstream's
+ *     systematic()[randint]);
+ *   - trees are capped at PGB_MAX_NODES nodes and PGB_MAX_DEPTH depth.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pgbart.h"
+#include "pgbart_spec.h"
+
+#define MAXN PGB_MAX_NODES
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+const char* pgb_last_error(void) { return g_err; }
+const char* pgb_backend_name(void) { return "oracle-cpu"; }
+
+typedef struct {
+  int32_t var; /* -1 leaf */
+  int32_t left, right, depth;
+  int32_t label; /* leaf label (left child inherits its parent's) */
+  double split;
+  int64_t cnt;
+  int64_t q_st, q_r, q_r2; /* fixed-point sums over the node rows */
+  double value, sse;
+  int64_t seg; /* arena offset of the sorted row list (oracle only) */
+} onode;
+
+typedef struct {
+  int32_t n_nodes, n_leaves, next_pop;
+  double sse_tot, sse_orph;
+  onode nd[MAXN];
+} otree;
+
+struct pgb_handle {
+  pgb_settings s;
+  pgb_scales sc;
+  double* X; /* column-major p x n */
+  double* y;
+  int32_t* rules;
+  double* alpha_vec; /* p */
+  double* cdf;       /* p */
+  int* col_has_nan;
+  double* st; /* sum_trees n */
+  double* r;  /* y - noi */
+  double* oldv;
+  double* rs_mean;
+  double* rs_m2;
+  int64_t rs_count;
+  double leaf_sd;
+  double inv_sigma2;
+  int64_t iter;
+  int32_t lower;
+  otree* trees;     /* m accepted trees */
+  uint8_t* lid;     /* m x n leaf labels of accepted trees */
+  otree* part;      /* P particles (index 0 unused) */
+  otree* part2;     /* resampling scratch */
+  int32_t* arena;   /* row-index segments */
+  int64_t arena_len, arena_cap;
+  int32_t* vi;      /* p */
+  int32_t* last_ids;
+  int32_t n_last;
+  pgb_counters ctr;
+  double sse0; /* reference particle */
+  int have_data, have_y;
+};
+
+/* ------------------------------------------------------------------ helpers */
+static void copy_tree(otree* d, const otree* s) {
+  d->n_nodes = s->n_nodes;
+  d->n_leaves = s->n_leaves;
+  d->next_pop = s->next_pop;
+  d->sse_tot = s->sse_tot;
+  d->sse_orph = s->sse_orph;
+  memcpy(d->nd, s->nd, sizeof(onode) * (size_t)s->n_nodes);
+}
+
+static void build_cdf(pgb_handle* h) {
+  /* [U] SampleSplittingVariable: cumsum(alpha_vec / alpha_vec.sum()) */
+  int p = h->s.p;
+  double tot = 0.0;
+  for (int j = 0; j < p; ++j) tot += h->alpha_vec[j];
+  double c = 0.0;
+  for (int j = 0; j < p; ++j) {
+    c += h->alpha_vec[j];
+    h->cdf[j] = c / tot;
+  }
+}
+
+static int sample_var(const pgb_handle* h, double u) {
+  /* [U] rvs(): first i with u <= cdf[i]; fallback p-1 */
+  int p = h->s.p;
+  for (int j = 0; j < p; ++j)
+    if (u <= h->cdf[j]) return j;
+  return p - 1;
+}
+
+static int64_t arena_alloc(pgb_handle* h, int64_t len) {
+  if (h->arena_len + len > h->arena_cap) {
+    int64_t nc = h->arena_cap * 2;
+    while (nc < h->arena_len + len) nc *= 2;
+    int32_t* na = (int32_t*)realloc(h->arena, sizeof(int32_t) * (size_t)nc);
+    if (!na) abort();
+    h->arena = na;
+    h->arena_cap = nc;
+  }
+  int64_t off = h->arena_len;
+  h->arena_len += len;
+  return off;
+}
+
+/* ------------------------------------------------------------------ ABI: lifecycle */
+int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
+  (void)stream;
+  if (!s || !out) return fail(PGB_E_INVALID, "null argument");
+  if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
+  if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
+    return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
+  if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
+  if (s->family != PGB_FAMILY_NORMAL) return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
+  if (!h) return fail(PGB_E_NOMEM, "calloc");
+  h->s = *s;
+  h->sc = pgb_make_scales(s->n, s->range_exp);
+  int64_t n = s->n;
+  int p = s->p, m = s->m, P = s->num_particles;
+  h->X = (double*)malloc(sizeof(double) * (size_t)n * p);
+  h->y = (double*)malloc(sizeof(double) * n);
+  h->rules = (int32_t*)calloc(p, sizeof(int32_t));
+  h->alpha_vec = (double*)malloc(sizeof(double) * p);
+  h->cdf = (double*)malloc(sizeof(double) * p);
+  h->col_has_nan = (int*)calloc(p, sizeof(int));
+  h->st = (double*)malloc(sizeof(double) * n);
+  h->r = (double*)malloc(sizeof(double) * n);
+  h->oldv = (double*)malloc(sizeof(double) * n);
+  h->rs_mean = (double*)calloc(n, sizeof(double));
+  h->rs_m2 = (double*)calloc(n, sizeof(double));
+  h->trees = (otree*)calloc(m, sizeof(otree));
+  h->lid = (uint8_t*)calloc((size_t)m * n, 1);
+  h->part = (otree*)calloc(P, sizeof(otree));
+  h->part2 = (otree*)calloc(P, sizeof(otree));
+  h->arena_cap = 4 * n + 1024;
+  h->arena = (int32_t*)malloc(sizeof(int32_t) * (size_t)h->arena_cap);
+  h->vi = (int32_t*)calloc(p, sizeof(int32_t));
+  h->last_ids = (int32_t*)calloc(m, sizeof(int32_t));
+  for (int64_t i = 0; i < n; ++i) {
+    h->st[i] = s->init_sum;
+    h->arena[i] = (int32_t)i; /* root segment: all rows, ascending */
+  }
+  for (int t = 0; t < m; ++t) {
+    otree* T = &h->trees[t];
+    T->n_nodes = 1;
+    T->n_leaves = 1;
+    T->next_pop = 1;
+    onode* z = &T->nd[0];
+    memset(z, 0, sizeof *z);
+    z->var = -1;
+    z->left = z->right = -1;
+    z->cnt = n;
+    z->value = s->init_leaf;
+  }
+  h->leaf_sd = s->init_leaf_sd;
+  h->inv_sigma2 = 1.0;
+  *out = h;
+  return PGB_OK;
+}
+
+int pgb_destroy(pgb_handle* h) {
+  if (!h) return PGB_OK;
+  free(h->X); free(h->y); free(h->rules); free(h->alpha_vec); free(h->cdf); free(h->col_has_nan);
+  free(h->st); free(h->r); free(h->oldv); free(h->rs_mean); free(h->rs_m2); free(h->trees);
+  free(h->lid); free(h->part); free(h->part2); free(h->arena); free(h->vi); free(h->last_ids);
+  free(h);
+  return PGB_OK;
+}
+
+int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rules,
+                 const double* split_prior) {
+  if (!h || !X || !rules || !split_prior) return fail(PGB_E_INVALID, "null argument");
+  int64_t n = h->s.n;
+  int p = h->s.p;
+  if (ldx < p) return fail(PGB_E_INVALID, "ldx < p");
+  for (int j = 0; j < p; ++j) {
+    if (rules[j] != PGB_RULE_CONTINUOUS && rules[j] != PGB_RULE_ONEHOT)
+      return fail(PGB_E_UNSUPPORTED, "unknown split rule");
+    if (!(split_prior[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
+    h->rules[j] = rules[j];
+    h->alpha_vec[j] = split_prior[j];
+    int has = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      double x = X[i * ldx + j];
+      h->X[(size_t)j * n + i] = x;
+      if (x != x) has = 1;
+    }
+    h->col_has_nan[j] = has;
+  }
+  build_cdf(h);
+  h->have_data = 1;
+  return PGB_OK;
+}
+
+int pgb_set_response(pgb_handle* h, const double* y) {
+  if (!h || !y) return fail(PGB_E_INVALID, "null argument");
+  memcpy(h->y, y, sizeof(double) * h->s.n);
+  h->have_y = 1;
+  return PGB_OK;
+}
+
+int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
+  if (!h || !params) return fail(PGB_E_INVALID, "null argument");
+  if (h->s.family == PGB_FAMILY_NORMAL) {
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
+    h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+  }
+  return PGB_OK;
+}
+
+/* ------------------------------------------------------------------ one tree update */
+static void o_tree_begin(pgb_handle* h, int tree_id) {
+  /* [U] sum_trees_noi = sum_trees - old_tree.predict(); init_particles */
+  const pgb_settings* s = &h->s;
+  int64_t n = s->n;
+  const otree* T = &h->trees[tree_id];
+  double lv[256];
+  for (int k = 0; k < 256; ++k) lv[k] = 0.0;
+  for (int k = 0; k < T->n_nodes; ++k)
+    if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].value;
+  const uint8_t* lid = h->lid + (size_t)tree_id * n;
+  unsigned sat = 0;
+  int64_t A = 0, B = 0, C = 0, E0 = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    double o = lv[lid[i]];
+    double noi = h->st[i] - o;
+    double r = h->y[i] - noi;
+    h->oldv[i] = o;
+    h->r[i] = r;
+    A += pgb_quant(h->st[i], h->sc.c1, &sat);
+    B += pgb_quant(r, h->sc.c1, &sat);
+    C += pgb_quant(r * r, h->sc.c2, &sat);
+    double e = r - o;
+    E0 += pgb_quant(e * e, h->sc.c2, &sat);
+  }
+  h->ctr.saturations += sat;
+  h->sse0 = (double)E0 * h->sc.inv_c2;
+  h->arena_len = n; /* keep the root segment, drop everything else */
+  for (int q = 1; q < s->num_particles; ++q) {
+    otree* Pq = &h->part[q];
+    Pq->n_nodes = 1;
+    Pq->n_leaves = 1;
+    Pq->next_pop = 0;
+    onode* z = &Pq->nd[0];
+    memset(z, 0, sizeof *z);
+    z->var = -1;
+    z->left = z->right = -1;
+    z->depth = 0;
+    z->label = 0;
+    z->cnt = n;
+    z->q_st = A;
+    z->q_r = B;
+    z->q_r2 = C;
+    z->value = s->init_leaf;
+    z->sse = pgb_leaf_sse(n, B, C, z->value, h->sc.inv_c1, h->sc.inv_c2);
+    z->seg = 0;
+    Pq->sse_tot = z->sse;
+    Pq->sse_orph = 0.0;
+  }
+}
+
+/* [U] ParticleTree.sample_tree + grow_tree for particle q in round `round`. */
+static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
+  const pgb_settings* s = &h->s;
+  otree* T = &h->part[q];
+  if (T->next_pop >= T->n_nodes) return;
+  h->ctr.particle_steps += 1;
+  int l = T->next_pop++;
+  onode nd = T->nd[l];
+  uint32_t it = (uint32_t)h->iter;
+  pgb_u2 u = pgb_draw2(s->seed, it, round, (uint32_t)q, PGB_RNG_PROPOSE, 0);
+  double pl = nd.depth < PGB_MAX_DEPTH ? s->prior_leaf[nd.depth] : 1.0;
+  if (!(pl < u.u0)) return;                 /* stays a leaf */
+  if (T->n_nodes + 2 > MAXN) return;        /* node cap */
+  if (nd.cnt < 2) return;                   /* [U] needs more than one candidate */
+  int j = sample_var(h, u.u1);
+  const double* xc = h->X + (size_t)j * s->n;
+  const int32_t* seg = h->arena + nd.seg;
+  double v = 0.0;
+  int found = 0;
+  for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
+    pgb_u2 us = pgb_draw2(s->seed, it, round, (uint32_t)q, PGB_RNG_SELECT, tr);
+    int64_t k = (int64_t)(us.u0 * (double)nd.cnt);
+    if (k > nd.cnt - 1) k = nd.cnt - 1;
+    double x = xc[seg[k]];
+    if (x == x) {
+      v = x;
+      found = 1;
+    }
+  }
+  if (!found) return;
+  h->ctr.rows_touched += nd.cnt;
+  int rule = h->rules[j];
+  /* stable partition of the sorted segment; NaN rows fall in neither child [U] */
+  int64_t offL = arena_alloc(h, nd.cnt);
+  int64_t offR = arena_alloc(h, nd.cnt);
+  seg = h->arena + nd.seg; /* arena may have moved */
+  int32_t* sl = h->arena + offL;
+  int32_t* sr = h->arena + offR;
+  int64_t cL = 0, cR = 0, cN = 0;
+  int64_t aL = 0, bL = 0, c2L = 0, aN = 0, bN = 0, c2N = 0;
+  unsigned sat = 0;
+  for (int64_t k = 0; k < nd.cnt; ++k) {
+    int32_t i = seg[k];
+    double x = xc[i];
+    int64_t qa = pgb_quant(h->st[i], h->sc.c1, &sat);
+    int64_t qb = pgb_quant(h->r[i], h->sc.c1, &sat);
+    int64_t qc = pgb_quant(h->r[i] * h->r[i], h->sc.c2, &sat);
+    if (x != x) {
+      cN++; aN += qa; bN += qb; c2N += qc;
+    } else if (rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v)) {
+      sl[cL++] = i; aL += qa; bL += qb; c2L += qc;
+    } else {
+      sr[cR++] = i;
+    }
+  }
+  h->ctr.saturations += sat;
+  /* give back the unused tail of the two segments */
+  /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
+  if (rule == PGB_RULE_ONEHOT && cR == 0) return; /* [U] one-hot needs two distinct values */
+  int64_t aR = nd.q_st - aL - aN, bR = nd.q_r - bL - bN, c2R = nd.q_r2 - c2L - c2N;
+  /* the rows dropped by NaN now predict 0 from this tree */
+  T->sse_orph += (double)c2N * h->sc.inv_c2;
+  pgb_u2 ul = pgb_draw2(s->seed, it, round, (uint32_t)q, PGB_RNG_LEAF, 0);
+  double z0, z1;
+  pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+  int L = T->n_nodes, R = T->n_nodes + 1;
+  onode* pn = &T->nd[l];
+  pn->var = j;
+  pn->split = v;
+  pn->left = L;
+  pn->right = R;
+  onode* a = &T->nd[L];
+  onode* b = &T->nd[R];
+  memset(a, 0, sizeof *a);
+  memset(b, 0, sizeof *b);
+  a->var = b->var = -1;
+  a->left = a->right = b->left = b->right = -1;
+  a->depth = b->depth = nd.depth + 1;
+  a->label = nd.label;
+  b->label = T->n_leaves;
+  a->cnt = cL; a->q_st = aL; a->q_r = bL; a->q_r2 = c2L; a->seg = offL;
+  b->cnt = cR; b->q_st = aR; b->q_r = bR; b->q_r2 = c2R; b->seg = offR;
+  a->value = pgb_leaf_value(cL, aL, h->sc.inv_c1, (double)s->m, z0, h->leaf_sd);
+  b->value = pgb_leaf_value(cR, aR, h->sc.inv_c1, (double)s->m, z1, h->leaf_sd);
+  a->sse = pgb_leaf_sse(cL, bL, c2L, a->value, h->sc.inv_c1, h->sc.inv_c2);
+  b->sse = pgb_leaf_sse(cR, bR, c2R, b->value, h->sc.inv_c1, h->sc.inv_c2);
+  T->sse_tot = ((T->sse_tot - nd.sse) + a->sse) + b->sse;
+  T->n_nodes += 2;
+  T->n_leaves += 1;
+}
+
+/* [U] normalize (softmax + 1e-12) over `cnt` log-weights, serial cumulative sum. */
+static void o_normalize(const double* lw, int cnt, double* cum) {
+  double mx = lw[0];
+  for (int i = 1; i < cnt; ++i)
+    if (lw[i] > mx) mx = lw[i];
+  double w[PGB_MAX_PARTICLES];
+  double tot = 0.0;
+  for (int i = 0; i < cnt; ++i) {
+    w[i] = pgb_exp(lw[i] - mx) + 1e-12;
+    tot += w[i];
+  }
+  double c = 0.0;
+  for (int i = 0; i < cnt; ++i) {
+    c += w[i] / tot;
+    cum[i] = c;
+  }
+}
+
+static double o_logw(const pgb_handle* h, const otree* T) {
+  return (T->sse_tot + T->sse_orph) * (-0.5 * h->inv_sigma2);
+}
+
+/* [U] resample: systematic resampling of particles 1..P-1 */
+static void o_resample(pgb_handle* h, uint32_t round) {
+  int P = h->s.num_particles, Lc = P - 1;
+  double lw[PGB_MAX_PARTICLES], cum[PGB_MAX_PARTICLES];
+  for (int q = 1; q < P; ++q) lw[q - 1] = o_logw(h, &h->part[q]);
+  o_normalize(lw, Lc, cum);
+  pgb_u2 u = pgb_draw2(h->s.seed, (uint32_t)h->iter, round, 0, PGB_RNG_RESAMPLE, 0);
+  for (int i = 0; i < Lc; ++i) {
+    double ui = (u.u0 + (double)i) / (double)Lc;
+    int a = 0;
+    while (a < Lc - 1 && ui > cum[a]) ++a;
+    copy_tree(&h->part2[i + 1], &h->part[a + 1]);
+  }
+  otree* t = h->part;
+  h->part = h->part2;
+  h->part2 = t;
+}
+
+static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
+  const pgb_settings* s = &h->s;
+  int64_t n = s->n;
+  int P = s->num_particles;
+  double lw[PGB_MAX_PARTICLES], cum[PGB_MAX_PARTICLES];
+  lw[0] = h->sse0 * (-0.5 * h->inv_sigma2);
+  for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
+  o_normalize(lw, P, cum);
+  pgb_u2 u = pgb_draw2(s->seed, (uint32_t)h->iter, 0, 0, PGB_RNG_FINAL, 0);
+  int sel = 0;
+  while (sel < P - 1 && u.u0 > cum[sel]) ++sel;
+  uint8_t* lid = h->lid + (size_t)tree_id * n;
+  otree* T = &h->trees[tree_id];
+  if (sel > 0) {
+    copy_tree(T, &h->part[sel]);
+    memset(lid, PGB_ORPHAN, (size_t)n);
+    for (int k = 0; k < T->n_nodes; ++k)
+      if (T->nd[k].var < 0) {
+        const int32_t* seg = h->arena + T->nd[k].seg;
+        for (int64_t c = 0; c < T->nd[k].cnt; ++c) lid[seg[c]] = (uint8_t)T->nd[k].label;
+      }
+  }
+  double lv[256];
+  for (int k = 0; k < 256; ++k) lv[k] = 0.0;
+  for (int k = 0; k < T->n_nodes; ++k)
+    if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].value;
+  /* [U] sum_trees = sum_trees_noi + new_tree.predict() */
+  if (tune) h->rs_count += 1;
+  unsigned sat = 0;
+  int64_t qstd = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    double nv = lv[lid[i]];
+    double noi = h->st[i] - h->oldv[i];
+    h->st[i] = noi + nv;
+    if (tune) { /* [U] RunningSd.update (Welford) */
+      double cntf = (double)h->rs_count;
+      double delta = nv - h->rs_mean[i];
+      double mean = h->rs_mean[i] + delta / cntf;
+      double delta2 = nv - mean;
+      double m2 = h->rs_m2[i] + delta * delta2;
+      h->rs_mean[i] = mean;
+      h->rs_m2[i] = m2;
+      qstd += pgb_quant(PGB_SQRT(m2 / cntf), h->sc.c1, &sat);
+    }
+  }
+  h->ctr.saturations += sat;
+  if (tune) {
+    if (h->iter > s->m) build_cdf(h); /* [U] ssv rebuilt before this tree's counts are added */
+    for (int k = 0; k < T->n_nodes; ++k)
+      if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += 1.0;
+    if (h->iter > 2) h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
+  } else {
+    for (int k = 0; k < T->n_nodes; ++k)
+      if (T->nd[k].var >= 0) h->vi[T->nd[k].var] += 1;
+  }
+  h->ctr.tree_updates += 1;
+}
+
+static int o_step(pgb_handle* h, int tune) {
+  const pgb_settings* s = &h->s;
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  memset(h->vi, 0, sizeof(int32_t) * s->p);
+  int bs = tune ? s->batch_tune : s->batch_draw;
+  int upper = h->lower + bs;
+  if (upper > s->m) upper = s->m;
+  h->n_last = 0;
+  for (int tree_id = h->lower; tree_id < upper; ++tree_id) {
+    h->iter += 1;
+    h->last_ids[h->n_last++] = tree_id;
+    o_tree_begin(h, tree_id);
+    for (uint32_t round = 0;; ++round) {
+      for (int q = 1; q < s->num_particles; ++q) o_particle_step(h, q, round);
+      h->ctr.rounds += 1;
+      int stop = 1;
+      for (int q = 1; q < s->num_particles; ++q)
+        if (h->part[q].next_pop < h->part[q].n_nodes) stop = 0;
+      if (stop) break;
+      o_resample(h, round);
+    }
+    o_tree_end(h, tree_id, tune);
+  }
+  h->lower = upper < s->m ? upper : 0;
+  return PGB_OK;
+}
+
+int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_out, int32_t* vi_out,
+             pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  int rc = o_step(h, tune);
+  if (rc) return rc;
+  if (sum_trees_out) memcpy(sum_trees_out, h->st, sizeof(double) * h->s.n);
+  if (vi_out) memcpy(vi_out, h->vi, sizeof(int32_t) * h->s.p);
+  if (counters_out) *counters_out = h->ctr;
+  return PGB_OK;
+}
+
+int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  for (int i = 0; i < n_steps; ++i) {
+    int rc = o_step(h, tune);
+    if (rc) return rc;
+  }
+  return PGB_OK;
+}
+
+int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (counters_out) *counters_out = h->ctr;
+  return PGB_OK;
+}
+
+int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  int nt = which == 0 ? h->n_last : h->s.m;
+  int total = 0;
+  for (int t = 0; t < nt; ++t) total += h->trees[which == 0 ? h->last_ids[t] : t].n_nodes;
+  if (!out->var) {
+    out->n_trees = nt;
+    out->n_outputs = 1;
+    out->total_nodes = total;
+    return PGB_OK;
+  }
+  if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
+  int off = 0;
+  for (int t = 0; t < nt; ++t) {
+    int id = which == 0 ? h->last_ids[t] : t;
+    const otree* T = &h->trees[id];
+    out->tree_id[t] = id;
+    out->node_off[t] = off;
+    for (int k = 0; k < T->n_nodes; ++k) {
+      const onode* z = &T->nd[k];
+      out->var[off + k] = z->var;
+      out->split[off + k] = z->var >= 0 ? z->split : 0.0;
+      out->left[off + k] = z->left;
+      out->right[off + k] = z->right;
+      out->count[off + k] = z->cnt;
+      out->value[off + k] = z->var < 0 ? z->value : 0.0;
+    }
+    off += T->n_nodes;
+  }
+  out->node_off[nt] = off;
+  return PGB_OK;
+}
+
+int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (leaf_sd_out) leaf_sd_out[0] = h->leaf_sd;
+  if (iter_out) *iter_out = h->iter;
+  if (lower_out) *lower_out = h->lower;
+  return PGB_OK;
+}
+
+int pgb_get_split_weights(pgb_handle* h, double* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  memcpy(out, h->alpha_vec, sizeof(double) * h->s.p);
+  return PGB_OK;
+}
+
+/* ------------------------------------------------------------------ prediction */
+/* [U] Tree.predict with `excluded` (CHANGELOG.md:410-411): at a split on an excluded
+ * variable or a NaN value, the count-weighted mean of both subtrees. */
+static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const double* x,
+                          const uint8_t* excl, const int32_t* rules, int K, double w,
+                          double* acc) {
+  for (;;) {
+    int g = base + k;
+    if (T->var[g] < 0) {
+      for (int o = 0; o < K; ++o) acc[o] += w * T->value[(size_t)g * K + o];
+      return;
+    }
+    int j = T->var[g];
+    double xv = x[j];
+    if (excl[j] || xv != xv) {
+      int l = T->left[g], r = T->right[g];
+      double cl = (double)T->count[base + l], cr = (double)T->count[base + r];
+      double tot = cl + cr;
+      if (!(tot > 0.0)) return;
+      o_predict_rec(T, base, l, x, excl, rules, K, w * (cl / tot), acc);
+      o_predict_rec(T, base, r, x, excl, rules, K, w * (cr / tot), acc);
+      return;
+    }
+    int rule = rules[j];
+    int go_left = rule == PGB_RULE_CONTINUOUS ? (xv <= T->split[g]) : (xv == T->split[g]);
+    k = go_left ? T->left[g] : T->right[g];
+  }
+}
+
+int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
+                int32_t m, const double* X, int64_t n_rows, int32_t p, int64_t ldx,
+                const int32_t* rules, const int32_t* excluded, int32_t n_excluded, double* out,
+                void* stream) {
+  (void)stream;
+  if (!trees || !forest_tree_idx || !X || !out || !rules)
+    return fail(PGB_E_INVALID, "null argument");
+  int K = trees->n_outputs;
+  uint8_t* excl = (uint8_t*)calloc(p, 1);
+  for (int e = 0; e < n_excluded; ++e)
+    if (excluded[e] >= 0 && excluded[e] < p) excl[excluded[e]] = 1;
+  double acc[PGB_MAX_OUTPUTS];
+  for (int d = 0; d < n_forests; ++d)
+    for (int64_t i = 0; i < n_rows; ++i) {
+      for (int o = 0; o < K; ++o) acc[o] = 0.0;
+      for (int t = 0; t < m; ++t) {
+        int ti = forest_tree_idx[(size_t)d * m + t];
+        o_predict_rec(trees, trees->node_off[ti], 0, X + i * ldx, excl, rules, K, 1.0, acc);
+      }
+      for (int o = 0; o < K; ++o) out[((size_t)d * K + o) * n_rows + i] = acc[o];
+    }
+  free(excl);
+  return PGB_OK;
+}
+
+int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out) {
+  (void)h;
+  (void)enable;
+  if (kernel_ms_out) *kernel_ms_out = 0.0;
+  if (launches_out) *launches_out = 0;
+  return PGB_OK;
+}

@@ -1,0 +1,191 @@
+"""ctypes binding of the C ABI declared in ``include/pgbart.h``.
+
+This is the stub a pymc-bart maintainer would add in place of the PyO3 import
+``from bartrs.bartrs import PosteriorSampler, PyBartSettings, PySampler, TreeArrays``
+(reference ``pymc_bart/pymc_bart.py:2``).  It binds any shared library exporting the
+``pgb_*`` symbols; the product only ever loads the gfx950 HIP build
+(:func:`load_hip_library`) and raises if it is missing -- there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PGB_OK = 0
+MAX_DEPTH = 64
+MAX_PARTICLES = 64
+MAX_NODES = 255
+
+RULE_CONTINUOUS = 0
+RULE_ONEHOT = 1
+RULES = {
+    "ContinuousSplit": RULE_CONTINUOUS,
+    "ContinuousSplitRule": RULE_CONTINUOUS,
+    "OneHotSplit": RULE_ONEHOT,
+    "OneHotSplitRule": RULE_ONEHOT,
+}
+
+FAMILY_NORMAL = 0
+FAMILY_BERNOULLI_PROBIT = 1
+FAMILY_BERNOULLI_LOGIT = 2
+FAMILY_CATEGORICAL = 3
+FAMILIES = {
+    "normal": FAMILY_NORMAL,
+    "bernoulli_probit": FAMILY_BERNOULLI_PROBIT,
+    "bernoulli_logit": FAMILY_BERNOULLI_LOGIT,
+    "categorical": FAMILY_CATEGORICAL,
+}
+
+#: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "pgb_last_error",
+    "pgb_backend_name",
+    "pgb_create",
+    "pgb_destroy",
+    "pgb_set_data",
+    "pgb_set_response",
+    "pgb_set_likelihood",
+    "pgb_step",
+    "pgb_step_async",
+    "pgb_sync",
+    "pgb_export_trees",
+    "pgb_get_state",
+    "pgb_get_split_weights",
+    "pgb_predict",
+    "pgb_profile",
+)
+
+
+class Settings(C.Structure):
+    """``pgb_settings`` -- counterpart of bartrs' ``PyBartSettings``."""
+
+    _fields_ = [
+        ("n", C.c_int64),
+        ("p", C.c_int32),
+        ("m", C.c_int32),
+        ("num_particles", C.c_int32),
+        ("n_outputs", C.c_int32),
+        ("family", C.c_int32),
+        ("batch_tune", C.c_int32),
+        ("batch_draw", C.c_int32),
+        ("range_exp", C.c_int32),
+        ("seed", C.c_uint64),
+        ("init_sum", C.c_double),
+        ("init_leaf", C.c_double),
+        ("init_leaf_sd", C.c_double),
+        ("prior_leaf", C.c_double * MAX_DEPTH),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("particle_steps", C.c_int64),
+        ("tree_updates", C.c_int64),
+        ("rows_touched", C.c_int64),
+        ("rounds", C.c_int64),
+        ("saturations", C.c_int64),
+        ("slots", C.c_int64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+class TreeArraysC(C.Structure):
+    """``pgb_tree_arrays`` -- counterpart of bartrs' ``TreeArrays``."""
+
+    _fields_ = [
+        ("n_trees", C.c_int32),
+        ("n_outputs", C.c_int32),
+        ("total_nodes", C.c_int32),
+        ("tree_id", C.POINTER(C.c_int32)),
+        ("node_off", C.POINTER(C.c_int32)),
+        ("var", C.POINTER(C.c_int32)),
+        ("split", C.POINTER(C.c_double)),
+        ("left", C.POINTER(C.c_int32)),
+        ("right", C.POINTER(C.c_int32)),
+        ("count", C.POINTER(C.c_int64)),
+        ("value", C.POINTER(C.c_double)),
+    ]
+
+
+class PGBError(RuntimeError):
+    pass
+
+
+def _ptr(arr: np.ndarray, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class PGBLibrary:
+    """A loaded shared library implementing ``include/pgbart.h``."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        lib = self.lib
+        vp = C.c_void_p
+        lib.pgb_last_error.restype = C.c_char_p
+        lib.pgb_last_error.argtypes = []
+        lib.pgb_backend_name.restype = C.c_char_p
+        lib.pgb_backend_name.argtypes = []
+        lib.pgb_create.argtypes = [C.POINTER(Settings), vp, C.POINTER(vp)]
+        lib.pgb_destroy.argtypes = [vp]
+        lib.pgb_set_data.argtypes = [vp, vp, C.c_int64, vp, vp]
+        lib.pgb_set_response.argtypes = [vp, vp]
+        lib.pgb_set_likelihood.argtypes = [vp, vp, C.c_int32]
+        lib.pgb_step.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
+        lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]
+        lib.pgb_sync.argtypes = [vp, C.POINTER(Counters)]
+        lib.pgb_export_trees.argtypes = [vp, C.c_int32, C.POINTER(TreeArraysC)]
+        lib.pgb_get_state.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        lib.pgb_get_split_weights.argtypes = [vp, vp]
+        lib.pgb_predict.argtypes = [
+            C.POINTER(TreeArraysC), vp, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32,
+            C.c_int64, vp, vp, C.c_int32, vp, vp,
+        ]
+        lib.pgb_profile.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        for name in SYMBOLS:
+            fn = getattr(lib, name)
+            if name not in ("pgb_last_error", "pgb_backend_name"):
+                fn.restype = C.c_int
+
+    @property
+    def backend_name(self) -> str:
+        return self.lib.pgb_backend_name().decode()
+
+    def check(self, rc: int, what: str) -> None:
+        if rc != PGB_OK:
+            msg = self.lib.pgb_last_error()
+            raise PGBError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+_HIP_LIB: PGBLibrary | None = None
+
+
+def hip_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpgbart_hip.so")
+
+
+def load_hip_library() -> PGBLibrary:
+    """Load the gfx950 HIP build.  Fails loudly when it has not been built."""
+    global _HIP_LIB
+    if _HIP_LIB is None:
+        path = hip_library_path()
+        if not os.path.exists(path):
+            raise PGBError(
+                f"{path} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` at the repository root. "
+                "pymc_bart_amd has no CPU fallback."
+            )
+        # The library must share ONE HIP runtime with the torch tensors that hold its device
+        # buffers: import torch first so that its libamdhip64.so.7 is the one already loaded.
+        import torch  # noqa: F401
+
+        _HIP_LIB = PGBLibrary(path)
+    return _HIP_LIB

@@ -1,0 +1,50 @@
+"""Device-memory holder for the HIP backend.
+
+PyTorch-ROCm is used for exactly three things: allocating HBM buffers, naming the
+HIP stream the kernels are enqueued on, and ``torch.distributed`` (RCCL) for the
+end-of-run gather.  All compute goes through ``libpgbart_hip.so``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+class TorchHipMemory:
+    """HBM buffers held as torch tensors on one GPU.  Raises if no GPU is visible."""
+
+    def __init__(self, device: int | None = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "pymc_bart_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                "there is no CPU fallback."
+            )
+        self.torch = torch
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device))
+        torch.cuda.set_device(self.device)
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def from_host(self, arr: np.ndarray):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        return t.to(self.device, non_blocking=False)
+
+    def empty(self, shape, dtype=np.float64):
+        tdt = {np.float64: self.torch.float64, np.int32: self.torch.int32}[np.dtype(dtype).type]
+        return self.torch.empty(shape, dtype=tdt, device=self.device)
+
+    @staticmethod
+    def ptr(buf) -> int:
+        return int(buf.data_ptr())
+
+    def to_host(self, buf) -> np.ndarray:
+        return buf.cpu().numpy()
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.device)

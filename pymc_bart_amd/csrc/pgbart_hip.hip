@@ -1,0 +1,1484 @@
+// pgbart_hip.hip -- particle-Gibbs BART for MI355X (gfx950 / CDNA4), C ABI of include/pgbart.h.
+//
+// Replaces the native sampler the reference imports from the external `bartrs` wheel
+// (pymc_bart/pymc_bart.py:2; call site tests/test_bart.py:231-235).  Algorithm: SURVEY.md
+// Appendix A (upstream PGBART.astep) under the numeric contract of include/pgbart_spec.h.
+//
+// Design:
+//   * The whole astep is a DEVICE-RESIDENT STATE MACHINE.  The host only enqueues identical
+//     "slots" = { k_ctrl ; k_rows } on one HIP stream; it never waits for the device inside
+//     a tree update.  k_ctrl (one 256-thread workgroup per particle) finishes the previous
+//     SMC round from the integer statistics the row pass produced -- leaf values, particle
+//     weights, systematic resampling on one wave, the next growth proposal incl. the exact
+//     "k-th row of the leaf" selection -- and writes one job per particle.  k_rows streams the
+//     rows: every workgroup owns a 1024-row chunk of one particle, relabels the rows of the
+//     leaf being split and reduces the children's sufficient statistics.
+//   * HBM layout: X column-major (coalesced column streams), {sum_trees, residual} packed as
+//     double2 per row, one BYTE leaf label per row per particle (3 generations, so a failed
+//     split rolls back for free and resampling copies are fused into the next row pass).
+//   * All row reductions are integer (fixed point) => bit-reproducible, independent of
+//     launch geometry and atomics order, and identical to the CPU oracle.
+//   * No MFMA: the path is gather / partition / reduce (HBM / L2 bound).
+//
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "pgbart.h"
+#include "pgbart_spec.h"
+
+#define CH 1024 /* rows per chunk = rows per k_rows workgroup */
+#define BT 256  /* threads per workgroup */
+#define RPT (CH / BT)
+#define MAXN PGB_MAX_NODES
+#define MAXP PGB_MAX_PARTICLES
+#define CC_ROUNDS 256
+
+// ------------------------------------------------------------------ device structs
+struct DNode {  // 64 bytes
+  double split, value, sse;
+  long long q_st, q_r, q_r2;
+  int32_t cnt;
+  int32_t var;     // -1 leaf
+  int32_t cc_row;  // chunk-count row of this node (-1: root => all rows)
+  uint8_t left, right, depth, label;
+};
+
+struct DTree {  // an accepted tree
+  int32_t n_nodes, n_leaves;
+  int32_t pad[2];
+  DNode nd[MAXN];
+};
+
+struct DPart {  // a particle
+  int32_t n_nodes, n_leaves, next_pop;
+  int32_t loc_gen, loc_slot;  // where its leaf labels live (slot -1: implicit root labels)
+  int32_t pad;
+  double sse_tot, sse_orph;
+  DNode nd[MAXN];
+};
+
+struct Job {  // one particle's work for a PARTITION row pass
+  int32_t active;
+  int32_t src_gen, src_slot;
+  int32_t node, label, new_label;
+  int32_t var, rule, check_nan;
+  int32_t ccL, ccR;
+  int32_t cnt;
+  double v;
+};
+
+struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right = parent - both)
+  unsigned long long cnts;  // cntL | cntN << 32
+  long long aL, bL, c2L, aN, bN, c2N;
+  long long pad;
+};
+
+struct InitAcc {
+  long long A, B, C, E0, QSTD;
+  long long pad[3];
+};
+
+enum { CMD_NOOP = 0, CMD_PARTITION = 1, CMD_INIT = 2, CMD_FINAL = 4 /* FINAL|INIT = 6 */ };
+enum { PH_IDLE = 0, PH_BEGIN = 1, PH_ROUND = 2 };
+
+struct Cmd {
+  int32_t kind;
+  int32_t tree_old, tree_new;
+  int32_t sel_gen, sel_slot;  // sel_slot == -2: the old tree was kept
+  int32_t tune, dst_gen, pad;
+  long long rs_count;
+  double lv_new[256], lv_next[256];
+};
+
+struct Ctrl {
+  int32_t phase, k, batch_n, lower;
+  int32_t tune, round, lid_gen, steps_left;
+  int32_t pend_leafsd, pad;
+  long long iter, rs_count, pend_iter;
+  double leaf_sd, inv_sigma2;
+  double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
+};
+
+struct Dev {  // kernel argument block (by value)
+  long long n, n_pad;
+  int32_t p, m, P, nchunks;
+  int32_t batch_tune, batch_draw;
+  unsigned long long seed;
+  double init_leaf, mdouble;
+  pgb_scales sc;
+  double prior_leaf[PGB_MAX_DEPTH];
+  const double* XT;  // [p][n_pad]
+  const double* y;   // [n_pad]
+  double* st;        // [n_pad] sum_trees
+  double2* pack;     // [n_pad] {sum_trees, y - noi}
+  double* rs_mean;
+  double* rs_m2;
+  uint8_t* tree_lid;  // [m][n_pad]
+  uint8_t* lid;       // [3][P][n_pad]
+  uint16_t* cc;       // [CC_ROUNDS*MAXP*2][nchunks]
+  DTree* trees;       // [m]
+  DPart* parts;       // [2][P]
+  Job* jobs;          // [2][P]
+  Acc* acc;           // [2][P]
+  InitAcc* initacc;   // [2]
+  Cmd* cmd;           // [2]
+  Ctrl* ctrl;         // [2]
+  unsigned long long* counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
+  int32_t* vi;        // [p]
+  double* alpha_vec;  // [p]
+  double* cdf;        // [p]
+  const int32_t* rules;
+  const int32_t* col_nan;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of NV long long values; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(long long (&v)[NV], long long* sm /* [NV*4] */) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = wave_sum(v[i]);
+    if (lane == 0) sm[i * 4 + w] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = sm[i * 4] + sm[i * 4 + 1] + sm[i * 4 + 2] + sm[i * 4 + 3];
+  }
+  __syncthreads();
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix,
+// total via *tot (all threads)
+__device__ __forceinline__ int block_excl_scan(int x, int* sm /* [8] */, int* tot) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += sm[i];
+  *tot = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  return base + inc - x;
+}
+
+__device__ __forceinline__ int sample_var(const double* cdf, int p, double u) {
+  // first j with u <= cdf[j]; fallback p-1   ([U] SampleSplittingVariable.rvs)
+  int lo = 0, hi = p - 1;
+  if (!(u <= cdf[p - 1])) return p - 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (u <= cdf[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ bool go_left(int rule, double x, double v) {
+  return rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v);
+}
+
+// label -> leaf value table of a node array (ORPHAN and unused labels -> 0)
+__device__ __forceinline__ void build_lv(const DNode* nd, int n_nodes, double* lv /*[256] global*/) {
+  for (int i = threadIdx.x; i < 256; i += BT) lv[i] = 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_nodes; i += BT)
+    if (nd[i].var < 0) lv[nd[i].label] = nd[i].value;
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ k_begin
+__global__ void k_begin(Dev S, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
+  Ctrl* c = &S.ctrl[par];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    c->tune = tune;
+    c->steps_left = n_steps;
+    if (set_sigma) c->inv_sigma2 = inv_sigma2;
+    int bs = tune ? S.batch_tune : S.batch_draw;
+    int upper = c->lower + bs;
+    if (upper > S.m) upper = S.m;
+    c->batch_n = upper - c->lower;
+    c->k = 0;
+    c->phase = PH_BEGIN;
+  }
+  for (int j = threadIdx.x; j < S.p; j += blockDim.x) S.vi[j] = 0;
+}
+
+// ------------------------------------------------------------------ k_ctrl
+struct Fin {  // result of finishing the pending split of an old particle
+  int ok;     // 1: children created, 0: no pending split, -1: rolled back
+  int cL, cR;
+  long long aL, aR, bL, bR, c2L, c2R;
+  double vL, vR, sseL, sseR, sse_tot, sse_orph;
+  int n_nodes;
+};
+
+__global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
+  __shared__ double s_lw[MAXP], s_cum[MAXP];
+  __shared__ int s_any[MAXP];
+  __shared__ Fin s_fin[MAXP];
+  __shared__ int s_scan[8];
+  __shared__ int s_i[8];
+  __shared__ double s_d[4];
+  __shared__ long long s_ll[4];
+
+  const Ctrl c = S.ctrl[par];
+  Ctrl* co = &S.ctrl[par ^ 1];
+  const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
+  const int P = S.P, Lc = P - 1;
+  Cmd* cmd = &S.cmd[par];
+  const InitAcc ia = S.initacc[par ^ 1];
+
+  // pending leaf_sd from the FINAL pass of the previous slot ([U] RunningSd -> leaf_sd)
+  double leaf_sd = c.leaf_sd;
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
+
+  if (b == 0 && tid == 0) {
+    S.initacc[par] = InitAcc{0, 0, 0, 0, 0, {0, 0, 0}};
+    if (c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
+  }
+  if (tid == 0) {
+    Acc z;
+    memset(&z, 0, sizeof z);
+    S.acc[par * MAXP + p] = z;
+  }
+
+  if (c.phase == PH_IDLE) {
+    if (b == 0 && tid == 0) {
+      Ctrl o = c;
+      o.leaf_sd = leaf_sd;
+      o.pend_leafsd = 0;
+      *co = o;
+      cmd->kind = CMD_NOOP;
+    }
+    return;
+  }
+
+  if (c.phase == PH_BEGIN) {  // first tree of a step: only an INIT row pass
+    if (b == 0) {
+      int tree_new = c.lower + c.k;
+      build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+      if (tid == 0) {
+        cmd->kind = CMD_INIT;
+        cmd->tree_new = tree_new;
+        Ctrl o = c;
+        o.leaf_sd = leaf_sd;
+        o.pend_leafsd = 0;
+        o.phase = PH_ROUND;
+        o.round = 0;
+        o.iter = c.iter + 1;
+        *co = o;
+      }
+    }
+    return;
+  }
+
+  // ---------------- PH_ROUND
+  const int r = c.round;
+  const uint32_t it = (uint32_t)c.iter;
+  const DPart* OT = S.parts + (size_t)par * MAXP;
+  DPart* NT = S.parts + (size_t)(par ^ 1) * MAXP;
+  const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs of the previous slot
+  Job* JN = S.jobs + (size_t)par * MAXP;
+  DPart* me = &NT[p];
+
+  int anc = p;  // ancestor (old particle index) of new particle p
+  bool stop = false;
+
+  if (r == 0) {
+    // fresh particles ([U] init_particles): a stump with the initial leaf value
+    if (tid == 0) {
+      me->n_nodes = 1;
+      me->n_leaves = 1;
+      me->next_pop = 0;
+      me->loc_gen = 0;
+      me->loc_slot = -1;
+      DNode z;
+      memset(&z, 0, sizeof z);
+      z.var = -1;
+      z.cc_row = -1;
+      z.cnt = (int32_t)S.n;
+      z.q_st = ia.A;
+      z.q_r = ia.B;
+      z.q_r2 = ia.C;
+      z.value = S.init_leaf;
+      z.sse = pgb_leaf_sse(S.n, ia.B, ia.C, z.value, S.sc.inv_c1, S.sc.inv_c2);
+      me->nd[0] = z;
+      me->sse_tot = z.sse;
+      me->sse_orph = 0.0;
+    }
+    __syncthreads();
+  } else {
+    // -------- finish round r-1 for every old particle (lane q-1 <-> old particle q)
+    if (tid < Lc) {
+      int q = tid + 1;
+      const DPart* T = &OT[q];
+      const Job j = JP[q];
+      Fin f;
+      f.ok = 0;
+      f.n_nodes = T->n_nodes;
+      f.sse_tot = T->sse_tot;
+      f.sse_orph = T->sse_orph;
+      if (j.active) {
+        const Acc a = S.acc[(par ^ 1) * MAXP + q];
+        const DNode nd = T->nd[j.node];
+        int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32);
+        int cR = nd.cnt - cL - cN;
+        if (j.rule == PGB_RULE_ONEHOT && cR == 0) {
+          f.ok = -1;  // [U] one-hot split needs two distinct values: roll back
+        } else {
+          f.ok = 1;
+          f.cL = cL;
+          f.cR = cR;
+          f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
+          f.aR = nd.q_st - a.aL - a.aN;
+          f.bR = nd.q_r - a.bL - a.bN;
+          f.c2R = nd.q_r2 - a.c2L - a.c2N;
+          f.sse_orph = T->sse_orph + (double)a.c2N * S.sc.inv_c2;
+          pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
+          double z0, z1;
+          pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+          f.vL = pgb_leaf_value(cL, f.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
+          f.vR = pgb_leaf_value(cR, f.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
+          f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
+          f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
+          f.sse_tot = ((T->sse_tot - nd.sse) + f.sseL) + f.sseR;
+          f.n_nodes = T->n_nodes + 2;
+        }
+      }
+      s_fin[q] = f;
+      s_any[q] = T->next_pop < f.n_nodes;
+      s_lw[q] = (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int any = 0;
+      for (int q = 1; q < P; ++q) any |= s_any[q];
+      s_i[0] = !any;
+    }
+    __syncthreads();
+    stop = s_i[0] != 0;
+
+    if (!stop) {
+      // -------- [U] normalize + systematic resampling of particles 1..P-1
+      if (tid == 0) {
+        double mx = s_lw[1];
+        for (int q = 2; q < P; ++q) mx = s_lw[q] > mx ? s_lw[q] : mx;
+        double tot = 0.0;
+        for (int q = 1; q < P; ++q) {
+          double w = pgb_exp(s_lw[q] - mx) + 1e-12;
+          s_cum[q] = w;
+          tot += w;
+        }
+        double cs = 0.0;
+        for (int q = 1; q < P; ++q) {
+          cs += s_cum[q] / tot;
+          s_cum[q] = cs;
+        }
+        pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
+        double ui = (u.u0 + (double)(p - 1)) / (double)Lc;
+        int a = 0;
+        while (a < Lc - 1 && ui > s_cum[a + 1]) ++a;
+        s_i[1] = a + 1;
+      }
+      __syncthreads();
+      anc = s_i[1];
+    } else {
+      // -------- final choice among all P particles ([U] get_particle_tree)
+      if (tid == 0) {
+        double lw0 = c.sse0 * (-0.5 * c.inv_sigma2);
+        s_lw[0] = lw0;
+        double mx = lw0;
+        for (int q = 1; q < P; ++q) mx = s_lw[q] > mx ? s_lw[q] : mx;
+        double tot = 0.0;
+        for (int q = 0; q < P; ++q) {
+          double w = pgb_exp(s_lw[q] - mx) + 1e-12;
+          s_cum[q] = w;
+          tot += w;
+        }
+        double cs = 0.0;
+        for (int q = 0; q < P; ++q) {
+          cs += s_cum[q] / tot;
+          s_cum[q] = cs;
+        }
+        pgb_u2 u = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
+        int sel = 0;
+        while (sel < P - 1 && u.u0 > s_cum[sel]) ++sel;
+        s_i[1] = sel;
+      }
+      __syncthreads();
+      anc = p;  // no resampling in the final slot: particle p finishes itself
+    }
+
+    // -------- new particle p := old particle anc with its pending split applied
+    {
+      const DPart* A = &OT[anc];
+      const Fin f = s_fin[anc];
+      const Job j = JP[anc];
+      int nn = A->n_nodes;
+      for (int i = tid; i < nn; i += BT) me->nd[i] = A->nd[i];
+      __syncthreads();
+      if (tid == 0) {
+        me->n_leaves = A->n_leaves;
+        me->next_pop = A->next_pop;
+        me->loc_gen = A->loc_gen;
+        me->loc_slot = A->loc_slot;
+        me->sse_tot = f.sse_tot;
+        me->sse_orph = f.sse_orph;
+        me->n_nodes = f.n_nodes;
+        if (f.ok == 1) {
+          DNode par_nd = A->nd[j.node];
+          DNode L, R;
+          memset(&L, 0, sizeof L);
+          memset(&R, 0, sizeof R);
+          L.var = R.var = -1;
+          L.depth = R.depth = par_nd.depth + 1;
+          L.label = par_nd.label;
+          R.label = (uint8_t)j.new_label;
+          L.cnt = f.cL; L.q_st = f.aL; L.q_r = f.bL; L.q_r2 = f.c2L;
+          R.cnt = f.cR; R.q_st = f.aR; R.q_r = f.bR; R.q_r2 = f.c2R;
+          L.value = f.vL; R.value = f.vR;
+          L.sse = f.sseL; R.sse = f.sseR;
+          L.cc_row = j.ccL; R.cc_row = j.ccR;
+          par_nd.var = j.var;
+          par_nd.split = j.v;
+          par_nd.left = (uint8_t)nn;
+          par_nd.right = (uint8_t)(nn + 1);
+          me->nd[j.node] = par_nd;
+          me->nd[nn] = L;
+          me->nd[nn + 1] = R;
+          me->n_leaves = A->n_leaves + 1;
+        }
+        // where the labels of this particle live: the previous row pass wrote (lid_gen, anc)
+        // unless the split was rolled back or the particle still is an untouched root
+        if (f.ok == -1) {
+          me->loc_gen = j.src_gen;
+          me->loc_slot = j.src_slot;
+        } else {
+          me->loc_gen = c.lid_gen;
+          me->loc_slot = anc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // =================================================================== final slot
+  if (stop) {
+    const int sel = s_i[1];
+    const int tree_old = c.lower + c.k;
+    const bool more = (c.k + 1 < c.batch_n);
+    const bool next_step = (!more && c.steps_left > 1);
+    // next tree to initialise (if any)
+    int lower_next = c.lower, k_next = c.k + 1, batch_next = c.batch_n;
+    if (!more) {
+      int upper = c.lower + c.batch_n;
+      lower_next = upper < S.m ? upper : 0;
+      k_next = 0;
+      int bs = c.tune ? S.batch_tune : S.batch_draw;
+      int up2 = lower_next + bs;
+      if (up2 > S.m) up2 = S.m;
+      batch_next = up2 - lower_next;
+    }
+    const int tree_new = lower_next + k_next;
+    const bool has_init = more || next_step;
+
+    if (sel >= 1 && p == sel) {
+      // accepted a grown particle: store it as the tree and publish its label->value table
+      DTree* T = &S.trees[tree_old];
+      int nn = me->n_nodes;
+      for (int i = tid; i < nn; i += BT) T->nd[i] = me->nd[i];
+      if (tid == 0) {
+        T->n_nodes = nn;
+        T->n_leaves = me->n_leaves;
+        cmd->sel_gen = me->loc_gen;
+        cmd->sel_slot = me->loc_slot;  // may be -1 (untouched root labels)
+      }
+      build_lv(me->nd, nn, cmd->lv_new);
+    }
+    if (b == 0) {
+      if (sel == 0) {  // the old tree is kept: nobody writes S.trees[tree_old] in this slot
+        if (tid == 0) {
+          cmd->sel_slot = -2;
+          cmd->sel_gen = 0;
+        }
+        build_lv(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, cmd->lv_new);
+      }
+      // label table of the next tree to update (a different tree unless m == 1)
+      if (has_init && tree_new != tree_old)
+        build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+    }
+    // Bookkeeping that needs the accepted tree's split variables is done by the workgroup
+    // that owns a complete copy of that tree.
+    const bool owner = (sel == 0) ? (b == 0) : (p == sel);
+    if (owner) {
+      const DNode* snd = sel == 0 ? S.trees[tree_old].nd : me->nd;
+      const int nn = sel == 0 ? S.trees[tree_old].n_nodes : me->n_nodes;
+      if (c.tune) {
+        if (c.iter > S.m) {  // [U] ssv rebuilt before this tree's counts are added
+          if (tid == 0) {
+            double tot = 0.0;
+            for (int j = 0; j < S.p; ++j) tot += S.alpha_vec[j];
+            double cs = 0.0;
+            for (int j = 0; j < S.p; ++j) {
+              cs += S.alpha_vec[j];
+              S.cdf[j] = cs / tot;
+            }
+          }
+          __syncthreads();
+        }
+        if (tid == 0)
+          for (int i = 0; i < nn; ++i)
+            if (snd[i].var >= 0) S.alpha_vec[snd[i].var] += 1.0;
+      } else {
+        if (tid == 0)
+          for (int i = 0; i < nn; ++i)
+            if (snd[i].var >= 0) S.vi[snd[i].var] += 1;
+      }
+      if (tree_new == tree_old && has_init) {  // m == 1 corner: next update is this very tree
+        __syncthreads();
+        build_lv(snd, nn, cmd->lv_next);
+      }
+    }
+    if (b == 0 && tid == 0) {
+      cmd->kind = CMD_FINAL | (has_init ? CMD_INIT : 0);
+      cmd->tree_old = tree_old;
+      cmd->tree_new = tree_new;
+      cmd->tune = c.tune;
+      cmd->rs_count = c.rs_count + (c.tune ? 1 : 0);
+      Ctrl o = c;
+      o.leaf_sd = leaf_sd;
+      o.rs_count = c.rs_count + (c.tune ? 1 : 0);
+      o.pend_leafsd = c.tune ? 1 : 0;
+      o.pend_iter = c.iter;
+      o.round = 0;
+      o.k = k_next;
+      o.lower = lower_next;
+      o.batch_n = batch_next;
+      if (has_init) {
+        o.phase = PH_ROUND;
+        o.iter = c.iter + 1;
+        if (!more) o.steps_left = c.steps_left - 1;
+      } else {
+        o.phase = PH_IDLE;
+        o.steps_left = 0;
+      }
+      *co = o;
+      atomicAdd(&S.counters[1], 1ull);
+      atomicAdd(&S.counters[3], 1ull);
+    }
+    if (tid == 0) {
+      Job z;
+      memset(&z, 0, sizeof z);
+      JN[p] = z;
+    }
+    return;
+  }
+
+  // =================================================================== propose round r
+  // [U] ParticleTree.sample_tree / grow_tree for new particle p
+  Job job;
+  memset(&job, 0, sizeof job);
+  job.src_gen = me->loc_gen;
+  job.src_slot = me->loc_slot;
+  bool attempt = false;
+  int node = -1;
+  DNode nd;
+  if (tid == 0) {
+    int np = me->next_pop;
+    if (np < me->n_nodes) {
+      atomicAdd(&S.counters[0], 1ull);
+      node = np;
+      me->next_pop = np + 1;
+      nd = me->nd[node];
+      pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_PROPOSE, 0);
+      double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
+      attempt = (pl < u.u0) && (me->n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
+      if (attempt) {
+        int j = sample_var(S.cdf, S.p, u.u1);
+        s_i[2] = j;
+      }
+    }
+    s_i[3] = attempt ? 1 : 0;
+    s_i[4] = node;
+  }
+  __syncthreads();
+  attempt = s_i[3] != 0;
+  node = s_i[4];
+  if (attempt) {
+    nd = me->nd[node];
+    const int j = s_i[2];
+    const double* xc = S.XT + (size_t)j * S.n_pad;
+    const uint8_t* lid =
+        job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
+    const uint16_t* ccr = nd.cc_row >= 0 ? S.cc + (size_t)nd.cc_row * S.nchunks : nullptr;
+    int found = 0;
+    double v = 0.0;
+    for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
+      // the k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
+      pgb_u2 us = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_SELECT, tr);
+      long long k = (long long)(us.u0 * (double)nd.cnt);
+      if (k > nd.cnt - 1) k = nd.cnt - 1;
+      long long row;
+      if (lid == nullptr) {
+        row = k;  // untouched root: every row belongs to it
+      } else {
+        // (1) which chunk: scan the per-chunk counts of this node
+        int per = (S.nchunks + BT - 1) / BT;
+        int c0 = tid * per, c1 = c0 + per;
+        if (c1 > S.nchunks) c1 = S.nchunks;
+        int part = 0;
+        for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
+        int tot;
+        int pre = block_excl_scan(part, s_scan, &tot);
+        if ((long long)pre <= k && k < (long long)pre + part) {
+          int kk = (int)(k - pre);
+          int cc = c0;
+          while (kk >= ccr[cc]) {
+            kk -= ccr[cc];
+            ++cc;
+          }
+          s_i[5] = cc;
+          s_i[6] = kk;
+        }
+        __syncthreads();
+        int cstar = s_i[5], kk = s_i[6];
+        // (2) which row inside the chunk: scan the labels
+        uint32_t ids = *(const uint32_t*)(lid + (size_t)cstar * CH + tid * RPT);
+        int mcnt = 0;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) mcnt += (((ids >> (8 * e)) & 255u) == (uint32_t)nd.label);
+        int tot2;
+        int pre2 = block_excl_scan(mcnt, s_scan, &tot2);
+        if (pre2 <= kk && kk < pre2 + mcnt) {
+          int rem = kk - pre2;
+          int e = 0;
+          for (; e < RPT; ++e)
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)nd.label) {
+              if (rem == 0) break;
+              --rem;
+            }
+          s_ll[0] = (long long)cstar * CH + tid * RPT + e;
+        }
+        __syncthreads();
+        row = s_ll[0];
+      }
+      if (tid == 0) {
+        double x = xc[row];
+        s_d[0] = x;
+        s_i[7] = (x == x) ? 1 : 0;
+      }
+      __syncthreads();
+      found = s_i[7];
+      v = s_d[0];
+      __syncthreads();
+    }
+    if (found) {
+      job.active = 1;
+      job.node = node;
+      job.label = nd.label;
+      job.new_label = me->n_leaves;
+      job.var = j;
+      job.rule = S.rules[j];
+      job.check_nan = S.col_nan[j];
+      job.ccL = ((r * MAXP + p) * 2);
+      job.ccR = job.ccL + 1;
+      job.cnt = nd.cnt;
+      job.v = v;
+      if (tid == 0) atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
+    }
+  }
+  if (tid == 0) JN[p] = job;
+  if (b == 0 && tid == 0) {
+    cmd->kind = CMD_PARTITION;
+    cmd->dst_gen = (c.lid_gen + 1) % 3;
+    Ctrl o = c;
+    o.leaf_sd = leaf_sd;
+    o.pend_leafsd = 0;
+    o.round = r + 1;
+    o.lid_gen = (c.lid_gen + 1) % 3;
+    if (r == 0) o.sse0 = (double)ia.E0 * S.sc.inv_c2;  // [U] init_particles: weight of p0
+    *co = o;
+    if (r > 0) atomicAdd(&S.counters[3], 1ull);
+  }
+}
+
+// ------------------------------------------------------------------ k_rows
+// PARTITION: workgroup (chunk, particle).  FINAL/INIT: workgroups with blockIdx.y == 0.
+__global__ __launch_bounds__(BT) void k_rows(Dev S, int par) {
+  __shared__ long long s_red[8 * 4];
+  __shared__ double s_lv[2][256];
+  const Cmd* cmd = &S.cmd[par];
+  const int kind = cmd->kind;
+  if (kind == CMD_NOOP) return;
+  const int tid = threadIdx.x;
+  const long long base = (long long)blockIdx.x * CH + tid * RPT;
+
+  if (kind == CMD_PARTITION) {
+    const int p = blockIdx.y + 1;
+    const Job j = S.jobs[(size_t)par * MAXP + p];
+    uint8_t* dst = S.lid + ((size_t)cmd->dst_gen * MAXP + p) * S.n_pad;
+    uint32_t ids;
+    if (j.src_slot < 0) {
+      ids = 0;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+        if (base + e >= S.n) ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+    } else {
+      ids = *(const uint32_t*)(S.lid + ((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad + base);
+    }
+    if (!j.active) {
+      *(uint32_t*)(dst + base) = ids;
+      return;
+    }
+    const double* xc = S.XT + (size_t)j.var * S.n_pad;
+    uint32_t out = ids;
+    long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
+    unsigned sat = 0;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      if (((ids >> (8 * e)) & 255u) == (uint32_t)j.label) {
+        const long long row = base + e;
+        const double x = xc[row];
+        const double2 sr = S.pack[row];
+        const long long qa = pgb_quant(sr.x, S.sc.c1, &sat);
+        const long long qb = pgb_quant(sr.y, S.sc.c1, &sat);
+        const long long qc = pgb_quant(sr.y * sr.y, S.sc.c2, &sat);
+        if (x != x) {
+          out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+          v[0] += 1ll << 40;
+          v[4] += qa; v[5] += qb; v[6] += qc;
+        } else if (go_left(j.rule, x, j.v)) {
+          v[0] += 1;
+          v[1] += qa; v[2] += qb; v[3] += qc;
+        } else {
+          out = (out & ~(255u << (8 * e))) | ((uint32_t)j.new_label << (8 * e));
+          v[0] += 1ll << 20;
+        }
+      }
+    }
+    *(uint32_t*)(dst + base) = out;
+    if (j.check_nan) {
+      block_sum<7>(v, s_red);
+    } else {
+      long long w[4] = {v[0], v[1], v[2], v[3]};
+      block_sum<4>(w, s_red);
+      v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+    }
+    if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+    if (tid == 0) {
+      const int cL = (int)(v[0] & 0xFFFFF), cR = (int)((v[0] >> 20) & 0xFFFFF), cN = (int)(v[0] >> 40);
+      S.cc[(size_t)j.ccL * S.nchunks + blockIdx.x] = (uint16_t)cL;
+      S.cc[(size_t)j.ccR * S.nchunks + blockIdx.x] = (uint16_t)cR;
+      Acc* a = &S.acc[(size_t)par * MAXP + p];
+      if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+      if (cL) {
+        atomicAdd((unsigned long long*)&a->aL, (unsigned long long)v[1]);
+        atomicAdd((unsigned long long*)&a->bL, (unsigned long long)v[2]);
+        atomicAdd((unsigned long long*)&a->c2L, (unsigned long long)v[3]);
+      }
+      if (cN) {
+        atomicAdd((unsigned long long*)&a->aN, (unsigned long long)v[4]);
+        atomicAdd((unsigned long long*)&a->bN, (unsigned long long)v[5]);
+        atomicAdd((unsigned long long*)&a->c2N, (unsigned long long)v[6]);
+      }
+    }
+    return;
+  }
+
+  // ---------------- FINAL and/or INIT: one pass over the rows
+  if (blockIdx.y != 0) return;
+  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
+  for (int i = tid; i < 256; i += BT) {
+    s_lv[0][i] = cmd->lv_new[i];
+    s_lv[1][i] = cmd->lv_next[i];
+  }
+  __syncthreads();
+  long long v[5] = {0, 0, 0, 0, 0};  // A, B, C, E0, QSTD
+  unsigned sat = 0;
+  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
+  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
+  uint32_t ids_next = 0;
+  if (do_init) ids_next = *(const uint32_t*)(tl_new + base);
+  uint32_t ids_sel = 0;
+  if (do_final) {
+    if (cmd->sel_slot == -2) {
+      ids_sel = *(const uint32_t*)(tl_old + base);
+    } else if (cmd->sel_slot < 0) {
+      ids_sel = 0;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+        if (base + e >= S.n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+    } else {
+      ids_sel = *(const uint32_t*)(S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad + base);
+    }
+    if (cmd->sel_slot != -2) *(uint32_t*)(tl_old + base) = ids_sel;
+    if (do_init && cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+  }
+  const double cntf = (double)cmd->rs_count;
+#pragma unroll
+  for (int e = 0; e < RPT; ++e) {
+    const long long row = base + e;
+    if (row >= S.n) continue;
+    double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
+    if (do_final) {
+      // [U] sum_trees = sum_trees_noi + new_tree.predict()
+      const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+      st = st + nv;
+      if (cmd->tune) {  // [U] RunningSd.update (Welford)
+        const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+        const double delta = nv - mean0;
+        const double mean = mean0 + delta / cntf;
+        const double delta2 = nv - mean;
+        const double m2 = m20 + delta * delta2;
+        S.rs_mean[row] = mean;
+        S.rs_m2[row] = m2;
+        v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
+      }
+    }
+    if (do_init) {
+      // [U] sum_trees_noi = sum_trees - old_tree.predict()
+      const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+      const double noi = st - o;
+      const double r = S.y[row] - noi;
+      S.pack[row] = make_double2(st, r);
+      S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
+      v[0] += pgb_quant(st, S.sc.c1, &sat);
+      v[1] += pgb_quant(r, S.sc.c1, &sat);
+      v[2] += pgb_quant(r * r, S.sc.c2, &sat);
+      const double er = r - o;
+      v[3] += pgb_quant(er * er, S.sc.c2, &sat);
+    } else {
+      S.st[row] = st;
+    }
+  }
+  block_sum<5>(v, s_red);
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+  if (tid == 0) {
+    InitAcc* a = &S.initacc[par];
+    if (do_init) {
+      atomicAdd((unsigned long long*)&a->A, (unsigned long long)v[0]);
+      atomicAdd((unsigned long long*)&a->B, (unsigned long long)v[1]);
+      atomicAdd((unsigned long long*)&a->C, (unsigned long long)v[2]);
+      atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v[3]);
+    }
+    if (do_final && cmd->tune) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
+  }
+}
+
+// ------------------------------------------------------------------ setup kernels
+// X row-major [n][ldx] -> XT column-major [p][n_pad]; LDS-tiled 32x32 transpose so that both
+// the read and the write are coalesced.  Also flags columns that contain NaN.
+__global__ __launch_bounds__(BT) void k_transpose(const double* __restrict__ X, long long ldx,
+                                                  double* __restrict__ XT, long long n,
+                                                  long long n_pad, int p, int32_t* col_nan) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const long long r0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  for (int k = ty; k < 32; k += 8) {
+    long long r = r0 + k;
+    int c = c0 + tx;
+    tile[k][tx] = (r < n && c < p) ? X[r * ldx + c] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k;
+    long long r = r0 + tx;
+    if (c < p && r < n_pad) {
+      double x = tile[tx][k];
+      XT[(size_t)c * n_pad + r] = x;
+      if (x != x) col_nan[c] = 1;
+    }
+  }
+}
+
+__global__ void k_fill_f64(double* a, long long n, double v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+__global__ void k_init_tree_lid(uint8_t* a, long long n, long long n_pad, int m) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad * m) a[i] = (i % n_pad) < n ? 0 : PGB_ORPHAN;
+}
+
+__global__ void k_init_trees(DTree* trees, int m, long long n, double init_leaf) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  DTree* T = &trees[t];
+  T->n_nodes = 1;
+  T->n_leaves = 1;
+  DNode z;
+  memset(&z, 0, sizeof z);
+  z.var = -1;
+  z.cc_row = -1;
+  z.cnt = (int32_t)n;
+  z.value = init_leaf;
+  T->nd[0] = z;
+}
+
+__global__ void k_build_cdf(const double* alpha_vec, double* cdf, int p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double tot = 0.0;
+    for (int j = 0; j < p; ++j) tot += alpha_vec[j];
+    double cs = 0.0;
+    for (int j = 0; j < p; ++j) {
+      cs += alpha_vec[j];
+      cdf[j] = cs / tot;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ prediction
+// out[d][k][row] = sum over the m trees of forest d of the leaf value reached by X[row,:]
+// (PosteriorSampler.sample_posterior, utils.py:66-69); excluded / NaN splits average both
+// subtrees by their training counts (CHANGELOG.md:410-411).  One thread per (row, forest).
+struct PredTrees {
+  const int32_t* node_off;
+  const int32_t* var;
+  const double* split;
+  const int32_t* left;
+  const int32_t* right;
+  const long long* count;
+  const double* value;
+};
+
+__global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* forest_idx, int n_forests,
+                                                int m, int K, const double* __restrict__ X,
+                                                long long n_rows, int p, long long ldx,
+                                                const int32_t* rules, const uint8_t* excl,
+                                                double* out) {
+  const long long row = (long long)blockIdx.x * BT + threadIdx.x;
+  const int d = blockIdx.y;
+  if (row >= n_rows) return;
+  const double* x = X + row * ldx;
+  double acc[PGB_MAX_OUTPUTS];
+  for (int o = 0; o < K; ++o) acc[o] = 0.0;
+  int stk_node[PGB_MAX_DEPTH + 2];
+  double stk_w[PGB_MAX_DEPTH + 2];
+  for (int t = 0; t < m; ++t) {
+    const int base = T.node_off[forest_idx[(size_t)d * m + t]];
+    int sp = 0;
+    stk_node[0] = 0;
+    stk_w[0] = 1.0;
+    sp = 1;
+    while (sp > 0) {
+      --sp;
+      int k = stk_node[sp];
+      double w = stk_w[sp];
+      for (;;) {
+        const int g = base + k;
+        const int j = T.var[g];
+        if (j < 0) {
+          for (int o = 0; o < K; ++o) acc[o] += w * T.value[(size_t)g * K + o];
+          break;
+        }
+        const double xv = x[j];
+        if (excl[j] || xv != xv) {
+          const int l = T.left[g], r = T.right[g];
+          const double cl = (double)T.count[base + l], cr = (double)T.count[base + r];
+          const double tot = cl + cr;
+          if (!(tot > 0.0)) break;
+          // depth-first, left first (same summation order as the oracle's recursion)
+          stk_node[sp] = r;
+          stk_w[sp] = w * (cr / tot);
+          ++sp;
+          k = l;
+          w = w * (cl / tot);
+          continue;
+        }
+        const bool gl = rules[j] == PGB_RULE_CONTINUOUS ? (xv <= T.split[g]) : (xv == T.split[g]);
+        k = gl ? T.left[g] : T.right[g];
+      }
+    }
+  }
+  for (int o = 0; o < K; ++o) out[((size_t)d * K + o) * n_rows + row] = acc[o];
+}
+
+// ------------------------------------------------------------------ host side
+static thread_local char g_err[512];
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return PGB_E_DEVICE;
+}
+#define HIPCHK(expr)                                     \
+  do {                                                   \
+    hipError_t e_ = (expr);                              \
+    if (e_ != hipSuccess) return fail_hip(e_, #expr);    \
+  } while (0)
+
+struct pgb_handle {
+  pgb_settings s;
+  Dev d;
+  hipStream_t stream;
+  std::vector<void*> allocs;
+  long long slot;  // next slot index (parity = slot & 1)
+  int have_data, have_y;
+  int sigma_dirty;
+  double inv_sigma2;
+  int lower_host;      // mirror of the batch cursor
+  int last_lower, last_n;
+  double slots_per_step;  // running estimate
+  pgb_counters ctr;
+  // profiling of the dominant kernel (k_rows)
+  int prof;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  double prof_ms;
+  long long prof_launches;
+};
+
+template <typename T>
+static int dalloc(pgb_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return PGB_OK;
+}
+
+extern "C" const char* pgb_last_error(void) { return g_err; }
+extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
+
+extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
+  if (!s || !out) return fail(PGB_E_INVALID, "null argument");
+  if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
+  if (s->n >= (1ll << 31) - CH) return fail(PGB_E_UNSUPPORTED, "n too large");
+  if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
+    return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
+  if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
+  if (s->family != PGB_FAMILY_NORMAL) return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  int ndev = 0;
+  hipError_t e0 = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev < 1) {
+    snprintf(g_err, sizeof g_err, "no HIP device visible (%s, count %d); this backend has no CPU fallback",
+             hipGetErrorString(e0), ndev);
+    return PGB_E_DEVICE;
+  }
+  pgb_handle* h = new pgb_handle();
+  h->s = *s;
+  h->stream = (hipStream_t)stream;
+  h->slot = 0;
+  h->inv_sigma2 = 1.0;
+  h->sigma_dirty = 1;
+  h->slots_per_step = 0.0;
+  memset(&h->ctr, 0, sizeof h->ctr);
+  Dev& d = h->d;
+  memset(&d, 0, sizeof d);
+  d.n = s->n;
+  d.nchunks = (int)((s->n + CH - 1) / CH);
+  d.n_pad = (long long)d.nchunks * CH;
+  d.p = s->p;
+  d.m = s->m;
+  d.P = s->num_particles;
+  d.batch_tune = s->batch_tune;
+  d.batch_draw = s->batch_draw;
+  d.seed = s->seed;
+  d.init_leaf = s->init_leaf;
+  d.mdouble = (double)s->m;
+  d.sc = pgb_make_scales(s->n, s->range_exp);
+  for (int i = 0; i < PGB_MAX_DEPTH; ++i) d.prior_leaf[i] = s->prior_leaf[i];
+  int rc;
+  double *XT, *y, *st, *rs_mean, *rs_m2, *alpha_vec, *cdf;
+  double2* pack;
+  uint8_t *tree_lid, *lid;
+  uint16_t* cc;
+  int32_t *vi, *rules, *col_nan;
+#define DA(ptr, cnt) \
+  if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
+  DA(XT, (size_t)d.p * d.n_pad);
+  DA(y, d.n_pad);
+  DA(st, d.n_pad);
+  DA(pack, d.n_pad);
+  DA(rs_mean, d.n_pad);
+  DA(rs_m2, d.n_pad);
+  DA(tree_lid, (size_t)d.m * d.n_pad);
+  DA(lid, (size_t)3 * MAXP * d.n_pad);
+  DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
+  DA(d.trees, d.m);
+  DA(d.parts, 2 * MAXP);
+  DA(d.jobs, 2 * MAXP);
+  DA(d.acc, 2 * MAXP);
+  DA(d.initacc, 2);
+  DA(d.cmd, 2);
+  DA(d.ctrl, 2);
+  DA(d.counters, 8);
+  DA(vi, d.p);
+  DA(alpha_vec, d.p);
+  DA(cdf, d.p);
+  DA(rules, d.p);
+  DA(col_nan, d.p);
+#undef DA
+  d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
+  d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha_vec = alpha_vec; d.cdf = cdf;
+  d.rules = rules; d.col_nan = col_nan;
+  hipStream_t sm = h->stream;
+  hipError_t e;
+#define HC(expr) \
+  if ((e = (expr)) != hipSuccess) { int r_ = fail_hip(e, #expr); pgb_destroy(h); return r_; }
+  HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
+  HC(hipMemsetAsync(rs_mean, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(rs_m2, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)3 * MAXP * d.n_pad, sm));
+  HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
+  HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
+  HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
+  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.initacc, 0, 2 * sizeof(InitAcc), sm));
+  HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
+  HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
+  HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
+  HC(hipMemsetAsync(col_nan, 0, d.p * sizeof(int32_t), sm));
+  Ctrl c0;
+  memset(&c0, 0, sizeof c0);
+  c0.phase = PH_IDLE;
+  c0.leaf_sd = s->init_leaf_sd;
+  c0.inv_sigma2 = 1.0;
+  Ctrl cc2[2] = {c0, c0};
+  HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
+  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, sm, st, d.n_pad,
+                     s->init_sum);
+  hipLaunchKernelGGL(k_init_tree_lid, dim3((unsigned)((d.n_pad * d.m + 255) / 256)), dim3(256), 0, sm,
+                     tree_lid, d.n, d.n_pad, d.m);
+  hipLaunchKernelGGL(k_init_trees, dim3((d.m + 63) / 64), dim3(64), 0, sm, d.trees, d.m, d.n,
+                     s->init_leaf);
+  HC(hipGetLastError());
+  HC(hipStreamSynchronize(sm));
+#undef HC
+  *out = h;
+  return PGB_OK;
+}
+
+extern "C" int pgb_destroy(pgb_handle* h) {
+  if (!h) return PGB_OK;
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
+                            const double* split_prior_host) {
+  if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
+  Dev& d = h->d;
+  if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
+  for (int j = 0; j < d.p; ++j) {
+    if (rules_host[j] != PGB_RULE_CONTINUOUS && rules_host[j] != PGB_RULE_ONEHOT)
+      return fail(PGB_E_UNSUPPORTED, "unknown split rule");
+    if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
+  }
+  hipStream_t sm = h->stream;
+  HIPCHK(hipMemcpyAsync((void*)d.rules, rules_host, d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
+  HIPCHK(hipMemcpyAsync(d.alpha_vec, split_prior_host, d.p * sizeof(double), hipMemcpyHostToDevice, sm));
+  HIPCHK(hipMemsetAsync((void*)d.col_nan, 0, d.p * sizeof(int32_t), sm));
+  dim3 grid((unsigned)(d.n_pad / 32), (unsigned)((d.p + 31) / 32));
+  hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
+                     d.n_pad, d.p, (int32_t*)d.col_nan);
+  hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(64), 0, sm, d.alpha_vec, d.cdf, d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(sm));
+  h->have_data = 1;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
+  if (!h || !y_dev) return fail(PGB_E_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_y = 1;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
+  if (!h || !params) return fail(PGB_E_INVALID, "null argument");
+  if (h->s.family == PGB_FAMILY_NORMAL) {
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
+    h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+    h->sigma_dirty = 1;
+  }
+  return PGB_OK;
+}
+
+static int enqueue_slots(pgb_handle* h, int count) {
+  Dev& d = h->d;
+  dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)d.nchunks, (unsigned)(d.P - 1));
+  for (int i = 0; i < count; ++i) {
+    int par = (int)(h->slot & 1);
+    hipLaunchKernelGGL(k_ctrl, gctrl, dim3(BT), 0, h->stream, d, par);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+      if (h->ev_used + 2 > h->ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+          return fail(PGB_E_DEVICE, "hipEventCreate");
+        h->ev.push_back(a);
+        h->ev.push_back(b);
+      }
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+      (void)hipEventRecord(e0, h->stream);
+    }
+    hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, d, par);
+    if (h->prof) (void)hipEventRecord(e1, h->stream);
+    h->slot += 1;
+  }
+  HIPCHK(hipGetLastError());
+  return PGB_OK;
+}
+
+static int harvest_profile(pgb_handle* h) {
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    h->prof_ms += ms;
+    h->prof_launches += 1;
+  }
+  h->ev_used = 0;
+  return PGB_OK;
+}
+
+// Enqueue slots until the device state machine reports PH_IDLE.
+static int run_until_idle(pgb_handle* h, int n_steps) {
+  Dev& d = h->d;
+  int guess = h->slots_per_step > 0.0 ? (int)(h->slots_per_step * n_steps * 1.08) + 6
+                                      : 16 * d.batch_draw * n_steps + 8;
+  long long start = h->slot;
+  long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
+  const long long used0 = h->ctr.slots;
+  unsigned long long used1 = 0;
+  int rc;
+  for (;;) {
+    if (guess & 1) ++guess;  // keep slot parity aligned for k_begin
+    if ((rc = enqueue_slots(h, guess)) != PGB_OK) return rc;
+    Ctrl c;
+    HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&used1, &d.counters[5], sizeof used1, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
+    if (c.phase == PH_IDLE) break;
+    if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
+    guess = 8;
+  }
+  // slots the device actually needed (idle slots are not counted by the device)
+  double used = (double)((long long)used1 - used0) / n_steps;
+  h->ctr.slots = (long long)used1;
+  h->slots_per_step = h->slots_per_step > 0.0 ? 0.8 * h->slots_per_step + 0.2 * used : used;
+  return PGB_OK;
+}
+
+static int begin_steps(pgb_handle* h, int tune, int n_steps) {
+  Dev& d = h->d;
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  int par = (int)(h->slot & 1);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, d, par, tune, n_steps, h->inv_sigma2,
+                     h->sigma_dirty);
+  h->sigma_dirty = 0;
+  // host mirror of the batch cursor ([U] PGBART.astep batching)
+  for (int i = 0; i < n_steps; ++i) {
+    int bs = tune ? d.batch_tune : d.batch_draw;
+    int upper = h->lower_host + bs;
+    if (upper > d.m) upper = d.m;
+    h->last_lower = h->lower_host;
+    h->last_n = upper - h->lower_host;
+    h->lower_host = upper < d.m ? upper : 0;
+  }
+  return PGB_OK;
+}
+
+static int fetch_counters(pgb_handle* h, pgb_counters* out) {
+  unsigned long long c[8];
+  HIPCHK(hipMemcpyAsync(c, h->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->ctr.particle_steps = (int64_t)c[0];
+  h->ctr.tree_updates = (int64_t)c[1];
+  h->ctr.rows_touched = (int64_t)c[2];
+  h->ctr.rounds = (int64_t)c[3];
+  h->ctr.saturations = (int64_t)c[4];
+  h->ctr.slots = (int64_t)c[5];
+  if (out) *out = h->ctr;
+  return PGB_OK;
+}
+
+extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi_counts_host_out,
+                        pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  int rc;
+  if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
+  if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
+  if (sum_trees_dev_out)
+    HIPCHK(hipMemcpyAsync(sum_trees_dev_out, h->d.st, h->d.n * sizeof(double), hipMemcpyDeviceToDevice,
+                          h->stream));
+  if (vi_counts_host_out)
+    HIPCHK(hipMemcpyAsync(vi_counts_host_out, h->d.vi, h->d.p * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          h->stream));
+  if ((rc = fetch_counters(h, counters_out)) != PGB_OK) return rc;
+  return PGB_OK;
+}
+
+extern "C" int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
+  if (!h || n_steps < 1) return fail(PGB_E_INVALID, "bad argument");
+  int rc;
+  if ((rc = begin_steps(h, tune, n_steps)) != PGB_OK) return rc;
+  return run_until_idle(h, n_steps);
+}
+
+extern "C" int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  return fetch_counters(h, counters_out);
+}
+
+extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  Dev& d = h->d;
+  int first = which == 0 ? h->last_lower : 0;
+  int nt = which == 0 ? h->last_n : d.m;
+  std::vector<DTree> host(nt);
+  if (nt > 0) {
+    HIPCHK(hipMemcpyAsync(host.data(), d.trees + first, sizeof(DTree) * nt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  int total = 0;
+  for (int t = 0; t < nt; ++t) total += host[t].n_nodes;
+  if (!out->var) {
+    out->n_trees = nt;
+    out->n_outputs = 1;
+    out->total_nodes = total;
+    return PGB_OK;
+  }
+  if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
+  int off = 0;
+  for (int t = 0; t < nt; ++t) {
+    const DTree& T = host[t];
+    out->tree_id[t] = first + t;
+    out->node_off[t] = off;
+    for (int k = 0; k < T.n_nodes; ++k) {
+      const DNode& z = T.nd[k];
+      out->var[off + k] = z.var;
+      out->split[off + k] = z.var >= 0 ? z.split : 0.0;
+      out->left[off + k] = z.var >= 0 ? (int32_t)z.left : -1;
+      out->right[off + k] = z.var >= 0 ? (int32_t)z.right : -1;
+      out->count[off + k] = z.cnt;
+      out->value[off + k] = z.var < 0 ? z.value : 0.0;
+    }
+    off += T.n_nodes;
+  }
+  out->node_off[nt] = off;
+  return PGB_OK;
+}
+
+extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  Dev& d = h->d;
+  Ctrl c;
+  InitAcc ia;
+  HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&ia, &d.initacc[(h->slot & 1) ^ 1], sizeof ia, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double leaf_sd = c.leaf_sd;
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * d.sc.inv_c1) / (double)d.n;
+  if (leaf_sd_out) leaf_sd_out[0] = leaf_sd;
+  if (iter_out) *iter_out = c.iter;
+  if (lower_out) *lower_out = c.lower;
+  return PGB_OK;
+}
+
+extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(out, h->d.alpha_vec, h->d.p * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PGB_OK;
+}
+
+extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
+                           int32_t m, const double* X_dev, int64_t n_rows, int32_t p, int64_t ldx,
+                           const int32_t* rules_host, const int32_t* excluded_host, int32_t n_excluded,
+                           double* out_dev, void* stream) {
+  if (!trees || !forest_tree_idx || !X_dev || !out_dev || !rules_host)
+    return fail(PGB_E_INVALID, "null argument");
+  if (trees->n_outputs < 1 || trees->n_outputs > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "n_outputs");
+  if (n_forests < 1 || n_rows < 1) return PGB_OK;
+  hipStream_t sm = (hipStream_t)stream;
+  const int K = trees->n_outputs, N = trees->total_nodes, NT = trees->n_trees;
+  std::vector<uint8_t> excl((size_t)p, 0);
+  for (int e = 0; e < n_excluded; ++e)
+    if (excluded_host[e] >= 0 && excluded_host[e] < p) excl[excluded_host[e]] = 1;
+  // one upload buffer: [node_off | var | left | right | rules | fidx] int32, then 8-byte arrays
+  size_t n_i32 = (size_t)(NT + 1) + 3 * (size_t)N + p + (size_t)n_forests * m;
+  size_t off8 = ((n_i32 * 4 + 7) / 8) * 8;
+  size_t bytes = off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p;
+  std::vector<uint8_t> hb(bytes);
+  int32_t* hi = (int32_t*)hb.data();
+  size_t o = 0;
+  memcpy(hi + o, trees->node_off, (NT + 1) * 4); size_t o_off = o; o += NT + 1;
+  memcpy(hi + o, trees->var, N * 4); size_t o_var = o; o += N;
+  memcpy(hi + o, trees->left, N * 4); size_t o_l = o; o += N;
+  memcpy(hi + o, trees->right, N * 4); size_t o_r = o; o += N;
+  memcpy(hi + o, rules_host, p * 4); size_t o_rules = o; o += p;
+  memcpy(hi + o, forest_tree_idx, (size_t)n_forests * m * 4); size_t o_f = o; o += (size_t)n_forests * m;
+  uint8_t* h8 = hb.data() + off8;
+  memcpy(h8, trees->split, (size_t)N * 8);
+  memcpy(h8 + (size_t)N * 8, trees->count, (size_t)N * 8);
+  memcpy(h8 + (size_t)N * 16, trees->value, (size_t)N * K * 8);
+  memcpy(h8 + (size_t)N * 16 + (size_t)N * K * 8, excl.data(), p);
+  uint8_t* db = nullptr;
+  HIPCHK(hipMalloc((void**)&db, bytes));
+  hipError_t e = hipMemcpyAsync(db, hb.data(), bytes, hipMemcpyHostToDevice, sm);
+  if (e != hipSuccess) { (void)hipFree(db); return fail_hip(e, "hipMemcpyAsync"); }
+  const int32_t* di = (const int32_t*)db;
+  PredTrees T;
+  T.node_off = di + o_off;
+  T.var = di + o_var;
+  T.left = di + o_l;
+  T.right = di + o_r;
+  T.split = (const double*)(db + off8);
+  T.count = (const long long*)(db + off8 + (size_t)N * 8);
+  T.value = (const double*)(db + off8 + (size_t)N * 16);
+  const uint8_t* dexcl = db + off8 + (size_t)N * 16 + (size_t)N * K * 8;
+  dim3 grid((unsigned)((n_rows + BT - 1) / BT), (unsigned)n_forests);
+  hipLaunchKernelGGL(k_predict, grid, dim3(BT), 0, sm, T, di + o_f, n_forests, m, K, X_dev,
+                     (long long)n_rows, p, (long long)ldx, di + o_rules, dexcl, out_dev);
+  e = hipGetLastError();
+  hipError_t e2 = hipStreamSynchronize(sm);
+  (void)hipFree(db);
+  if (e != hipSuccess) return fail_hip(e, "k_predict launch");
+  if (e2 != hipSuccess) return fail_hip(e2, "k_predict");
+  return PGB_OK;
+}
+
+extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (kernel_ms_out) *kernel_ms_out = h->prof_ms;
+  if (launches_out) *launches_out = h->prof_launches;
+  if (enable && !h->prof) {
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    h->ev_used = 0;
+  }
+  h->prof = enable ? 1 : 0;
+  return PGB_OK;
+}

@@ -1,0 +1,242 @@
+"""``PySampler`` / ``PyBartSettings``: Python owners of a native sampler handle.
+
+Counterparts of ``bartrs.bartrs.PySampler`` and ``PyBartSettings`` (reference
+``pymc_bart/pymc_bart.py:2``).  :class:`PySampler` owns one ``pgb_handle`` bound to
+one GPU and one HIP stream; every call is a thin ctypes hop into
+``libpgbart_hip.so``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _abi
+from .trees import TreeArrays
+
+
+@dataclass
+class Backend:
+    """A loaded ABI library plus the memory holder its "device" pointers live in."""
+
+    lib: _abi.PGBLibrary
+    mem: object
+
+
+_DEFAULT_BACKEND: Backend | None = None
+
+
+def default_backend(device: int | None = None) -> Backend:
+    """The HIP backend on the current GPU.  Raises if the extension or the GPU is
+    missing -- by design there is no CPU fallback in the product path."""
+    global _DEFAULT_BACKEND
+    if _DEFAULT_BACKEND is None or device is not None:
+        from ._device import TorchHipMemory
+
+        lib = _abi.load_hip_library()
+        be = Backend(lib=lib, mem=TorchHipMemory(device))
+        if device is not None:
+            return be
+        _DEFAULT_BACKEND = be
+    return _DEFAULT_BACKEND
+
+
+def prior_leaf_table(alpha: float, beta: float) -> np.ndarray:
+    """P(node at depth d stays a leaf) = 1 - alpha (1 + d)^-beta  (reference
+    ``bart.py:107-109``).  As upstream, the table is cut once it reaches 0.9999:
+    deeper nodes never split."""
+    tab = np.ones(_abi.MAX_DEPTH, np.float64)
+    for d in range(_abi.MAX_DEPTH):
+        v = 1.0 - alpha * (1.0 + d) ** (-beta)
+        if v >= 0.9999:
+            break
+        tab[d] = v
+    return tab
+
+
+def range_exponent(Y: np.ndarray) -> int:
+    """Fixed-point range: |sum_trees| and residuals stay below 2^e, with 8x headroom."""
+    a = float(np.max(np.abs(Y))) if Y.size else 1.0
+    a = max(a, 1e-30)
+    return int(math.ceil(math.log2(a))) + 3
+
+
+def jitter_duplicated(col: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """Upstream pre-processing of whole-number continuous columns: every repeated
+    non-zero value gets N(0, nanstd/12) added so that split values are distinct
+    (reference ``CHANGELOG.md:329-332``, NaN-safe ``:305``).  Vectorised; the first
+    occurrence of each value is kept."""
+    finite = col[~np.isnan(col)]
+    if finite.size == 0 or not np.all(np.mod(finite, 1) == 0):
+        return col
+    std = float(np.nanstd(col))
+    out = col.copy()
+    _, first = np.unique(col, return_index=True)
+    dup = np.ones(col.shape[0], bool)
+    dup[first] = False
+    dup &= ~np.isnan(col) & (np.abs(col) > 0)
+    out[dup] = col[dup] + rng.normal(0.0, std / 12.0, size=int(dup.sum()))
+    return out
+
+
+@dataclass
+class PyBartSettings:
+    """Sampler settings (counterpart of ``bartrs.bartrs.PyBartSettings``)."""
+
+    n: int
+    p: int
+    m: int = 50
+    num_particles: int = 10
+    n_outputs: int = 1
+    family: str = "normal"
+    alpha: float = 0.95
+    beta: float = 2.0
+    batch: tuple = (0.1, 0.1)
+    seed: int = 0
+    init_sum: float = 0.0
+    init_leaf: float = 0.0
+    init_leaf_sd: float = 1.0
+    range_exp: int = 4
+    prior_leaf: np.ndarray = field(default_factory=lambda: np.ones(_abi.MAX_DEPTH))
+
+    @classmethod
+    def from_data(cls, X, Y, m=50, num_particles=10, n_outputs=1, family="normal", alpha=0.95,
+                  beta=2.0, batch=(0.1, 0.1), seed=0) -> "PyBartSettings":
+        Y = np.asarray(Y, np.float64)
+        n, p = X.shape
+        mean = float(Y.mean())
+        is_binary = bool(np.all((Y == 0) | (Y == 1)))
+        # [U] leaf_sd = 3/sqrt(m) for 0/1 responses, std(Y)/sqrt(m) otherwise
+        leaf_sd = 3.0 / math.sqrt(m) if is_binary else float(Y.std()) / math.sqrt(m)
+        return cls(
+            n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
+            alpha=alpha, beta=beta, batch=tuple(batch), seed=int(seed), init_sum=mean,
+            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=range_exponent(Y),
+            prior_leaf=prior_leaf_table(alpha, beta),
+        )
+
+    def batch_sizes(self) -> tuple[int, int]:
+        # [U] batch = (max(1, int(m*0.1)), max(1, int(m*0.1))); ints are taken as counts
+        out = []
+        for b in self.batch:
+            out.append(int(b) if b >= 1 else max(1, int(self.m * b)))
+        return out[0], out[1]
+
+    def as_c(self) -> _abi.Settings:
+        s = _abi.Settings()
+        s.n, s.p, s.m = self.n, self.p, self.m
+        s.num_particles = self.num_particles
+        s.n_outputs = self.n_outputs
+        s.family = _abi.FAMILIES[self.family]
+        s.batch_tune, s.batch_draw = self.batch_sizes()
+        s.range_exp = self.range_exp
+        s.seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        s.init_sum = self.init_sum
+        s.init_leaf = self.init_leaf
+        s.init_leaf_sd = self.init_leaf_sd
+        for d in range(_abi.MAX_DEPTH):
+            s.prior_leaf[d] = float(self.prior_leaf[d])
+        return s
+
+
+class PySampler:
+    """One chain's native sampler state (counterpart of ``bartrs.bartrs.PySampler``)."""
+
+    def __init__(self, settings: PyBartSettings, X: np.ndarray, y_obs: np.ndarray,
+                 rules: np.ndarray, split_prior: np.ndarray, backend: Backend | None = None):
+        self.backend = backend if backend is not None else default_backend()
+        self.settings = settings
+        lib, mem = self.backend.lib, self.backend.mem
+        self._h = C.c_void_p()
+        cs = settings.as_c()
+        lib.check(lib.lib.pgb_create(C.byref(cs), mem.stream_ptr, C.byref(self._h)), "pgb_create")
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._rules = np.ascontiguousarray(rules, dtype=np.int32)
+        prior = np.ascontiguousarray(split_prior, dtype=np.float64)
+        xd = mem.from_host(X)
+        lib.check(
+            lib.lib.pgb_set_data(self._h, mem.ptr(xd), X.shape[1], self._rules.ctypes.data,
+                                 prior.ctypes.data),
+            "pgb_set_data",
+        )
+        del xd  # the library keeps its own column-major copy
+        self._y = mem.from_host(np.ascontiguousarray(y_obs, dtype=np.float64))
+        lib.check(lib.lib.pgb_set_response(self._h, mem.ptr(self._y)), "pgb_set_response")
+        self._out = mem.empty((settings.n_outputs * settings.n,), np.float64)
+        self._vi = np.zeros(settings.p, np.int32)
+        self.counters = _abi.Counters()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.backend.lib.lib.pgb_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # -- likelihood parameters at the current point -------------------------------
+    def set_likelihood(self, params) -> None:
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(params, np.float64)))
+        lib = self.backend.lib
+        lib.check(lib.lib.pgb_set_likelihood(self._h, a.ctypes.data, a.size), "pgb_set_likelihood")
+
+    # -- one astep -----------------------------------------------------------------
+    def step(self, tune: bool, fetch: bool = True):
+        lib, mem = self.backend.lib, self.backend.mem
+        rc = lib.lib.pgb_step(self._h, int(bool(tune)), mem.ptr(self._out), self._vi.ctypes.data,
+                              C.byref(self.counters))
+        lib.check(rc, "pgb_step")
+        st = None
+        if fetch:
+            st = mem.to_host(self._out)
+            K = self.settings.n_outputs
+            st = st.reshape(K, self.settings.n) if K > 1 else st.reshape(self.settings.n)
+        return st, self._vi.copy()
+
+    def step_async(self, tune: bool, n_steps: int) -> None:
+        lib = self.backend.lib
+        lib.check(lib.lib.pgb_step_async(self._h, int(bool(tune)), int(n_steps)), "pgb_step_async")
+
+    def sync(self) -> dict:
+        lib = self.backend.lib
+        lib.check(lib.lib.pgb_sync(self._h, C.byref(self.counters)), "pgb_sync")
+        return self.counters.as_dict()
+
+    def sum_trees_device(self):
+        """The device buffer the last ``step`` wrote ``sum_trees`` into."""
+        return self._out
+
+    # -- tree export -----------------------------------------------------------------
+    def export_trees(self, which: int) -> TreeArrays:
+        lib = self.backend.lib
+        c = _abi.TreeArraysC()
+        lib.check(lib.lib.pgb_export_trees(self._h, which, C.byref(c)), "pgb_export_trees(size)")
+        ta = TreeArrays.empty(c.n_trees, c.total_nodes, c.n_outputs)
+        c2 = ta.as_c()
+        lib.check(lib.lib.pgb_export_trees(self._h, which, C.byref(c2)), "pgb_export_trees")
+        return ta
+
+    def state(self) -> dict:
+        lib = self.backend.lib
+        sd = np.zeros(self.settings.n_outputs, np.float64)
+        it = C.c_int64()
+        lo = C.c_int32()
+        lib.check(lib.lib.pgb_get_state(self._h, sd.ctypes.data, C.byref(it), C.byref(lo)),
+                  "pgb_get_state")
+        return {"leaf_sd": sd, "iter": int(it.value), "lower": int(lo.value)}
+
+    def split_weights(self) -> np.ndarray:
+        lib = self.backend.lib
+        a = np.zeros(self.settings.p, np.float64)
+        lib.check(lib.lib.pgb_get_split_weights(self._h, a.ctypes.data), "pgb_get_split_weights")
+        return a
+
+    def profile(self, enable: bool) -> tuple[float, int]:
+        lib = self.backend.lib
+        ms = C.c_double()
+        nl = C.c_int64()
+        lib.check(lib.lib.pgb_profile(self._h, int(enable), C.byref(ms), C.byref(nl)), "pgb_profile")
+        return float(ms.value), int(nl.value)

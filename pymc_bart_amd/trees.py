@@ -1,0 +1,211 @@
+"""Tree storage, tree history and prediction from stored trees.
+
+Counterparts of the native classes the reference imports from ``bartrs``
+(``pymc_bart/pymc_bart.py:2``): :class:`TreeArrays` and :class:`PosteriorSampler`.
+The per-chain history layout ``(baseline_forest, batches)`` is the one consumed at
+reference ``utils.py:124-127``; the prediction contract is ``utils.py:60-71,93-107``:
+``sample_posterior(X, draw_indices, excluded) -> (len(draw_indices), n_outputs, n_rows)``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _abi
+
+
+@dataclass
+class TreeArrays:
+    """SoA storage of a list of trees (``pgb_tree_arrays``).  Plain numpy => picklable,
+    so it can travel through the ``multiprocessing.Manager().list()`` mailbox the
+    reference attaches to the op (``bart.py:133-135``)."""
+
+    n_outputs: int
+    tree_id: np.ndarray   # int32 [n_trees]
+    node_off: np.ndarray  # int32 [n_trees + 1]
+    var: np.ndarray       # int32 [nodes]
+    split: np.ndarray     # float64 [nodes]
+    left: np.ndarray      # int32 [nodes]
+    right: np.ndarray     # int32 [nodes]
+    count: np.ndarray     # int64 [nodes]
+    value: np.ndarray     # float64 [nodes, n_outputs]
+
+    @property
+    def n_trees(self) -> int:
+        return int(self.tree_id.shape[0])
+
+    @property
+    def total_nodes(self) -> int:
+        return int(self.var.shape[0])
+
+    @classmethod
+    def empty(cls, n_trees: int, total_nodes: int, n_outputs: int) -> "TreeArrays":
+        return cls(
+            n_outputs=n_outputs,
+            tree_id=np.zeros(n_trees, np.int32),
+            node_off=np.zeros(n_trees + 1, np.int32),
+            var=np.zeros(total_nodes, np.int32),
+            split=np.zeros(total_nodes, np.float64),
+            left=np.zeros(total_nodes, np.int32),
+            right=np.zeros(total_nodes, np.int32),
+            count=np.zeros(total_nodes, np.int64),
+            value=np.zeros((total_nodes, n_outputs), np.float64),
+        )
+
+    def as_c(self) -> _abi.TreeArraysC:
+        c = _abi.TreeArraysC()
+        c.n_trees = self.n_trees
+        c.n_outputs = self.n_outputs
+        c.total_nodes = self.total_nodes
+        c.tree_id = _abi._ptr(self.tree_id, C.c_int32)
+        c.node_off = _abi._ptr(self.node_off, C.c_int32)
+        c.var = _abi._ptr(self.var, C.c_int32)
+        c.split = _abi._ptr(self.split, C.c_double)
+        c.left = _abi._ptr(self.left, C.c_int32)
+        c.right = _abi._ptr(self.right, C.c_int32)
+        c.count = _abi._ptr(self.count, C.c_int64)
+        c.value = _abi._ptr(self.value, C.c_double)
+        return c
+
+    def split_variables(self, t: int) -> np.ndarray:
+        a, b = self.node_off[t], self.node_off[t + 1]
+        v = self.var[a:b]
+        return v[v >= 0]
+
+    @staticmethod
+    def concat(parts: list["TreeArrays"]) -> "TreeArrays":
+        K = parts[0].n_outputs
+        offs = [0]
+        for p in parts:
+            offs.append(offs[-1] + p.total_nodes)
+        node_off = np.concatenate(
+            [p.node_off[:-1] + o for p, o in zip(parts, offs[:-1])] + [np.array([offs[-1]], np.int32)]
+        ).astype(np.int32)
+        return TreeArrays(
+            n_outputs=K,
+            tree_id=np.concatenate([p.tree_id for p in parts]).astype(np.int32),
+            node_off=node_off,
+            var=np.concatenate([p.var for p in parts]).astype(np.int32),
+            split=np.concatenate([p.split for p in parts]),
+            left=np.concatenate([p.left for p in parts]).astype(np.int32),
+            right=np.concatenate([p.right for p in parts]).astype(np.int32),
+            count=np.concatenate([p.count for p in parts]).astype(np.int64),
+            value=np.concatenate([p.value for p in parts], axis=0),
+        )
+
+
+def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rules: np.ndarray,
+                  excluded=None) -> np.ndarray:
+    """Slow host restatement of ``pgb_predict`` used by tests only (tiny inputs)."""
+    X = np.asarray(X, np.float64)
+    n_rows, p = X.shape
+    K = trees.n_outputs
+    excl = np.zeros(p, bool)
+    if excluded is not None:
+        excl[list(excluded)] = True
+    out = np.zeros((forest_idx.shape[0], K, n_rows))
+
+    def rec(base, k, x, w, acc):
+        g = base + k
+        while trees.var[g] >= 0:
+            j = trees.var[g]
+            if excl[j] or np.isnan(x[j]):
+                l, r = trees.left[g], trees.right[g]
+                cl, cr = float(trees.count[base + l]), float(trees.count[base + r])
+                tot = cl + cr
+                if not tot > 0:
+                    return
+                rec(base, l, x, w * (cl / tot), acc)
+                rec(base, r, x, w * (cr / tot), acc)
+                return
+            go_left = x[j] <= trees.split[g] if rules[j] == _abi.RULE_CONTINUOUS else x[j] == trees.split[g]
+            k = trees.left[g] if go_left else trees.right[g]
+            g = base + k
+        acc += w * trees.value[g]
+
+    for d in range(forest_idx.shape[0]):
+        for i in range(n_rows):
+            acc = np.zeros(K)
+            for ti in forest_idx[d]:
+                rec(trees.node_off[ti], 0, X[i], 1.0, acc)
+            out[d, :, i] = acc
+    return out
+
+
+class PosteriorSampler:
+    """Prediction-only sampler rebuilt from one chain's tree history.
+
+    ``from_history(batches, baseline_forest, m, n_outputs)`` mirrors the call at
+    reference ``utils.py:124-127``.  Draw ``d`` is the baseline forest with batches
+    ``0..d`` applied (each batch replaces the trees at its ``tree_id`` slots).
+    Prediction runs in the HIP library (``pgb_predict``).
+    """
+
+    def __init__(self, pool: TreeArrays, forest_idx: np.ndarray, m: int, n_outputs: int,
+                 rules: np.ndarray, backend=None):
+        self.pool = pool
+        self.forest_idx = np.ascontiguousarray(forest_idx, dtype=np.int32)
+        self.m = int(m)
+        self._n_outputs = int(n_outputs)
+        self.rules = np.ascontiguousarray(rules, dtype=np.int32)
+        self._backend = backend
+
+    @classmethod
+    def from_history(cls, batches, baseline_forest: TreeArrays, m: int, n_outputs: int,
+                     rules=None, backend=None) -> "PosteriorSampler":
+        parts = [baseline_forest] + list(batches)
+        pool = TreeArrays.concat(parts)
+        cur = np.empty(m, np.int64)
+        cur[baseline_forest.tree_id] = np.arange(baseline_forest.n_trees)
+        table = np.empty((len(batches), m), np.int32)
+        off = baseline_forest.n_trees
+        for d, b in enumerate(batches):
+            cur[b.tree_id] = off + np.arange(b.n_trees)
+            off += b.n_trees
+            table[d] = cur
+        if rules is None:
+            p = int(pool.var.max()) + 1 if pool.total_nodes else 1
+            rules = np.zeros(max(p, 1), np.int32)
+        return cls(pool, table, m, n_outputs, rules, backend=backend)
+
+    @property
+    def n_draws(self) -> int:
+        return int(self.forest_idx.shape[0])
+
+    @property
+    def n_outputs(self) -> int:
+        return self._n_outputs
+
+    def _get_backend(self):
+        if self._backend is None:
+            from .sampler import default_backend
+
+            self._backend = default_backend()
+        return self._backend
+
+    def sample_posterior(self, X, draw_indices, excluded=None) -> np.ndarray:
+        be = self._get_backend()
+        X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        if X.ndim == 1:
+            X = X[:, None]
+        n_rows, p = X.shape
+        rules = self.rules
+        if rules.shape[0] < p:
+            rules = np.concatenate([rules, np.zeros(p - rules.shape[0], np.int32)])
+        idx = np.asarray(draw_indices, dtype=np.int64)
+        fidx = np.ascontiguousarray(self.forest_idx[idx], dtype=np.int32)
+        excl = np.ascontiguousarray(np.asarray([] if excluded is None else excluded, dtype=np.int32))
+        K = self._n_outputs
+        xd = be.mem.from_host(X)
+        outd = be.mem.empty((fidx.shape[0] * K * n_rows,), np.float64)
+        carr = self.pool.as_c()
+        rc = be.lib.lib.pgb_predict(
+            C.byref(carr), fidx.ctypes.data, fidx.shape[0], self.m, be.mem.ptr(xd), n_rows, p, p,
+            rules.ctypes.data, excl.ctypes.data if excl.size else None, int(excl.size),
+            be.mem.ptr(outd), be.mem.stream_ptr,
+        )
+        be.lib.check(rc, "pgb_predict")
+        return be.mem.to_host(outd).reshape(fidx.shape[0], K, n_rows)
