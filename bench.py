@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the PGBART hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one PGBART.astep (a batch of 10% of the m trees re-sampled by particle Gibbs) on
+the configuration BASELINE.json's metric is quoted on: n=100k, p=50, m=200 trees, 40
+particles, Gaussian likelihood (cfg2), synthetic data resident in HBM.  With N>1, N independent
+chains run one per GPU (weak scaling, no data-path collective); draws are gathered over RCCL
+after the timed region.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(w, seed, budget_s=20.0):
+    """The CPU oracle (oracle/, a single-threaded C restatement) on a bounded sample of the
+    same workload.  Reported baseline, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import oracle_backend
+    from pymc_bart_amd.sampler import PyBartSettings, PySampler
+
+    X, Y = w["X"], w["Y"]
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed)
+    s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]),
+                  backend=oracle_backend())
+    s.set_likelihood([1.0])
+    s.step(False, fetch=False)  # warm-up (page in)
+    c0 = s.counters.as_dict()
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        s.step(False, fetch=False)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s or steps >= 64:
+            break
+    dt = time.perf_counter() - t0
+    c1 = s.counters.as_dict()
+    ps = c1["particle_steps"] - c0["particle_steps"]
+    tu = c1["tree_updates"] - c0["tree_updates"]
+    return {
+        "value": ps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} asteps ({tu} tree updates, {dt:.1f} s) of the same cfg2 data after 1 "
+                  "warm-up astep; restated CPU baseline (oracle/), not the reference binary",
+        "tree_updates_per_s": tu / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--p", type=int, default=50)
+    ap.add_argument("--m", type=int, default=200)
+    ap.add_argument("--particles", type=int, default=40)
+    ap.add_argument("--tune", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from pymc_bart_amd import workloads
+    from pymc_bart_amd.sampler import PyBartSettings, PySampler, default_backend
+
+    seed = 3415 + rank  # independent chains: SURVEY.md 8e
+    w = workloads.cfg2(seed=3415, n=args.n, p=args.p, m=args.m, num_particles=args.particles)
+    X, Y = w["X"], w["Y"]
+    n = X.shape[0]
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed)
+    be = default_backend(local_rank)
+    s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
+    s.set_likelihood([1.0])  # sigma fixed at 1 for the throughput run
+    tune = bool(args.tune)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        s.step_async(tune, args.warmup)
+    s.sync()
+    c0 = s.counters.as_dict()
+    barrier()
+    t0 = time.perf_counter()
+    s.step_async(tune, args.steps)  # returns when the device state machine is idle again
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = s.sync()
+    dps = c1["particle_steps"] - c0["particle_steps"]
+    dtu = c1["tree_updates"] - c0["tree_updates"]
+    drt = c1["rows_touched"] - c0["rows_touched"]
+
+    # whole-job aggregate: max time over ranks, sum of units over ranks
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_max = float(tt.item())
+        uu = torch.tensor([dps, dtu, drt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        tot_ps, tot_tu, tot_rt = (float(x) for x in uu.tolist())
+    else:
+        dt_max, tot_ps, tot_tu, tot_rt = dt, float(dps), float(dtu), float(drt)
+
+    # roofline of the dominant kernel (k_rows): a second identical region with HIP events
+    roofline = None
+    if not args.no_roofline:
+        s.profile(True)
+        cp0 = s.sync()
+        s.step_async(tune, args.steps)
+        cp1 = s.sync()
+        ms, launches = s.profile(False)
+        tu = cp1["tree_updates"] - cp0["tree_updates"]
+        rt = cp1["rows_touched"] - cp0["rows_touched"]
+        alg = workloads.bytes_per_tree_update(n, rt / max(tu, 1)) * tu
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "k_rows", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
+            "algorithmic_bytes_per_launch": alg / max(launches, 1),
+            "note": "algorithmic bytes = sum over tree updates of 48 n + 40 rows_touched "
+                    "(SURVEY.md 8d) / k_rows launches; HIP events on the sampler's stream",
+        }
+
+    # end-of-run gather of the draws (the only collective; outside the timed region)
+    gather_ms = None
+    if dist is not None:
+        draw = s.sum_trees_device().clone()
+        outs = [torch.empty_like(draw) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.gather(draw, outs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, seed)
+
+    if rank == 0:
+        line = {
+            "metric": "particle-steps/sec (n=100k, p=50, m=200, 40 particles)",
+            "value": tot_ps / dt_max,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": w["name"] + f", sigma=1 fixed, tune={int(tune)}, "
+                            f"{st.batch_sizes()[0 if tune else 1]} trees per step",
+                "chains": world, "parallelism": f"chains{world}",
+            },
+            "tree_updates_per_s": tot_tu / dt_max,
+            "rows_touched_per_tree": tot_rt / max(tot_tu, 1.0),
+            "algorithmic_GBps_whole_step": workloads.bytes_per_tree_update(
+                n, tot_rt / max(tot_tu, 1.0)) * tot_tu / dt_max / 1e9,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = line["value"] / cpu["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
