@@ -663,3 +663,37 @@ int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* l
   if (launches_out) *launches_out = 0;
   return PGB_OK;
 }
+
+/* ------------------------------------------------------------------ test hooks
+ * (pgbo_*: exported only by the oracle so that tests can pin the numeric primitives of
+ * pgbart_spec.h against known-answer vectors and libm) */
+void pgbo_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                 uint32_t* out) {
+  pgb_u32x4 r = pgb_philox4x32_10(k0, k1, c0, c1, c2, c3);
+  for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+void pgbo_draw2(uint64_t seed, uint32_t iter, uint32_t round, uint32_t particle, uint32_t purpose,
+                uint32_t sub, double* out) {
+  pgb_u2 u = pgb_draw2(seed, iter, round, particle, purpose, sub);
+  out[0] = u.u0;
+  out[1] = u.u1;
+}
+void pgbo_math(const double* x, int64_t n, double* e, double* l, double* s, double* c) {
+  for (int64_t i = 0; i < n; ++i) {
+    e[i] = pgb_exp(x[i]);
+    l[i] = pgb_log(x[i]);
+    pgb_sincos2pi(x[i], &s[i], &c[i]);
+  }
+}
+void pgbo_normal2(const double* u0, const double* u1, int64_t n, double* z0, double* z1) {
+  for (int64_t i = 0; i < n; ++i) pgb_normal2(u0[i], u1[i], &z0[i], &z1[i]);
+}
+int64_t pgbo_quant(double x, double scale, uint32_t* sat) { return pgb_quant(x, scale, sat); }
+void pgbo_scales(int64_t n, int range_exp, double* out6) {
+  pgb_scales s = pgb_make_scales(n, range_exp);
+  out6[0] = s.c1; out6[1] = s.c2; out6[2] = s.cl;
+  out6[3] = s.inv_c1; out6[4] = s.inv_c2; out6[5] = s.inv_cl;
+}
+int64_t pgbo_sizeof_settings(void) { return (int64_t)sizeof(pgb_settings); }
+int64_t pgbo_sizeof_counters(void) { return (int64_t)sizeof(pgb_counters); }
+int64_t pgbo_sizeof_tree_arrays(void) { return (int64_t)sizeof(pgb_tree_arrays); }

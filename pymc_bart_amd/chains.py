@@ -1,0 +1,104 @@
+"""Chain driver: a minimal sampling loop around :class:`PGBART` and the one-chain-per-GPU
+sharding of independent chains.
+
+The reference runs chains as PyMC worker processes that return tree history through a
+``multiprocessing.Manager().list()`` (``bart.py:133-135``, consumed at ``utils.py:124-127``).
+Here each rank of a ``torch.distributed`` job owns one chain on its own MI355X; there is no
+communication during sampling and ONE gather at the end (RCCL over xGMI when the backend is
+"nccl"; "gloo" in the CPU tests).  PyMC itself is not required: the loop below is the small
+part of ``pm.sample`` the hot path needs -- call ``step.astep``, Gibbs-update ``sigma`` of the
+Normal likelihood, keep the draws.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .pgbart import PGBART, BARTOp, NormalLikelihood
+from .utils import _decode_vi
+
+
+def sample_chain(op: BARTOp, tune: int, draws: int, num_particles: int = 10, random_seed: int = 0,
+                 chain: int = 0, batch=(0.1, 0.1), sigma: float | None = None,
+                 sigma_prior=(1.0, 1.0), backend=None, keep_draws: bool = True) -> dict:
+    """Run one chain.  ``sigma=None``: sigma^2 ~ InvGamma(a0, b0) is Gibbs-updated from the
+    residuals after every step (conjugate stand-in for the HalfNormal+NUTS of the reference
+    tests); otherwise sigma is held fixed."""
+    rng = np.random.default_rng(np.random.SeedSequence([int(random_seed), int(chain), 77]))
+    lik = NormalLikelihood("sigma")
+    step = PGBART([op], num_particles=num_particles, batch=batch, likelihood=lik,
+                  random_seed=random_seed, chain=chain, backend=backend)
+    Y = np.asarray(op.Y, np.float64)
+    n = Y.shape[0]
+    cur_sigma = float(sigma) if sigma is not None else float(Y.std()) or 1.0
+    mu_draws = np.empty((draws, n)) if keep_draws else None
+    sig_draws = np.empty(draws)
+    vi_stats = []
+    for it in range(tune + draws):
+        if it == tune:
+            step.stop_tuning()
+        point = {"sigma": cur_sigma}
+        mu, stats = step.astep(None, point)
+        if sigma is None:
+            res = Y - mu
+            a0, b0 = sigma_prior
+            cur_sigma = float(np.sqrt((b0 + 0.5 * float(res @ res)) / rng.gamma(a0 + 0.5 * n)))
+        if it >= tune:
+            d = it - tune
+            if keep_draws:
+                mu_draws[d] = mu
+            sig_draws[d] = cur_sigma
+            vi_stats.append(stats[0]["variable_inclusion"])
+    p = step.num_variates
+    vi = np.array([_decode_vi(s, p) for s in vi_stats], dtype=np.int64).reshape(-1, p)
+    return {
+        "chain": chain,
+        "mu": mu_draws,
+        "sigma": sig_draws,
+        "variable_inclusion": vi_stats,
+        "vi_counts": vi,
+        "history": (step._baseline, step._batches),
+        "counters": step.counters,
+        "step": step,
+    }
+
+
+def gather_chains(result: dict, dist=None, dst: int = 0):
+    """The single end-of-run collective: gather every rank's draws and tree history on ``dst``.
+
+    Dense draws travel as one tensor per rank (``all_gather`` over RCCL/xGMI on GPUs: each rank's
+    shard moves over its own links in parallel); the small ragged pieces (VI strings, tree
+    history) travel pickled with ``gather_object``.  Returns the list of per-chain results on
+    ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``.
+    """
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [{k: v for k, v in result.items() if k != "step"}]
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    dense = torch.from_numpy(np.concatenate([result["mu"], result["sigma"][:, None]], axis=1)).to(dev)
+    parts = [torch.empty_like(dense) for _ in range(world)]
+    dist.all_gather(parts, dense)
+    small = {k: result[k] for k in ("chain", "variable_inclusion", "vi_counts", "history", "counters")}
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(small, gathered, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        d = parts[r].cpu().numpy()
+        item = dict(gathered[r])
+        item["mu"] = d[:, :-1]
+        item["sigma"] = d[:, -1]
+        out.append(item)
+    return out
+
+
+def attach_history(op: BARTOp, chains: list[dict]) -> None:
+    """Put the gathered per-chain histories where the reference's predictors look for them
+    (``op.all_trees``, ``utils.py:124-127``)."""
+    del op.all_trees[:]
+    for c in chains:
+        op.all_trees.append(c["history"])

@@ -1,0 +1,210 @@
+"""``PGBART`` -- the particle-Gibbs step method, drop-in for ``bartrs.PGBART``.
+
+Reference boundary (the only direct use in the reference tree): ``tests/test_bart.py:231-235``
+``PGBART([mu1], num_particles=5)`` passed to ``pm.sample(step=[...])``; auto-assignment relies
+on ``competence`` (``pymc_bart/__init__.py:15-18``).  Stats wire format: ``tests/test_bart.py:59``
+and ``utils.py:1387-1398``; tree hand-off: ``bart.py:134-135`` -> ``utils.py:124-127``.
+
+The class works duck-typed without PyMC (PyMC is not installed on the build box):
+``vars`` entries may be PyMC BART random variables (``var.owner.op`` carries the attributes set at
+``bart.py:141-158``) or any object with those attributes, e.g. :class:`BARTOp`.  All sampling
+work happens in ``libpgbart_hip.so``; this file only marshals.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .sampler import PyBartSettings, PySampler, jitter_duplicated
+from .utils import _encode_vi
+
+try:  # pragma: no cover - PyMC is optional
+    from pymc.step_methods.arraystep import ArrayStepShared as _Base
+    from pymc.step_methods.compound import Competence as _Competence
+
+    _HAVE_PYMC = True
+except Exception:  # noqa: BLE001
+    _Base = object
+    _Competence = None
+    _HAVE_PYMC = False
+
+
+class BARTOp:
+    """Stand-in for the per-instance ``BART_<name>`` op of the reference (``bart.py:141-158``):
+    a mailbox of settings plus the ``all_trees`` history list."""
+
+    def __init__(self, X, Y, m=50, alpha=0.95, beta=2.0, response="constant", split_rules=None,
+                 split_prior=None, name="mu", all_trees=None):
+        if response != "constant":
+            raise NotImplementedError(
+                "response='linear'/'mix' are experimental upstream (bart.py:128-132) and not "
+                "implemented by the MI355X backend"
+            )
+        self.name = name
+        self.X = np.asarray(X, dtype=float)
+        self.Y = np.asarray(Y, dtype=float)
+        self.m = int(m)
+        self.alpha = float(alpha)
+        self.beta = float(beta)
+        self.response = response
+        self.split_rules = split_rules
+        self.split_prior = np.array([]) if split_prior is None else np.asarray(split_prior)
+        self.all_trees = [] if all_trees is None else all_trees
+        self.initval = float(self.Y.mean())
+
+
+class NormalLikelihood:
+    """``y ~ Normal(mu = BART, sigma)``; ``sigma`` is read from the point by name or fixed."""
+
+    family = "normal"
+
+    def __init__(self, sigma=1.0):
+        self.sigma = sigma
+
+    def params(self, point=None):
+        s = self.sigma
+        if isinstance(s, str):
+            if point is None or s not in point:
+                raise KeyError(f"point has no value for {s!r}")
+            s = point[s]
+        return [float(np.asarray(s))]
+
+
+def _op_of(var):
+    owner = getattr(var, "owner", None)
+    return owner.op if owner is not None and hasattr(owner, "op") else var
+
+
+def _eval(x):
+    return x.eval() if hasattr(x, "eval") and not isinstance(x, np.ndarray) else x
+
+
+class PGBART(_Base):
+    """Particle Gibbs BART sampling step.
+
+    Parameters
+    ----------
+    vars : list
+        One BART variable (PyMC RV or :class:`BARTOp`).
+    num_particles : int
+        Number of particles, including the reference particle (upstream default 10).
+    batch : tuple
+        Fraction (or count) of the ``m`` trees re-sampled per step during (tuning, draws).
+    """
+
+    name = "pgbart"
+    default_blocked = False
+    generates_stats = True
+    stats_dtypes_shapes = {"variable_inclusion": (object, []), "tune": (bool, [])}
+    # older PyMC versions read this attribute instead
+    stats_dtypes = [{"variable_inclusion": object, "tune": bool}]
+
+    def __init__(self, vars=None, num_particles=10, batch=(0.1, 0.1), model=None,  # noqa: A002
+                 initial_point=None, compile_kwargs=None, *, likelihood=None, observed=None,
+                 random_seed=None, chain=0, backend=None):
+        if vars is None or len(vars) != 1:
+            raise ValueError("PGBART samples exactly one BART variable per step method")
+        self._var = vars[0]
+        op = _op_of(self._var)
+        self.bart = op
+        X = np.asarray(_eval(op.X), dtype=np.float64)
+        Y = np.asarray(_eval(op.Y), dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be 2-dimensional")
+        self.num_observations, self.num_variates = X.shape
+        self.m = int(op.m)
+        if getattr(op, "response", "constant") != "constant":
+            raise NotImplementedError("only response='constant' is implemented")
+        split_prior = np.asarray(getattr(op, "split_prior", np.array([])), dtype=np.float64)
+        if split_prior.size == 0:  # bart.py:139 -> all covariates equally likely
+            split_prior = np.ones(self.num_variates)
+        rules = getattr(op, "split_rules", None)
+        if not rules:
+            rule_ids = np.zeros(self.num_variates, np.int32)
+        else:
+            try:
+                rule_ids = np.array(
+                    [_abi.RULES[r if isinstance(r, str) else getattr(r, "__name__", str(r))]
+                     for r in rules], np.int32)
+            except KeyError as e:
+                raise NotImplementedError(f"split rule {e} is not implemented") from e
+        seed = int(np.random.SeedSequence(random_seed).generate_state(1, np.uint64)[0]) \
+            if random_seed is None else int(random_seed)
+        seed = (seed + 0x9E3779B97F4A7C15 * int(chain)) & 0xFFFFFFFFFFFFFFFF
+        # [U] whole-number continuous columns are jittered (CHANGELOG.md:329-332)
+        jrng = np.random.default_rng(seed)
+        X = X.copy()
+        for j in range(self.num_variates):
+            if rule_ids[j] == _abi.RULE_CONTINUOUS:
+                X[:, j] = jitter_duplicated(X[:, j], jrng)
+        self.likelihood = likelihood if likelihood is not None else NormalLikelihood(1.0)
+        y_obs = Y if observed is None else np.asarray(observed, np.float64)
+        n_outputs = 1
+        self.settings = PyBartSettings.from_data(
+            X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
+            family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
+            batch=batch, seed=seed,
+        )
+        self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
+        # the op is a mailbox: utils.py:125 reads op.n_outputs, which the step method sets
+        op.n_outputs = n_outputs
+        op._rule_ids = rule_ids
+        self.tune = True
+        self._baseline = None
+        self._batches = []
+        self._registered = False
+        self.shape = (self.num_observations,)
+        if _HAVE_PYMC and model is not None:  # pragma: no cover
+            shared = {}
+            super().__init__(vars, shared)
+
+    # -- PyMC step-method surface ---------------------------------------------------
+    @staticmethod
+    def competence(var, has_grad=False):
+        """IDEAL for BART variables (upstream: ``isinstance(var.owner.op, BARTRV)``)."""
+        op = _op_of(var)
+        is_bart = all(hasattr(op, a) for a in ("X", "Y", "m", "alpha", "beta", "all_trees"))
+        if _Competence is not None:  # pragma: no cover
+            return _Competence.IDEAL if is_bart else _Competence.INCOMPATIBLE
+        return 3 if is_bart else 0
+
+    def stop_tuning(self):
+        self.tune = False
+
+    def astep(self, _q=None, point=None):
+        """Re-sample the next batch of trees; returns ``(sum_trees, [stats])``."""
+        self.sampler.set_likelihood(self.likelihood.params(point))
+        if not self.tune and self._baseline is None:
+            # first draw: freeze the forest the per-draw batches are deltas of (utils.py:124-127)
+            self._baseline = self.sampler.export_trees(1)
+        sum_trees, vi = self.sampler.step(self.tune)
+        if not self.tune:
+            self._batches.append(self.sampler.export_trees(0))
+            self._publish()
+        stats = {"variable_inclusion": _encode_vi(vi), "tune": self.tune}
+        return sum_trees, [stats]
+
+    def step(self, point):
+        """Duck-typed ``step``: writes the new ``sum_trees`` into ``point[<bart name>]``."""
+        sum_trees, stats = self.astep(None, point)
+        out = dict(point)
+        out[getattr(self.bart, "name", "mu")] = sum_trees
+        return out, stats
+
+    def _publish(self):
+        entry = (self._baseline, self._batches)
+        trees = self.bart.all_trees
+        if not self._registered:
+            trees.append(entry)
+            self._slot = len(trees) - 1
+            self._registered = True
+        else:
+            try:
+                trees[self._slot] = entry  # Manager().list() proxies need re-assignment
+            except Exception:  # noqa: BLE001
+                pass
+
+    @property
+    def counters(self) -> dict:
+        return self.sampler.counters.as_dict()

@@ -1,0 +1,118 @@
+"""Seeded parity cases shared by the golden-fixture generator and the GPU parity tests."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from pymc_bart_amd.sampler import PyBartSettings, PySampler
+
+
+def make_case(name: str):
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else int(hashlib.sha1(name.encode()).hexdigest()[:8], 16))
+    c = dict(name=name, m=10, P=10, steps=24, batch=(0.1, 0.1), rules=None, prior=None, seed=3415)
+    if name == "cfg1_friedman":  # BASELINE.json configs[0]
+        n, p = 500, 5
+        X = rng.uniform(0, 1, (n, p))
+        Y = (10 * np.sin(np.pi * X[:, 0] * X[:, 1]) + 20 * (X[:, 2] - 0.5) ** 2 + 10 * X[:, 3]
+             + 5 * X[:, 4] + rng.normal(0, 1, n))
+        c.update(m=50, P=10, steps=40)
+    elif name == "nan_onehot_prior":
+        n, p = 5000, 8
+        X = rng.normal(size=(n, p))
+        X[:, 6] = rng.integers(0, 5, n)
+        X[:, 7] = rng.integers(0, 2, n)
+        X[rng.random(n) < 0.1, 1] = np.nan
+        X[rng.random(n) < 0.3, 6] = np.nan
+        Y = X[:, 0] * 2 + np.where(X[:, 7] > 0, 1.5, -1.5) + rng.normal(0, 0.5, n)
+        rules = np.zeros(p, np.int32)
+        rules[6:] = 1
+        c.update(m=20, P=20, steps=40, rules=rules, prior=np.array([3, 1, 1, 1, 1, 0.5, 2, 2.0]))
+    elif name == "ragged_1025":
+        n, p = 1025, 3
+        X = rng.normal(size=(n, p))
+        Y = np.abs(X[:, 0]) + rng.normal(0, 0.1, n)
+        c.update(m=7, P=6, steps=30, batch=(3, 2))
+    elif name == "tiny_n3":
+        n, p = 3, 2
+        X = rng.normal(size=(n, p))
+        Y = np.array([0.0, 1.0, 5.0])
+        c.update(m=4, P=4, steps=16)
+    elif name == "one_tree_two_particles":
+        n, p = 300, 2
+        X = rng.normal(size=(n, p))
+        Y = X[:, 0] + rng.normal(0, 0.1, n)
+        c.update(m=1, P=2, steps=30)
+    elif name == "max_particles":
+        n, p = 2100, 4
+        X = rng.normal(size=(n, p))
+        Y = np.sin(3 * X[:, 0]) * 4 + rng.normal(0, 0.3, n)
+        c.update(m=6, P=64, steps=12)
+    elif name == "duplicates":
+        n, p = 4096, 3
+        X = rng.integers(0, 3, (n, p)).astype(float)  # heavy ties, no jitter at this level
+        Y = X[:, 0] - X[:, 1] + rng.normal(0, 0.2, n)
+        rules = np.array([0, 1, 1], np.int32)
+        c.update(m=8, P=12, steps=30, rules=rules)
+    elif name == "deep_trees":
+        n, p = 3000, 3
+        X = rng.normal(size=(n, p))
+        Y = np.sin(5 * X[:, 0]) + np.cos(3 * X[:, 1]) + rng.normal(0, 0.05, n)
+        c.update(m=5, P=10, steps=20, alpha=0.999, beta=0.3)
+    else:
+        raise KeyError(name)
+    c.update(X=X, Y=Y)
+    return c
+
+
+CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
+         "max_particles", "duplicates", "deep_trees"]
+
+
+def run_case(c, backend, record_every: int = 1):
+    """Run the case on a backend; returns everything the two backends must agree on."""
+    X, Y = c["X"], c["Y"]
+    p = X.shape[1]
+    st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
+                                  alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0))
+    rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
+    prior = np.ones(p) if c["prior"] is None else c["prior"]
+    s = PySampler(st, X, Y, rules, prior, backend=backend)
+    sig_rng = np.random.default_rng(99)
+    sums, vis, trees = [], [], []
+    half = c["steps"] // 2
+    for it in range(c["steps"]):
+        s.set_likelihood([float(0.5 + sig_rng.random())])  # sigma moves like a Gibbs/NUTS neighbour
+        stv, vi = s.step(tune=it < half)
+        if it % record_every == 0:
+            sums.append(stv)
+            vis.append(vi)
+            ta = s.export_trees(0)
+            trees.append(np.concatenate([ta.tree_id, ta.node_off, ta.var, ta.left, ta.right,
+                                         ta.count, ta.split.view(np.int64), ta.value.ravel().view(np.int64)]))
+    forest = s.export_trees(1)
+    ctr = s.counters.as_dict()
+    ctr.pop("slots")
+    return dict(sum_trees=np.array(sums), vi=np.array(vis), trees=trees, forest=forest, counters=ctr,
+                state=s.state(), split_weights=s.split_weights(), sampler=s)
+
+
+def digest(res) -> dict:
+    """Compact, exact fingerprint of a run (what the golden fixture stores)."""
+    h = hashlib.sha256()
+    h.update(res["sum_trees"].tobytes())
+    h.update(res["vi"].astype(np.int32).tobytes())
+    for t in res["trees"]:
+        h.update(np.ascontiguousarray(t).tobytes())
+    f = res["forest"]
+    for a in (f.var, f.left, f.right, f.count, f.split, f.value):
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(res["split_weights"].tobytes())
+    h.update(np.asarray(res["state"]["leaf_sd"]).tobytes())
+    return {
+        "sha256": h.hexdigest(),
+        "counters": {k: int(v) for k, v in res["counters"].items()},
+        "last_sum_trees_head": res["sum_trees"][-1][:8].tolist(),
+        "leaf_sd": float(res["state"]["leaf_sd"][0]),
+        "iter": int(res["state"]["iter"]),
+    }

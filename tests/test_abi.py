@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/pgbart.h declares
+(no compute calls here: the HIP backend has no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from pymc_bart_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pgbart.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgb_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_abi.SYMBOLS)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    path = _abi.hip_library_path()
+    assert os.path.exists(path), "run __graft_entry__.build() first"
+    lib = _abi.load_hip_library()
+    for name in _declared_symbols():
+        assert hasattr(lib.lib, name), name
+    assert lib.backend_name == "hip-gfx950"
+
+
+def test_oracle_exports_the_same_abi(oracle):
+    for name in _declared_symbols():
+        assert hasattr(oracle.lib.lib, name), name
+    assert oracle.lib.backend_name == "oracle-cpu"
+
+
+def test_struct_layouts_match_the_c_side(oracle):
+    lib = oracle.lib.lib
+    for fn, struct in (("pgbo_sizeof_settings", _abi.Settings), ("pgbo_sizeof_counters", _abi.Counters),
+                       ("pgbo_sizeof_tree_arrays", _abi.TreeArraysC)):
+        f = getattr(lib, fn)
+        f.restype = C.c_int64
+        assert f() == C.sizeof(struct), fn
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pymc_bart_amd.sampler import default_backend
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        default_backend()
+
+
+def test_product_package_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "pymc_bart_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "libpgbart_oracle" not in text and "from _oracle" not in text, f
+                assert "import oracle" not in text, f

@@ -1,0 +1,258 @@
+"""The CPU oracle against the behavioural pins of the reference's own tests.
+
+The reference pins no numeric outputs on the sampler path, only properties; each test cites the
+reference assertion it restates.  Passing these is what licenses the oracle as the checker of
+the HIP kernels.
+"""
+import numpy as np
+import pytest
+
+from pymc_bart_amd import _abi
+from pymc_bart_amd.chains import sample_chain
+from pymc_bart_amd.pgbart import PGBART, BARTOp, NormalLikelihood
+from pymc_bart_amd.sampler import PyBartSettings, PySampler
+from pymc_bart_amd.trees import PosteriorSampler, predict_numpy
+from pymc_bart_amd.utils import _decode_vi, _get_posterior_sampler, _sample_posterior
+
+
+def _sampler(oracle, X, Y, m=10, P=10, seed=3415, rules=None, batch=(0.1, 0.1), prior=None):
+    p = X.shape[1]
+    st = PyBartSettings.from_data(X, Y, m=m, num_particles=P, seed=seed, batch=batch)
+    return PySampler(st, X, Y, np.zeros(p, np.int32) if rules is None else rules,
+                     np.ones(p) if prior is None else prior, backend=oracle)
+
+
+def test_bart_vi_important_variable_dominates(oracle):
+    # reference tests/test_bart.py:44-64: X[:,0] ~ Y, m=10, tune=draws=200 -> var_imp[0] > rest
+    rng = np.random.default_rng(3415)
+    X = rng.normal(0, 1, size=(250, 3))
+    Y = rng.normal(0, 1, size=250)
+    X[:, 0] = rng.normal(Y, 0.1)
+    res = sample_chain(BARTOp(X, Y, m=10), tune=200, draws=200, random_seed=3415, backend=oracle)
+    vi_vals = res["variable_inclusion"]
+    var_imp = np.array([_decode_vi(v, 3) for v in vi_vals]).sum(axis=0)
+    var_imp = var_imp / var_imp.sum()
+    assert var_imp[0] > var_imp[1:].sum()
+    np.testing.assert_almost_equal(var_imp.sum(), 1)
+    assert res["mu"].shape == (200, 250)
+
+
+def test_missing_data_samples_without_error(oracle):
+    # reference tests/test_bart.py:67-81
+    rng = np.random.default_rng(0)
+    X = rng.normal(0, 1, size=(50, 2))
+    Y = rng.normal(0, 1, size=50)
+    X[10:20, 0] = np.nan
+    res = sample_chain(BARTOp(X, Y, m=10), tune=100, draws=100, random_seed=3415, backend=oracle)
+    assert np.all(np.isfinite(res["mu"]))
+    assert res["counters"]["saturations"] == 0
+
+
+def test_same_seed_same_draws_and_different_seed_differs(oracle):
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(300, 4))
+    Y = X[:, 0] + rng.normal(0, 0.3, 300)
+    a = sample_chain(BARTOp(X, Y, m=8), 20, 20, random_seed=5, backend=oracle)
+    b = sample_chain(BARTOp(X, Y, m=8), 20, 20, random_seed=5, backend=oracle)
+    c = sample_chain(BARTOp(X, Y, m=8), 20, 20, random_seed=6, backend=oracle)
+    assert np.array_equal(a["mu"], b["mu"]) and a["variable_inclusion"] == b["variable_inclusion"]
+    assert not np.array_equal(a["mu"], c["mu"])
+    d = sample_chain(BARTOp(X, Y, m=8), 20, 20, random_seed=5, chain=1, backend=oracle)
+    assert not np.array_equal(a["mu"], d["mu"])  # chains are independent streams
+
+
+def test_sum_trees_equals_sum_of_tree_predictions(oracle):
+    # the sampler's running sum must be the sum of its stored trees evaluated on the training X
+    rng = np.random.default_rng(2)
+    X = rng.uniform(size=(400, 3))
+    Y = np.sin(6 * X[:, 0]) + X[:, 1] + rng.normal(0, 0.2, 400)
+    s = _sampler(oracle, X, Y, m=12)
+    s.set_likelihood([0.3])
+    for it in range(40):
+        st, _ = s.step(tune=it < 20)
+    forest = s.export_trees(1)
+    pred = predict_numpy(forest, np.arange(12)[None, :], X, np.zeros(3, np.int32))[0, 0]
+    np.testing.assert_allclose(pred, st, rtol=0, atol=1e-9)
+    # structural invariants of every tree
+    for t in range(forest.n_trees):
+        a, b = forest.node_off[t], forest.node_off[t + 1]
+        var, left, right, cnt = forest.var[a:b], forest.left[a:b], forest.right[a:b], forest.count[a:b]
+        assert cnt[0] == 400
+        for k in range(b - a):
+            if var[k] >= 0:
+                assert cnt[left[k]] + cnt[right[k]] == cnt[k]  # no NaNs -> nothing dropped
+                assert left[k] > k and right[k] == left[k] + 1   # breadth-first creation order
+            else:
+                assert left[k] == -1 and right[k] == -1
+
+
+def test_sample_posterior_row_subset_consistency(oracle):
+    # reference tests/test_utils.py:24-32: same rng seed => prediction on X[:10] equals the first
+    # 10 rows of the prediction on X (4 decimals); shapes (2, 50, 1) and (10, 1)
+    rng0 = np.random.default_rng(3415)
+    X = np.hstack([rng0.normal(0, 1, size=(50, 2)), rng0.binomial(1, 0.5, size=(50, 1))])
+    Y = rng0.normal(0, 1, size=50)
+    op = BARTOp(X, Y, m=10)
+    sample_chain(op, tune=50, draws=50, random_seed=3415, backend=oracle)
+    sampler = _get_posterior_sampler(op, backend=oracle)
+    assert sampler.n_draws == 50
+    pred_all = _sample_posterior(sampler, X=X, rng=np.random.default_rng(3), size=2)
+    pred_first = _sample_posterior(sampler, X=X[:10], rng=np.random.default_rng(3))
+    np.testing.assert_almost_equal(pred_first, pred_all[0, :10], decimal=4)
+    assert pred_all.shape == (2, 50, 1)
+    assert pred_first.shape == (10, 1)
+
+
+def test_posterior_draw_reproduces_the_sampled_sum_trees(oracle):
+    # draw d of the history (baseline + batches 0..d) evaluated on the training X is astep's output
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(120, 3))
+    Y = X[:, 0] ** 2 + rng.normal(0, 0.1, 120)
+    op = BARTOp(X, Y, m=6)
+    res = sample_chain(op, tune=15, draws=12, random_seed=11, backend=oracle)
+    base, batches = res["history"]
+    ps = PosteriorSampler.from_history(batches, base, 6, 1, rules=np.zeros(3, np.int32), backend=oracle)
+    pred = ps.sample_posterior(res["step"].sampler.settings and X, list(range(12)))
+    np.testing.assert_allclose(pred[:, 0, :], res["mu"], rtol=0, atol=1e-9)
+
+
+def test_excluded_variable_is_marginalised(oracle):
+    # [U] CHANGELOG.md:410-411: a split on an excluded variable averages both subtrees by count
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(200, 2))
+    Y = 3 * X[:, 0] + rng.normal(0, 0.1, 200)
+    op = BARTOp(X, Y, m=5)
+    res = sample_chain(op, tune=30, draws=5, random_seed=1, backend=oracle)
+    base, batches = res["history"]
+    ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
+    full = ps.sample_posterior(X, [4])
+    excl_all = ps.sample_posterior(X, [4], excluded=[0, 1])
+    assert np.allclose(excl_all, excl_all[..., :1])  # no covariate left => constant prediction
+    ref = predict_numpy(ps.pool, ps.forest_idx[[4]], X, np.zeros(2, np.int32), excluded=[0])
+    np.testing.assert_allclose(ps.sample_posterior(X, [4], excluded=[0]), ref, atol=1e-12)
+    assert not np.allclose(full, excl_all)
+    # NaN in a used covariate behaves like an exclusion for that row
+    Xn = X.copy()
+    Xn[:, 0] = np.nan
+    np.testing.assert_allclose(ps.sample_posterior(Xn, [4]), ps.sample_posterior(X, [4], excluded=[0]),
+                               atol=1e-12)
+
+
+def test_onehot_rule_recovers_a_categorical_effect(oracle):
+    # reference tests/test_bart.py:140-164 uses split_rules=["OneHotSplit"]*5 on integer covariates
+    rng = np.random.default_rng(12345)
+    cat = rng.integers(0, 4, size=300)
+    X = np.column_stack([cat, rng.integers(0, 6, size=(300, 2))]).astype(float)
+    eff = np.array([-2.0, 0.0, 1.0, 3.0])
+    Y = eff[cat] + rng.normal(0, 0.2, 300)
+    op = BARTOp(X, Y, m=10, split_rules=["OneHotSplit"] * 3)
+    res = sample_chain(op, tune=150, draws=50, random_seed=3415, backend=oracle)
+    fit = res["mu"].mean(axis=0)
+    assert np.sqrt(np.mean((fit - eff[cat]) ** 2)) < 0.35
+    assert res["vi_counts"].sum(axis=0)[0] > res["vi_counts"].sum(axis=0)[1:].sum()
+    # one-hot splits never produce an empty right child ([U] needs two distinct values)
+    base, batches = res["history"]
+    for ta in [base] + batches:
+        inner = ta.var >= 0
+        assert np.all(ta.count[ta.right[inner] + np.repeat(ta.node_off[:-1], np.diff(ta.node_off))[inner]] > 0)
+
+
+def test_batch_cursor_visits_every_tree(oracle):
+    # [U] astep: batches of max(1, int(0.1 m)) trees, cursor wraps at m
+    rng = np.random.default_rng(6)
+    X = rng.normal(size=(60, 2))
+    Y = rng.normal(size=60)
+    s = _sampler(oracle, X, Y, m=25)
+    s.set_likelihood([1.0])
+    assert s.settings.batch_sizes() == (2, 2)
+    seen = []
+    for _ in range(13):
+        s.step(False)
+        seen += list(s.export_trees(0).tree_id)
+    assert seen == list(range(25))  # the last batch is cut at m, then the cursor wraps
+    assert s.counters.tree_updates == 25 and s.state()["iter"] == 25 and s.state()["lower"] == 0
+    s.step(False)
+    assert list(s.export_trees(0).tree_id) == [0, 1]
+
+
+def test_single_tree_and_two_particles_corner(oracle):
+    rng = np.random.default_rng(7)
+    X = rng.normal(size=(40, 2))
+    Y = X[:, 0] + rng.normal(0, 0.1, 40)
+    s = _sampler(oracle, X, Y, m=1, P=2)
+    s.set_likelihood([0.5])
+    for it in range(30):
+        st, _ = s.step(tune=it < 10)
+    f = s.export_trees(1)
+    pred = predict_numpy(f, np.zeros((1, 1), np.int64), X, np.zeros(2, np.int32))[0, 0]
+    np.testing.assert_allclose(pred, st, atol=1e-12)
+
+
+def test_tuning_updates_split_prior_and_leaf_sd(oracle):
+    # [U] alpha_vec[j] += 1 per split variable while tuning; leaf_sd follows the running std
+    rng = np.random.default_rng(8)
+    X = rng.normal(size=(200, 3))
+    Y = 2 * X[:, 1] + rng.normal(0, 0.2, 200)
+    s = _sampler(oracle, X, Y, m=10)
+    s.set_likelihood([0.2])
+    sd0 = s.state()["leaf_sd"][0]
+    assert np.isclose(sd0, Y.std() / np.sqrt(10))
+    for _ in range(100):
+        s.step(True)
+    w = s.split_weights()
+    assert w.sum() > 3 and np.all(w >= 1) and np.argmax(w) == 1
+    assert s.state()["leaf_sd"][0] != sd0
+    frozen = w.copy()
+    _, vi = s.step(False)  # draws no longer touch the prior, they count inclusion instead
+    assert np.array_equal(s.split_weights(), frozen) and vi.sum() >= 0
+
+
+def test_error_paths(oracle):
+    X = np.zeros((10, 2))
+    Y = np.zeros(10)
+    st = PyBartSettings.from_data(X, Y, m=3, num_particles=1)
+    with pytest.raises(_abi.PGBError, match="num_particles"):
+        PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    st = PyBartSettings.from_data(X, Y, m=3, num_particles=4)
+    with pytest.raises(_abi.PGBError, match="split_prior"):
+        PySampler(st, X, Y, np.zeros(2, np.int32), np.array([1.0, 0.0]), backend=oracle)
+    s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    with pytest.raises(_abi.PGBError, match="sigma"):
+        s.set_likelihood([-1.0])
+    with pytest.raises(NotImplementedError):
+        BARTOp(X, Y, response="linear")
+    with pytest.raises(NotImplementedError):
+        PGBART([BARTOp(X, Y, split_rules=["SubsetSplit", "SubsetSplit"])], backend=oracle)
+
+
+def test_constant_response_and_duplicate_rows(oracle):
+    # degenerate data: all rows identical -> continuous splits put everything left; must not hang
+    X = np.ones((64, 2))
+    Y = np.full(64, 2.5)
+    s = _sampler(oracle, X, Y, m=4, P=5)
+    s.set_likelihood([1.0])
+    for it in range(10):
+        st, _ = s.step(it < 5)
+    assert np.all(np.isfinite(st))
+
+
+def test_pgbart_astep_contract(oracle):
+    # astep -> (sum_trees ndarray (n,), [ {"variable_inclusion": b64, "tune": bool} ])
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(30, 2))
+    Y = rng.normal(size=30)
+    op = BARTOp(X, Y, m=3)
+    step = PGBART([op], num_particles=5, likelihood=NormalLikelihood(1.0), random_seed=1, backend=oracle)
+    assert PGBART.competence(op) and not PGBART.competence(object())
+    assert step.generates_stats and "variable_inclusion" in step.stats_dtypes_shapes
+    out, stats = step.astep(None)
+    assert out.shape == (30,) and stats[0]["tune"] is True
+    assert _decode_vi(stats[0]["variable_inclusion"], 2) == [0, 0]  # no inclusion counts while tuning
+    assert len(op.all_trees) == 0
+    step.stop_tuning()
+    point, stats = step.step({"sigma": 1.0})
+    assert stats[0]["tune"] is False and point["mu"].shape == (30,)
+    assert len(op.all_trees) == 1 and op.n_outputs == 1
+    step.astep(None)
+    base, batches = op.all_trees[0]
+    assert base.n_trees == 3 and len(batches) == 2

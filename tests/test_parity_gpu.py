@@ -1,0 +1,146 @@
+"""Parity of the gfx950 HIP backend with the CPU oracle -- through the C ABI, bit for bit.
+
+Integer decisions (split variables, rows, resampling indices, counts) AND floating-point outputs
+(sum_trees, leaf values, leaf_sd) must be identical: the numeric contract (include/pgbart_spec.h)
+makes every result independent of execution order, so the tolerance is 0.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _cases import CASES, digest, make_case, run_case
+from pymc_bart_amd import workloads
+from pymc_bart_amd.chains import sample_chain
+from pymc_bart_amd.pgbart import BARTOp
+from pymc_bart_amd.sampler import PyBartSettings, PySampler
+from pymc_bart_amd.trees import PosteriorSampler, predict_numpy
+from pymc_bart_amd.utils import _get_posterior_sampler, _sample_posterior
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_runs.json")))
+
+
+def _assert_same(a, b):
+    assert np.array_equal(a["sum_trees"], b["sum_trees"])
+    assert np.array_equal(a["vi"], b["vi"])
+    assert len(a["trees"]) == len(b["trees"])
+    for x, y in zip(a["trees"], b["trees"]):
+        assert np.array_equal(x, y)
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["split_weights"], b["split_weights"])
+    assert np.array_equal(a["state"]["leaf_sd"], b["state"]["leaf_sd"])
+    assert a["state"]["iter"] == b["state"]["iter"] and a["state"]["lower"] == b["state"]["lower"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_equals_oracle_and_golden(hip, oracle, name):
+    c = make_case(name)
+    g = run_case(c, hip)
+    o = run_case(c, oracle)
+    _assert_same(g, o)
+    assert digest(g) == GOLD[name]          # committed fixture
+    assert g["counters"]["saturations"] == 0
+
+
+def test_hip_is_deterministic_across_runs(hip):
+    c = make_case("nan_onehot_prior")
+    assert digest(run_case(c, hip)) == digest(run_case(c, hip))
+
+
+def test_step_async_equals_stepwise(hip):
+    c = make_case("cfg1_friedman")
+    X, Y = c["X"], c["Y"]
+    st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=7)
+    mk = lambda: PySampler(st, X, Y, np.zeros(5, np.int32), np.ones(5), backend=hip)  # noqa: E731
+    a, b = mk(), mk()
+    for s in (a, b):
+        s.set_likelihood([1.0])
+    for _ in range(6):
+        sa, _ = a.step(True)
+    b.step_async(True, 5)
+    sb, _ = b.step(True)
+    assert np.array_equal(sa, sb)
+    ca, cb = a.sync(), b.sync()
+    for k in ("particle_steps", "tree_updates", "rows_touched", "rounds"):
+        assert ca[k] == cb[k]
+
+
+def test_predict_kernel_matches_oracle_and_numpy(hip, oracle):
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(700, 4))
+    X[:, 3] = rng.integers(0, 3, 700)
+    Y = 3 * X[:, 0] + (X[:, 3] == 1) + rng.normal(0, 0.1, 700)
+    rules = ["ContinuousSplit"] * 3 + ["OneHotSplit"]
+    res_g = sample_chain(BARTOp(X, Y, m=8, split_rules=rules), 20, 10, random_seed=1, backend=hip)
+    res_o = sample_chain(BARTOp(X, Y, m=8, split_rules=rules), 20, 10, random_seed=1, backend=oracle)
+    assert np.array_equal(res_g["mu"], res_o["mu"])
+    rid = np.array([0, 0, 0, 1], np.int32)
+    base, batches = res_g["history"]
+    pg = PosteriorSampler.from_history(batches, base, 8, 1, rules=rid, backend=hip)
+    po = PosteriorSampler.from_history(batches, base, 8, 1, rules=rid, backend=oracle)
+    Xn = rng.normal(size=(333, 4))
+    Xn[:, 3] = rng.integers(0, 3, 333)
+    Xn[::7, 0] = np.nan
+    for excl in (None, [0], [1, 3], [0, 1, 2, 3]):
+        a = pg.sample_posterior(Xn, [0, 3, 9, 9], excl)
+        b = po.sample_posterior(Xn, [0, 3, 9, 9], excl)
+        assert a.shape == (4, 1, 333)
+        assert np.array_equal(a, b)
+    ref = predict_numpy(pg.pool, pg.forest_idx[[2]], Xn[:40], rid, excluded=[1])
+    np.testing.assert_allclose(pg.sample_posterior(Xn[:40], [2], [1]), ref, atol=1e-12)
+    # every stored draw evaluated on the training X is the sampled sum_trees
+    np.testing.assert_allclose(pg.sample_posterior(X, list(range(10)))[:, 0, :], res_g["mu"], atol=1e-9)
+
+
+def test_sample_posterior_row_subset_consistency_gpu(hip):
+    # reference tests/test_utils.py:24-32 on the HIP path
+    rng0 = np.random.default_rng(3415)
+    X = np.hstack([rng0.normal(0, 1, size=(50, 2)), rng0.binomial(1, 0.5, size=(50, 1))])
+    Y = rng0.normal(0, 1, size=50)
+    op = BARTOp(X, Y, m=10)
+    sample_chain(op, tune=40, draws=40, random_seed=3415, backend=hip)
+    sampler = _get_posterior_sampler(op, backend=hip)
+    pred_all = _sample_posterior(sampler, X=X, rng=np.random.default_rng(3), size=2)
+    pred_first = _sample_posterior(sampler, X=X[:10], rng=np.random.default_rng(3))
+    np.testing.assert_almost_equal(pred_first, pred_all[0, :10], decimal=4)
+    assert pred_all.shape == (2, 50, 1) and pred_first.shape == (10, 1)
+
+
+def test_full_size_cfg2_parity_and_invariants(hip, oracle):
+    """BASELINE.json configs[1] at full size: n=100k, p=50, m=200, 40 particles."""
+    w = workloads.cfg2(seed=3415)
+    X, Y = w["X"], w["Y"]
+    n, p = X.shape
+    st = PyBartSettings.from_data(X, Y, m=200, num_particles=40, seed=3415)
+    g = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=hip)
+    o = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=oracle)
+    for s in (g, o):
+        s.set_likelihood([1.0])
+    # (1) exact agreement with the oracle on a bounded number of steps (oracle: ~1 s per step)
+    for it in range(4):
+        a, va = g.step(tune=it < 2)
+        b, vb = o.step(tune=it < 2)
+        assert np.array_equal(a, b) and np.array_equal(va, vb)
+    cg, co = g.counters.as_dict(), o.counters.as_dict()
+    for k in ("particle_steps", "tree_updates", "rows_touched", "rounds", "saturations"):
+        assert cg[k] == co[k]
+    # (2) size-independent properties after a longer GPU-only run
+    g.step_async(False, 10)
+    st_dev, _ = g.step(False)
+    forest = g.export_trees(1)
+    assert forest.n_trees == 200
+    roots = forest.node_off[:-1]
+    assert np.all(forest.count[roots] == n)            # every tree still owns every row
+    inner = np.flatnonzero(forest.var >= 0)
+    base = np.repeat(forest.node_off[:-1], np.diff(forest.node_off))
+    assert np.all(forest.count[base[inner] + forest.left[inner]] + forest.count[base[inner] + forest.right[inner]]
+                  == forest.count[inner])              # children partition their parent (no NaN here)
+    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, np.zeros(p, np.int32),
+                          backend=hip)
+    pred = ps.sample_posterior(X, [0])[0, 0]
+    np.testing.assert_allclose(pred, st_dev, rtol=0, atol=1e-8)  # sum_trees == sum of its trees
+    assert g.counters.saturations == 0
+    rmse = float(np.sqrt(np.mean((st_dev - w["f"]) ** 2)))
+    assert rmse < np.std(w["f"])                        # it is actually learning the signal

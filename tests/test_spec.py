@@ -1,0 +1,118 @@
+"""Pin the numeric primitives of include/pgbart_spec.h (through the oracle's pgbo_* hooks)."""
+import ctypes as C
+
+import numpy as np
+
+
+def _lib(oracle):
+    return oracle.lib.lib
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors for philox4x32-10
+    kats = [
+        ((0, 0), (0, 0, 0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF,) * 4, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0xA4093822, 0x299F31D0), (0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    f = _lib(oracle).pgbo_philox
+    f.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+    f.restype = None
+    for key, ctr, want in kats:
+        out = np.zeros(4, np.uint32)
+        f(key[0], key[1], *ctr, out.ctypes.data)
+        assert tuple(int(x) for x in out) == want
+
+
+def test_uniform_range_and_addressing(oracle):
+    f = _lib(oracle).pgbo_draw2
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f.restype = None
+    seen = set()
+    for it in range(4):
+        for rnd in range(3):
+            for part in range(5):
+                for purpose in range(1, 6):
+                    out = np.zeros(2)
+                    f(3415, it, rnd, part, purpose, 0, out.ctypes.data)
+                    assert 0.0 <= out[0] < 1.0 and 0.0 <= out[1] < 1.0
+                    seen.add((out[0], out[1]))
+    assert len(seen) == 4 * 3 * 5 * 5  # every address is its own draw
+    a, b = np.zeros(2), np.zeros(2)
+    f(3415, 7, 1, 2, 3, 0, a.ctypes.data)
+    f(3415, 7, 1, 2, 3, 0, b.ctypes.data)
+    assert np.array_equal(a, b)  # pure function of the address
+
+
+def test_math_against_libm(oracle):
+    f = _lib(oracle).pgbo_math
+    f.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
+    f.restype = None
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(0, 1, 20000)])
+    e, l, s, c = (np.zeros_like(x) for _ in range(4))
+    f(x.ctypes.data, x.size, e.ctypes.data, l.ctypes.data, s.ctypes.data, c.ctypes.data)
+    assert np.max(np.abs(e / np.exp(x) - 1)) < 1e-15
+    pos = x > 1e-300
+    ref = np.log(x[pos])
+    big = np.abs(ref) > 1e-3
+    assert np.max(np.abs(l[pos][big] / ref[big] - 1)) < 2e-15
+    u = x[(x >= 0) & (x < 1)]
+    su, cu = s[(x >= 0) & (x < 1)], c[(x >= 0) & (x < 1)]
+    assert np.max(np.abs(su - np.sin(2 * np.pi * u))) < 2e-15
+    assert np.max(np.abs(cu - np.cos(2 * np.pi * u))) < 2e-15
+    assert np.max(np.abs(su * su + cu * cu - 1)) < 1e-15
+
+
+def test_box_muller_is_standard_normal(oracle):
+    f = _lib(oracle).pgbo_normal2
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    f.restype = None
+    rng = np.random.default_rng(1)
+    n = 200_000
+    u0, u1 = rng.random(n), rng.random(n)
+    z0, z1 = np.zeros(n), np.zeros(n)
+    f(u0.ctypes.data, u1.ctypes.data, n, z0.ctypes.data, z1.ctypes.data)
+    z = np.concatenate([z0, z1])
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    assert abs(np.mean(z ** 3)) < 0.03 and abs(np.mean(z ** 4) - 3) < 0.06
+    assert abs(np.corrcoef(z0, z1)[0, 1]) < 0.01
+    # u0 = 0 must not produce inf/nan (log(1-u0))
+    a, b = np.zeros(1), np.zeros(1)
+    f(np.zeros(1).ctypes.data, np.zeros(1).ctypes.data, 1, a.ctypes.data, b.ctypes.data)
+    assert np.isfinite(a[0]) and np.isfinite(b[0])
+
+
+def test_quantisation_is_round_half_even_and_saturates(oracle):
+    f = _lib(oracle).pgbo_quant
+    f.argtypes = [C.c_double, C.c_double, C.c_void_p]
+    f.restype = C.c_int64
+    sat = np.zeros(1, np.uint32)
+    assert f(2.5, 1.0, sat.ctypes.data) == 2
+    assert f(3.5, 1.0, sat.ctypes.data) == 4
+    assert f(-2.5, 1.0, sat.ctypes.data) == -2
+    assert f(0.1, 1024.0, sat.ctypes.data) == 102
+    assert sat[0] == 0
+    assert f(1e300, 1.0, sat.ctypes.data) == 2 ** 50
+    assert f(-1e300, 1.0, sat.ctypes.data) == -(2 ** 50)
+    assert f(float("nan"), 1.0, sat.ctypes.data) == 0
+    assert sat[0] == 3
+    rng = np.random.default_rng(2)
+    xs = rng.normal(0, 100, 2000)
+    for x in xs:
+        assert f(float(x), 2.0 ** 20, sat.ctypes.data) == int(np.rint(x * 2.0 ** 20))
+
+
+def test_scales_leave_headroom_for_n_terms(oracle):
+    f = _lib(oracle).pgbo_scales
+    f.argtypes = [C.c_int64, C.c_int, C.c_void_p]
+    f.restype = None
+    for n, e in [(1, 0), (500, 5), (100_000, 8), (1_000_000, 3), (2 ** 30, 10)]:
+        out = np.zeros(6)
+        f(n, e, out.ctypes.data)
+        c1, c2, cl = out[:3]
+        assert c1 * out[3] == 1 and c2 * out[4] == 1 and cl * out[5] == 1
+        assert n * (2.0 ** e) * c1 <= 2.0 ** 62      # n saturated terms fit an int64
+        assert n * (2.0 ** (2 * e)) * c2 <= 2.0 ** 62
+        assert (2.0 ** e) * c1 <= 2.0 ** 50          # a term stays inside the exact-rounding window
