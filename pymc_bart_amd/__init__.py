@@ -1,8 +1,17 @@
-"""MI355X-native particle-Gibbs BART sampler behind PyMC-BART's PGBART step API."""
+"""MI355X-native particle-Gibbs BART sampler behind PyMC-BART's PGBART step API.
+
+Public names mirror what the reference imports from the external ``bartrs`` wheel
+(``pymc_bart/pymc_bart.py:2``, ``tests/test_bart.py:4``).  All compute runs in
+``csrc/libpgbart_hip.so`` (gfx950); there is no CPU fallback.
+"""
 
 from . import _abi
+from .pgbart import PGBART, BARTOp, NormalLikelihood
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
 
 __version__ = "0.1.0"
-__all__ = ["PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "_abi"]
+__all__ = [
+    "PGBART", "BARTOp", "NormalLikelihood",
+    "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "_abi",
+]
