@@ -102,6 +102,7 @@ struct Ctrl {
   long long iter, rs_count, pend_iter;
   double leaf_sd, inv_sigma2;
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
+  long long steps_done;  // asteps completed since creation (mirrored to the host flag)
 };
 
 struct Dev {  // kernel argument block (by value)
@@ -134,6 +135,7 @@ struct Dev {  // kernel argument block (by value)
   double* cdf;        // [p]
   const int32_t* rules;
   const int32_t* col_nan;
+  unsigned long long* host_flag;  // pinned host word: number of completed asteps
 };
 
 // ------------------------------------------------------------------ device helpers
@@ -179,17 +181,6 @@ __device__ __forceinline__ int block_excl_scan(int x, int* sm /* [8] */, int* to
   return base + inc - x;
 }
 
-__device__ __forceinline__ int sample_var(const double* cdf, int p, double u) {
-  // first j with u <= cdf[j]; fallback p-1   ([U] SampleSplittingVariable.rvs)
-  int lo = 0, hi = p - 1;
-  if (!(u <= cdf[p - 1])) return p - 1;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (u <= cdf[mid]) hi = mid; else lo = mid + 1;
-  }
-  return lo;
-}
-
 __device__ __forceinline__ bool go_left(int rule, double x, double v) {
   return rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v);
 }
@@ -203,8 +194,62 @@ __device__ __forceinline__ void build_lv(const DNode* nd, int n_nodes, double* l
   __syncthreads();
 }
 
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// [U] normalize: softmax(+1e-12) of s_lw[first .. first+cnt) -> cumulative normalised weights in
+// s_cum.  exp and the divisions run one particle per lane; the two sums are serial (lane 0) so
+// that their rounding order is the one the numeric contract fixes.
+__device__ __forceinline__ void normalize_weights(const double* s_lw, double* s_cum, double* s_tmp,
+                                                  int first, int cnt) {
+  const int tid = threadIdx.x;
+  const bool act = tid >= first && tid < first + cnt;
+  if (tid < 64) {
+    double lw = act ? s_lw[tid] : -1.0e308;
+    double mx = wave_max_d(lw);
+    if (act) s_cum[tid] = pgb_exp(lw - mx) + 1e-12;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = first; i < first + cnt; ++i) tot += s_cum[i];
+    s_tmp[0] = tot;
+  }
+  __syncthreads();
+  if (act) s_cum[tid] = s_cum[tid] / s_tmp[0];
+  __syncthreads();
+  if (tid == 0) {
+    double cs = 0.0;
+    for (int i = first; i < first + cnt; ++i) {
+      cs += s_cum[i];
+      s_cum[i] = cs;
+    }
+  }
+  __syncthreads();
+}
+
+// first j with u <= cdf[j], fallback p-1, searched 64 entries at a time by wave 0
+__device__ __forceinline__ int sample_var_wave(const double* cdf, int p, double u) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < p; base += 64) {
+    int j = base + lane;
+    bool hit = j < p && u <= cdf[j];
+    unsigned long long m = __ballot(hit);
+    if (m) return base + __ffsll((long long)m) - 1;
+  }
+  return p - 1;
+}
+
 // ------------------------------------------------------------------ k_begin
-__global__ void k_begin(Dev S, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
+__global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
+  const Dev& S = *Sp;
   Ctrl* c = &S.ctrl[par];
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     c->tune = tune;
@@ -229,7 +274,8 @@ struct Fin {  // result of finishing the pending split of an old particle
   int n_nodes;
 };
 
-__global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
+__global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
   __shared__ double s_lw[MAXP], s_cum[MAXP];
   __shared__ int s_any[MAXP];
   __shared__ Fin s_fin[MAXP];
@@ -367,30 +413,16 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
       s_lw[q] = (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2);
     }
     __syncthreads();
-    if (tid == 0) {
+    {
       int any = 0;
-      for (int q = 1; q < P; ++q) any |= s_any[q];
-      s_i[0] = !any;
+      for (int q = 1; q < P; ++q) any |= s_any[q];  // LDS broadcast reads, every thread
+      stop = !any;
     }
-    __syncthreads();
-    stop = s_i[0] != 0;
 
     if (!stop) {
       // -------- [U] normalize + systematic resampling of particles 1..P-1
+      normalize_weights(s_lw, s_cum, s_d, 1, Lc);
       if (tid == 0) {
-        double mx = s_lw[1];
-        for (int q = 2; q < P; ++q) mx = s_lw[q] > mx ? s_lw[q] : mx;
-        double tot = 0.0;
-        for (int q = 1; q < P; ++q) {
-          double w = pgb_exp(s_lw[q] - mx) + 1e-12;
-          s_cum[q] = w;
-          tot += w;
-        }
-        double cs = 0.0;
-        for (int q = 1; q < P; ++q) {
-          cs += s_cum[q] / tot;
-          s_cum[q] = cs;
-        }
         pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
         double ui = (u.u0 + (double)(p - 1)) / (double)Lc;
         int a = 0;
@@ -401,22 +433,10 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
       anc = s_i[1];
     } else {
       // -------- final choice among all P particles ([U] get_particle_tree)
+      if (tid == 0) s_lw[0] = c.sse0 * (-0.5 * c.inv_sigma2);
+      __syncthreads();
+      normalize_weights(s_lw, s_cum, s_d, 0, P);
       if (tid == 0) {
-        double lw0 = c.sse0 * (-0.5 * c.inv_sigma2);
-        s_lw[0] = lw0;
-        double mx = lw0;
-        for (int q = 1; q < P; ++q) mx = s_lw[q] > mx ? s_lw[q] : mx;
-        double tot = 0.0;
-        for (int q = 0; q < P; ++q) {
-          double w = pgb_exp(s_lw[q] - mx) + 1e-12;
-          s_cum[q] = w;
-          tot += w;
-        }
-        double cs = 0.0;
-        for (int q = 0; q < P; ++q) {
-          cs += s_cum[q] / tot;
-          s_cum[q] = cs;
-        }
         pgb_u2 u = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
         int sel = 0;
         while (sel < P - 1 && u.u0 > s_cum[sel]) ++sel;
@@ -579,7 +599,11 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
         o.phase = PH_IDLE;
         o.steps_left = 0;
       }
+      if (!more) o.steps_done = c.steps_done + 1;
       *co = o;
+      if (!more)  // progress word the host polls (the row pass of this slot is still to run)
+        __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(&S.counters[1], 1ull);
       atomicAdd(&S.counters[3], 1ull);
     }
@@ -610,10 +634,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
       pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_PROPOSE, 0);
       double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
       attempt = (pl < u.u0) && (me->n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
-      if (attempt) {
-        int j = sample_var(S.cdf, S.p, u.u1);
-        s_i[2] = j;
-      }
+      s_d[1] = u.u1;
     }
     s_i[3] = attempt ? 1 : 0;
     s_i[4] = node;
@@ -622,6 +643,11 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
   attempt = s_i[3] != 0;
   node = s_i[4];
   if (attempt) {
+    if (tid < 64) {
+      int jj = sample_var_wave(S.cdf, S.p, s_d[1]);
+      if (tid == 0) s_i[2] = jj;
+    }
+    __syncthreads();
     nd = me->nd[node];
     const int j = s_i[2];
     const double* xc = S.XT + (size_t)j * S.n_pad;
@@ -721,7 +747,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(Dev S, int par) {
 
 // ------------------------------------------------------------------ k_rows
 // PARTITION: workgroup (chunk, particle).  FINAL/INIT: workgroups with blockIdx.y == 0.
-__global__ __launch_bounds__(BT) void k_rows(Dev S, int par) {
+__global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
   __shared__ long long s_red[8 * 4];
   __shared__ double s_lv[2][256];
   const Cmd* cmd = &S.cmd[par];
@@ -1031,6 +1058,11 @@ static int fail_hip(hipError_t e, const char* what) {
 struct pgb_handle {
   pgb_settings s;
   Dev d;
+  Dev* d_dev;                          // device-resident copy passed to every kernel
+  volatile unsigned long long* flag;   // pinned host word written by k_ctrl (completed asteps)
+  long long steps_target;              // asteps requested so far
+  std::vector<hipEvent_t> bundle_ev;   // throttle: at most 3 bundles of slots in flight
+  long long bundles;
   hipStream_t stream;
   std::vector<void*> allocs;
   long long slot;  // next slot index (parity = slot & 1)
@@ -1082,6 +1114,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->s = *s;
   h->stream = (hipStream_t)stream;
   h->slot = 0;
+  h->d_dev = nullptr;
+  h->flag = nullptr;
+  h->steps_target = 0;
+  h->bundles = 0;
   h->inv_sigma2 = 1.0;
   h->sigma_dirty = 1;
   h->slots_per_step = 0.0;
@@ -1139,6 +1175,22 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   hipError_t e;
 #define HC(expr) \
   if ((e = (expr)) != hipSuccess) { int r_ = fail_hip(e, #expr); pgb_destroy(h); return r_; }
+  {
+    void* hp = nullptr;
+    HC(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    h->flag = (volatile unsigned long long*)hp;
+    *h->flag = 0;
+    void* dp = nullptr;
+    HC(hipHostGetDevicePointer(&dp, hp, 0));
+    d.host_flag = (unsigned long long*)dp;
+    if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
+    HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
+    for (int i = 0; i < 4; ++i) {
+      hipEvent_t ev;
+      HC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->bundle_ev.push_back(ev);
+    }
+  }
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
   HC(hipMemsetAsync(rs_mean, 0, d.n_pad * sizeof(double), sm));
@@ -1176,6 +1228,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
 extern "C" int pgb_destroy(pgb_handle* h) {
   if (!h) return PGB_OK;
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->bundle_ev) (void)hipEventDestroy(e);
+  if (h->flag) (void)hipHostFree((void*)h->flag);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return PGB_OK;
@@ -1228,7 +1282,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)d.nchunks, (unsigned)(d.P - 1));
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-    hipLaunchKernelGGL(k_ctrl, gctrl, dim3(BT), 0, h->stream, d, par);
+    hipLaunchKernelGGL(k_ctrl, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
       if (h->ev_used + 2 > h->ev.size()) {
@@ -1243,7 +1297,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
       h->ev_used += 2;
       (void)hipEventRecord(e0, h->stream);
     }
-    hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, d, par);
+    hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     if (h->prof) (void)hipEventRecord(e1, h->stream);
     h->slot += 1;
   }
@@ -1262,32 +1316,33 @@ static int harvest_profile(pgb_handle* h) {
   return PGB_OK;
 }
 
-// Enqueue slots until the device state machine reports PH_IDLE.
+// Enqueue bundles of slots until the device reports that all requested asteps are complete.
+// The device publishes its progress in a pinned host word (k_ctrl, final slot of a step); the
+// host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
+// are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
+#define BUNDLE 8
 static int run_until_idle(pgb_handle* h, int n_steps) {
   Dev& d = h->d;
-  int guess = h->slots_per_step > 0.0 ? (int)(h->slots_per_step * n_steps * 1.08) + 6
-                                      : 16 * d.batch_draw * n_steps + 8;
   long long start = h->slot;
   long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
-  const long long used0 = h->ctr.slots;
-  unsigned long long used1 = 0;
   int rc;
-  for (;;) {
-    if (guess & 1) ++guess;  // keep slot parity aligned for k_begin
-    if ((rc = enqueue_slots(h, guess)) != PGB_OK) return rc;
-    Ctrl c;
-    HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&used1, &d.counters[5], sizeof used1, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
-    if (c.phase == PH_IDLE) break;
+  while (*h->flag < (unsigned long long)h->steps_target) {
+    hipEvent_t ev = h->bundle_ev[h->bundles & 3];
+    if (h->bundles >= 3) {
+      // wait for bundle (bundles - 3) before reusing its event: keeps <= 3 bundles queued
+      HIPCHK(hipEventSynchronize(h->bundle_ev[(h->bundles - 3) & 3]));
+      if (*h->flag >= (unsigned long long)h->steps_target) break;
+    }
+    if ((rc = enqueue_slots(h, BUNDLE)) != PGB_OK) return rc;
+    HIPCHK(hipEventRecord(ev, h->stream));
+    h->bundles += 1;
     if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
-    guess = 8;
   }
-  // slots the device actually needed (idle slots are not counted by the device)
-  double used = (double)((long long)used1 - used0) / n_steps;
-  h->ctr.slots = (long long)used1;
-  h->slots_per_step = h->slots_per_step > 0.0 ? 0.8 * h->slots_per_step + 0.2 * used : used;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
+  Ctrl c;
+  HIPCHK(hipMemcpy(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost));
+  if (c.phase != PH_IDLE) return fail(PGB_E_STATE, "device not idle after the progress flag fired");
   return PGB_OK;
 }
 
@@ -1295,8 +1350,9 @@ static int begin_steps(pgb_handle* h, int tune, int n_steps) {
   Dev& d = h->d;
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   int par = (int)(h->slot & 1);
-  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, d, par, tune, n_steps, h->inv_sigma2,
-                     h->sigma_dirty);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, h->d_dev, par, tune, n_steps,
+                     h->inv_sigma2, h->sigma_dirty);
+  h->steps_target += n_steps;
   h->sigma_dirty = 0;
   // host mirror of the batch cursor ([U] PGBART.astep batching)
   for (int i = 0; i < n_steps; ++i) {
