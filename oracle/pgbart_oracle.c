@@ -371,7 +371,22 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   h->ctr.saturations += sat;
   /* give back the unused tail of the two segments */
   /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
-  if (rule == PGB_RULE_ONEHOT && cR == 0) return; /* [U] one-hot needs two distinct values */
+  if (rule == PGB_RULE_ONEHOT && cR == 0) {
+    /* [U] a one-hot split needs two distinct values: the grow fails and the node stays a leaf.
+       Rows with a missing split value have been dropped by the partition; the leaf sheds them
+       (an identity when there are none).  Same arithmetic as the HIP backend. */
+    onode* pn = &T->nd[l];
+    double new_sse = pgb_leaf_sse(cL, bL, c2L, nd.value, h->sc.inv_c1, h->sc.inv_c2);
+    T->sse_orph += (double)c2N * h->sc.inv_c2;
+    T->sse_tot = (T->sse_tot - nd.sse) + new_sse;
+    pn->cnt = cL;
+    pn->q_st = aL;
+    pn->q_r = bL;
+    pn->q_r2 = c2L;
+    pn->sse = new_sse;
+    pn->seg = offL;
+    return;
+  }
   int64_t aR = nd.q_st - aL - aN, bR = nd.q_r - bL - bN, c2R = nd.q_r2 - c2L - c2N;
   /* the rows dropped by NaN now predict 0 from this tree */
   T->sse_orph += (double)c2N * h->sc.inv_c2;

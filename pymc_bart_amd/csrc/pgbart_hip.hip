@@ -37,6 +37,7 @@
 #define MAXN PGB_MAX_NODES
 #define MAXP PGB_MAX_PARTICLES
 #define CC_ROUNDS 256
+#define NGEN 8 /* generations of particle leaf labels (ring) */
 
 // ------------------------------------------------------------------ device structs
 struct DNode {  // 64 bytes
@@ -62,14 +63,22 @@ struct DPart {  // a particle
   DNode nd[MAXN];
 };
 
-struct Job {  // one particle's work for a PARTITION row pass
+struct Job {  // one particle's work for a PARTITION row pass + what the next k_ctrl needs (128 B)
   int32_t active;
+  int32_t copy;  // no split, but the labels must be copied forward (their generation is next to be reused)
   int32_t src_gen, src_slot;
   int32_t node, label, new_label;
   int32_t var, rule, check_nan;
   int32_t ccL, ccR;
   int32_t cnt;
   double v;
+  // statistics of the node being split (the parent of the children the pass creates)
+  long long p_q_st, p_q_r, p_q_r2;
+  double p_sse, p_value;
+  // particle header after this round's pop (so that the next k_ctrl needs one load per particle)
+  double h_sse_tot, h_sse_orph;
+  int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
+  int32_t pad_;
 };
 
 struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right = parent - both)
@@ -103,6 +112,7 @@ struct Ctrl {
   double leaf_sd, inv_sigma2;
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
   long long steps_done;  // asteps completed since creation (mirrored to the host flag)
+  long long slot_no;     // k_ctrl launches so far
 };
 
 struct Dev {  // kernel argument block (by value)
@@ -120,7 +130,7 @@ struct Dev {  // kernel argument block (by value)
   double* rs_mean;
   double* rs_m2;
   uint8_t* tree_lid;  // [m][n_pad]
-  uint8_t* lid;       // [3][P][n_pad]
+  uint8_t* lid;       // [NGEN][MAXP][n_pad]
   uint16_t* cc;       // [CC_ROUNDS*MAXP*2][nchunks]
   DTree* trees;       // [m]
   DPart* parts;       // [2][P]
@@ -136,7 +146,19 @@ struct Dev {  // kernel argument block (by value)
   const int32_t* rules;
   const int32_t* col_nan;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
+  long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
 };
+
+#ifdef PGB_TRACE
+#define TRACE_SLOTS 4096
+#define TR(i)                                                                              \
+  do {                                                                                     \
+    if (blockIdx.x == 1 && threadIdx.x == 0)                                               \
+      S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64();         \
+  } while (0)
+#else
+#define TR(i) ((void)0)
+#endif
 
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long wave_sum(long long v) {
@@ -204,37 +226,6 @@ __device__ __forceinline__ double wave_max_d(double v) {
   return v;
 }
 
-// [U] normalize: softmax(+1e-12) of s_lw[first .. first+cnt) -> cumulative normalised weights in
-// s_cum.  exp and the divisions run one particle per lane; the two sums are serial (lane 0) so
-// that their rounding order is the one the numeric contract fixes.
-__device__ __forceinline__ void normalize_weights(const double* s_lw, double* s_cum, double* s_tmp,
-                                                  int first, int cnt) {
-  const int tid = threadIdx.x;
-  const bool act = tid >= first && tid < first + cnt;
-  if (tid < 64) {
-    double lw = act ? s_lw[tid] : -1.0e308;
-    double mx = wave_max_d(lw);
-    if (act) s_cum[tid] = pgb_exp(lw - mx) + 1e-12;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int i = first; i < first + cnt; ++i) tot += s_cum[i];
-    s_tmp[0] = tot;
-  }
-  __syncthreads();
-  if (act) s_cum[tid] = s_cum[tid] / s_tmp[0];
-  __syncthreads();
-  if (tid == 0) {
-    double cs = 0.0;
-    for (int i = first; i < first + cnt; ++i) {
-      cs += s_cum[i];
-      s_cum[i] = cs;
-    }
-  }
-  __syncthreads();
-}
-
 // first j with u <= cdf[j], fallback p-1, searched 64 entries at a time by wave 0
 __device__ __forceinline__ int sample_var_wave(const double* cdf, int p, double u) {
   const int lane = threadIdx.x & 63;
@@ -266,24 +257,56 @@ __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_ste
 }
 
 // ------------------------------------------------------------------ k_ctrl
-struct Fin {  // result of finishing the pending split of an old particle
+struct Fin {  // result of finishing the pending split of an old particle (kept in LDS)
   int ok;     // 1: children created, 0: no pending split, -1: rolled back
   int cL, cR;
+  int nn_old, n_nodes, n_leaves, next_pop;
+  int loc_gen, loc_slot;
+  int node, var, new_label, ccL, ccR;
+  uint8_t depth, label;
   long long aL, aR, bL, bR, c2L, c2R;
-  double vL, vR, sseL, sseR, sse_tot, sse_orph;
-  int n_nodes;
+  double split, vL, vR, sseL, sseR, sse_tot, sse_orph;
 };
+
+// [U] normalize + inverse-CDF pick on ONE wave, one particle per lane.  Lanes [first, first+cnt)
+// hold log-weights.  exp / division run in parallel; the two sums are serial chains over
+// v_readlane broadcasts so that their rounding order is the one the numeric contract fixes
+// (index order), without LDS round trips.  Returns the first i in [first, first+cnt-1) with
+// !(u > cum[i]), else first+cnt-1   ([U] inverse_cdf walk).
+__device__ __forceinline__ double readlane_d(double v, int lane /* wave-uniform */) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u) {
+  const int lane = threadIdx.x & 63;
+  const bool act = lane >= first && lane < first + cnt;
+  const double mx = wave_max_d(act ? lw : -1.0e308);
+  const double w = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
+  double tot = 0.0;
+  for (int i = first; i < first + cnt; ++i) tot += readlane_d(w, i);
+  const double wn = w / tot;
+  double cs = 0.0, mycum = 0.0;
+  for (int i = first; i < first + cnt; ++i) {
+    cs += readlane_d(wn, i);
+    if (lane == i) mycum = cs;
+  }
+  const bool hit = act && (lane < first + cnt - 1) && !(u > mycum);
+  const unsigned long long m = __ballot(hit);
+  return m ? (int)__ffsll((long long)m) - 1 : first + cnt - 1;
+}
 
 __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
-  __shared__ double s_lw[MAXP], s_cum[MAXP];
-  __shared__ int s_any[MAXP];
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_scan[8];
   __shared__ int s_i[8];
   __shared__ double s_d[4];
   __shared__ long long s_ll[4];
 
+  TR(0);
   const Ctrl c = S.ctrl[par];
   Ctrl* co = &S.ctrl[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   if (c.phase == PH_IDLE) {
     if (b == 0 && tid == 0) {
       Ctrl o = c;
+      o.slot_no = c.slot_no + 1;
       o.leaf_sd = leaf_sd;
       o.pend_leafsd = 0;
       *co = o;
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         cmd->kind = CMD_INIT;
         cmd->tree_new = tree_new;
         Ctrl o = c;
+        o.slot_no = c.slot_no + 1;
         o.leaf_sd = leaf_sd;
         o.pend_leafsd = 0;
         o.phase = PH_ROUND;
@@ -336,25 +361,30 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   }
 
   // ---------------- PH_ROUND
+  TR(1);
   const int r = c.round;
   const uint32_t it = (uint32_t)c.iter;
   const DPart* OT = S.parts + (size_t)par * MAXP;
   DPart* NT = S.parts + (size_t)(par ^ 1) * MAXP;
-  const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs of the previous slot
+  const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs (+ particle headers) of the previous slot
   Job* JN = S.jobs + (size_t)par * MAXP;
   DPart* me = &NT[p];
 
   int anc = p;  // ancestor (old particle index) of new particle p
   bool stop = false;
+  int sel = 0;
 
   if (r == 0) {
     // fresh particles ([U] init_particles): a stump with the initial leaf value
     if (tid == 0) {
-      me->n_nodes = 1;
-      me->n_leaves = 1;
-      me->next_pop = 0;
-      me->loc_gen = 0;
-      me->loc_slot = -1;
+      Fin f;
+      memset(&f, 0, sizeof f);
+      f.nn_old = 1;
+      f.n_nodes = 1;
+      f.n_leaves = 1;
+      f.next_pop = 0;
+      f.loc_gen = 0;
+      f.loc_slot = -1;
       DNode z;
       memset(&z, 0, sizeof z);
       z.var = -1;
@@ -366,142 +396,156 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       z.value = S.init_leaf;
       z.sse = pgb_leaf_sse(S.n, ia.B, ia.C, z.value, S.sc.inv_c1, S.sc.inv_c2);
       me->nd[0] = z;
-      me->sse_tot = z.sse;
-      me->sse_orph = 0.0;
+      f.sse_tot = z.sse;
+      f.sse_orph = 0.0;
+      s_fin[p] = f;
     }
     __syncthreads();
   } else {
-    // -------- finish round r-1 for every old particle (lane q-1 <-> old particle q)
-    if (tid < Lc) {
-      int q = tid + 1;
-      const DPart* T = &OT[q];
-      const Job j = JP[q];
+    // -------- wave 0: finish round r-1 for every old particle (lane q <-> old particle q),
+    //          then decide stop / ancestor / final choice
+    if (tid < 64) {
+      const int q = tid;
+      const bool isp = q >= 1 && q < P;
       Fin f;
-      f.ok = 0;
-      f.n_nodes = T->n_nodes;
-      f.sse_tot = T->sse_tot;
-      f.sse_orph = T->sse_orph;
-      if (j.active) {
-        const Acc a = S.acc[(par ^ 1) * MAXP + q];
-        const DNode nd = T->nd[j.node];
-        int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32);
-        int cR = nd.cnt - cL - cN;
-        if (j.rule == PGB_RULE_ONEHOT && cR == 0) {
-          f.ok = -1;  // [U] one-hot split needs two distinct values: roll back
-        } else {
-          f.ok = 1;
-          f.cL = cL;
-          f.cR = cR;
-          f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
-          f.aR = nd.q_st - a.aL - a.aN;
-          f.bR = nd.q_r - a.bL - a.bN;
-          f.c2R = nd.q_r2 - a.c2L - a.c2N;
-          f.sse_orph = T->sse_orph + (double)a.c2N * S.sc.inv_c2;
-          pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
-          double z0, z1;
-          pgb_normal2(ul.u0, ul.u1, &z0, &z1);
-          f.vL = pgb_leaf_value(cL, f.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
-          f.vR = pgb_leaf_value(cR, f.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
-          f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
-          f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
-          f.sse_tot = ((T->sse_tot - nd.sse) + f.sseL) + f.sseR;
-          f.n_nodes = T->n_nodes + 2;
+      memset(&f, 0, sizeof f);
+      double lw = 0.0;
+      bool pending = false;
+      if (isp) {
+        const Job j = JP[q];
+        f.nn_old = j.h_n_nodes;
+        f.n_nodes = j.h_n_nodes;
+        f.n_leaves = j.h_n_leaves;
+        f.next_pop = j.h_next_pop;
+        f.sse_tot = j.h_sse_tot;
+        f.sse_orph = j.h_sse_orph;
+        // labels: wherever they were, unless the previous row pass rewrote them (split / refresh)
+        f.loc_gen = j.src_gen;
+        f.loc_slot = j.src_slot;
+        if (j.copy) {
+          f.loc_gen = c.lid_gen;
+          f.loc_slot = q;
         }
+        if (j.active) {
+          const Acc a = S.acc[(par ^ 1) * MAXP + q];
+          const int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32);
+          const int cR = j.cnt - cL - cN;
+          f.loc_gen = c.lid_gen;  // the row pass wrote this particle's labels here
+          f.loc_slot = q;
+          if (j.rule == PGB_RULE_ONEHOT && cR == 0) {
+            // [U] a one-hot split needs two distinct values: the grow fails and the node stays a
+            // leaf.  No row was relabelled except rows with a missing split value, which the pass
+            // dropped; the leaf sheds them (identity when there are none).
+            f.ok = -1;
+            f.node = j.node;
+            f.cL = cL;
+            f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
+            f.ccL = j.ccL;
+            f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
+            f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, j.p_value, S.sc.inv_c1, S.sc.inv_c2);
+            f.sse_tot = (j.h_sse_tot - j.p_sse) + f.sseL;
+          } else {
+            f.ok = 1;
+            f.cL = cL;
+            f.cR = cR;
+            f.node = j.node; f.var = j.var; f.split = j.v; f.new_label = j.new_label;
+            f.ccL = j.ccL; f.ccR = j.ccR;
+            f.depth = (uint8_t)j.p_depth; f.label = (uint8_t)j.label;
+            f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
+            f.aR = j.p_q_st - a.aL - a.aN;
+            f.bR = j.p_q_r - a.bL - a.bN;
+            f.c2R = j.p_q_r2 - a.c2L - a.c2N;
+            f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
+            pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
+            double z0, z1;
+            pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+            f.vL = pgb_leaf_value(cL, f.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
+            f.vR = pgb_leaf_value(cR, f.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
+            f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
+            f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
+            f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
+            f.n_nodes = j.h_n_nodes + 2;
+            f.n_leaves = j.h_n_leaves + 1;
+          }
+        }
+        s_fin[q] = f;
+        pending = f.next_pop < f.n_nodes;
+        lw = (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2);
       }
-      s_fin[q] = f;
-      s_any[q] = T->next_pop < f.n_nodes;
-      s_lw[q] = (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2);
+      TR(2);
+      stop = __ballot(pending) == 0ull;
+      int pick;
+      if (!stop) {
+        // [U] systematic resampling of particles 1..P-1: ancestor of new particle p
+        pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
+        const double ui = (u.u0 + (double)(p - 1)) / (double)Lc;
+        pick = wave_pick(lw, 1, Lc, ui);
+      } else {
+        // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
+        if (q == 0) lw = c.sse0 * (-0.5 * c.inv_sigma2);
+        pgb_u2 u = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
+        pick = wave_pick(lw, 0, P, u.u0);
+      }
+      if (tid == 0) {
+        s_i[0] = stop ? 1 : 0;
+        s_i[1] = pick;
+      }
     }
     __syncthreads();
-    {
-      int any = 0;
-      for (int q = 1; q < P; ++q) any |= s_any[q];  // LDS broadcast reads, every thread
-      stop = !any;
-    }
-
-    if (!stop) {
-      // -------- [U] normalize + systematic resampling of particles 1..P-1
-      normalize_weights(s_lw, s_cum, s_d, 1, Lc);
-      if (tid == 0) {
-        pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
-        double ui = (u.u0 + (double)(p - 1)) / (double)Lc;
-        int a = 0;
-        while (a < Lc - 1 && ui > s_cum[a + 1]) ++a;
-        s_i[1] = a + 1;
-      }
-      __syncthreads();
-      anc = s_i[1];
-    } else {
-      // -------- final choice among all P particles ([U] get_particle_tree)
-      if (tid == 0) s_lw[0] = c.sse0 * (-0.5 * c.inv_sigma2);
-      __syncthreads();
-      normalize_weights(s_lw, s_cum, s_d, 0, P);
-      if (tid == 0) {
-        pgb_u2 u = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
-        int sel = 0;
-        while (sel < P - 1 && u.u0 > s_cum[sel]) ++sel;
-        s_i[1] = sel;
-      }
-      __syncthreads();
+    stop = s_i[0] != 0;
+    if (stop) {
+      sel = s_i[1];
       anc = p;  // no resampling in the final slot: particle p finishes itself
+    } else {
+      anc = s_i[1];
     }
-
-    // -------- new particle p := old particle anc with its pending split applied
+    TR(3);
+    // -------- new particle p := old particle anc with its pending split applied (all threads)
     {
       const DPart* A = &OT[anc];
-      const Fin f = s_fin[anc];
-      const Job j = JP[anc];
-      int nn = A->n_nodes;
-      for (int i = tid; i < nn; i += BT) me->nd[i] = A->nd[i];
-      __syncthreads();
-      if (tid == 0) {
-        me->n_leaves = A->n_leaves;
-        me->next_pop = A->next_pop;
-        me->loc_gen = A->loc_gen;
-        me->loc_slot = A->loc_slot;
-        me->sse_tot = f.sse_tot;
-        me->sse_orph = f.sse_orph;
-        me->n_nodes = f.n_nodes;
-        if (f.ok == 1) {
-          DNode par_nd = A->nd[j.node];
-          DNode L, R;
-          memset(&L, 0, sizeof L);
-          memset(&R, 0, sizeof R);
-          L.var = R.var = -1;
-          L.depth = R.depth = par_nd.depth + 1;
-          L.label = par_nd.label;
-          R.label = (uint8_t)j.new_label;
-          L.cnt = f.cL; L.q_st = f.aL; L.q_r = f.bL; L.q_r2 = f.c2L;
-          R.cnt = f.cR; R.q_st = f.aR; R.q_r = f.bR; R.q_r2 = f.c2R;
-          L.value = f.vL; R.value = f.vR;
-          L.sse = f.sseL; R.sse = f.sseR;
-          L.cc_row = j.ccL; R.cc_row = j.ccR;
-          par_nd.var = j.var;
-          par_nd.split = j.v;
-          par_nd.left = (uint8_t)nn;
-          par_nd.right = (uint8_t)(nn + 1);
-          me->nd[j.node] = par_nd;
-          me->nd[nn] = L;
-          me->nd[nn + 1] = R;
-          me->n_leaves = A->n_leaves + 1;
+      const Fin& f = s_fin[anc];
+      const int nn = f.nn_old;
+      for (int i = tid; i < nn; i += BT) {
+        DNode z = A->nd[i];
+        if (f.ok == 1 && i == f.node) {
+          z.var = f.var;
+          z.split = f.split;
+          z.left = (uint8_t)nn;
+          z.right = (uint8_t)(nn + 1);
+        } else if (f.ok == -1 && i == f.node) {
+          z.cnt = f.cL;
+          z.q_st = f.aL;
+          z.q_r = f.bL;
+          z.q_r2 = f.c2L;
+          z.sse = f.sseL;
+          z.cc_row = f.ccL;
         }
-        // where the labels of this particle live: the previous row pass wrote (lid_gen, anc)
-        // unless the split was rolled back or the particle still is an untouched root
-        if (f.ok == -1) {
-          me->loc_gen = j.src_gen;
-          me->loc_slot = j.src_slot;
-        } else {
-          me->loc_gen = c.lid_gen;
-          me->loc_slot = anc;
-        }
+        me->nd[i] = z;
       }
-      __syncthreads();
+      if (f.ok == 1 && tid >= BT - 2) {
+        const bool isL = tid == BT - 2;
+        DNode z;
+        memset(&z, 0, sizeof z);
+        z.var = -1;
+        z.depth = f.depth + 1;
+        z.label = isL ? f.label : (uint8_t)f.new_label;
+        z.cnt = isL ? f.cL : f.cR;
+        z.q_st = isL ? f.aL : f.aR;
+        z.q_r = isL ? f.bL : f.bR;
+        z.q_r2 = isL ? f.c2L : f.c2R;
+        z.value = isL ? f.vL : f.vR;
+        z.sse = isL ? f.sseL : f.sseR;
+        z.cc_row = isL ? f.ccL : f.ccR;
+        me->nd[nn + (isL ? 0 : 1)] = z;
+      }
     }
   }
+  TR(4);
+  const Fin& F = s_fin[anc];  // state of new particle p before this round's pop
 
   // =================================================================== final slot
   if (stop) {
-    const int sel = s_i[1];
+    __syncthreads();  // the node copy above is complete (this workgroup reads it back below)
     const int tree_old = c.lower + c.k;
     const bool more = (c.k + 1 < c.batch_n);
     const bool next_step = (!more && c.steps_left > 1);
@@ -519,16 +563,25 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     const int tree_new = lower_next + k_next;
     const bool has_init = more || next_step;
 
+    if (tid == 0) {  // particle header (kept for inspection / export)
+      me->n_nodes = F.n_nodes;
+      me->n_leaves = F.n_leaves;
+      me->next_pop = F.next_pop;
+      me->loc_gen = F.loc_gen;
+      me->loc_slot = F.loc_slot;
+      me->sse_tot = F.sse_tot;
+      me->sse_orph = F.sse_orph;
+    }
     if (sel >= 1 && p == sel) {
       // accepted a grown particle: store it as the tree and publish its label->value table
       DTree* T = &S.trees[tree_old];
-      int nn = me->n_nodes;
+      const int nn = F.n_nodes;
       for (int i = tid; i < nn; i += BT) T->nd[i] = me->nd[i];
       if (tid == 0) {
         T->n_nodes = nn;
-        T->n_leaves = me->n_leaves;
-        cmd->sel_gen = me->loc_gen;
-        cmd->sel_slot = me->loc_slot;  // may be -1 (untouched root labels)
+        T->n_leaves = F.n_leaves;
+        cmd->sel_gen = F.loc_gen;
+        cmd->sel_slot = F.loc_slot;  // may be -1 (untouched root labels)
       }
       build_lv(me->nd, nn, cmd->lv_new);
     }
@@ -549,7 +602,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     const bool owner = (sel == 0) ? (b == 0) : (p == sel);
     if (owner) {
       const DNode* snd = sel == 0 ? S.trees[tree_old].nd : me->nd;
-      const int nn = sel == 0 ? S.trees[tree_old].n_nodes : me->n_nodes;
+      const int nn = sel == 0 ? S.trees[tree_old].n_nodes : F.n_nodes;
       if (c.tune) {
         if (c.iter > S.m) {  // [U] ssv rebuilt before this tree's counts are added
           if (tid == 0) {
@@ -583,6 +636,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       cmd->tune = c.tune;
       cmd->rs_count = c.rs_count + (c.tune ? 1 : 0);
       Ctrl o = c;
+      o.slot_no = c.slot_no + 1;
       o.leaf_sd = leaf_sd;
       o.rs_count = c.rs_count + (c.tune ? 1 : 0);
       o.pend_leafsd = c.tune ? 1 : 0;
@@ -619,22 +673,45 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   // [U] ParticleTree.sample_tree / grow_tree for new particle p
   Job job;
   memset(&job, 0, sizeof job);
-  job.src_gen = me->loc_gen;
-  job.src_slot = me->loc_slot;
+  job.src_gen = F.loc_gen;
+  job.src_slot = F.loc_slot;
+  job.h_n_nodes = F.n_nodes;
+  job.h_n_leaves = F.n_leaves;
+  job.h_next_pop = F.next_pop;
+  job.h_sse_tot = F.sse_tot;
+  job.h_sse_orph = F.sse_orph;
   bool attempt = false;
   int node = -1;
   DNode nd;
+  memset(&nd, 0, sizeof nd);
   if (tid == 0) {
-    int np = me->next_pop;
-    if (np < me->n_nodes) {
+    const int np = F.next_pop;
+    if (np < F.n_nodes) {
       atomicAdd(&S.counters[0], 1ull);
       node = np;
-      me->next_pop = np + 1;
-      nd = me->nd[node];
+      // the popped node: an old node of the ancestor, or one of the children just created
+      if (np < F.nn_old) {
+        nd = r == 0 ? me->nd[0] : OT[anc].nd[np];
+      } else {
+        const bool isL = np == F.nn_old;
+        nd.var = -1;
+        nd.depth = F.depth + 1;
+        nd.label = isL ? F.label : (uint8_t)F.new_label;
+        nd.cnt = isL ? F.cL : F.cR;
+        nd.q_st = isL ? F.aL : F.aR;
+        nd.q_r = isL ? F.bL : F.bR;
+        nd.q_r2 = isL ? F.c2L : F.c2R;
+        nd.sse = isL ? F.sseL : F.sseR;
+        nd.value = isL ? F.vL : F.vR;
+        nd.cc_row = isL ? F.ccL : F.ccR;
+      }
       pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_PROPOSE, 0);
       double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
-      attempt = (pl < u.u0) && (me->n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
+      attempt = (pl < u.u0) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
       s_d[1] = u.u1;
+      s_i[5] = nd.cnt;
+      s_i[6] = nd.cc_row;
+      s_i[7] = nd.label;
     }
     s_i[3] = attempt ? 1 : 0;
     s_i[4] = node;
@@ -642,25 +719,28 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   __syncthreads();
   attempt = s_i[3] != 0;
   node = s_i[4];
+  job.h_next_pop = F.next_pop + (node >= 0 ? 1 : 0);
+  TR(5);
   if (attempt) {
+    const int ncnt = s_i[5], ncc = s_i[6], nlabel = s_i[7];
     if (tid < 64) {
       int jj = sample_var_wave(S.cdf, S.p, s_d[1]);
       if (tid == 0) s_i[2] = jj;
     }
     __syncthreads();
-    nd = me->nd[node];
     const int j = s_i[2];
     const double* xc = S.XT + (size_t)j * S.n_pad;
     const uint8_t* lid =
         job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
-    const uint16_t* ccr = nd.cc_row >= 0 ? S.cc + (size_t)nd.cc_row * S.nchunks : nullptr;
+    const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
     int found = 0;
     double v = 0.0;
+    TR(6);
     for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
       // the k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
       pgb_u2 us = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_SELECT, tr);
-      long long k = (long long)(us.u0 * (double)nd.cnt);
-      if (k > nd.cnt - 1) k = nd.cnt - 1;
+      long long k = (long long)(us.u0 * (double)ncnt);
+      if (k > ncnt - 1) k = ncnt - 1;
       long long row;
       if (lid == nullptr) {
         row = k;  // untouched root: every row belongs to it
@@ -689,14 +769,14 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         uint32_t ids = *(const uint32_t*)(lid + (size_t)cstar * CH + tid * RPT);
         int mcnt = 0;
 #pragma unroll
-        for (int e = 0; e < RPT; ++e) mcnt += (((ids >> (8 * e)) & 255u) == (uint32_t)nd.label);
+        for (int e = 0; e < RPT; ++e) mcnt += (((ids >> (8 * e)) & 255u) == (uint32_t)nlabel);
         int tot2;
         int pre2 = block_excl_scan(mcnt, s_scan, &tot2);
         if (pre2 <= kk && kk < pre2 + mcnt) {
           int rem = kk - pre2;
           int e = 0;
           for (; e < RPT; ++e)
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)nd.label) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)nlabel) {
               if (rem == 0) break;
               --rem;
             }
@@ -708,37 +788,69 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       if (tid == 0) {
         double x = xc[row];
         s_d[0] = x;
-        s_i[7] = (x == x) ? 1 : 0;
+        s_i[0] = (x == x) ? 1 : 0;
       }
       __syncthreads();
-      found = s_i[7];
+      found = s_i[0];
       v = s_d[0];
       __syncthreads();
     }
     if (found) {
       job.active = 1;
       job.node = node;
-      job.label = nd.label;
-      job.new_label = me->n_leaves;
+      job.label = nlabel;
+      job.new_label = F.n_leaves;
       job.var = j;
       job.rule = S.rules[j];
       job.check_nan = S.col_nan[j];
       job.ccL = ((r * MAXP + p) * 2);
       job.ccR = job.ccL + 1;
-      job.cnt = nd.cnt;
+      job.cnt = ncnt;
       job.v = v;
-      if (tid == 0) atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
     }
   }
-  if (tid == 0) JN[p] = job;
+  TR(7);
+  // Labels are only rewritten when a particle splits.  A particle that idles keeps pointing at
+  // its old generation; it is copied forward only when that generation is the next to be reused.
+  {
+    const int dst = (c.lid_gen + 1) % NGEN;
+    job.copy = (!job.active && job.src_slot >= 0 && job.src_gen == (dst + 1) % NGEN) ? 1 : 0;
+  }
+  if (tid == 0) {
+    if (job.active) {  // parent statistics travel with the job (the next slot needs nothing else)
+      job.p_q_st = nd.q_st;
+      job.p_q_r = nd.q_r;
+      job.p_q_r2 = nd.q_r2;
+      job.p_sse = nd.sse;
+      job.p_value = nd.value;
+      job.p_depth = nd.depth;
+      atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
+    }
+    JN[p] = job;
+    me->n_nodes = F.n_nodes;
+    me->n_leaves = F.n_leaves;
+    me->next_pop = job.h_next_pop;
+    me->loc_gen = F.loc_gen;
+    me->loc_slot = F.loc_slot;
+    me->sse_tot = F.sse_tot;
+    me->sse_orph = F.sse_orph;
+  }
+#ifdef PGB_TRACE
+  if (b == 1 && tid == 0) {
+    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 15] = r;
+    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 14] = attempt;
+    TR(8);
+  }
+#endif
   if (b == 0 && tid == 0) {
     cmd->kind = CMD_PARTITION;
-    cmd->dst_gen = (c.lid_gen + 1) % 3;
+    cmd->dst_gen = (c.lid_gen + 1) % NGEN;
     Ctrl o = c;
+    o.slot_no = c.slot_no + 1;
     o.leaf_sd = leaf_sd;
     o.pend_leafsd = 0;
     o.round = r + 1;
-    o.lid_gen = (c.lid_gen + 1) % 3;
+    o.lid_gen = (c.lid_gen + 1) % NGEN;
     if (r == 0) o.sse0 = (double)ia.E0 * S.sc.inv_c2;  // [U] init_particles: weight of p0
     *co = o;
     if (r > 0) atomicAdd(&S.counters[3], 1ull);
@@ -746,91 +858,151 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
 }
 
 // ------------------------------------------------------------------ k_rows
-// PARTITION: workgroup (chunk, particle).  FINAL/INIT: workgroups with blockIdx.y == 0.
+// Persistent grid (<= 1024 workgroups): work items are looped over, because on MI355X the
+// dispatch of a workgroup costs ~3-4 ns and a (chunk x particle) grid of thousands of
+// workgroups was dispatch-bound, not bandwidth-bound (profiles/r01_*).
+//
+// PARTITION item = (1024-row chunk, group of G particles with work).  The workgroup loads and
+// quantises {sum_trees, r} of its rows ONCE and then, for each particle of the group, relabels
+// the rows of the leaf being split and reduces the left child's statistics.  Particles without
+// work in this round are not touched at all: their labels stay where they are (NGEN generations).
+// FINAL/INIT item = 256 rows.
+
+// 64-bit wave sum with DPP row shifts/broadcasts (gfx9 DPP); the result lands in lane 63.
+__device__ __forceinline__ long long wave_sum_dpp(long long v) {
+  int lo = (int)v, hi = (int)(v >> 32);
+#define PGB_DPP_STEP(ctrl, rm)                                                   \
+  {                                                                              \
+    int tl = __builtin_amdgcn_update_dpp(0, lo, ctrl, rm, 0xf, 0);               \
+    int th = __builtin_amdgcn_update_dpp(0, hi, ctrl, rm, 0xf, 0);               \
+    long long a = ((long long)hi << 32) | (unsigned)lo;                          \
+    long long b = ((long long)th << 32) | (unsigned)tl;                          \
+    a += b;                                                                      \
+    lo = (int)a;                                                                 \
+    hi = (int)(a >> 32);                                                         \
+  }
+  PGB_DPP_STEP(0x111, 0xf)  // row_shr:1
+  PGB_DPP_STEP(0x112, 0xf)  // row_shr:2
+  PGB_DPP_STEP(0x114, 0xf)  // row_shr:4
+  PGB_DPP_STEP(0x118, 0xf)  // row_shr:8
+  PGB_DPP_STEP(0x142, 0xa)  // row_bcast:15
+  PGB_DPP_STEP(0x143, 0xc)  // row_bcast:31
+#undef PGB_DPP_STEP
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+
+#define ROWS_TARGET_ITEMS 1024
+
 __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
-  __shared__ long long s_red[8 * 4];
+  __shared__ long long s_red[MAXP * 7 * 4];
   __shared__ double s_lv[2][256];
+  __shared__ int s_act[MAXP];
+  __shared__ int s_n[2];
   const Cmd* cmd = &S.cmd[par];
   const int kind = cmd->kind;
   if (kind == CMD_NOOP) return;
-  const int tid = threadIdx.x;
-  const long long base = (long long)blockIdx.x * CH + tid * RPT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
   if (kind == CMD_PARTITION) {
-    const int p = blockIdx.y + 1;
-    const Job j = S.jobs[(size_t)par * MAXP + p];
-    uint8_t* dst = S.lid + ((size_t)cmd->dst_gen * MAXP + p) * S.n_pad;
-    uint32_t ids;
-    if (j.src_slot < 0) {
-      ids = 0;
+    const Job* jobs = S.jobs + (size_t)par * MAXP;
+    // list of particles with work in this pass (split or forced label refresh)
+    if (tid < 64) {
+      const bool has = tid >= 1 && tid < S.P && (jobs[tid].active | jobs[tid].copy);
+      const unsigned long long m = __ballot(has);
+      if (has) s_act[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) s_n[0] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = s_n[0];
+    if (nact == 0) return;
+    int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+    if (G < 1) G = 1;
+    const int ngroups = (nact + G - 1) / G;
+    const int nitems = S.nchunks * ngroups;
+    const uint8_t* lid0 = S.lid;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      const int chunk = item % S.nchunks, grp = item / S.nchunks;
+      const long long base = (long long)chunk * CH + tid * RPT;
+      // rows of this thread: quantise once, reuse for every particle of the group
+      long long qa[RPT], qb[RPT], qc[RPT];
+      unsigned sat = 0;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) {
+        const double2 sr = S.pack[base + e];
+        qa[e] = pgb_quant(sr.x, S.sc.c1, &sat);
+        qb[e] = pgb_quant(sr.y, S.sc.c1, &sat);
+        qc[e] = pgb_quant(sr.y * sr.y, S.sc.c2, &sat);
+      }
+      uint32_t root_ids = 0;
 #pragma unroll
       for (int e = 0; e < RPT; ++e)
-        if (base + e >= S.n) ids |= (uint32_t)PGB_ORPHAN << (8 * e);
-    } else {
-      ids = *(const uint32_t*)(S.lid + ((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad + base);
-    }
-    if (!j.active) {
-      *(uint32_t*)(dst + base) = ids;
-      return;
-    }
-    const double* xc = S.XT + (size_t)j.var * S.n_pad;
-    uint32_t out = ids;
-    long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
-    unsigned sat = 0;
+        if (base + e >= S.n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      for (int g = g0; g < g1; ++g) {
+        const int p = s_act[g];
+        const Job j = jobs[p];
+        const uint32_t ids = j.src_slot < 0
+                                 ? root_ids
+                                 : *(const uint32_t*)(lid0 + ((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad + base);
+        uint32_t out = ids;
+        long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
+        if (j.active) {
+          const double* xc = S.XT + (size_t)j.var * S.n_pad;
 #pragma unroll
-    for (int e = 0; e < RPT; ++e) {
-      if (((ids >> (8 * e)) & 255u) == (uint32_t)j.label) {
-        const long long row = base + e;
-        const double x = xc[row];
-        const double2 sr = S.pack[row];
-        const long long qa = pgb_quant(sr.x, S.sc.c1, &sat);
-        const long long qb = pgb_quant(sr.y, S.sc.c1, &sat);
-        const long long qc = pgb_quant(sr.y * sr.y, S.sc.c2, &sat);
-        if (x != x) {
-          out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
-          v[0] += 1ll << 40;
-          v[4] += qa; v[5] += qb; v[6] += qc;
-        } else if (go_left(j.rule, x, j.v)) {
-          v[0] += 1;
-          v[1] += qa; v[2] += qb; v[3] += qc;
-        } else {
-          out = (out & ~(255u << (8 * e))) | ((uint32_t)j.new_label << (8 * e));
-          v[0] += 1ll << 20;
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)j.label) {
+              const double x = xc[base + e];
+              if (x != x) {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+                v[0] += 1ll << 40;
+                v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
+              } else if (go_left(j.rule, x, j.v)) {
+                v[0] += 1;
+                v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
+              } else {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)j.new_label << (8 * e));
+                v[0] += 1ll << 20;
+              }
+            }
+          }
+        }
+        *(uint32_t*)(S.lid + ((size_t)cmd->dst_gen * MAXP + p) * S.n_pad + base) = out;
+        if (j.active) {
+          const int nv = j.check_nan ? 7 : 4;
+          const int slot = (g - g0) * 7;
+          for (int i = 0; i < nv; ++i) {
+            const long long s = wave_sum_dpp(v[i]);
+            if (lane == 63) s_red[(slot + i) * 4 + w] = s;
+          }
         }
       }
-    }
-    *(uint32_t*)(dst + base) = out;
-    if (j.check_nan) {
-      block_sum<7>(v, s_red);
-    } else {
-      long long w[4] = {v[0], v[1], v[2], v[3]};
-      block_sum<4>(w, s_red);
-      v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
-    }
-    if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
-    if (tid == 0) {
-      const int cL = (int)(v[0] & 0xFFFFF), cR = (int)((v[0] >> 20) & 0xFFFFF), cN = (int)(v[0] >> 40);
-      S.cc[(size_t)j.ccL * S.nchunks + blockIdx.x] = (uint16_t)cL;
-      S.cc[(size_t)j.ccR * S.nchunks + blockIdx.x] = (uint16_t)cR;
-      Acc* a = &S.acc[(size_t)par * MAXP + p];
-      if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
-      if (cL) {
-        atomicAdd((unsigned long long*)&a->aL, (unsigned long long)v[1]);
-        atomicAdd((unsigned long long*)&a->bL, (unsigned long long)v[2]);
-        atomicAdd((unsigned long long*)&a->c2L, (unsigned long long)v[3]);
+      __syncthreads();
+      // one thread per (particle of the group, statistic): combine the 4 waves, publish
+      for (int t = tid; t < (g1 - g0) * 7; t += BT) {
+        const int gi = t / 7, i = t % 7;
+        const int p = s_act[g0 + gi];
+        const Job* j = &jobs[p];
+        if (!j->active || (i >= 4 && !j->check_nan)) continue;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        Acc* a = &S.acc[(size_t)par * MAXP + p];
+        if (i == 0) {
+          const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
+          S.cc[(size_t)j->ccL * S.nchunks + chunk] = (uint16_t)cL;
+          S.cc[(size_t)j->ccR * S.nchunks + chunk] = (uint16_t)cR;
+          if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+        } else if (s != 0) {
+          long long* dst = i == 1 ? &a->aL : i == 2 ? &a->bL : i == 3 ? &a->c2L : i == 4 ? &a->aN : i == 5 ? &a->bN : &a->c2N;
+          atomicAdd((unsigned long long*)dst, (unsigned long long)s);
+        }
       }
-      if (cN) {
-        atomicAdd((unsigned long long*)&a->aN, (unsigned long long)v[4]);
-        atomicAdd((unsigned long long*)&a->bN, (unsigned long long)v[5]);
-        atomicAdd((unsigned long long*)&a->c2N, (unsigned long long)v[6]);
-      }
+      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+      __syncthreads();
     }
     return;
   }
 
-  // ---------------- FINAL and/or INIT: one pass over the rows
-  if (blockIdx.y != 0) return;
+  // ---------------- FINAL and/or INIT: one pass over the rows, 256 rows per item
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
   for (int i = tid; i < 256; i += BT) {
     s_lv[0][i] = cmd->lv_new[i];
@@ -841,32 +1013,26 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
   unsigned sat = 0;
   uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
   const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
-  uint32_t ids_next = 0;
-  if (do_init) ids_next = *(const uint32_t*)(tl_new + base);
-  uint32_t ids_sel = 0;
-  if (do_final) {
-    if (cmd->sel_slot == -2) {
-      ids_sel = *(const uint32_t*)(tl_old + base);
-    } else if (cmd->sel_slot < 0) {
-      ids_sel = 0;
-#pragma unroll
-      for (int e = 0; e < RPT; ++e)
-        if (base + e >= S.n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
-    } else {
-      ids_sel = *(const uint32_t*)(S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad + base);
-    }
-    if (cmd->sel_slot != -2) *(uint32_t*)(tl_old + base) = ids_sel;
-    if (do_init && cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
-  }
+  const uint8_t* sel_lid =
+      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
   const double cntf = (double)cmd->rs_count;
-#pragma unroll
-  for (int e = 0; e < RPT; ++e) {
-    const long long row = base + e;
+  const int nitems = (int)(S.n_pad / BT);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long long row = (long long)item * BT + tid;
     if (row >= S.n) continue;
+    uint32_t id_next = do_init ? tl_new[row] : 0;
     double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
     if (do_final) {
+      uint32_t id_sel;
+      if (cmd->sel_slot == -2) {
+        id_sel = tl_old[row];  // old tree kept
+      } else {
+        id_sel = sel_lid ? sel_lid[row] : 0u;  // untouched root: label 0
+        tl_old[row] = (uint8_t)id_sel;
+      }
+      if (do_init && cmd->tree_new == cmd->tree_old) id_next = id_sel;
       // [U] sum_trees = sum_trees_noi + new_tree.predict()
-      const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+      const double nv = s_lv[0][id_sel];
       st = st + nv;
       if (cmd->tune) {  // [U] RunningSd.update (Welford)
         const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
@@ -881,7 +1047,7 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
     }
     if (do_init) {
       // [U] sum_trees_noi = sum_trees - old_tree.predict()
-      const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+      const double o = s_lv[1][id_next];
       const double noi = st - o;
       const double r = S.y[row] - noi;
       S.pack[row] = make_double2(st, r);
@@ -900,12 +1066,12 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
   if (tid == 0) {
     InitAcc* a = &S.initacc[par];
     if (do_init) {
-      atomicAdd((unsigned long long*)&a->A, (unsigned long long)v[0]);
-      atomicAdd((unsigned long long*)&a->B, (unsigned long long)v[1]);
-      atomicAdd((unsigned long long*)&a->C, (unsigned long long)v[2]);
-      atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v[3]);
+      if (v[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v[0]);
+      if (v[1]) atomicAdd((unsigned long long*)&a->B, (unsigned long long)v[1]);
+      if (v[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)v[2]);
+      if (v[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v[3]);
     }
-    if (do_final && cmd->tune) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
+    if (do_final && cmd->tune && v[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
   }
 }
 
@@ -1152,7 +1318,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(rs_mean, d.n_pad);
   DA(rs_m2, d.n_pad);
   DA(tree_lid, (size_t)d.m * d.n_pad);
-  DA(lid, (size_t)3 * MAXP * d.n_pad);
+  DA(lid, (size_t)NGEN * MAXP * d.n_pad);
   DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
@@ -1183,6 +1349,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     void* dp = nullptr;
     HC(hipHostGetDevicePointer(&dp, hp, 0));
     d.host_flag = (unsigned long long*)dp;
+#ifdef PGB_TRACE
+    if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * 16)) != PGB_OK) { pgb_destroy(h); return rc; }
+    HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * 16 * sizeof(long long), sm));
+#endif
     if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
     HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
     for (int i = 0; i < 4; ++i) {
@@ -1195,7 +1365,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
   HC(hipMemsetAsync(rs_mean, 0, d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(rs_m2, 0, d.n_pad * sizeof(double), sm));
-  HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)3 * MAXP * d.n_pad, sm));
+  HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)NGEN * MAXP * d.n_pad, sm));
   HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
@@ -1279,7 +1449,10 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
 
 static int enqueue_slots(pgb_handle* h, int count) {
   Dev& d = h->d;
-  dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)d.nchunks, (unsigned)(d.P - 1));
+  long long want = (long long)d.nchunks * (d.P - 1);
+  if (want < d.n_pad / BT) want = d.n_pad / BT;
+  if (want > 1024) want = 1024;
+  dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
     hipLaunchKernelGGL(k_ctrl, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
@@ -1538,3 +1711,10 @@ extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out,
   h->prof = enable ? 1 : 0;
   return PGB_OK;
 }
+
+#ifdef PGB_TRACE
+extern "C" int pgb_debug_trace(pgb_handle* h, long long* out, int n_slots) {
+  HIPCHK(hipMemcpy(out, h->d.trace, (size_t)n_slots * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  return PGB_OK;
+}
+#endif
