@@ -353,13 +353,13 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   int32_t* sr = h->arena + offR;
   int64_t cL = 0, cR = 0, cN = 0;
   int64_t aL = 0, bL = 0, c2L = 0, aN = 0, bN = 0, c2N = 0;
-  unsigned sat = 0;
   for (int64_t k = 0; k < nd.cnt; ++k) {
     int32_t i = seg[k];
     double x = xc[i];
-    int64_t qa = pgb_quant(h->st[i], h->sc.c1, &sat);
-    int64_t qb = pgb_quant(h->r[i], h->sc.c1, &sat);
-    int64_t qc = pgb_quant(h->r[i] * h->r[i], h->sc.c2, &sat);
+    /* saturation of these very values was already counted in o_tree_begin */
+    int64_t qa = pgb_quant(h->st[i], h->sc.c1, NULL);
+    int64_t qb = pgb_quant(h->r[i], h->sc.c1, NULL);
+    int64_t qc = pgb_quant(h->r[i] * h->r[i], h->sc.c2, NULL);
     if (x != x) {
       cN++; aN += qa; bN += qb; c2N += qc;
     } else if (rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v)) {
@@ -368,7 +368,6 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
       sr[cR++] = i;
     }
   }
-  h->ctr.saturations += sat;
   /* give back the unused tail of the two segments */
   /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
   if (rule == PGB_RULE_ONEHOT && cR == 0) {

@@ -87,7 +87,8 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
   long long pad;
 };
 
-struct InitAcc {
+#define IA_SLOTS 8 /* the row pass spreads its atomics over this many cache lines */
+struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;
   long long pad[3];
 };
@@ -136,7 +137,7 @@ struct Dev {  // kernel argument block (by value)
   DPart* parts;       // [2][P]
   Job* jobs;          // [2][P]
   Acc* acc;           // [2][P]
-  InitAcc* initacc;   // [2]
+  InitAcc* initacc;   // [2][IA_SLOTS]
   Cmd* cmd;           // [2]
   Ctrl* ctrl;         // [2]
   unsigned long long* counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
@@ -226,6 +227,19 @@ __device__ __forceinline__ double wave_max_d(double v) {
   return v;
 }
 
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// inclusive wave scan of one int per lane (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, 0);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, 0);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, 0);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, 0);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, 0);  // row_bcast:15
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, 0);  // row_bcast:31
+  return x;
+}
+
 // first j with u <= cdf[j], fallback p-1, searched 64 entries at a time by wave 0
 __device__ __forceinline__ int sample_var_wave(const double* cdf, int p, double u) {
   const int lane = threadIdx.x & 63;
@@ -312,14 +326,21 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
   const int P = S.P, Lc = P - 1;
   Cmd* cmd = &S.cmd[par];
-  const InitAcc ia = S.initacc[par ^ 1];
+  InitAcc ia;  // statistics of the previous FINAL/INIT row pass (integer sums over IA_SLOTS lines)
+  {
+    const InitAcc* src = S.initacc + (size_t)(par ^ 1) * IA_SLOTS;
+    ia = src[0];
+#pragma unroll
+    for (int k = 1; k < IA_SLOTS; ++k) {
+      ia.A += src[k].A; ia.B += src[k].B; ia.C += src[k].C; ia.E0 += src[k].E0; ia.QSTD += src[k].QSTD;
+    }
+  }
 
   // pending leaf_sd from the FINAL pass of the previous slot ([U] RunningSd -> leaf_sd)
   double leaf_sd = c.leaf_sd;
   if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
 
   if (b == 0 && tid == 0) {
-    S.initacc[par] = InitAcc{0, 0, 0, 0, 0, {0, 0, 0}};
     if (c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
   }
   if (tid == 0) {
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     memset(&z, 0, sizeof z);
     S.acc[par * MAXP + p] = z;
   }
+  if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, {0, 0, 0}};
 
   if (c.phase == PH_IDLE) {
     if (b == 0 && tid == 0) {
@@ -411,8 +433,21 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       memset(&f, 0, sizeof f);
       double lw = 0.0;
       bool pending = false;
+      // RNG + Box-Muller do not depend on memory: they run while the loads below are in flight
+      Job j;
+      Acc a;
       if (isp) {
-        const Job j = JP[q];
+        j = JP[q];
+        a = S.acc[(par ^ 1) * MAXP + q];
+      }
+      const pgb_u2 u_res = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
+      const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
+      double z0, z1;
+      {
+        const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
+        pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+      }
+      if (isp) {
         f.nn_old = j.h_n_nodes;
         f.n_nodes = j.h_n_nodes;
         f.n_leaves = j.h_n_leaves;
@@ -427,7 +462,6 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
           f.loc_slot = q;
         }
         if (j.active) {
-          const Acc a = S.acc[(par ^ 1) * MAXP + q];
           const int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32);
           const int cR = j.cnt - cL - cN;
           f.loc_gen = c.lid_gen;  // the row pass wrote this particle's labels here
@@ -456,9 +490,6 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
             f.bR = j.p_q_r - a.bL - a.bN;
             f.c2R = j.p_q_r2 - a.c2L - a.c2N;
             f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
-            pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
-            double z0, z1;
-            pgb_normal2(ul.u0, ul.u1, &z0, &z1);
             f.vL = pgb_leaf_value(cL, f.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
             f.vR = pgb_leaf_value(cR, f.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
@@ -477,14 +508,12 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       int pick;
       if (!stop) {
         // [U] systematic resampling of particles 1..P-1: ancestor of new particle p
-        pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
-        const double ui = (u.u0 + (double)(p - 1)) / (double)Lc;
+        const double ui = (u_res.u0 + (double)(p - 1)) / (double)Lc;
         pick = wave_pick(lw, 1, Lc, ui);
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
         if (q == 0) lw = c.sse0 * (-0.5 * c.inv_sigma2);
-        pgb_u2 u = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
-        pick = wave_pick(lw, 0, P, u.u0);
+        pick = wave_pick(lw, 0, P, u_fin.u0);
       }
       if (tid == 0) {
         s_i[0] = stop ? 1 : 0;
@@ -723,79 +752,89 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   TR(5);
   if (attempt) {
     const int ncnt = s_i[5], ncc = s_i[6], nlabel = s_i[7];
+    // Everything below runs on wave 0 only (no workgroup barriers): split variable, then the
+    // k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
     if (tid < 64) {
-      int jj = sample_var_wave(S.cdf, S.p, s_d[1]);
-      if (tid == 0) s_i[2] = jj;
-    }
-    __syncthreads();
-    const int j = s_i[2];
-    const double* xc = S.XT + (size_t)j * S.n_pad;
-    const uint8_t* lid =
-        job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
-    const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
-    int found = 0;
-    double v = 0.0;
-    TR(6);
-    for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
-      // the k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
-      pgb_u2 us = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_SELECT, tr);
-      long long k = (long long)(us.u0 * (double)ncnt);
-      if (k > ncnt - 1) k = ncnt - 1;
-      long long row;
-      if (lid == nullptr) {
-        row = k;  // untouched root: every row belongs to it
-      } else {
-        // (1) which chunk: scan the per-chunk counts of this node
-        int per = (S.nchunks + BT - 1) / BT;
-        int c0 = tid * per, c1 = c0 + per;
-        if (c1 > S.nchunks) c1 = S.nchunks;
-        int part = 0;
+      const int j = sample_var_wave(S.cdf, S.p, s_d[1]);
+      const double* xc = S.XT + (size_t)j * S.n_pad;
+      const uint8_t* lid =
+          job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
+      const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
+      int found = 0;
+      double v = 0.0;
+      TR(6);
+      // per-lane partial sums of the node's per-chunk row counts (independent of the retry)
+      const int per = (S.nchunks + 63) / 64;
+      const int c0 = lane_id() * per;
+      int c1 = c0 + per;
+      if (c1 > S.nchunks) c1 = S.nchunks;
+      int part = 0, pre = 0;
+      if (lid != nullptr) {
         for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
-        int tot;
-        int pre = block_excl_scan(part, s_scan, &tot);
-        if ((long long)pre <= k && k < (long long)pre + part) {
-          int kk = (int)(k - pre);
-          int cc = c0;
-          while (kk >= ccr[cc]) {
-            kk -= ccr[cc];
-            ++cc;
-          }
-          s_i[5] = cc;
-          s_i[6] = kk;
-        }
-        __syncthreads();
-        int cstar = s_i[5], kk = s_i[6];
-        // (2) which row inside the chunk: scan the labels
-        uint32_t ids = *(const uint32_t*)(lid + (size_t)cstar * CH + tid * RPT);
-        int mcnt = 0;
-#pragma unroll
-        for (int e = 0; e < RPT; ++e) mcnt += (((ids >> (8 * e)) & 255u) == (uint32_t)nlabel);
-        int tot2;
-        int pre2 = block_excl_scan(mcnt, s_scan, &tot2);
-        if (pre2 <= kk && kk < pre2 + mcnt) {
-          int rem = kk - pre2;
-          int e = 0;
-          for (; e < RPT; ++e)
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)nlabel) {
-              if (rem == 0) break;
-              --rem;
+        pre = wave_incl_scan(part) - part;
+      }
+      for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
+        pgb_u2 us = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_SELECT, tr);
+        long long k = (long long)(us.u0 * (double)ncnt);
+        if (k > ncnt - 1) k = ncnt - 1;
+        long long row;
+        if (lid == nullptr) {
+          row = k;  // untouched root: every row belongs to it
+        } else {
+          // (1) which chunk holds the k-th row
+          const bool own = (long long)pre <= k && k < (long long)pre + part;
+          int cstar = 0, kk = 0;
+          if (own) {
+            kk = (int)(k - pre);
+            cstar = c0;
+            while (kk >= ccr[cstar]) {
+              kk -= ccr[cstar];
+              ++cstar;
             }
-          s_ll[0] = (long long)cstar * CH + tid * RPT + e;
+          }
+          const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
+          cstar = __builtin_amdgcn_readlane(cstar, ol);
+          kk = __builtin_amdgcn_readlane(kk, ol);
+          // (2) which row inside the chunk: 16 label bytes per lane
+          const uint4 ids = *(const uint4*)(lid + (size_t)cstar * CH + lane_id() * 16);
+          const uint32_t wds[4] = {ids.x, ids.y, ids.z, ids.w};
+          int mcnt = 0;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mcnt += (((wds[wd] >> (8 * e)) & 255u) == (uint32_t)nlabel);
+          const int pre2 = wave_incl_scan(mcnt) - mcnt;
+          const bool own2 = pre2 <= kk && kk < pre2 + mcnt;
+          int off = 0;
+          if (own2) {
+            int rem = kk - pre2;
+            for (int bb = 0; bb < 16; ++bb) {
+              if (((wds[bb >> 2] >> (8 * (bb & 3))) & 255u) == (uint32_t)nlabel) {
+                if (rem == 0) {
+                  off = bb;
+                  break;
+                }
+                --rem;
+              }
+            }
+          }
+          const int ol2 = (int)__ffsll((long long)__ballot(own2)) - 1;
+          off = __builtin_amdgcn_readlane(off, ol2);
+          row = (long long)cstar * CH + ol2 * 16 + off;
         }
-        __syncthreads();
-        row = s_ll[0];
+        const double x = xc[row];
+        found = (x == x) ? 1 : 0;
+        v = x;
       }
       if (tid == 0) {
-        double x = xc[row];
-        s_d[0] = x;
-        s_i[0] = (x == x) ? 1 : 0;
+        s_i[0] = found;
+        s_i[2] = j;
+        s_d[0] = v;
       }
-      __syncthreads();
-      found = s_i[0];
-      v = s_d[0];
-      __syncthreads();
     }
-    if (found) {
+    __syncthreads();
+    if (s_i[0]) {
+      const int j = s_i[2];
       job.active = 1;
       job.node = node;
       job.label = nlabel;
@@ -806,7 +845,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       job.ccL = ((r * MAXP + p) * 2);
       job.ccR = job.ccL + 1;
       job.cnt = ncnt;
-      job.v = v;
+      job.v = s_d[0];
     }
   }
   TR(7);
@@ -892,12 +931,20 @@ __device__ __forceinline__ long long wave_sum_dpp(long long v) {
 }
 
 #define ROWS_TARGET_ITEMS 1024
+#define PB 4 /* particles processed per batch inside a work item */
 
-__global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par) {
+struct RJob {  // the fields of a Job the row pass needs, cached in LDS
+  long long src;   // byte offset of the source labels in S.lid, -1: implicit root labels
+  long long xoff;  // element offset of the split column in S.XT
+  double v;
+  int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
+};
+
+__global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 7 * 4];
   __shared__ double s_lv[2][256];
-  __shared__ int s_act[MAXP];
+  __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
   const Cmd* cmd = &S.cmd[par];
   const int kind = cmd->kind;
@@ -906,11 +953,28 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
 
   if (kind == CMD_PARTITION) {
     const Job* jobs = S.jobs + (size_t)par * MAXP;
-    // list of particles with work in this pass (split or forced label refresh)
+    // list of particles with work in this pass (split or forced label refresh); their job
+    // fields are cached in LDS once per workgroup
     if (tid < 64) {
       const bool has = tid >= 1 && tid < S.P && (jobs[tid].active | jobs[tid].copy);
       const unsigned long long m = __ballot(has);
-      if (has) s_act[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      if (has) {
+        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        const Job j = jobs[tid];
+        RJob rj;
+        rj.p = tid;
+        rj.active = j.active;
+        rj.check_nan = j.check_nan;
+        rj.rule = j.rule;
+        rj.label = j.label;
+        rj.new_label = j.new_label;
+        rj.ccL = j.ccL;
+        rj.ccR = j.ccR;
+        rj.v = j.v;
+        rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+        rj.xoff = (long long)((size_t)j.var * S.n_pad);
+        s_job[k] = rj;
+      }
       if (tid == 0) s_n[0] = __popcll(m);
     }
     __syncthreads();
@@ -920,58 +984,85 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
     if (G < 1) G = 1;
     const int ngroups = (nact + G - 1) / G;
     const int nitems = S.nchunks * ngroups;
-    const uint8_t* lid0 = S.lid;
+    uint8_t* __restrict__ const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+    const uint8_t* __restrict__ const lid0 = S.lid;
+    const double* __restrict__ const XT = S.XT;
+    const double c1 = S.sc.c1, c2 = S.sc.c2;
+    const long long n = S.n, n_pad = S.n_pad;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
       const int chunk = item % S.nchunks, grp = item / S.nchunks;
       const long long base = (long long)chunk * CH + tid * RPT;
-      // rows of this thread: quantise once, reuse for every particle of the group
+      // rows of this thread: quantise once, reuse for every particle of the group.  Saturation
+      // of these very values was already counted by the INIT pass that produced `pack`.
       long long qa[RPT], qb[RPT], qc[RPT];
-      unsigned sat = 0;
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         const double2 sr = S.pack[base + e];
-        qa[e] = pgb_quant(sr.x, S.sc.c1, &sat);
-        qb[e] = pgb_quant(sr.y, S.sc.c1, &sat);
-        qc[e] = pgb_quant(sr.y * sr.y, S.sc.c2, &sat);
+        qa[e] = pgb_quant(sr.x, c1, nullptr);
+        qb[e] = pgb_quant(sr.y, c1, nullptr);
+        qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
       }
       uint32_t root_ids = 0;
 #pragma unroll
       for (int e = 0; e < RPT; ++e)
-        if (base + e >= S.n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+        if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
       const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
       for (int g = g0; g < g1; ++g) {
-        const int p = s_act[g];
-        const Job j = jobs[p];
-        const uint32_t ids = j.src_slot < 0
-                                 ? root_ids
-                                 : *(const uint32_t*)(lid0 + ((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad + base);
+        const RJob& rj = s_job[g];
+        const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rj.src + base);
         uint32_t out = ids;
-        long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
-        if (j.active) {
-          const double* xc = S.XT + (size_t)j.var * S.n_pad;
+        uint8_t* __restrict__ const dp = dst0 + (size_t)rj.p * n_pad + base;
+        if (!rj.active) {  // forced refresh only
+          *(uint32_t*)dp = out;
+          continue;
+        }
+        const double2* __restrict__ xp = (const double2*)(XT + rj.xoff + base);
+        const double2 t0 = xp[0], t1 = xp[1];
+        const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        const int slot = (g - g0) * 7;
+        if (!rj.check_nan) {  // common case: the split column has no missing values
+          long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)j.label) {
-              const double x = xc[base + e];
-              if (x != x) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+              if (go_left(rj.rule, x[e], rj.v)) {
+                v0 += 1;
+                v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
+              } else {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+                v0 += 1ll << 20;
+              }
+            }
+          }
+          *(uint32_t*)dp = out;
+          v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2); v3 = wave_sum_dpp(v3);
+          if (lane == 63) {
+            s_red[(slot + 0) * 4 + w] = v0;
+            s_red[(slot + 1) * 4 + w] = v1;
+            s_red[(slot + 2) * 4 + w] = v2;
+            s_red[(slot + 3) * 4 + w] = v3;
+          }
+        } else {
+          long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+              const double xv = x[e];
+              if (xv != xv) {
                 out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
                 v[0] += 1ll << 40;
                 v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
-              } else if (go_left(j.rule, x, j.v)) {
+              } else if (go_left(rj.rule, xv, rj.v)) {
                 v[0] += 1;
                 v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
               } else {
-                out = (out & ~(255u << (8 * e))) | ((uint32_t)j.new_label << (8 * e));
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
                 v[0] += 1ll << 20;
               }
             }
           }
-        }
-        *(uint32_t*)(S.lid + ((size_t)cmd->dst_gen * MAXP + p) * S.n_pad + base) = out;
-        if (j.active) {
-          const int nv = j.check_nan ? 7 : 4;
-          const int slot = (g - g0) * 7;
-          for (int i = 0; i < nv; ++i) {
+          *(uint32_t*)dp = out;
+          for (int i = 0; i < 7; ++i) {
             const long long s = wave_sum_dpp(v[i]);
             if (lane == 63) s_red[(slot + i) * 4 + w] = s;
           }
@@ -981,22 +1072,20 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
       // one thread per (particle of the group, statistic): combine the 4 waves, publish
       for (int t = tid; t < (g1 - g0) * 7; t += BT) {
         const int gi = t / 7, i = t % 7;
-        const int p = s_act[g0 + gi];
-        const Job* j = &jobs[p];
-        if (!j->active || (i >= 4 && !j->check_nan)) continue;
+        const RJob& rj = s_job[g0 + gi];
+        if (!rj.active || (i >= 4 && !rj.check_nan)) continue;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
-        Acc* a = &S.acc[(size_t)par * MAXP + p];
+        Acc* a = &S.acc[(size_t)par * MAXP + rj.p];
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
-          S.cc[(size_t)j->ccL * S.nchunks + chunk] = (uint16_t)cL;
-          S.cc[(size_t)j->ccR * S.nchunks + chunk] = (uint16_t)cR;
+          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
           if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
         } else if (s != 0) {
           long long* dst = i == 1 ? &a->aL : i == 2 ? &a->bL : i == 3 ? &a->c2L : i == 4 ? &a->aN : i == 5 ? &a->bN : &a->c2N;
           atomicAdd((unsigned long long*)dst, (unsigned long long)s);
         }
       }
-      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
       __syncthreads();
     }
     return;
@@ -1016,55 +1105,67 @@ __global__ __launch_bounds__(BT) void k_rows(const Dev* __restrict__ Sp, int par
   const uint8_t* sel_lid =
       (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
   const double cntf = (double)cmd->rs_count;
-  const int nitems = (int)(S.n_pad / BT);
+  const int nitems = S.nchunks;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const long long row = (long long)item * BT + tid;
-    if (row >= S.n) continue;
-    uint32_t id_next = do_init ? tl_new[row] : 0;
-    double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
+    const long long base = (long long)item * CH + tid * RPT;
+    uint32_t ids_next = do_init ? *(const uint32_t*)(tl_new + base) : 0u;
+    uint32_t ids_sel = 0;
     if (do_final) {
-      uint32_t id_sel;
       if (cmd->sel_slot == -2) {
-        id_sel = tl_old[row];  // old tree kept
+        ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
       } else {
-        id_sel = sel_lid ? sel_lid[row] : 0u;  // untouched root: label 0
-        tl_old[row] = (uint8_t)id_sel;
+        if (sel_lid) {
+          ids_sel = *(const uint32_t*)(sel_lid + base);
+        } else {  // untouched root: label 0 (pad rows: orphan)
+#pragma unroll
+          for (int e = 0; e < RPT; ++e)
+            if (base + e >= S.n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+        }
+        *(uint32_t*)(tl_old + base) = ids_sel;
       }
-      if (do_init && cmd->tree_new == cmd->tree_old) id_next = id_sel;
-      // [U] sum_trees = sum_trees_noi + new_tree.predict()
-      const double nv = s_lv[0][id_sel];
-      st = st + nv;
-      if (cmd->tune) {  // [U] RunningSd.update (Welford)
-        const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
-        const double delta = nv - mean0;
-        const double mean = mean0 + delta / cntf;
-        const double delta2 = nv - mean;
-        const double m2 = m20 + delta * delta2;
-        S.rs_mean[row] = mean;
-        S.rs_m2[row] = m2;
-        v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
-      }
+      if (do_init && cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
     }
-    if (do_init) {
-      // [U] sum_trees_noi = sum_trees - old_tree.predict()
-      const double o = s_lv[1][id_next];
-      const double noi = st - o;
-      const double r = S.y[row] - noi;
-      S.pack[row] = make_double2(st, r);
-      S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
-      v[0] += pgb_quant(st, S.sc.c1, &sat);
-      v[1] += pgb_quant(r, S.sc.c1, &sat);
-      v[2] += pgb_quant(r * r, S.sc.c2, &sat);
-      const double er = r - o;
-      v[3] += pgb_quant(er * er, S.sc.c2, &sat);
-    } else {
-      S.st[row] = st;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      const long long row = base + e;
+      if (row >= S.n) continue;
+      double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
+      if (do_final) {
+        // [U] sum_trees = sum_trees_noi + new_tree.predict()
+        const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+        st = st + nv;
+        if (cmd->tune) {  // [U] RunningSd.update (Welford)
+          const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+          const double delta = nv - mean0;
+          const double mean = mean0 + delta / cntf;
+          const double delta2 = nv - mean;
+          const double m2 = m20 + delta * delta2;
+          S.rs_mean[row] = mean;
+          S.rs_m2[row] = m2;
+          v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
+        }
+      }
+      if (do_init) {
+        // [U] sum_trees_noi = sum_trees - old_tree.predict()
+        const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+        const double noi = st - o;
+        const double r = S.y[row] - noi;
+        S.pack[row] = make_double2(st, r);
+        S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
+        v[0] += pgb_quant(st, S.sc.c1, &sat);
+        v[1] += pgb_quant(r, S.sc.c1, &sat);
+        v[2] += pgb_quant(r * r, S.sc.c2, &sat);
+        const double er = r - o;
+        v[3] += pgb_quant(er * er, S.sc.c2, &sat);
+      } else {
+        S.st[row] = st;
+      }
     }
   }
   block_sum<5>(v, s_red);
   if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
   if (tid == 0) {
-    InitAcc* a = &S.initacc[par];
+    InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
     if (do_init) {
       if (v[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v[0]);
       if (v[1]) atomicAdd((unsigned long long*)&a->B, (unsigned long long)v[1]);
@@ -1324,7 +1425,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
   DA(d.acc, 2 * MAXP);
-  DA(d.initacc, 2);
+  DA(d.initacc, 2 * IA_SLOTS);
   DA(d.cmd, 2);
   DA(d.ctrl, 2);
   DA(d.counters, 8);
@@ -1370,7 +1471,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
   HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * sizeof(Acc), sm));
-  HC(hipMemsetAsync(d.initacc, 0, 2 * sizeof(InitAcc), sm));
+  HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
   HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
   HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
   HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
@@ -1624,12 +1725,15 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
   if (!h) return fail(PGB_E_INVALID, "null handle");
   Dev& d = h->d;
   Ctrl c;
-  InitAcc ia;
+  InitAcc ia[IA_SLOTS];
   HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(&ia, &d.initacc[(h->slot & 1) ^ 1], sizeof ia, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ia, &d.initacc[(size_t)((h->slot & 1) ^ 1) * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost,
+                        h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   double leaf_sd = c.leaf_sd;
-  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * d.sc.inv_c1) / (double)d.n;
+  long long qstd = 0;
+  for (int k = 0; k < IA_SLOTS; ++k) qstd += ia[k].QSTD;
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)qstd * d.sc.inv_c1) / (double)d.n;
   if (leaf_sd_out) leaf_sd_out[0] = leaf_sd;
   if (iter_out) *iter_out = c.iter;
   if (lower_out) *lower_out = c.lower;
