@@ -304,6 +304,43 @@ PGB_HD pgb_scales pgb_make_scales(int64_t n, int range_exp) {
   return s;
 }
 
+/* ------------------------------------------------------------------ particle weights */
+/* Inclusive scan of 64 doubles in the FIXED association order of a wave64 DPP scan
+ * (row_shr:1,2,4,8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3, then
+ * row_bcast:31 into rows 2 and 3).  The numeric contract defines the cumulative particle
+ * weights as THIS scan so that the GPU can use 6 cross-lane steps instead of a 64-step serial
+ * chain; a CPU backend evaluates the same tree of additions with this function.  Unused
+ * entries must be 0.0 (x + 0.0 is exact). */
+PGB_HD void pgb_scan64(double* x) {
+  double t[64];
+  for (int d = 1; d <= 8; d <<= 1) {
+    for (int i = 0; i < 64; ++i) t[i] = ((i & 15) >= d) ? x[i] + x[i - d] : x[i];
+    for (int i = 0; i < 64; ++i) x[i] = t[i];
+  }
+  for (int i = 16; i < 32; ++i) x[i] = x[i] + x[15];
+  for (int i = 48; i < 64; ++i) x[i] = x[i] + x[47];
+  for (int i = 32; i < 64; ++i) x[i] = x[i] + x[31];
+}
+
+/* [U] normalize + inverse_cdf: particles occupy entries [first, first+cnt) of a 64-entry
+ * array of log-weights.  w_i = exp(lw_i - max) + 1e-12, W = pgb_scan64(w), total = W[last].
+ * pgb_pick returns the first i in [first, last) with !(u * total > W[i]), else last. */
+PGB_HD void pgb_weights_scan(const double* lw, int first, int cnt, double* W) {
+  double mx = lw[first];
+  for (int i = first + 1; i < first + cnt; ++i)
+    if (lw[i] > mx) mx = lw[i];
+  for (int i = 0; i < 64; ++i) W[i] = 0.0;
+  for (int i = first; i < first + cnt; ++i) W[i] = pgb_exp(lw[i] - mx) + 1e-12;
+  pgb_scan64(W);
+}
+PGB_HD int pgb_pick(const double* W, int first, int cnt, double u) {
+  const int last = first + cnt - 1;
+  const double thr = u * W[last];
+  for (int i = first; i < last; ++i)
+    if (!(thr > W[i])) return i;
+  return last;
+}
+
 /* ------------------------------------------------------------------ leaf algebra */
 /* Normal family: sum of squared errors of a leaf with value v from the integer
  * sufficient statistics (count, sum r, sum r^2), r = y - sum_trees_noi:

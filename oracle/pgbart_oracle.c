@@ -418,40 +418,22 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   T->n_leaves += 1;
 }
 
-/* [U] normalize (softmax + 1e-12) over `cnt` log-weights, serial cumulative sum. */
-static void o_normalize(const double* lw, int cnt, double* cum) {
-  double mx = lw[0];
-  for (int i = 1; i < cnt; ++i)
-    if (lw[i] > mx) mx = lw[i];
-  double w[PGB_MAX_PARTICLES];
-  double tot = 0.0;
-  for (int i = 0; i < cnt; ++i) {
-    w[i] = pgb_exp(lw[i] - mx) + 1e-12;
-    tot += w[i];
-  }
-  double c = 0.0;
-  for (int i = 0; i < cnt; ++i) {
-    c += w[i] / tot;
-    cum[i] = c;
-  }
-}
-
 static double o_logw(const pgb_handle* h, const otree* T) {
   return (T->sse_tot + T->sse_orph) * (-0.5 * h->inv_sigma2);
 }
 
-/* [U] resample: systematic resampling of particles 1..P-1 */
+/* [U] resample: normalize (softmax + 1e-12) + systematic resampling of particles 1..P-1.
+ * Cumulative weights and the inverse-CDF walk are pgb_weights_scan / pgb_pick (numeric contract). */
 static void o_resample(pgb_handle* h, uint32_t round) {
   int P = h->s.num_particles, Lc = P - 1;
-  double lw[PGB_MAX_PARTICLES], cum[PGB_MAX_PARTICLES];
-  for (int q = 1; q < P; ++q) lw[q - 1] = o_logw(h, &h->part[q]);
-  o_normalize(lw, Lc, cum);
+  double lw[64], W[64];
+  for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
+  pgb_weights_scan(lw, 1, Lc, W);
   pgb_u2 u = pgb_draw2(h->s.seed, (uint32_t)h->iter, round, 0, PGB_RNG_RESAMPLE, 0);
   for (int i = 0; i < Lc; ++i) {
     double ui = (u.u0 + (double)i) / (double)Lc;
-    int a = 0;
-    while (a < Lc - 1 && ui > cum[a]) ++a;
-    copy_tree(&h->part2[i + 1], &h->part[a + 1]);
+    int a = pgb_pick(W, 1, Lc, ui);
+    copy_tree(&h->part2[i + 1], &h->part[a]);
   }
   otree* t = h->part;
   h->part = h->part2;
@@ -462,13 +444,12 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   const pgb_settings* s = &h->s;
   int64_t n = s->n;
   int P = s->num_particles;
-  double lw[PGB_MAX_PARTICLES], cum[PGB_MAX_PARTICLES];
+  double lw[64], W[64];
   lw[0] = h->sse0 * (-0.5 * h->inv_sigma2);
   for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
-  o_normalize(lw, P, cum);
+  pgb_weights_scan(lw, 0, P, W);
   pgb_u2 u = pgb_draw2(s->seed, (uint32_t)h->iter, 0, 0, PGB_RNG_FINAL, 0);
-  int sel = 0;
-  while (sel < P - 1 && u.u0 > cum[sel]) ++sel;
+  int sel = pgb_pick(W, 0, P, u.u0);
   uint8_t* lid = h->lid + (size_t)tree_id * n;
   otree* T = &h->trees[tree_id];
   if (sel > 0) {
@@ -711,3 +692,10 @@ void pgbo_scales(int64_t n, int range_exp, double* out6) {
 int64_t pgbo_sizeof_settings(void) { return (int64_t)sizeof(pgb_settings); }
 int64_t pgbo_sizeof_counters(void) { return (int64_t)sizeof(pgb_counters); }
 int64_t pgbo_sizeof_tree_arrays(void) { return (int64_t)sizeof(pgb_tree_arrays); }
+void pgbo_scan64(double* x) { pgb_scan64(x); }
+int pgbo_pick(const double* lw, int first, int cnt, double u, double* W_out) {
+  double W[64];
+  pgb_weights_scan(lw, first, cnt, W);
+  if (W_out) memcpy(W_out, W, sizeof W);
+  return pgb_pick(W, first, cnt, u);
+}

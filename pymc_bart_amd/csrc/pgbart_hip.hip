@@ -218,13 +218,33 @@ __device__ __forceinline__ void build_lv(const DNode* nd, int n_nodes, double* l
 }
 
 
+__device__ __forceinline__ double readlane_d(double v, int lane /* wave-uniform */) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// max over the wave (order-free), DPP reduction to lane 63 + broadcast
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
+#define PGB_MAX_STEP(ctrl, rm)                                                        \
+  {                                                                                   \
+    int lo = __double2loint(v), hi = __double2hiint(v);                               \
+    int tl = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rm, 0xf, 0);                   \
+    int th = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rm, 0xf, 0);                   \
+    double t = __hiloint2double(th, tl);                                              \
+    v = t > v ? t : v;                                                                \
   }
-  return v;
+  PGB_MAX_STEP(0x111, 0xf)
+  PGB_MAX_STEP(0x112, 0xf)
+  PGB_MAX_STEP(0x114, 0xf)
+  PGB_MAX_STEP(0x118, 0xf)
+  PGB_MAX_STEP(0x142, 0xa)
+  PGB_MAX_STEP(0x143, 0xc)
+#undef PGB_MAX_STEP
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -282,34 +302,33 @@ struct Fin {  // result of finishing the pending split of an old particle (kept 
   double split, vL, vR, sseL, sseR, sse_tot, sse_orph;
 };
 
-// [U] normalize + inverse-CDF pick on ONE wave, one particle per lane.  Lanes [first, first+cnt)
-// hold log-weights.  exp / division run in parallel; the two sums are serial chains over
-// v_readlane broadcasts so that their rounding order is the one the numeric contract fixes
-// (index order), without LDS round trips.  Returns the first i in [first, first+cnt-1) with
-// !(u > cum[i]), else first+cnt-1   ([U] inverse_cdf walk).
-__device__ __forceinline__ double readlane_d(double v, int lane /* wave-uniform */) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
-
+// [U] normalize + inverse-CDF pick on ONE wave, one particle per lane: lanes [first, first+cnt)
+// hold log-weights.  Cumulative weights are the fixed-order wave scan the numeric contract
+// defines (pgb_scan64 / pgb_weights_scan / pgb_pick in include/pgbart_spec.h).
 __device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u) {
   const int lane = threadIdx.x & 63;
   const bool act = lane >= first && lane < first + cnt;
   const double mx = wave_max_d(act ? lw : -1.0e308);
-  const double w = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
-  double tot = 0.0;
-  for (int i = first; i < first + cnt; ++i) tot += readlane_d(w, i);
-  const double wn = w / tot;
-  double cs = 0.0, mycum = 0.0;
-  for (int i = first; i < first + cnt; ++i) {
-    cs += readlane_d(wn, i);
-    if (lane == i) mycum = cs;
+  double W = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
+  // pgb_scan64 on the wave: same additions, same order (include/pgbart_spec.h)
+#define PGB_SCAN_STEP(ctrl, rm)                                                       \
+  {                                                                                   \
+    const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(W), ctrl, rm, 0xf, 0); \
+    const int th = __builtin_amdgcn_update_dpp(0, __double2hiint(W), ctrl, rm, 0xf, 0); \
+    W = W + __hiloint2double(th, tl);                                                 \
   }
-  const bool hit = act && (lane < first + cnt - 1) && !(u > mycum);
+  PGB_SCAN_STEP(0x111, 0xf)  // row_shr:1
+  PGB_SCAN_STEP(0x112, 0xf)  // row_shr:2
+  PGB_SCAN_STEP(0x114, 0xf)  // row_shr:4
+  PGB_SCAN_STEP(0x118, 0xf)  // row_shr:8
+  PGB_SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+  PGB_SCAN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef PGB_SCAN_STEP
+  const int last = first + cnt - 1;
+  const double thr = u * readlane_d(W, last);
+  const bool hit = act && (lane < last) && !(thr > W);
   const unsigned long long m = __ballot(hit);
-  return m ? (int)__ffsll((long long)m) - 1 : first + cnt - 1;
+  return m ? (int)__ffsll((long long)m) - 1 : last;
 }
 
 __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
@@ -319,6 +338,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   __shared__ int s_i[8];
   __shared__ double s_d[4];
   __shared__ long long s_ll[4];
+  __shared__ double s_pre[PGB_SELECT_TRIES + 2];
 
   TR(0);
   const Ctrl c = S.ctrl[par];
@@ -396,6 +416,18 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   bool stop = false;
   int sel = 0;
 
+  // wave 1: the draws of THIS round's proposal depend only on (iter, round, particle), so they
+  // are made while wave 0 finishes the previous round: prior coin, split variable, row draws
+  if (tid >= 64 && tid < 128) {
+    const int l = tid - 64;
+    const pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p,
+                               l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
+    if (l <= PGB_SELECT_TRIES) s_pre[l] = u.u0;  // [0]: coin, [1 + t]: row draw of try t
+    const double u1 = readlane_d(u.u1, 0);
+    const int jj = sample_var_wave(S.cdf, S.p, u1);
+    if (l == 0) s_i[2] = jj;
+  }
+
   if (r == 0) {
     // fresh particles ([U] init_particles): a stump with the initial leaf value
     if (tid == 0) {
@@ -440,11 +472,12 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         j = JP[q];
         a = S.acc[(par ^ 1) * MAXP + q];
       }
-      const pgb_u2 u_res = pgb_draw2(S.seed, it, (uint32_t)(r - 1), 0, PGB_RNG_RESAMPLE, 0);
-      const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
-      double z0, z1;
+      // one Philox evaluation per lane: lane 0 draws the resampling offset, lane q the leaf noise
+      double z0, z1, u_res;
       {
-        const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_LEAF, 0);
+        const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q,
+                                    q == 0 ? PGB_RNG_RESAMPLE : PGB_RNG_LEAF, 0);
+        u_res = readlane_d(ul.u0, 0);
         pgb_normal2(ul.u0, ul.u1, &z0, &z1);
       }
       if (isp) {
@@ -508,11 +541,12 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       int pick;
       if (!stop) {
         // [U] systematic resampling of particles 1..P-1: ancestor of new particle p
-        const double ui = (u_res.u0 + (double)(p - 1)) / (double)Lc;
+        const double ui = (u_res + (double)(p - 1)) / (double)Lc;
         pick = wave_pick(lw, 1, Lc, ui);
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
         if (q == 0) lw = c.sse0 * (-0.5 * c.inv_sigma2);
+        const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
         pick = wave_pick(lw, 0, P, u_fin.u0);
       }
       if (tid == 0) {
@@ -734,10 +768,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         nd.value = isL ? F.vL : F.vR;
         nd.cc_row = isL ? F.ccL : F.ccR;
       }
-      pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_PROPOSE, 0);
       double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
-      attempt = (pl < u.u0) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
-      s_d[1] = u.u1;
+      attempt = (pl < s_pre[0]) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
       s_i[5] = nd.cnt;
       s_i[6] = nd.cc_row;
       s_i[7] = nd.label;
@@ -755,7 +787,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     // Everything below runs on wave 0 only (no workgroup barriers): split variable, then the
     // k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
     if (tid < 64) {
-      const int j = sample_var_wave(S.cdf, S.p, s_d[1]);
+      const int j = s_i[2];
       const double* xc = S.XT + (size_t)j * S.n_pad;
       const uint8_t* lid =
           job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
@@ -774,8 +806,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         pre = wave_incl_scan(part) - part;
       }
       for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
-        pgb_u2 us = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p, PGB_RNG_SELECT, tr);
-        long long k = (long long)(us.u0 * (double)ncnt);
+        long long k = (long long)(s_pre[1 + tr] * (double)ncnt);
         if (k > ncnt - 1) k = ncnt - 1;
         long long row;
         if (lid == nullptr) {

@@ -116,3 +116,41 @@ def test_scales_leave_headroom_for_n_terms(oracle):
         assert n * (2.0 ** e) * c1 <= 2.0 ** 62      # n saturated terms fit an int64
         assert n * (2.0 ** (2 * e)) * c2 <= 2.0 ** 62
         assert (2.0 ** e) * c1 <= 2.0 ** 50          # a term stays inside the exact-rounding window
+
+
+def test_scan64_is_an_inclusive_scan_in_fixed_order(oracle):
+    f = _lib(oracle).pgbo_scan64
+    f.argtypes = [C.c_void_p]
+    f.restype = None
+    x = np.arange(1, 65, dtype=np.float64)
+    y = x.copy()
+    f(y.ctypes.data)
+    assert np.array_equal(y, np.cumsum(x))                       # exact on integers
+    rng = np.random.default_rng(3)
+    x = rng.random(64)
+    y = x.copy()
+    f(y.ctypes.data)
+    np.testing.assert_allclose(y, np.cumsum(x), rtol=1e-14)
+    # the association order is part of the contract: row-local Hillis-Steele, then row carries
+    t = x.copy()
+    for d in (1, 2, 4, 8):
+        t = np.array([t[i] + t[i - d] if (i & 15) >= d else t[i] for i in range(64)])
+    t[16:32] += t[15]
+    t[48:64] += t[47]
+    t[32:64] += t[31]
+    assert np.array_equal(y, t)
+
+
+def test_weight_pick_follows_inverse_cdf(oracle):
+    f = _lib(oracle).pgbo_pick
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    f.restype = C.c_int
+    lw = np.zeros(64)
+    lw[1:6] = np.log([0.1, 0.2, 0.3, 0.25, 0.15])
+    W = np.zeros(64)
+    picks = [f(lw.ctypes.data, 1, 5, u, W.ctypes.data) for u in (0.0, 0.05, 0.1, 0.29, 0.31, 0.61, 0.86, 0.999)]
+    assert picks == [1, 1, 1, 2, 3, 4, 5, 5]
+    np.testing.assert_allclose(W[1:6] / W[5], np.cumsum([0.1, 0.2, 0.3, 0.25, 0.15]), atol=1e-10)
+    # overwhelming weight differences (the n=100k regime): never NaN, picks the heavy particle
+    lw[1:6] = [-1e6, -3.0, -1e5, -2e6, -1e9]
+    assert [f(lw.ctypes.data, 1, 5, u, None) for u in (0.01, 0.5, 0.99)] == [2, 2, 2]
