@@ -123,7 +123,7 @@ struct Dev {  // kernel argument block (by value)
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
-  double prior_leaf[PGB_MAX_DEPTH];
+  const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
   const double* XT;  // [p][n_pad]
   const double* y;   // [n_pad]
   double* st;        // [n_pad] sum_trees
@@ -168,14 +168,37 @@ __device__ __forceinline__ long long wave_sum(long long v) {
   return v;
 }
 
+// 64-bit wave sum with DPP row shifts/broadcasts (gfx9 DPP); the result lands in lane 63.
+__device__ __forceinline__ long long wave_sum_dpp(long long v) {
+  int lo = (int)v, hi = (int)(v >> 32);
+#define PGB_DPP_STEP(ctrl, rm)                                                   \
+  {                                                                              \
+    int tl = __builtin_amdgcn_update_dpp(0, lo, ctrl, rm, 0xf, 0);               \
+    int th = __builtin_amdgcn_update_dpp(0, hi, ctrl, rm, 0xf, 0);               \
+    long long a = ((long long)hi << 32) | (unsigned)lo;                          \
+    long long b = ((long long)th << 32) | (unsigned)tl;                          \
+    a += b;                                                                      \
+    lo = (int)a;                                                                 \
+    hi = (int)(a >> 32);                                                         \
+  }
+  PGB_DPP_STEP(0x111, 0xf)  // row_shr:1
+  PGB_DPP_STEP(0x112, 0xf)  // row_shr:2
+  PGB_DPP_STEP(0x114, 0xf)  // row_shr:4
+  PGB_DPP_STEP(0x118, 0xf)  // row_shr:8
+  PGB_DPP_STEP(0x142, 0xa)  // row_bcast:15
+  PGB_DPP_STEP(0x143, 0xc)  // row_bcast:31
+#undef PGB_DPP_STEP
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+
 // block-wide sum of NV long long values; result valid in thread 0
 template <int NV>
 __device__ __forceinline__ void block_sum(long long (&v)[NV], long long* sm /* [NV*4] */) {
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = wave_sum(v[i]);
-    if (lane == 0) sm[i * 4 + w] = v[i];
+    v[i] = wave_sum_dpp(v[i]);
+    if (lane == 63) sm[i * 4 + w] = v[i];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -332,7 +355,7 @@ __device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u
 }
 
 __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
-  const Dev& S = *Sp;
+  const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_scan[8];
   __shared__ int s_i[8];
@@ -938,29 +961,6 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
 // work in this round are not touched at all: their labels stay where they are (NGEN generations).
 // FINAL/INIT item = 256 rows.
 
-// 64-bit wave sum with DPP row shifts/broadcasts (gfx9 DPP); the result lands in lane 63.
-__device__ __forceinline__ long long wave_sum_dpp(long long v) {
-  int lo = (int)v, hi = (int)(v >> 32);
-#define PGB_DPP_STEP(ctrl, rm)                                                   \
-  {                                                                              \
-    int tl = __builtin_amdgcn_update_dpp(0, lo, ctrl, rm, 0xf, 0);               \
-    int th = __builtin_amdgcn_update_dpp(0, hi, ctrl, rm, 0xf, 0);               \
-    long long a = ((long long)hi << 32) | (unsigned)lo;                          \
-    long long b = ((long long)th << 32) | (unsigned)tl;                          \
-    a += b;                                                                      \
-    lo = (int)a;                                                                 \
-    hi = (int)(a >> 32);                                                         \
-  }
-  PGB_DPP_STEP(0x111, 0xf)  // row_shr:1
-  PGB_DPP_STEP(0x112, 0xf)  // row_shr:2
-  PGB_DPP_STEP(0x114, 0xf)  // row_shr:4
-  PGB_DPP_STEP(0x118, 0xf)  // row_shr:8
-  PGB_DPP_STEP(0x142, 0xa)  // row_bcast:15
-  PGB_DPP_STEP(0x143, 0xc)  // row_bcast:31
-#undef PGB_DPP_STEP
-  return ((long long)hi << 32) | (unsigned)lo;
-}
-
 #define ROWS_TARGET_ITEMS 1024
 #define PB 4 /* particles processed per batch inside a work item */
 
@@ -987,11 +987,14 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
     // list of particles with work in this pass (split or forced label refresh); their job
     // fields are cached in LDS once per workgroup
     if (tid < 64) {
-      const bool has = tid >= 1 && tid < S.P && (jobs[tid].active | jobs[tid].copy);
+      Job j;
+      j.active = 0;
+      j.copy = 0;
+      if (tid >= 1 && tid < S.P) j = jobs[tid];  // one round trip: the whole job
+      const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
       if (has) {
         const int k = __popcll(m & ((1ull << tid) - 1ull));
-        const Job j = jobs[tid];
         RJob rj;
         rj.p = tid;
         rj.active = j.active;
@@ -1136,61 +1139,50 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
   const uint8_t* sel_lid =
       (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
   const double cntf = (double)cmd->rs_count;
-  const int nitems = S.nchunks;
+  const int nitems = (int)(S.n_pad / BT);  // 256 rows per item, one row per thread
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const long long base = (long long)item * CH + tid * RPT;
-    uint32_t ids_next = do_init ? *(const uint32_t*)(tl_new + base) : 0u;
-    uint32_t ids_sel = 0;
+    const long long row = (long long)item * BT + tid;
+    if (row >= S.n) continue;
+    uint32_t id_next = do_init ? (uint32_t)tl_new[row] : 0u;
+    double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
+    const double yv = do_init ? S.y[row] : 0.0;
     if (do_final) {
+      uint32_t id_sel;
       if (cmd->sel_slot == -2) {
-        ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
+        id_sel = tl_old[row];  // old tree kept
       } else {
-        if (sel_lid) {
-          ids_sel = *(const uint32_t*)(sel_lid + base);
-        } else {  // untouched root: label 0 (pad rows: orphan)
-#pragma unroll
-          for (int e = 0; e < RPT; ++e)
-            if (base + e >= S.n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
-        }
-        *(uint32_t*)(tl_old + base) = ids_sel;
+        id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;  // untouched root: label 0
+        tl_old[row] = (uint8_t)id_sel;
       }
-      if (do_init && cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+      if (do_init && cmd->tree_new == cmd->tree_old) id_next = id_sel;
+      // [U] sum_trees = sum_trees_noi + new_tree.predict()
+      const double nv = s_lv[0][id_sel];
+      st = st + nv;
+      if (cmd->tune) {  // [U] RunningSd.update (Welford)
+        const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+        const double delta = nv - mean0;
+        const double mean = mean0 + delta / cntf;
+        const double delta2 = nv - mean;
+        const double m2 = m20 + delta * delta2;
+        S.rs_mean[row] = mean;
+        S.rs_m2[row] = m2;
+        v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
+      }
     }
-#pragma unroll
-    for (int e = 0; e < RPT; ++e) {
-      const long long row = base + e;
-      if (row >= S.n) continue;
-      double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
-      if (do_final) {
-        // [U] sum_trees = sum_trees_noi + new_tree.predict()
-        const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
-        st = st + nv;
-        if (cmd->tune) {  // [U] RunningSd.update (Welford)
-          const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
-          const double delta = nv - mean0;
-          const double mean = mean0 + delta / cntf;
-          const double delta2 = nv - mean;
-          const double m2 = m20 + delta * delta2;
-          S.rs_mean[row] = mean;
-          S.rs_m2[row] = m2;
-          v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
-        }
-      }
-      if (do_init) {
-        // [U] sum_trees_noi = sum_trees - old_tree.predict()
-        const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
-        const double noi = st - o;
-        const double r = S.y[row] - noi;
-        S.pack[row] = make_double2(st, r);
-        S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
-        v[0] += pgb_quant(st, S.sc.c1, &sat);
-        v[1] += pgb_quant(r, S.sc.c1, &sat);
-        v[2] += pgb_quant(r * r, S.sc.c2, &sat);
-        const double er = r - o;
-        v[3] += pgb_quant(er * er, S.sc.c2, &sat);
-      } else {
-        S.st[row] = st;
-      }
+    if (do_init) {
+      // [U] sum_trees_noi = sum_trees - old_tree.predict()
+      const double o = s_lv[1][id_next];
+      const double noi = st - o;
+      const double r = yv - noi;
+      S.pack[row] = make_double2(st, r);
+      S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
+      v[0] += pgb_quant(st, S.sc.c1, &sat);
+      v[1] += pgb_quant(r, S.sc.c1, &sat);
+      v[2] += pgb_quant(r * r, S.sc.c2, &sat);
+      const double er = r - o;
+      v[3] += pgb_quant(er * er, S.sc.c2, &sat);
+    } else {
+      S.st[row] = st;
     }
   }
   block_sum<5>(v, s_red);
@@ -1434,9 +1426,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.init_leaf = s->init_leaf;
   d.mdouble = (double)s->m;
   d.sc = pgb_make_scales(s->n, s->range_exp);
-  for (int i = 0; i < PGB_MAX_DEPTH; ++i) d.prior_leaf[i] = s->prior_leaf[i];
   int rc;
-  double *XT, *y, *st, *rs_mean, *rs_m2, *alpha_vec, *cdf;
+  double *XT, *y, *st, *rs_mean, *rs_m2, *alpha_vec, *cdf, *prior_leaf;
   double2* pack;
   uint8_t *tree_lid, *lid;
   uint16_t* cc;
@@ -1463,12 +1454,13 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(vi, d.p);
   DA(alpha_vec, d.p);
   DA(cdf, d.p);
+  DA(prior_leaf, PGB_MAX_DEPTH);
   DA(rules, d.p);
   DA(col_nan, d.p);
 #undef DA
   d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
   d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha_vec = alpha_vec; d.cdf = cdf;
-  d.rules = rules; d.col_nan = col_nan;
+  d.rules = rules; d.col_nan = col_nan; d.prior_leaf = prior_leaf;
   hipStream_t sm = h->stream;
   hipError_t e;
 #define HC(expr) \
@@ -1493,6 +1485,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
       h->bundle_ev.push_back(ev);
     }
   }
+  HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
   HC(hipMemsetAsync(rs_mean, 0, d.n_pad * sizeof(double), sm));
