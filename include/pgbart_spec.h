@@ -128,6 +128,8 @@ PGB_HD double pgb_u2d(uint64_t u) {
   return x;
 }
 
+PGB_HD double pgb_pow2(int e) { return pgb_u2d((uint64_t)(e + 1023) << 52); }
+
 /* ------------------------------------------------------------------ exp */
 /* exp(x) for the softmax of particle weights: x is clamped to [-700, 700].
  * Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor in Horner
@@ -287,8 +289,6 @@ typedef struct {
   double inv_c1, inv_c2, inv_cl; /* 2^-S1, 2^-S2, 2^-SL */
 } pgb_scales;
 
-PGB_HD double pgb_pow2(int e) { return pgb_u2d((uint64_t)(e + 1023) << 52); }
-
 PGB_HD pgb_scales pgb_make_scales(int64_t n, int range_exp) {
   int bits = 0;
   while (((int64_t)1 << bits) < n + 1) ++bits;
@@ -302,6 +302,27 @@ PGB_HD pgb_scales pgb_make_scales(int64_t n, int range_exp) {
   s.inv_c2 = pgb_pow2(-(frac - 2 * range_exp));
   s.inv_cl = pgb_pow2(-(frac - 11));
   return s;
+}
+
+/* ------------------------------------------------------------------ split-variable sampler */
+/* [U] SampleSplittingVariable.  Split weights are integers: A_j = rne(prior_j * 2^24 / max prior)
+ * plus PGB_ALPHA_UNIT-scaled tuning counts, so their prefix sums S_j are exact and independent of
+ * summation order (any workgroup can rebuild them in parallel).  A draw u picks the first j with
+ * u * S_{p-1} <= S_j (as doubles; S < 2^53), fallback p-1. */
+#define PGB_ALPHA_BITS 24
+PGB_HD int64_t pgb_alpha_unit(double max_prior) {  /* what one tuning count adds */
+  int64_t v = pgb_quant(pgb_pow2(PGB_ALPHA_BITS) / max_prior, 1.0, (unsigned*)0);
+  return v < 1 ? 1 : v;
+}
+PGB_HD int64_t pgb_alpha_init(double prior, double max_prior) {
+  int64_t v = pgb_quant(prior * (pgb_pow2(PGB_ALPHA_BITS) / max_prior), 1.0, (unsigned*)0);
+  return v < 1 ? 1 : v;
+}
+PGB_HD int pgb_sample_var(const int64_t* S, int p, double u) {
+  const double thr = u * (double)S[p - 1];
+  for (int j = 0; j < p; ++j)
+    if (thr <= (double)S[j]) return j;
+  return p - 1;
 }
 
 /* ------------------------------------------------------------------ particle weights */

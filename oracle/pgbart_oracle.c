@@ -84,8 +84,10 @@ struct pgb_handle {
   double* X; /* column-major p x n */
   double* y;
   int32_t* rules;
-  double* alpha_vec; /* p */
-  double* cdf;       /* p */
+  int64_t* alpha_vec; /* p  integer split weights (pgb_alpha_init + counts * unit) */
+  int64_t* cdf;       /* p  prefix sums the sampler currently uses */
+  int64_t alpha_unit;
+  double max_prior;
   int* col_has_nan;
   double* st; /* sum_trees n */
   double* r;  /* y - noi */
@@ -122,23 +124,17 @@ static void copy_tree(otree* d, const otree* s) {
 }
 
 static void build_cdf(pgb_handle* h) {
-  /* [U] SampleSplittingVariable: cumsum(alpha_vec / alpha_vec.sum()) */
-  int p = h->s.p;
-  double tot = 0.0;
-  for (int j = 0; j < p; ++j) tot += h->alpha_vec[j];
-  double c = 0.0;
-  for (int j = 0; j < p; ++j) {
+  /* [U] SampleSplittingVariable: cumulative split weights (exact integer prefix sums) */
+  int64_t c = 0;
+  for (int j = 0; j < h->s.p; ++j) {
     c += h->alpha_vec[j];
-    h->cdf[j] = c / tot;
+    h->cdf[j] = c;
   }
 }
 
 static int sample_var(const pgb_handle* h, double u) {
-  /* [U] rvs(): first i with u <= cdf[i]; fallback p-1 */
-  int p = h->s.p;
-  for (int j = 0; j < p; ++j)
-    if (u <= h->cdf[j]) return j;
-  return p - 1;
+  /* [U] rvs(): inverse CDF on one uniform */
+  return pgb_sample_var(h->cdf, h->s.p, u);
 }
 
 static int64_t arena_alloc(pgb_handle* h, int64_t len) {
@@ -174,8 +170,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   h->X = (double*)malloc(sizeof(double) * (size_t)n * p);
   h->y = (double*)malloc(sizeof(double) * n);
   h->rules = (int32_t*)calloc(p, sizeof(int32_t));
-  h->alpha_vec = (double*)malloc(sizeof(double) * p);
-  h->cdf = (double*)malloc(sizeof(double) * p);
+  h->alpha_vec = (int64_t*)malloc(sizeof(int64_t) * p);
+  h->cdf = (int64_t*)malloc(sizeof(int64_t) * p);
   h->col_has_nan = (int*)calloc(p, sizeof(int));
   h->st = (double*)malloc(sizeof(double) * n);
   h->r = (double*)malloc(sizeof(double) * n);
@@ -227,12 +223,18 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
   int64_t n = h->s.n;
   int p = h->s.p;
   if (ldx < p) return fail(PGB_E_INVALID, "ldx < p");
+  double mx = 0.0;
+  for (int j = 0; j < p; ++j) {
+    if (!(split_prior[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
+    if (split_prior[j] > mx) mx = split_prior[j];
+  }
+  h->max_prior = mx;
+  h->alpha_unit = pgb_alpha_unit(mx);
   for (int j = 0; j < p; ++j) {
     if (rules[j] != PGB_RULE_CONTINUOUS && rules[j] != PGB_RULE_ONEHOT)
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
-    if (!(split_prior[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
     h->rules[j] = rules[j];
-    h->alpha_vec[j] = split_prior[j];
+    h->alpha_vec[j] = pgb_alpha_init(split_prior[j], mx);
     int has = 0;
     for (int64_t i = 0; i < n; ++i) {
       double x = X[i * ldx + j];
@@ -488,7 +490,7 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   if (tune) {
     if (h->iter > s->m) build_cdf(h); /* [U] ssv rebuilt before this tree's counts are added */
     for (int k = 0; k < T->n_nodes; ++k)
-      if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += 1.0;
+      if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += h->alpha_unit;
     if (h->iter > 2) h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
   } else {
     for (int k = 0; k < T->n_nodes; ++k)
@@ -593,7 +595,9 @@ int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t
 
 int pgb_get_split_weights(pgb_handle* h, double* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
-  memcpy(out, h->alpha_vec, sizeof(double) * h->s.p);
+  /* in units of the caller's prior: prior_j + number of tuning counts (up to 2^-24 rounding) */
+  for (int j = 0; j < h->s.p; ++j)
+    out[j] = (double)h->alpha_vec[j] * (h->max_prior * pgb_pow2(-PGB_ALPHA_BITS));
   return PGB_OK;
 }
 

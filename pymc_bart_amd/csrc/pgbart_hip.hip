@@ -100,7 +100,7 @@ struct Cmd {
   int32_t kind;
   int32_t tree_old, tree_new;
   int32_t sel_gen, sel_slot;  // sel_slot == -2: the old tree was kept
-  int32_t tune, dst_gen, pad;
+  int32_t tune, dst_gen, st_cur;
   long long rs_count;
   double lv_new[256], lv_next[256];
 };
@@ -108,7 +108,8 @@ struct Cmd {
 struct Ctrl {
   int32_t phase, k, batch_n, lower;
   int32_t tune, round, lid_gen, steps_left;
-  int32_t pend_leafsd, pad;
+  int32_t pend_leafsd, st_cur;  // st_cur: which sum_trees buffer is current
+  int32_t alpha_cur, cdf_cur;   // current buffers of the split weights / their prefix sums
   long long iter, rs_count, pend_iter;
   double leaf_sd, inv_sigma2;
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
@@ -126,7 +127,7 @@ struct Dev {  // kernel argument block (by value)
   const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
   const double* XT;  // [p][n_pad]
   const double* y;   // [n_pad]
-  double* st;        // [n_pad] sum_trees
+  double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
   double2* pack;     // [n_pad] {sum_trees, y - noi}
   double* rs_mean;
   double* rs_m2;
@@ -142,8 +143,10 @@ struct Dev {  // kernel argument block (by value)
   Ctrl* ctrl;         // [2]
   unsigned long long* counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
   int32_t* vi;        // [p]
-  double* alpha_vec;  // [p]
-  double* cdf;        // [p]
+  long long* alpha;   // [2][p] integer split weights (pgb_alpha_init + counts * alpha_unit)
+  long long* cdfS;    // [2][p] their prefix sums, as used by the sampler
+  long long alpha_unit;
+  double max_prior;
   const int32_t* rules;
   const int32_t* col_nan;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
@@ -283,18 +286,6 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   return x;
 }
 
-// first j with u <= cdf[j], fallback p-1, searched 64 entries at a time by wave 0
-__device__ __forceinline__ int sample_var_wave(const double* cdf, int p, double u) {
-  const int lane = threadIdx.x & 63;
-  for (int base = 0; base < p; base += 64) {
-    int j = base + lane;
-    bool hit = j < p && u <= cdf[j];
-    unsigned long long m = __ballot(hit);
-    if (m) return base + __ffsll((long long)m) - 1;
-  }
-  return p - 1;
-}
-
 // ------------------------------------------------------------------ k_begin
 __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
   const Dev& S = *Sp;
@@ -315,7 +306,7 @@ __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_ste
 
 // ------------------------------------------------------------------ k_ctrl
 struct Fin {  // result of finishing the pending split of an old particle (kept in LDS)
-  int ok;     // 1: children created, 0: no pending split, -1: rolled back
+  int ok;     // 1: children created, 0: no pending split, -1: failed one-hot split
   int cL, cR;
   int nn_old, n_nodes, n_leaves, next_pop;
   int loc_gen, loc_slot;
@@ -333,7 +324,6 @@ __device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u
   const bool act = lane >= first && lane < first + cnt;
   const double mx = wave_max_d(act ? lw : -1.0e308);
   double W = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
-  // pgb_scan64 on the wave: same additions, same order (include/pgbart_spec.h)
 #define PGB_SCAN_STEP(ctrl, rm)                                                       \
   {                                                                                   \
     const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(W), ctrl, rm, 0xf, 0); \
@@ -354,14 +344,48 @@ __device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u
   return m ? (int)__ffsll((long long)m) - 1 : last;
 }
 
+// [U] SampleSplittingVariable.rvs on one wave, from stored prefix sums (pgb_sample_var)
+__device__ __forceinline__ int sample_var_prefix(const long long* Sarr, int p, double u) {
+  const int lane = threadIdx.x & 63;
+  const double thr = u * (double)Sarr[p - 1];
+  for (int base = 0; base < p; base += 64) {
+    const int j = base + lane;
+    const bool hit = j < p && thr <= (double)Sarr[j];
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + (int)__ffsll((long long)m) - 1;
+  }
+  return p - 1;
+}
+
+// The same draw from the integer split weights themselves (sampler being rebuilt by this slot):
+// exact prefix sums, 64 variables per step with a running carry.
+__device__ __forceinline__ int sample_var_weights(const long long* A, int p, double u) {
+  const int lane = threadIdx.x & 63;
+  long long part = 0;
+  for (int j = lane; j < p; j += 64) part += A[j];
+  part = wave_sum_dpp(part);
+  const long long tot = ((long long)__builtin_amdgcn_readlane((int)(part >> 32), 63) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)part, 63);
+  const double thr = u * (double)tot;
+  long long carry = 0;
+  for (int base = 0; base < p; base += 64) {
+    const int j = base + lane;
+    long long run = wave_sum_dpp(j < p ? A[j] : 0) + carry;  // inclusive prefix through variable j
+    const bool hit = j < p && thr <= (double)run;
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + (int)__ffsll((long long)m) - 1;
+    carry = ((long long)__builtin_amdgcn_readlane((int)(run >> 32), 63) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)run, 63);
+  }
+  return p - 1;
+}
+
 __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
-  __shared__ int s_scan[8];
-  __shared__ int s_i[8];
+  __shared__ int s_i[16];
   __shared__ double s_d[4];
-  __shared__ long long s_ll[4];
-  __shared__ double s_pre[PGB_SELECT_TRIES + 2];
+  __shared__ double s_pre[2][PGB_SELECT_TRIES + 2];  // [set][0: coin, 1+t: row draw of try t]
 
   TR(0);
   const Ctrl c = S.ctrl[par];
@@ -383,9 +407,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   double leaf_sd = c.leaf_sd;
   if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
 
-  if (b == 0 && tid == 0) {
-    if (c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
-  }
+  if (b == 0 && tid == 0 && c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
   if (tid == 0) {
     Acc z;
     memset(&z, 0, sizeof z);
@@ -405,80 +427,45 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     return;
   }
 
-  if (c.phase == PH_BEGIN) {  // first tree of a step: only an INIT row pass
-    if (b == 0) {
-      int tree_new = c.lower + c.k;
-      build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
-      if (tid == 0) {
-        cmd->kind = CMD_INIT;
-        cmd->tree_new = tree_new;
-        Ctrl o = c;
-        o.slot_no = c.slot_no + 1;
-        o.leaf_sd = leaf_sd;
-        o.pend_leafsd = 0;
-        o.phase = PH_ROUND;
-        o.round = 0;
-        o.iter = c.iter + 1;
-        *co = o;
-      }
-    }
-    return;
-  }
-
-  // ---------------- PH_ROUND
+  const bool begin = c.phase == PH_BEGIN;  // first tree of a step: nothing to finish
   TR(1);
-  const int r = c.round;
+  const int r = c.round;  // >= 1 in PH_ROUND: round 0 is proposed by the slot that starts the tree
   const uint32_t it = (uint32_t)c.iter;
   const DPart* OT = S.parts + (size_t)par * MAXP;
   DPart* NT = S.parts + (size_t)(par ^ 1) * MAXP;
   const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs (+ particle headers) of the previous slot
   Job* JN = S.jobs + (size_t)par * MAXP;
   DPart* me = &NT[p];
+  const long long* cdfS = S.cdfS + (size_t)c.cdf_cur * S.p;
+  const long long* alpha = S.alpha + (size_t)c.alpha_cur * S.p;
+  // the sampler of the NEXT tree is rebuilt from the weights when this tree ends while tuning
+  const bool rebuild = !begin && c.tune && c.iter > S.m;
+
+  // Waves 1 and 2 make the draws of the two proposals this slot may need while wave 0 finishes the
+  // previous round; they depend only on (iter, round, particle).
+  //   set 0: round r of the current tree            (iter,     r, p)
+  //   set 1: round 0 of the next tree to be updated (iter + 1, 0, p)
+  if (tid >= 64 && tid < 192) {
+    const int set = (tid >> 6) - 1, l = tid & 63;
+    const pgb_u2 u = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p,
+                               l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
+    if (l <= PGB_SELECT_TRIES) s_pre[set][l] = u.u0;
+    const double u1 = readlane_d(u.u1, 0);
+    const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
+    if (l == 0) s_i[8 + set] = jj;
+  }
 
   int anc = p;  // ancestor (old particle index) of new particle p
   bool stop = false;
   int sel = 0;
+  double sse0 = c.sse0;
 
-  // wave 1: the draws of THIS round's proposal depend only on (iter, round, particle), so they
-  // are made while wave 0 finishes the previous round: prior coin, split variable, row draws
-  if (tid >= 64 && tid < 128) {
-    const int l = tid - 64;
-    const pgb_u2 u = pgb_draw2(S.seed, it, (uint32_t)r, (uint32_t)p,
-                               l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
-    if (l <= PGB_SELECT_TRIES) s_pre[l] = u.u0;  // [0]: coin, [1 + t]: row draw of try t
-    const double u1 = readlane_d(u.u1, 0);
-    const int jj = sample_var_wave(S.cdf, S.p, u1);
-    if (l == 0) s_i[2] = jj;
-  }
-
-  if (r == 0) {
-    // fresh particles ([U] init_particles): a stump with the initial leaf value
-    if (tid == 0) {
-      Fin f;
-      memset(&f, 0, sizeof f);
-      f.nn_old = 1;
-      f.n_nodes = 1;
-      f.n_leaves = 1;
-      f.next_pop = 0;
-      f.loc_gen = 0;
-      f.loc_slot = -1;
-      DNode z;
-      memset(&z, 0, sizeof z);
-      z.var = -1;
-      z.cc_row = -1;
-      z.cnt = (int32_t)S.n;
-      z.q_st = ia.A;
-      z.q_r = ia.B;
-      z.q_r2 = ia.C;
-      z.value = S.init_leaf;
-      z.sse = pgb_leaf_sse(S.n, ia.B, ia.C, z.value, S.sc.inv_c1, S.sc.inv_c2);
-      me->nd[0] = z;
-      f.sse_tot = z.sse;
-      f.sse_orph = 0.0;
-      s_fin[p] = f;
-    }
-    __syncthreads();
-  } else {
+  if (!begin) {
+    // [U] init_particles: the root statistics of this tree arrive with the INIT pass that ran
+    // together with round 0; they are patched in here (round 1)
+    const bool r1 = r == 1;
+    const double root_sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
+    if (r1) sse0 = (double)ia.E0 * S.sc.inv_c2;  // weight of the reference particle p0
     // -------- wave 0: finish round r-1 for every old particle (lane q <-> old particle q),
     //          then decide stop / ancestor / final choice
     if (tid < 64) {
@@ -504,6 +491,14 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         pgb_normal2(ul.u0, ul.u1, &z0, &z1);
       }
       if (isp) {
+        if (r1) {  // round-0 jobs were written before the root statistics existed
+          j.p_q_st = ia.A;
+          j.p_q_r = ia.B;
+          j.p_q_r2 = ia.C;
+          j.p_sse = root_sse;
+          j.h_sse_tot = root_sse;
+          j.h_sse_orph = 0.0;
+        }
         f.nn_old = j.h_n_nodes;
         f.n_nodes = j.h_n_nodes;
         f.n_leaves = j.h_n_leaves;
@@ -568,7 +563,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         pick = wave_pick(lw, 1, Lc, ui);
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
-        if (q == 0) lw = c.sse0 * (-0.5 * c.inv_sigma2);
+        if (q == 0) lw = sse0 * (-0.5 * c.inv_sigma2);
         const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
         pick = wave_pick(lw, 0, P, u_fin.u0);
       }
@@ -593,6 +588,12 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       const int nn = f.nn_old;
       for (int i = tid; i < nn; i += BT) {
         DNode z = A->nd[i];
+        if (r1 && i == 0) {  // root statistics (see above)
+          z.q_st = ia.A;
+          z.q_r = ia.B;
+          z.q_r2 = ia.C;
+          z.sse = root_sse;
+        }
         if (f.ok == 1 && i == f.node) {
           z.var = f.var;
           z.split = f.split;
@@ -625,18 +626,26 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         me->nd[nn + (isL ? 0 : 1)] = z;
       }
     }
+  } else {
+    __syncthreads();  // waves 1/2 have published their draws
   }
   TR(4);
-  const Fin& F = s_fin[anc];  // state of new particle p before this round's pop
 
-  // =================================================================== final slot
+  // =================================================================== end of a tree
+  // bookkeeping of the accepted tree; then (if another tree follows) fall through and propose
+  // its round 0 in this very slot
+  bool fresh = begin;       // propose round 0 of a new tree (fresh stump) instead of round r
+  int tree_new = c.lower + c.k;  // PH_BEGIN: the tree to start
+  bool has_init = begin;
+  int lower_next = c.lower, k_next = c.k, batch_next = c.batch_n;
+  bool more = true;
   if (stop) {
+    const Fin& F = s_fin[p];
     __syncthreads();  // the node copy above is complete (this workgroup reads it back below)
     const int tree_old = c.lower + c.k;
-    const bool more = (c.k + 1 < c.batch_n);
+    more = (c.k + 1 < c.batch_n);
     const bool next_step = (!more && c.steps_left > 1);
-    // next tree to initialise (if any)
-    int lower_next = c.lower, k_next = c.k + 1, batch_next = c.batch_n;
+    k_next = c.k + 1;
     if (!more) {
       int upper = c.lower + c.batch_n;
       lower_next = upper < S.m ? upper : 0;
@@ -646,8 +655,9 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       if (up2 > S.m) up2 = S.m;
       batch_next = up2 - lower_next;
     }
-    const int tree_new = lower_next + k_next;
-    const bool has_init = more || next_step;
+    tree_new = lower_next + k_next;
+    has_init = more || next_step;
+    fresh = has_init;
 
     if (tid == 0) {  // particle header (kept for inspection / export)
       me->n_nodes = F.n_nodes;
@@ -690,21 +700,27 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       const DNode* snd = sel == 0 ? S.trees[tree_old].nd : me->nd;
       const int nn = sel == 0 ? S.trees[tree_old].n_nodes : F.n_nodes;
       if (c.tune) {
-        if (c.iter > S.m) {  // [U] ssv rebuilt before this tree's counts are added
-          if (tid == 0) {
-            double tot = 0.0;
-            for (int j = 0; j < S.p; ++j) tot += S.alpha_vec[j];
-            double cs = 0.0;
-            for (int j = 0; j < S.p; ++j) {
-              cs += S.alpha_vec[j];
-              S.cdf[j] = cs / tot;
+        // [U] the sampler is rebuilt from the weights BEFORE this tree's counts are added; weights
+        // and prefix sums are double-buffered (other workgroups read the current ones in this slot)
+        long long* alpha_o = S.alpha + (size_t)(c.alpha_cur ^ 1) * S.p;
+        if (rebuild) {
+          long long* cdf_o = S.cdfS + (size_t)(c.cdf_cur ^ 1) * S.p;
+          if (tid < 64) {
+            long long carry = 0;
+            for (int base = 0; base < S.p; base += 64) {
+              const int j = base + tid;
+              const long long run = wave_sum_dpp(j < S.p ? alpha[j] : 0) + carry;
+              if (j < S.p) cdf_o[j] = run;
+              carry = ((long long)__builtin_amdgcn_readlane((int)(run >> 32), 63) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)run, 63);
             }
           }
-          __syncthreads();
         }
+        for (int j = tid; j < S.p; j += BT) alpha_o[j] = alpha[j];
+        __syncthreads();
         if (tid == 0)
           for (int i = 0; i < nn; ++i)
-            if (snd[i].var >= 0) S.alpha_vec[snd[i].var] += 1.0;
+            if (snd[i].var >= 0) alpha_o[snd[i].var] += S.alpha_unit;
       } else {
         if (tid == 0)
           for (int i = 0; i < nn; ++i)
@@ -716,47 +732,73 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       }
     }
     if (b == 0 && tid == 0) {
-      cmd->kind = CMD_FINAL | (has_init ? CMD_INIT : 0);
       cmd->tree_old = tree_old;
-      cmd->tree_new = tree_new;
       cmd->tune = c.tune;
       cmd->rs_count = c.rs_count + (c.tune ? 1 : 0);
-      Ctrl o = c;
-      o.slot_no = c.slot_no + 1;
-      o.leaf_sd = leaf_sd;
-      o.rs_count = c.rs_count + (c.tune ? 1 : 0);
-      o.pend_leafsd = c.tune ? 1 : 0;
-      o.pend_iter = c.iter;
-      o.round = 0;
-      o.k = k_next;
-      o.lower = lower_next;
-      o.batch_n = batch_next;
-      if (has_init) {
-        o.phase = PH_ROUND;
-        o.iter = c.iter + 1;
-        if (!more) o.steps_left = c.steps_left - 1;
-      } else {
-        o.phase = PH_IDLE;
-        o.steps_left = 0;
-      }
-      if (!more) o.steps_done = c.steps_done + 1;
-      *co = o;
-      if (!more)  // progress word the host polls (the row pass of this slot is still to run)
-        __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(&S.counters[1], 1ull);
       atomicAdd(&S.counters[3], 1ull);
     }
-    if (tid == 0) {
-      Job z;
-      memset(&z, 0, sizeof z);
-      JN[p] = z;
+    if (!has_init) {  // last tree of the last requested step
+      if (b == 0 && tid == 0) {
+        cmd->kind = CMD_FINAL;
+        cmd->st_cur = c.st_cur;
+        Ctrl o = c;
+        o.slot_no = c.slot_no + 1;
+        o.leaf_sd = leaf_sd;
+        o.rs_count = c.rs_count + (c.tune ? 1 : 0);
+        o.pend_leafsd = c.tune ? 1 : 0;
+        o.pend_iter = c.iter;
+        o.round = 0;
+        o.k = k_next;
+        o.lower = lower_next;
+        o.batch_n = batch_next;
+        o.phase = PH_IDLE;
+        o.steps_left = 0;
+        o.steps_done = c.steps_done + 1;
+        if (c.tune) o.alpha_cur = c.alpha_cur ^ 1;
+        if (rebuild) o.cdf_cur = c.cdf_cur ^ 1;
+        *co = o;
+        // progress word the host polls (the row pass of this slot is still to run)
+        __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (tid == 0) {
+        Job z;
+        memset(&z, 0, sizeof z);
+        JN[p] = z;
+      }
+      return;
     }
-    return;
+  } else if (begin && b == 0) {
+    build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
   }
 
-  // =================================================================== propose round r
-  // [U] ParticleTree.sample_tree / grow_tree for new particle p
+  // =================================================================== propose
+  // [U] ParticleTree.sample_tree / grow_tree for new particle p: round r of the current tree, or
+  // round 0 of the tree this slot starts (fresh stump, [U] init_particles)
+  const int set = fresh ? 1 : 0;
+  const int rr = fresh ? 0 : r;  // round of the proposal
+  Fin F;
+  if (fresh) {
+    memset(&F, 0, sizeof F);
+    F.nn_old = 1;
+    F.n_nodes = 1;
+    F.n_leaves = 1;
+    F.next_pop = 0;
+    F.loc_gen = 0;
+    F.loc_slot = -1;
+    if (tid == 0) {  // root node; its statistics are patched in by the next slot
+      DNode z;
+      memset(&z, 0, sizeof z);
+      z.var = -1;
+      z.cc_row = -1;
+      z.cnt = (int32_t)S.n;
+      z.value = S.init_leaf;
+      me->nd[0] = z;
+    }
+  } else {
+    F = s_fin[anc];
+  }
   Job job;
   memset(&job, 0, sizeof job);
   job.src_gen = F.loc_gen;
@@ -775,9 +817,17 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     if (np < F.n_nodes) {
       atomicAdd(&S.counters[0], 1ull);
       node = np;
-      // the popped node: an old node of the ancestor, or one of the children just created
-      if (np < F.nn_old) {
-        nd = r == 0 ? me->nd[0] : OT[anc].nd[np];
+      // the popped node: the root of a fresh stump, an old node of the ancestor, or one of the
+      // children just created
+      if (fresh) {
+        nd.var = -1;
+        nd.cc_row = -1;
+        nd.cnt = (int32_t)S.n;
+        nd.value = S.init_leaf;
+      } else if (np < F.nn_old) {
+        nd = OT[anc].nd[np];
+        if (r == 1 && np == 0) nd.q_st = ia.A, nd.q_r = ia.B, nd.q_r2 = ia.C,
+            nd.sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
       } else {
         const bool isL = np == F.nn_old;
         nd.var = -1;
@@ -792,7 +842,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         nd.cc_row = isL ? F.ccL : F.ccR;
       }
       double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
-      attempt = (pl < s_pre[0]) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
+      attempt = (pl < s_pre[set][0]) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
       s_i[5] = nd.cnt;
       s_i[6] = nd.cc_row;
       s_i[7] = nd.label;
@@ -807,10 +857,10 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   TR(5);
   if (attempt) {
     const int ncnt = s_i[5], ncc = s_i[6], nlabel = s_i[7];
-    // Everything below runs on wave 0 only (no workgroup barriers): split variable, then the
-    // k-th row (ascending) of the leaf, k = floor(u * cnt)   ([U] get_split_value)
+    // Everything below runs on wave 0 only (no workgroup barriers): the k-th row (ascending) of
+    // the leaf, k = floor(u * cnt)   ([U] get_split_value)
     if (tid < 64) {
-      const int j = s_i[2];
+      const int j = s_i[8 + set];
       const double* xc = S.XT + (size_t)j * S.n_pad;
       const uint8_t* lid =
           job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
@@ -829,7 +879,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         pre = wave_incl_scan(part) - part;
       }
       for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
-        long long k = (long long)(s_pre[1 + tr] * (double)ncnt);
+        long long k = (long long)(s_pre[set][1 + tr] * (double)ncnt);
         if (k > ncnt - 1) k = ncnt - 1;
         long long row;
         if (lid == nullptr) {
@@ -882,13 +932,12 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       }
       if (tid == 0) {
         s_i[0] = found;
-        s_i[2] = j;
         s_d[0] = v;
       }
     }
     __syncthreads();
     if (s_i[0]) {
-      const int j = s_i[2];
+      const int j = s_i[8 + set];
       job.active = 1;
       job.node = node;
       job.label = nlabel;
@@ -896,7 +945,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       job.var = j;
       job.rule = S.rules[j];
       job.check_nan = S.col_nan[j];
-      job.ccL = ((r * MAXP + p) * 2);
+      job.ccL = ((rr * MAXP + p) * 2);
       job.ccR = job.ccL + 1;
       job.cnt = ncnt;
       job.v = s_d[0];
@@ -936,17 +985,45 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   }
 #endif
   if (b == 0 && tid == 0) {
-    cmd->kind = CMD_PARTITION;
     cmd->dst_gen = (c.lid_gen + 1) % NGEN;
+    cmd->st_cur = c.st_cur;
     Ctrl o = c;
     o.slot_no = c.slot_no + 1;
     o.leaf_sd = leaf_sd;
     o.pend_leafsd = 0;
-    o.round = r + 1;
     o.lid_gen = (c.lid_gen + 1) % NGEN;
-    if (r == 0) o.sse0 = (double)ia.E0 * S.sc.inv_c2;  // [U] init_particles: weight of p0
+    o.sse0 = sse0;
+    o.phase = PH_ROUND;
+    if (!fresh) {
+      cmd->kind = CMD_PARTITION;
+      o.round = r + 1;
+      atomicAdd(&S.counters[3], 1ull);  // round r-1 is complete
+    } else {
+      // this slot starts a tree: FINAL of the previous one (if any) + INIT + round 0 in one row pass
+      cmd->kind = (stop ? CMD_FINAL : 0) | CMD_INIT | CMD_PARTITION;
+      cmd->tree_new = tree_new;
+      o.round = 1;
+      o.iter = c.iter + 1;
+      o.st_cur = c.st_cur ^ 1;  // INIT writes sum_trees_noi into the other buffer
+      if (stop) {
+        o.rs_count = c.rs_count + (c.tune ? 1 : 0);
+        o.pend_leafsd = c.tune ? 1 : 0;
+        o.pend_iter = c.iter;
+        o.k = k_next;
+        o.lower = lower_next;
+        o.batch_n = batch_next;
+        if (!more) {
+          o.steps_left = c.steps_left - 1;
+          o.steps_done = c.steps_done + 1;
+        }
+        if (c.tune) o.alpha_cur = c.alpha_cur ^ 1;
+        if (rebuild) o.cdf_cur = c.cdf_cur ^ 1;
+      }
+    }
     *co = o;
-    if (r > 0) atomicAdd(&S.counters[3], 1ull);
+    if (fresh && stop && !more)  // a step completed (its FINAL runs in this slot's row pass)
+      __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -981,8 +1058,26 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
   const int kind = cmd->kind;
   if (kind == CMD_NOOP) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
+  const bool do_part = (kind & CMD_PARTITION) != 0;
 
-  if (kind == CMD_PARTITION) {
+  if (do_final || do_init) {
+    for (int i = tid; i < 256; i += BT) {
+      s_lv[0][i] = cmd->lv_new[i];
+      s_lv[1][i] = cmd->lv_next[i];
+    }
+  }
+  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
+  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
+  const uint8_t* sel_lid =
+      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
+  const double cntf = (double)cmd->rs_count;
+  // sum_trees buffers: an INIT reads st_in and writes sum_trees_noi to st_out (other workgroups of
+  // the same chunk still read st_in); a lone FINAL updates st_in in place
+  double* const st_in = S.st + (size_t)cmd->st_cur * S.n_pad;
+  double* const st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad;
+
+  if (do_part) {
     const Job* jobs = S.jobs + (size_t)par * MAXP;
     // list of particles with work in this pass (split or forced label refresh); their job
     // fields are cached in LDS once per workgroup
@@ -1013,28 +1108,92 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
     }
     __syncthreads();
     const int nact = s_n[0];
-    if (nact == 0) return;
+    if (nact == 0 && !do_init) return;
     int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
     if (G < 1) G = 1;
-    const int ngroups = (nact + G - 1) / G;
+    int ngroups = (nact + G - 1) / G;
+    if (ngroups < 1) ngroups = 1;  // an INIT must run even if no particle splits
     const int nitems = S.nchunks * ngroups;
     uint8_t* __restrict__ const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
     const uint8_t* __restrict__ const lid0 = S.lid;
     const double* __restrict__ const XT = S.XT;
     const double c1 = S.sc.c1, c2 = S.sc.c2;
     const long long n = S.n, n_pad = S.n_pad;
+    long long iv[5] = {0, 0, 0, 0, 0};  // INIT/FINAL statistics: A, B, C, E0, QSTD
+    unsigned sat = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
       const int chunk = item % S.nchunks, grp = item / S.nchunks;
       const long long base = (long long)chunk * CH + tid * RPT;
+      double2 sr[RPT];
+      if (do_init) {
+        // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
+        // residuals (INIT) on the fly; the first group of each chunk also writes them back
+        const bool writer = grp == 0;
+        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_sel = 0;
+        if (do_final) {
+          if (cmd->sel_slot == -2) {
+            ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
+          } else {
+            if (sel_lid) {
+              ids_sel = *(const uint32_t*)(sel_lid + base);
+            } else {  // untouched root: label 0 (pad rows: orphan)
+#pragma unroll
+              for (int e = 0; e < RPT; ++e)
+                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+            }
+            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+          }
+          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+        }
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          const long long row = base + e;
+          sr[e] = make_double2(0.0, 0.0);
+          if (row >= n) continue;
+          double st = st_in[row];  // sum_trees at a step boundary, sum_trees_noi inside an update
+          if (do_final) {
+            // [U] sum_trees = sum_trees_noi + new_tree.predict()
+            const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+            st = st + nv;
+            if (cmd->tune && writer) {  // [U] RunningSd.update (Welford)
+              const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+              const double delta = nv - mean0;
+              const double mean = mean0 + delta / cntf;
+              const double delta2 = nv - mean;
+              const double m2 = m20 + delta * delta2;
+              S.rs_mean[row] = mean;
+              S.rs_m2[row] = m2;
+              iv[4] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+            }
+          }
+          // [U] sum_trees_noi = sum_trees - old_tree.predict()
+          const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+          const double noi = st - o;
+          const double r = S.y[row] - noi;
+          sr[e] = make_double2(st, r);
+          if (writer) {
+            S.pack[row] = sr[e];
+            st_out[row] = noi;
+            iv[0] += pgb_quant(st, c1, &sat);
+            iv[1] += pgb_quant(r, c1, &sat);
+            iv[2] += pgb_quant(r * r, c2, &sat);
+            const double er = r - o;
+            iv[3] += pgb_quant(er * er, c2, &sat);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) sr[e] = S.pack[base + e];
+      }
       // rows of this thread: quantise once, reuse for every particle of the group.  Saturation
-      // of these very values was already counted by the INIT pass that produced `pack`.
+      // of these very values is counted where they are produced (INIT).
       long long qa[RPT], qb[RPT], qc[RPT];
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
-        const double2 sr = S.pack[base + e];
-        qa[e] = pgb_quant(sr.x, c1, nullptr);
-        qb[e] = pgb_quant(sr.y, c1, nullptr);
-        qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
+        qa[e] = pgb_quant(sr[e].x, c1, nullptr);
+        qb[e] = pgb_quant(sr[e].y, c1, nullptr);
+        qc[e] = pgb_quant(sr[e].y * sr[e].y, c2, nullptr);
       }
       uint32_t root_ids = 0;
 #pragma unroll
@@ -1122,80 +1281,57 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
       }
       __syncthreads();
     }
+    if (do_init) {  // statistics of the INIT (+FINAL) part, accumulated by the writer groups only
+      block_sum<5>(iv, s_red);
+      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (iv[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)iv[0]);
+        if (iv[1]) atomicAdd((unsigned long long*)&a->B, (unsigned long long)iv[1]);
+        if (iv[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)iv[2]);
+        if (iv[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)iv[3]);
+        if (iv[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)iv[4]);
+      }
+    }
     return;
   }
 
-  // ---------------- FINAL and/or INIT: one pass over the rows, 256 rows per item
-  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
-  for (int i = tid; i < 256; i += BT) {
-    s_lv[0][i] = cmd->lv_new[i];
-    s_lv[1][i] = cmd->lv_next[i];
-  }
+  // ---------------- lone FINAL (last tree of the last requested step): 256 rows per item
   __syncthreads();
-  long long v[5] = {0, 0, 0, 0, 0};  // A, B, C, E0, QSTD
+  long long v[5] = {0, 0, 0, 0, 0};
   unsigned sat = 0;
-  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
-  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
-  const uint8_t* sel_lid =
-      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
-  const double cntf = (double)cmd->rs_count;
-  const int nitems = (int)(S.n_pad / BT);  // 256 rows per item, one row per thread
+  const int nitems = (int)(S.n_pad / BT);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const long long row = (long long)item * BT + tid;
     if (row >= S.n) continue;
-    uint32_t id_next = do_init ? (uint32_t)tl_new[row] : 0u;
-    double st = S.st[row];  // sum_trees at a step boundary, sum_trees_noi inside a tree update
-    const double yv = do_init ? S.y[row] : 0.0;
-    if (do_final) {
-      uint32_t id_sel;
-      if (cmd->sel_slot == -2) {
-        id_sel = tl_old[row];  // old tree kept
-      } else {
-        id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;  // untouched root: label 0
-        tl_old[row] = (uint8_t)id_sel;
-      }
-      if (do_init && cmd->tree_new == cmd->tree_old) id_next = id_sel;
-      // [U] sum_trees = sum_trees_noi + new_tree.predict()
-      const double nv = s_lv[0][id_sel];
-      st = st + nv;
-      if (cmd->tune) {  // [U] RunningSd.update (Welford)
-        const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
-        const double delta = nv - mean0;
-        const double mean = mean0 + delta / cntf;
-        const double delta2 = nv - mean;
-        const double m2 = m20 + delta * delta2;
-        S.rs_mean[row] = mean;
-        S.rs_m2[row] = m2;
-        v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
-      }
-    }
-    if (do_init) {
-      // [U] sum_trees_noi = sum_trees - old_tree.predict()
-      const double o = s_lv[1][id_next];
-      const double noi = st - o;
-      const double r = yv - noi;
-      S.pack[row] = make_double2(st, r);
-      S.st[row] = noi;  // between INIT and FINAL, S.st holds sum_trees_noi
-      v[0] += pgb_quant(st, S.sc.c1, &sat);
-      v[1] += pgb_quant(r, S.sc.c1, &sat);
-      v[2] += pgb_quant(r * r, S.sc.c2, &sat);
-      const double er = r - o;
-      v[3] += pgb_quant(er * er, S.sc.c2, &sat);
+    double st = st_in[row];
+    uint32_t id_sel;
+    if (cmd->sel_slot == -2) {
+      id_sel = tl_old[row];  // old tree kept
     } else {
-      S.st[row] = st;
+      id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;  // untouched root: label 0
+      tl_old[row] = (uint8_t)id_sel;
     }
+    // [U] sum_trees = sum_trees_noi + new_tree.predict()
+    const double nv = s_lv[0][id_sel];
+    st = st + nv;
+    if (cmd->tune) {  // [U] RunningSd.update (Welford)
+      const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+      const double delta = nv - mean0;
+      const double mean = mean0 + delta / cntf;
+      const double delta2 = nv - mean;
+      const double m2 = m20 + delta * delta2;
+      S.rs_mean[row] = mean;
+      S.rs_m2[row] = m2;
+      v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
+    }
+    st_out[row] = st;
   }
   block_sum<5>(v, s_red);
   if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
-  if (tid == 0) {
+  if (tid == 0 && cmd->tune && v[4]) {
     InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
-    if (do_init) {
-      if (v[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v[0]);
-      if (v[1]) atomicAdd((unsigned long long*)&a->B, (unsigned long long)v[1]);
-      if (v[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)v[2]);
-      if (v[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v[3]);
-    }
-    if (do_final && cmd->tune && v[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
+    atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
   }
 }
 
@@ -1251,14 +1387,16 @@ __global__ void k_init_trees(DTree* trees, int m, long long n, double init_leaf)
   T->nd[0] = z;
 }
 
-__global__ void k_build_cdf(const double* alpha_vec, double* cdf, int p) {
+// integer split weights from the user's prior + their prefix sums (numeric contract:
+// pgb_alpha_init / pgb_sample_var)
+__global__ void k_init_alpha(const double* prior, double max_prior, long long* alpha, long long* cdfS, int p) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double tot = 0.0;
-    for (int j = 0; j < p; ++j) tot += alpha_vec[j];
-    double cs = 0.0;
+    long long cs = 0;
     for (int j = 0; j < p; ++j) {
-      cs += alpha_vec[j];
-      cdf[j] = cs / tot;
+      const long long a = pgb_alpha_init(prior[j], max_prior);
+      alpha[j] = a;
+      cs += a;
+      cdfS[j] = cs;
     }
   }
 }
@@ -1356,6 +1494,7 @@ struct pgb_handle {
   hipStream_t stream;
   std::vector<void*> allocs;
   long long slot;  // next slot index (parity = slot & 1)
+  int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
   int sigma_dirty;
   double inv_sigma2;
@@ -1404,6 +1543,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->s = *s;
   h->stream = (hipStream_t)stream;
   h->slot = 0;
+  h->st_cur = 0;
+  h->alpha_cur = 0;
   h->d_dev = nullptr;
   h->flag = nullptr;
   h->steps_target = 0;
@@ -1427,7 +1568,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.mdouble = (double)s->m;
   d.sc = pgb_make_scales(s->n, s->range_exp);
   int rc;
-  double *XT, *y, *st, *rs_mean, *rs_m2, *alpha_vec, *cdf, *prior_leaf;
+  double *XT, *y, *st, *rs_mean, *rs_m2, *prior_leaf;
+  long long *alpha, *cdfS;
   double2* pack;
   uint8_t *tree_lid, *lid;
   uint16_t* cc;
@@ -1436,7 +1578,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
   DA(XT, (size_t)d.p * d.n_pad);
   DA(y, d.n_pad);
-  DA(st, d.n_pad);
+  DA(st, 2 * d.n_pad);
   DA(pack, d.n_pad);
   DA(rs_mean, d.n_pad);
   DA(rs_m2, d.n_pad);
@@ -1452,14 +1594,14 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.ctrl, 2);
   DA(d.counters, 8);
   DA(vi, d.p);
-  DA(alpha_vec, d.p);
-  DA(cdf, d.p);
+  DA(alpha, 2 * d.p);
+  DA(cdfS, 2 * d.p);
   DA(prior_leaf, PGB_MAX_DEPTH);
   DA(rules, d.p);
   DA(col_nan, d.p);
 #undef DA
   d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
-  d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha_vec = alpha_vec; d.cdf = cdf;
+  d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha = alpha; d.cdfS = cdfS;
   d.rules = rules; d.col_nan = col_nan; d.prior_leaf = prior_leaf;
   hipStream_t sm = h->stream;
   hipError_t e;
@@ -1507,8 +1649,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   c0.inv_sigma2 = 1.0;
   Ctrl cc2[2] = {c0, c0};
   HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
-  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, sm, st, d.n_pad,
-                     s->init_sum);
+  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((2 * d.n_pad + 255) / 256)), dim3(256), 0, sm, st,
+                     2 * d.n_pad, s->init_sum);
   hipLaunchKernelGGL(k_init_tree_lid, dim3((unsigned)((d.n_pad * d.m + 255) / 256)), dim3(256), 0, sm,
                      tree_lid, d.n, d.n_pad, d.m);
   hipLaunchKernelGGL(k_init_trees, dim3((d.m + 63) / 64), dim3(64), 0, sm, d.trees, d.m, d.n,
@@ -1535,21 +1677,36 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
   Dev& d = h->d;
   if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
+  double mx = 0.0;
   for (int j = 0; j < d.p; ++j) {
     if (rules_host[j] != PGB_RULE_CONTINUOUS && rules_host[j] != PGB_RULE_ONEHOT)
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
     if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
+    if (split_prior_host[j] > mx) mx = split_prior_host[j];
   }
+  d.max_prior = mx;
+  d.alpha_unit = pgb_alpha_unit(mx);
   hipStream_t sm = h->stream;
   HIPCHK(hipMemcpyAsync((void*)d.rules, rules_host, d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
-  HIPCHK(hipMemcpyAsync(d.alpha_vec, split_prior_host, d.p * sizeof(double), hipMemcpyHostToDevice, sm));
+  // the prior is staged in the (not yet used) running-sd buffer and quantised on the device
+  HIPCHK(hipMemcpyAsync(d.rs_mean, split_prior_host, (size_t)(d.p < d.n_pad ? d.p : 0) * sizeof(double),
+                        hipMemcpyHostToDevice, sm));
   HIPCHK(hipMemsetAsync((void*)d.col_nan, 0, d.p * sizeof(int32_t), sm));
   dim3 grid((unsigned)(d.n_pad / 32), (unsigned)((d.p + 31) / 32));
   hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
                      d.n_pad, d.p, (int32_t*)d.col_nan);
-  hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(64), 0, sm, d.alpha_vec, d.cdf, d.p);
+  double* prior_stage = nullptr;
+  if (d.p >= d.n_pad) {  // more columns than padded rows: stage through a temporary
+    HIPCHK(hipMalloc((void**)&prior_stage, d.p * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(prior_stage, split_prior_host, d.p * sizeof(double), hipMemcpyHostToDevice, sm));
+  }
+  hipLaunchKernelGGL(k_init_alpha, dim3(1), dim3(64), 0, sm, prior_stage ? prior_stage : d.rs_mean, mx,
+                     d.alpha, d.cdfS, d.p);
+  HIPCHK(hipMemsetAsync(d.rs_mean, 0, d.n_pad * sizeof(double), sm));
+  HIPCHK(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));  // alpha_unit, max_prior
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(sm));
+  if (prior_stage) (void)hipFree(prior_stage);
   h->have_data = 1;
   return PGB_OK;
 }
@@ -1641,6 +1798,8 @@ static int run_until_idle(pgb_handle* h, int n_steps) {
   Ctrl c;
   HIPCHK(hipMemcpy(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost));
   if (c.phase != PH_IDLE) return fail(PGB_E_STATE, "device not idle after the progress flag fired");
+  h->st_cur = c.st_cur;
+  h->alpha_cur = c.alpha_cur;
   return PGB_OK;
 }
 
@@ -1685,8 +1844,8 @@ extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, 
   if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
   if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
   if (sum_trees_dev_out)
-    HIPCHK(hipMemcpyAsync(sum_trees_dev_out, h->d.st, h->d.n * sizeof(double), hipMemcpyDeviceToDevice,
-                          h->stream));
+    HIPCHK(hipMemcpyAsync(sum_trees_dev_out, h->d.st + (size_t)h->st_cur * h->d.n_pad, h->d.n * sizeof(double),
+                          hipMemcpyDeviceToDevice, h->stream));
   if (vi_counts_host_out)
     HIPCHK(hipMemcpyAsync(vi_counts_host_out, h->d.vi, h->d.p * sizeof(int32_t), hipMemcpyDeviceToHost,
                           h->stream));
@@ -1766,8 +1925,12 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
 
 extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
-  HIPCHK(hipMemcpyAsync(out, h->d.alpha_vec, h->d.p * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<long long> a((size_t)h->d.p);
+  HIPCHK(hipMemcpyAsync(a.data(), h->d.alpha + (size_t)h->alpha_cur * h->d.p, h->d.p * sizeof(long long),
+                        hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  // in units of the caller's prior: prior_j + number of tuning counts (up to 2^-24 rounding)
+  for (int j = 0; j < h->d.p; ++j) out[j] = (double)a[j] * (h->d.max_prior * pgb_pow2(-PGB_ALPHA_BITS));
   return PGB_OK;
 }
 
