@@ -160,8 +160,13 @@ struct Dev {  // kernel argument block (by value)
     if (blockIdx.x == 1 && threadIdx.x == 0)                                               \
       S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64();         \
   } while (0)
+#define TRX(i, cond)                                                                       \
+  do {                                                                                     \
+    if (cond) S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64(); \
+  } while (0)
 #else
 #define TR(i) ((void)0)
+#define TRX(i, cond) ((void)0)
 #endif
 
 // ------------------------------------------------------------------ device helpers
@@ -453,6 +458,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     const double u1 = readlane_d(u.u1, 0);
     const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
     if (l == 0) s_i[8 + set] = jj;
+    TRX(9 + set, blockIdx.x == 1 && l == 0);
   }
 
   int anc = p;  // ancestor (old particle index) of new particle p
@@ -778,16 +784,19 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   // round 0 of the tree this slot starts (fresh stump, [U] init_particles)
   const int set = fresh ? 1 : 0;
   const int rr = fresh ? 0 : r;  // round of the proposal
-  Fin F;
   if (fresh) {
-    memset(&F, 0, sizeof F);
-    F.nn_old = 1;
-    F.n_nodes = 1;
-    F.n_leaves = 1;
-    F.next_pop = 0;
-    F.loc_gen = 0;
-    F.loc_slot = -1;
-    if (tid == 0) {  // root node; its statistics are patched in by the next slot
+    __syncthreads();  // every reader of s_fin[] of the finished tree is done
+    if (tid == 0) {  // slot 0 of s_fin is never a particle: it holds the fresh stump
+      Fin f0;
+      memset(&f0, 0, sizeof f0);
+      f0.nn_old = 1;
+      f0.n_nodes = 1;
+      f0.n_leaves = 1;
+      f0.next_pop = 0;
+      f0.loc_gen = 0;
+      f0.loc_slot = -1;
+      s_fin[0] = f0;
+      // root node; its statistics are patched in by the next slot
       DNode z;
       memset(&z, 0, sizeof z);
       z.var = -1;
@@ -796,9 +805,9 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       z.value = S.init_leaf;
       me->nd[0] = z;
     }
-  } else {
-    F = s_fin[anc];
+    __syncthreads();
   }
+  const Fin& F = s_fin[fresh ? 0 : anc];
   Job job;
   memset(&job, 0, sizeof job);
   job.src_gen = F.loc_gen;
@@ -1024,6 +1033,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     if (fresh && stop && !more)  // a step completed (its FINAL runs in this slot's row pass)
       __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
+    TRX(11, true);
   }
 }
 
@@ -1048,7 +1058,7 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
 };
 
-__global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int par) {
+__global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 7 * 4];
   __shared__ double s_lv[2][256];
@@ -1124,7 +1134,8 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
       const int chunk = item % S.nchunks, grp = item / S.nchunks;
       const long long base = (long long)chunk * CH + tid * RPT;
-      double2 sr[RPT];
+      // rows of this thread: {sum_trees, r} quantised once, reused for every particle of the group
+      long long qa[RPT], qb[RPT], qc[RPT];
       if (do_init) {
         // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
         // residuals (INIT) on the fly; the first group of each chunk also writes them back
@@ -1149,7 +1160,7 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
           const long long row = base + e;
-          sr[e] = make_double2(0.0, 0.0);
+          qa[e] = qb[e] = qc[e] = 0;
           if (row >= n) continue;
           double st = st_in[row];  // sum_trees at a step boundary, sum_trees_noi inside an update
           if (do_final) {
@@ -1171,29 +1182,29 @@ __global__ __launch_bounds__(BT, 4) void k_rows(const Dev* __restrict__ Sp, int 
           const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
           const double noi = st - o;
           const double r = S.y[row] - noi;
-          sr[e] = make_double2(st, r);
-          if (writer) {
-            S.pack[row] = sr[e];
+          unsigned sat1 = 0;
+          qa[e] = pgb_quant(st, c1, &sat1);
+          qb[e] = pgb_quant(r, c1, &sat1);
+          qc[e] = pgb_quant(r * r, c2, &sat1);
+          if (writer) {  // saturation is counted where the values are produced, once
+            S.pack[row] = make_double2(st, r);
             st_out[row] = noi;
-            iv[0] += pgb_quant(st, c1, &sat);
-            iv[1] += pgb_quant(r, c1, &sat);
-            iv[2] += pgb_quant(r * r, c2, &sat);
+            sat += sat1;
+            iv[0] += qa[e];
+            iv[1] += qb[e];
+            iv[2] += qc[e];
             const double er = r - o;
             iv[3] += pgb_quant(er * er, c2, &sat);
           }
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < RPT; ++e) sr[e] = S.pack[base + e];
-      }
-      // rows of this thread: quantise once, reuse for every particle of the group.  Saturation
-      // of these very values is counted where they are produced (INIT).
-      long long qa[RPT], qb[RPT], qc[RPT];
-#pragma unroll
-      for (int e = 0; e < RPT; ++e) {
-        qa[e] = pgb_quant(sr[e].x, c1, nullptr);
-        qb[e] = pgb_quant(sr[e].y, c1, nullptr);
-        qc[e] = pgb_quant(sr[e].y * sr[e].y, c2, nullptr);
+        for (int e = 0; e < RPT; ++e) {
+          const double2 sr = S.pack[base + e];
+          qa[e] = pgb_quant(sr.x, c1, nullptr);
+          qb[e] = pgb_quant(sr.y, c1, nullptr);
+          qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
+        }
       }
       uint32_t root_ids = 0;
 #pragma unroll
