@@ -148,13 +148,23 @@ def main():
         rt = cp1["rows_touched"] - cp0["rows_touched"]
         alg = workloads.bytes_per_tree_update(n, rt / max(tu, 1)) * tu
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM traffic per launch cannot be measured inside this process: it comes from the PMC
+        # passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command,
+        # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); only for the default config
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40):
+            traffic = json.load(open(pmc))["k_rows"]["hbm_bytes_per_launch_corrected"]
         roofline = {
             "bound": "hbm", "kernel": "k_rows", "achieved": ach, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
             "algorithmic_bytes_per_launch": alg / max(launches, 1),
-            "note": "algorithmic bytes = sum over tree updates of 48 n + 40 rows_touched "
-                    "(SURVEY.md 8d) / k_rows launches; HIP events on the sampler's stream",
+            "note": "achieved = algorithmic bytes (sum over tree updates of 48 n + 40 rows_touched, "
+                    "SURVEY.md 8d) / total k_rows time from HIP events on the sampler's stream; "
+                    "traffic = HBM bytes per k_rows launch from profiles/r01_pmc_traffic.json: well "
+                    "BELOW the algorithmic bytes because the 39 particles share the X columns and "
+                    "{sum_trees, r} through L2 / Infinity Cache at this size",
         }
 
     # end-of-run gather of the draws (the only collective; outside the timed region)
