@@ -255,6 +255,53 @@ PGB_HD void pgb_normal2(double u0, double u1, double* z0, double* z1) {
   *z1 = rad * s;
 }
 
+/* ------------------------------------------------------------------ log-likelihoods */
+/* log Phi(x) (standard normal CDF), deterministic: |x|/sqrt2 < 2.5 -> positive-term series
+ * erf(z) = 2/sqrt(pi) e^{-z^2} sum_n 2^n z^(2n+1)/(2n+1)!! (40 terms, reciprocals tabulated);
+ * otherwise the continued fraction of erfc evaluated by the division-free forward recurrence
+ * (48 steps).  Absolute error < 3e-12 against scipy.special.log_ndtr on [-38, 10]. */
+PGB_HD double pgb_log_ndtr(double x) {
+  const double rodd[40] = {0.3333333333333333, 0.2, 0.14285714285714285, 0.1111111111111111, 0.09090909090909091, 0.07692307692307693, 0.06666666666666667, 0.058823529411764705, 0.05263157894736842, 0.047619047619047616, 0.043478260869565216, 0.04, 0.037037037037037035, 0.034482758620689655, 0.03225806451612903, 0.030303030303030304, 0.02857142857142857, 0.02702702702702703, 0.02564102564102564, 0.024390243902439025, 0.023255813953488372, 0.022222222222222223, 0.02127659574468085, 0.02040816326530612, 0.0196078431372549, 0.018867924528301886, 0.01818181818181818, 0.017543859649122806, 0.01694915254237288, 0.01639344262295082, 0.015873015873015872, 0.015384615384615385, 0.014925373134328358, 0.014492753623188406, 0.014084507042253521, 0.0136986301369863, 0.013333333333333334, 0.012987012987012988, 0.012658227848101266, 0.012345679012345678};
+  const double z = (x < 0.0 ? -x : x) * 0.70710678118654752440;
+  if (z < 2.5) {
+    double t = z, s = z;
+    const double z2 = 2.0 * z * z;
+    for (int n = 0; n < 40; ++n) {
+      t = (t * z2) * rodd[n];
+      s = s + t;
+    }
+    const double erf = (1.1283791670955125739 * pgb_exp(-(z * z))) * s;
+    return x >= 0.0 ? pgb_log(0.5 + 0.5 * erf) : pgb_log(0.5 * (1.0 - erf));
+  }
+  const double a = 1.0 / (2.0 * z * z);
+  double Am = 1.0, A = 1.0, Bm = 0.0, B = 1.0;
+  for (int k = 1; k <= 48; ++k) {
+    const double ak = (double)k * a;
+    const double An = A + ak * Am, Bn = B + ak * Bm;
+    Am = A; A = An;
+    Bm = B; B = Bn;
+  }
+  const double logerfc = (-(z * z) - pgb_log(z * 1.7724538509055160273)) + pgb_log(B / A);
+  return x >= 0.0 ? pgb_log(1.0 - 0.5 * pgb_exp(logerfc)) : (-0.69314718055994530942 + logerfc);
+}
+
+/* log(1 + e^t) */
+PGB_HD double pgb_softplus(double t) {
+  if (t > 36.0) return t;
+  return pgb_log(1.0 + pgb_exp(t));
+}
+
+/* Per-row log-likelihood of the closed families with one linear predictor mu (K = 1).
+ * y is the observed response (0/1 for the Bernoulli families).  Clamped to [-2047, 0] so that
+ * n terms fit the fixed-point accumulator (scale cl). */
+PGB_HD double pgb_loglik1(int family, double y, double mu) {
+  const double smu = y > 0.5 ? mu : -mu;
+  double ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr(smu) : -pgb_softplus(-smu);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 0.0) ll = 0.0;
+  return ll;
+}
+
 /* ------------------------------------------------------------------ fixed point */
 /* q = round-to-nearest-even(x * 2^s) saturated to |q| <= 2^50, via the 1.5*2^52
  * trick (exact for |x*2^s| < 2^51).  `scale` = 2^s.  NaN -> 0.  `sat` (may be

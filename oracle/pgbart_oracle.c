@@ -69,12 +69,14 @@ typedef struct {
   int64_t cnt;
   int64_t q_st, q_r, q_r2; /* fixed-point sums over the node rows */
   double value, sse;
+  int64_t ll;  /* Bernoulli families: fixed-point log-likelihood of the node's rows */
   int64_t seg; /* arena offset of the sorted row list (oracle only) */
 } onode;
 
 typedef struct {
   int32_t n_nodes, n_leaves, next_pop;
   double sse_tot, sse_orph;
+  int64_t ll_tot, ll_orph; /* Bernoulli families */
   onode nd[MAXN];
 } otree;
 
@@ -109,7 +111,8 @@ struct pgb_handle {
   int32_t* last_ids;
   int32_t n_last;
   pgb_counters ctr;
-  double sse0; /* reference particle */
+  double sse0; /* reference particle (Normal) */
+  int64_t ll0; /* reference particle (Bernoulli families) */
   int have_data, have_y;
 };
 
@@ -120,6 +123,8 @@ static void copy_tree(otree* d, const otree* s) {
   d->next_pop = s->next_pop;
   d->sse_tot = s->sse_tot;
   d->sse_orph = s->sse_orph;
+  d->ll_tot = s->ll_tot;
+  d->ll_orph = s->ll_orph;
   memcpy(d->nd, s->nd, sizeof(onode) * (size_t)s->n_nodes);
 }
 
@@ -159,7 +164,9 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
     return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
   if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
-  if (s->family != PGB_FAMILY_NORMAL) return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->family != PGB_FAMILY_NORMAL && s->family != PGB_FAMILY_BERNOULLI_PROBIT &&
+      s->family != PGB_FAMILY_BERNOULLI_LOGIT)
+    return fail(PGB_E_UNSUPPORTED, "family not supported yet");
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
   pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
   if (!h) return fail(PGB_E_NOMEM, "calloc");
@@ -260,6 +267,8 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
   if (h->s.family == PGB_FAMILY_NORMAL) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+  } else if (n_params != 0) {
+    return fail(PGB_E_INVALID, "this family has no parameters");
   }
   return PGB_OK;
 }
@@ -277,20 +286,29 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
   const uint8_t* lid = h->lid + (size_t)tree_id * n;
   unsigned sat = 0;
   int64_t A = 0, B = 0, C = 0, E0 = 0;
+  const int normal = s->family == PGB_FAMILY_NORMAL;
   for (int64_t i = 0; i < n; ++i) {
     double o = lv[lid[i]];
     double noi = h->st[i] - o;
-    double r = h->y[i] - noi;
     h->oldv[i] = o;
-    h->r[i] = r;
     A += pgb_quant(h->st[i], h->sc.c1, &sat);
-    B += pgb_quant(r, h->sc.c1, &sat);
-    C += pgb_quant(r * r, h->sc.c2, &sat);
-    double e = r - o;
-    E0 += pgb_quant(e * e, h->sc.c2, &sat);
+    if (normal) {
+      double r = h->y[i] - noi;
+      h->r[i] = r;
+      B += pgb_quant(r, h->sc.c1, &sat);
+      C += pgb_quant(r * r, h->sc.c2, &sat);
+      double e = r - o;
+      E0 += pgb_quant(e * e, h->sc.c2, &sat);
+    } else {
+      /* Bernoulli families: C = log-lik of a fresh stump, E0 = log-lik of the current tree */
+      h->r[i] = 0.0;
+      C += pgb_quant(pgb_loglik1(s->family, h->y[i], noi + s->init_leaf), h->sc.cl, &sat);
+      E0 += pgb_quant(pgb_loglik1(s->family, h->y[i], h->st[i]), h->sc.cl, &sat);
+    }
   }
   h->ctr.saturations += sat;
   h->sse0 = (double)E0 * h->sc.inv_c2;
+  h->ll0 = E0;
   h->arena_len = n; /* keep the root segment, drop everything else */
   for (int q = 1; q < s->num_particles; ++q) {
     otree* Pq = &h->part[q];
@@ -309,10 +327,27 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
     z->q_r2 = C;
     z->value = s->init_leaf;
     z->sse = pgb_leaf_sse(n, B, C, z->value, h->sc.inv_c1, h->sc.inv_c2);
+    z->ll = C;
     z->seg = 0;
     Pq->sse_tot = z->sse;
     Pq->sse_orph = 0.0;
+    Pq->ll_tot = C;
+    Pq->ll_orph = 0;
   }
+}
+
+/* Bernoulli families: fixed-point log-likelihood of `cnt` rows predicting `v` from this tree
+ * ([U] update_weight restricted to the rows whose prediction changed). */
+static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, double v) {
+  unsigned sat = 0;
+  int64_t acc = 0;
+  for (int64_t k = 0; k < cnt; ++k) {
+    int32_t i = seg[k];
+    double noi = h->st[i] - h->oldv[i];
+    acc += pgb_quant(pgb_loglik1(h->s.family, h->y[i], noi + v), h->sc.cl, &sat);
+  }
+  h->ctr.saturations += sat;
+  return acc;
 }
 
 /* [U] ParticleTree.sample_tree + grow_tree for particle q in round `round`. */
@@ -355,6 +390,9 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   int32_t* sr = h->arena + offR;
   int64_t cL = 0, cR = 0, cN = 0;
   int64_t aL = 0, bL = 0, c2L = 0, aN = 0, bN = 0, c2N = 0;
+  const int normal = s->family == PGB_FAMILY_NORMAL;
+  int32_t* sn = NULL; /* NaN-dropped rows (Bernoulli families need their log-likelihood) */
+  if (!normal && h->col_has_nan[j]) sn = (int32_t*)malloc(sizeof(int32_t) * (size_t)nd.cnt);
   for (int64_t k = 0; k < nd.cnt; ++k) {
     int32_t i = seg[k];
     double x = xc[i];
@@ -363,6 +401,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     int64_t qb = pgb_quant(h->r[i], h->sc.c1, NULL);
     int64_t qc = pgb_quant(h->r[i] * h->r[i], h->sc.c2, NULL);
     if (x != x) {
+      if (sn) sn[cN] = i;
       cN++; aN += qa; bN += qb; c2N += qc;
     } else if (rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v)) {
       sl[cL++] = i; aL += qa; bL += qb; c2L += qc;
@@ -380,6 +419,14 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     double new_sse = pgb_leaf_sse(cL, bL, c2L, nd.value, h->sc.inv_c1, h->sc.inv_c2);
     T->sse_orph += (double)c2N * h->sc.inv_c2;
     T->sse_tot = (T->sse_tot - nd.sse) + new_sse;
+    if (!normal) {
+      int64_t llL = o_seg_loglik(h, sl, cL, nd.value);
+      int64_t llN = sn ? o_seg_loglik(h, sn, cN, 0.0) : 0;
+      T->ll_orph += llN;
+      T->ll_tot = (T->ll_tot - nd.ll) + llL;
+      pn->ll = llL;
+      free(sn);
+    }
     pn->cnt = cL;
     pn->q_st = aL;
     pn->q_r = bL;
@@ -416,11 +463,21 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   a->sse = pgb_leaf_sse(cL, bL, c2L, a->value, h->sc.inv_c1, h->sc.inv_c2);
   b->sse = pgb_leaf_sse(cR, bR, c2R, b->value, h->sc.inv_c1, h->sc.inv_c2);
   T->sse_tot = ((T->sse_tot - nd.sse) + a->sse) + b->sse;
+  if (!normal) {
+    sl = h->arena + offL;
+    sr = h->arena + offR;
+    a->ll = o_seg_loglik(h, sl, cL, a->value);
+    b->ll = o_seg_loglik(h, sr, cR, b->value);
+    if (sn) T->ll_orph += o_seg_loglik(h, sn, cN, 0.0);
+    T->ll_tot = ((T->ll_tot - nd.ll) + a->ll) + b->ll;
+    free(sn);
+  }
   T->n_nodes += 2;
   T->n_leaves += 1;
 }
 
 static double o_logw(const pgb_handle* h, const otree* T) {
+  if (h->s.family != PGB_FAMILY_NORMAL) return (double)(T->ll_tot + T->ll_orph) * h->sc.inv_cl;
   return (T->sse_tot + T->sse_orph) * (-0.5 * h->inv_sigma2);
 }
 
@@ -447,7 +504,7 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   int64_t n = s->n;
   int P = s->num_particles;
   double lw[64], W[64];
-  lw[0] = h->sse0 * (-0.5 * h->inv_sigma2);
+  lw[0] = s->family == PGB_FAMILY_NORMAL ? h->sse0 * (-0.5 * h->inv_sigma2) : (double)h->ll0 * h->sc.inv_cl;
   for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
   pgb_weights_scan(lw, 0, P, W);
   pgb_u2 u = pgb_draw2(s->seed, (uint32_t)h->iter, 0, 0, PGB_RNG_FINAL, 0);
@@ -702,4 +759,10 @@ int pgbo_pick(const double* lw, int first, int cnt, double u, double* W_out) {
   pgb_weights_scan(lw, first, cnt, W);
   if (W_out) memcpy(W_out, W, sizeof W);
   return pgb_pick(W, first, cnt, u);
+}
+void pgbo_loglik(int family, const double* y, const double* mu, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik1(family, y[i], mu[i]);
+}
+void pgbo_log_ndtr(const double* x, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = pgb_log_ndtr(x[i]);
 }

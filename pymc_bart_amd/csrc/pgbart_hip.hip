@@ -79,12 +79,18 @@ struct Job {  // one particle's work for a PARTITION row pass + what the next k_
   double h_sse_tot, h_sse_orph;
   int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
   int32_t pad_;
+  // Bernoulli families: fixed-point log-likelihoods instead of the SSE algebra
+  long long p_ll, h_ll_tot, h_ll_orph;
 };
 
 struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right = parent - both)
   unsigned long long cnts;  // cntL | cntN << 32
   long long aL, bL, c2L, aN, bN, c2N;
   long long pad;
+  // Bernoulli families (k_loglik): log-likelihood of the left / right children and of the rows
+  // dropped by a missing split value (all three on their own cache line)
+  long long llL, llR, llN;
+  long long pad2[5];
 };
 
 #define IA_SLOTS 8 /* the row pass spreads its atomics over this many cache lines */
@@ -121,6 +127,7 @@ struct Dev {  // kernel argument block (by value)
   long long n, n_pad;
   int32_t p, m, P, nchunks;
   int32_t batch_tune, batch_draw;
+  int32_t family, pad_family;
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
@@ -309,6 +316,37 @@ __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_ste
   for (int j = threadIdx.x; j < S.p; j += blockDim.x) S.vi[j] = 0;
 }
 
+
+// Leaf values of the two children a PARTITION pass created for one particle ([U] draw_leaf_value),
+// from the pass statistics.  Shared by k_ctrl (which stores them) and k_loglik (which needs them
+// one launch earlier) so that both evaluate EXACTLY the same expressions.
+struct ChildVals {
+  int ok;  // 1: split, -1: failed one-hot split (the node stays a leaf and keeps its value)
+  int cL, cR, cN;
+  long long aL, aR;
+  double vL, vR;
+};
+__device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cnt, long long p_q_st,
+                                                  double p_value, const Acc& a, double z0, double z1,
+                                                  double leaf_sd) {
+  ChildVals c;
+  c.cL = (int)(a.cnts & 0xFFFFFFFFull);
+  c.cN = (int)(a.cnts >> 32);
+  c.cR = cnt - c.cL - c.cN;
+  c.aL = a.aL;
+  c.aR = p_q_st - a.aL - a.aN;
+  if (rule == PGB_RULE_ONEHOT && c.cR == 0) {
+    c.ok = -1;
+    c.vL = p_value;
+    c.vR = 0.0;
+  } else {
+    c.ok = 1;
+    c.vL = pgb_leaf_value(c.cL, c.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
+    c.vR = pgb_leaf_value(c.cR, c.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
+  }
+  return c;
+}
+
 // ------------------------------------------------------------------ k_ctrl
 struct Fin {  // result of finishing the pending split of an old particle (kept in LDS)
   int ok;     // 1: children created, 0: no pending split, -1: failed one-hot split
@@ -318,6 +356,7 @@ struct Fin {  // result of finishing the pending split of an old particle (kept 
   int node, var, new_label, ccL, ccR;
   uint8_t depth, label;
   long long aL, aR, bL, bR, c2L, c2R;
+  long long llL, llR, ll_tot, ll_orph;  // Bernoulli families
   double split, vL, vR, sseL, sseR, sse_tot, sse_orph;
 };
 
@@ -433,6 +472,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   }
 
   const bool begin = c.phase == PH_BEGIN;  // first tree of a step: nothing to finish
+  const bool normal = S.family == PGB_FAMILY_NORMAL;
   TR(1);
   const int r = c.round;  // >= 1 in PH_ROUND: round 0 is proposed by the slot that starts the tree
   const uint32_t it = (uint32_t)c.iter;
@@ -471,7 +511,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     // together with round 0; they are patched in here (round 1)
     const bool r1 = r == 1;
     const double root_sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
-    if (r1) sse0 = (double)ia.E0 * S.sc.inv_c2;  // weight of the reference particle p0
+    // weight of the reference particle p0: its SSE (Normal) or its log-likelihood (Bernoulli)
+    if (r1) sse0 = (double)ia.E0 * (normal ? S.sc.inv_c2 : S.sc.inv_cl);
     // -------- wave 0: finish round r-1 for every old particle (lane q <-> old particle q),
     //          then decide stop / ancestor / final choice
     if (tid < 64) {
@@ -504,6 +545,9 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
           j.p_sse = root_sse;
           j.h_sse_tot = root_sse;
           j.h_sse_orph = 0.0;
+          j.p_ll = ia.C;  // Bernoulli families: C carries the stump's log-likelihood
+          j.h_ll_tot = ia.C;
+          j.h_ll_orph = 0;
         }
         f.nn_old = j.h_n_nodes;
         f.n_nodes = j.h_n_nodes;
@@ -518,47 +562,51 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
           f.loc_gen = c.lid_gen;
           f.loc_slot = q;
         }
+        f.ll_tot = j.h_ll_tot;
+        f.ll_orph = j.h_ll_orph;
         if (j.active) {
-          const int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32);
-          const int cR = j.cnt - cL - cN;
+          const ChildVals cv = child_values(S, j.rule, j.cnt, j.p_q_st, j.p_value, a, z0, z1, leaf_sd);
+          const int cL = cv.cL, cR = cv.cR;
           f.loc_gen = c.lid_gen;  // the row pass wrote this particle's labels here
           f.loc_slot = q;
-          if (j.rule == PGB_RULE_ONEHOT && cR == 0) {
+          f.ok = cv.ok;
+          f.node = j.node;
+          f.cL = cL;
+          f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
+          f.ccL = j.ccL;
+          f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
+          f.ll_orph = j.h_ll_orph + a.llN;
+          f.llL = a.llL;
+          if (cv.ok == -1) {
             // [U] a one-hot split needs two distinct values: the grow fails and the node stays a
             // leaf.  No row was relabelled except rows with a missing split value, which the pass
             // dropped; the leaf sheds them (identity when there are none).
-            f.ok = -1;
-            f.node = j.node;
-            f.cL = cL;
-            f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
-            f.ccL = j.ccL;
-            f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, j.p_value, S.sc.inv_c1, S.sc.inv_c2);
             f.sse_tot = (j.h_sse_tot - j.p_sse) + f.sseL;
+            f.ll_tot = (j.h_ll_tot - j.p_ll) + a.llL;
           } else {
-            f.ok = 1;
-            f.cL = cL;
             f.cR = cR;
-            f.node = j.node; f.var = j.var; f.split = j.v; f.new_label = j.new_label;
-            f.ccL = j.ccL; f.ccR = j.ccR;
+            f.var = j.var; f.split = j.v; f.new_label = j.new_label;
+            f.ccR = j.ccR;
             f.depth = (uint8_t)j.p_depth; f.label = (uint8_t)j.label;
-            f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
-            f.aR = j.p_q_st - a.aL - a.aN;
+            f.aR = cv.aR;
             f.bR = j.p_q_r - a.bL - a.bN;
             f.c2R = j.p_q_r2 - a.c2L - a.c2N;
-            f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
-            f.vL = pgb_leaf_value(cL, f.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
-            f.vR = pgb_leaf_value(cR, f.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
+            f.vL = cv.vL;
+            f.vR = cv.vR;
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
             f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
             f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
+            f.llR = a.llR;
+            f.ll_tot = ((j.h_ll_tot - j.p_ll) + a.llL) + a.llR;
             f.n_nodes = j.h_n_nodes + 2;
             f.n_leaves = j.h_n_leaves + 1;
           }
         }
         s_fin[q] = f;
         pending = f.next_pop < f.n_nodes;
-        lw = (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2);
+        lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
+                    : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
       }
       TR(2);
       stop = __ballot(pending) == 0ull;
@@ -569,7 +617,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         pick = wave_pick(lw, 1, Lc, ui);
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
-        if (q == 0) lw = sse0 * (-0.5 * c.inv_sigma2);
+        if (q == 0) lw = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
         const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
         pick = wave_pick(lw, 0, P, u_fin.u0);
       }
@@ -596,7 +644,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         DNode z = A->nd[i];
         if (r1 && i == 0) {  // root statistics (see above)
           z.q_st = ia.A;
-          z.q_r = ia.B;
+          z.q_r = normal ? ia.B : ia.C;  // Bernoulli families keep the node's log-likelihood here
           z.q_r2 = ia.C;
           z.sse = root_sse;
         }
@@ -608,7 +656,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         } else if (f.ok == -1 && i == f.node) {
           z.cnt = f.cL;
           z.q_st = f.aL;
-          z.q_r = f.bL;
+          z.q_r = normal ? f.bL : f.llL;
           z.q_r2 = f.c2L;
           z.sse = f.sseL;
           z.cc_row = f.ccL;
@@ -624,7 +672,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         z.label = isL ? f.label : (uint8_t)f.new_label;
         z.cnt = isL ? f.cL : f.cR;
         z.q_st = isL ? f.aL : f.aR;
-        z.q_r = isL ? f.bL : f.bR;
+        z.q_r = normal ? (isL ? f.bL : f.bR) : (isL ? f.llL : f.llR);
         z.q_r2 = isL ? f.c2L : f.c2R;
         z.value = isL ? f.vL : f.vR;
         z.sse = isL ? f.sseL : f.sseR;
@@ -817,6 +865,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
   job.h_next_pop = F.next_pop;
   job.h_sse_tot = F.sse_tot;
   job.h_sse_orph = F.sse_orph;
+  job.h_ll_tot = F.ll_tot;
+  job.h_ll_orph = F.ll_orph;
   bool attempt = false;
   int node = -1;
   DNode nd;
@@ -835,7 +885,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         nd.value = S.init_leaf;
       } else if (np < F.nn_old) {
         nd = OT[anc].nd[np];
-        if (r == 1 && np == 0) nd.q_st = ia.A, nd.q_r = ia.B, nd.q_r2 = ia.C,
+        if (r == 1 && np == 0) nd.q_st = ia.A, nd.q_r = normal ? ia.B : ia.C, nd.q_r2 = ia.C,
             nd.sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
       } else {
         const bool isL = np == F.nn_old;
@@ -844,7 +894,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         nd.label = isL ? F.label : (uint8_t)F.new_label;
         nd.cnt = isL ? F.cL : F.cR;
         nd.q_st = isL ? F.aL : F.aR;
-        nd.q_r = isL ? F.bL : F.bR;
+        nd.q_r = normal ? (isL ? F.bL : F.bR) : (isL ? F.llL : F.llR);
         nd.q_r2 = isL ? F.c2L : F.c2R;
         nd.sse = isL ? F.sseL : F.sseR;
         nd.value = isL ? F.vL : F.vR;
@@ -972,6 +1022,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       job.p_q_st = nd.q_st;
       job.p_q_r = nd.q_r;
       job.p_q_r2 = nd.q_r2;
+      job.p_ll = nd.q_r;  // (Bernoulli families)
       job.p_sse = nd.sse;
       job.p_value = nd.value;
       job.p_depth = nd.depth;
@@ -1070,6 +1121,7 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
   const bool do_part = (kind & CMD_PARTITION) != 0;
+  const bool normal = S.family == PGB_FAMILY_NORMAL;
 
   if (do_final || do_init) {
     for (int i = tid; i < 256; i += BT) {
@@ -1181,7 +1233,8 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
           // [U] sum_trees_noi = sum_trees - old_tree.predict()
           const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
           const double noi = st - o;
-          const double r = S.y[row] - noi;
+          const double yv = S.y[row];
+          const double r = normal ? yv - noi : 0.0;  // Bernoulli families: no residual algebra
           unsigned sat1 = 0;
           qa[e] = pgb_quant(st, c1, &sat1);
           qb[e] = pgb_quant(r, c1, &sat1);
@@ -1192,9 +1245,15 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
             sat += sat1;
             iv[0] += qa[e];
             iv[1] += qb[e];
-            iv[2] += qc[e];
-            const double er = r - o;
-            iv[3] += pgb_quant(er * er, c2, &sat);
+            if (normal) {
+              iv[2] += qc[e];
+              const double er = r - o;
+              iv[3] += pgb_quant(er * er, c2, &sat);
+            } else {
+              // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
+              iv[2] += pgb_quant(pgb_loglik1(S.family, yv, noi + S.init_leaf), S.sc.cl, &sat);
+              iv[3] += pgb_quant(pgb_loglik1(S.family, yv, st), S.sc.cl, &sat);
+            }
           }
         }
       } else {
@@ -1344,6 +1403,139 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
     InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
     atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
   }
+}
+
+// ------------------------------------------------------------------ k_loglik
+// Bernoulli families only ([U] update_weight): after the PARTITION pass of a slot, the children's
+// leaf values are known (child_values, the same routine k_ctrl uses one launch later); this pass
+// evaluates the per-row log-likelihood of the rows of the leaf that was split -- left / right /
+// dropped by a missing value -- and reduces it in fixed point.  Same work items as PARTITION.
+struct LJob {
+  long long src, xoff;
+  double v, vL, vR;
+  int32_t p, rule, label, check_nan, ok, pad;
+};
+
+__global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
+  __shared__ long long s_red[MAXP * 3 * 4];
+  __shared__ LJob s_job[MAXP];
+  __shared__ int s_n[2];
+  const Cmd* cmd = &S.cmd[par];
+  if (!(cmd->kind & CMD_PARTITION)) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const Ctrl cn = S.ctrl[par ^ 1];  // the state this slot's k_ctrl produced
+  const int round = cn.round - 1;   // round of the proposals of this slot
+  const uint32_t it = (uint32_t)cn.iter;
+  // leaf_sd / root statistics in force for this round (k_ctrl of the NEXT slot resolves them the
+  // same way): a FINAL or INIT part of this slot's row pass may just have produced them
+  double leaf_sd = cn.leaf_sd;
+  long long rootA = 0;
+  {
+    const InitAcc* src = S.initacc + (size_t)par * IA_SLOTS;
+    long long qstd = 0;
+    for (int k = 0; k < IA_SLOTS; ++k) {
+      qstd += src[k].QSTD;
+      rootA += src[k].A;
+    }
+    if (cn.pend_leafsd && cn.pend_iter > 2) leaf_sd = ((double)qstd * S.sc.inv_c1) / (double)S.n;
+  }
+  const Job* jobs = S.jobs + (size_t)par * MAXP;
+  if (tid < 64) {
+    Job j;
+    j.active = 0;
+    if (tid >= 1 && tid < S.P) j = jobs[tid];
+    const bool has = j.active != 0;
+    const unsigned long long m = __ballot(has);
+    // one Philox evaluation per lane: the leaf noise of particle `tid` in this round
+    double z0, z1;
+    {
+      const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)round, (uint32_t)tid, PGB_RNG_LEAF, 0);
+      pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+    }
+    if (has) {
+      const int k = __popcll(m & ((1ull << tid) - 1ull));
+      const Acc a = S.acc[(size_t)par * MAXP + tid];
+      const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a,
+                                        z0, z1, leaf_sd);
+      LJob lj;
+      lj.p = tid;
+      lj.rule = j.rule;
+      lj.label = j.label;
+      lj.check_nan = j.check_nan;
+      lj.ok = cv.ok;
+      lj.v = j.v;
+      lj.vL = cv.vL;
+      lj.vR = cv.vR;
+      lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+      lj.xoff = (long long)((size_t)j.var * S.n_pad);
+      s_job[k] = lj;
+    }
+    if (tid == 0) s_n[0] = __popcll(m);
+  }
+  __syncthreads();
+  const int nact = s_n[0];
+  if (nact == 0) return;
+  int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+  if (G < 1) G = 1;
+  const int ngroups = (nact + G - 1) / G;
+  const int nitems = S.nchunks * ngroups;
+  const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * S.n_pad;
+  const double cl = S.sc.cl;
+  const long long n = S.n;
+  unsigned sat = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int chunk = item % S.nchunks, grp = item / S.nchunks;
+    const long long base = (long long)chunk * CH + tid * RPT;
+    double yv[RPT], nv[RPT];
+    uint32_t root_ids = 0;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      yv[e] = S.y[base + e];
+      nv[e] = noi[base + e];
+      if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+    }
+    const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+    for (int g = g0; g < g1; ++g) {
+      const LJob& lj = s_job[g];
+      const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
+      const double2* __restrict__ xp = (const double2*)(S.XT + lj.xoff + base);
+      const double2 t0 = xp[0], t1 = xp[1];
+      const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+      long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) {
+        if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+          const double xv = x[e];
+          if (xv != xv) {
+            v2 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e]), cl, &sat);  // dropped: predicts 0
+          } else if (go_left(lj.rule, xv, lj.v)) {
+            v0 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e] + lj.vL), cl, &sat);
+          } else {
+            v1 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e] + lj.vR), cl, &sat);
+          }
+        }
+      }
+      const int slot = (g - g0) * 3;
+      v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2);
+      if (lane == 63) {
+        s_red[(slot + 0) * 4 + w] = v0;
+        s_red[(slot + 1) * 4 + w] = v1;
+        s_red[(slot + 2) * 4 + w] = v2;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < (g1 - g0) * 3; t += BT) {
+      const int gi = t / 3, i = t % 3;
+      const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+      if (s != 0) {
+        Acc* a = &S.acc[(size_t)par * MAXP + s_job[g0 + gi].p];
+        atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
+      }
+    }
+    __syncthreads();
+  }
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
 }
 
 // ------------------------------------------------------------------ setup kernels
@@ -1541,7 +1733,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
     return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
   if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
-  if (s->family != PGB_FAMILY_NORMAL) return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->family != PGB_FAMILY_NORMAL && s->family != PGB_FAMILY_BERNOULLI_PROBIT &&
+      s->family != PGB_FAMILY_BERNOULLI_LOGIT)
+    return fail(PGB_E_UNSUPPORTED, "family not supported yet");
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -1572,6 +1766,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.p = s->p;
   d.m = s->m;
   d.P = s->num_particles;
+  d.family = s->family;
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
   d.seed = s->seed;
@@ -1736,6 +1931,8 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
     h->sigma_dirty = 1;
+  } else if (n_params != 0) {
+    return fail(PGB_E_INVALID, "this family has no parameters");
   }
   return PGB_OK;
 }
@@ -1765,6 +1962,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
     }
     hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     if (h->prof) (void)hipEventRecord(e1, h->stream);
+    if (d.family != PGB_FAMILY_NORMAL)  // per-row log-likelihood of the rows this round re-labelled
+      hipLaunchKernelGGL(k_loglik, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     h->slot += 1;
   }
   HIPCHK(hipGetLastError());

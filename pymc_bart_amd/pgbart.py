@@ -71,6 +71,18 @@ class NormalLikelihood:
         return [float(np.asarray(s))]
 
 
+class BernoulliLikelihood:
+    """``y ~ Bernoulli(link^-1(BART))`` with ``link`` "probit" (cfg4 of BASELINE.json) or "logit"."""
+
+    def __init__(self, link="probit"):
+        if link not in ("probit", "logit"):
+            raise ValueError("link must be 'probit' or 'logit'")
+        self.family = "bernoulli_" + link
+
+    def params(self, point=None):
+        return []
+
+
 def _op_of(var):
     owner = getattr(var, "owner", None)
     return owner.op if owner is not None and hasattr(owner, "op") else var

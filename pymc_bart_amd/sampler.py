@@ -111,10 +111,13 @@ class PyBartSettings:
         is_binary = bool(np.all((Y == 0) | (Y == 1)))
         # [U] leaf_sd = 3/sqrt(m) for 0/1 responses, std(Y)/sqrt(m) otherwise
         leaf_sd = 3.0 / math.sqrt(m) if is_binary else float(Y.std()) / math.sqrt(m)
+        rexp = range_exponent(Y)
+        if family != "normal":
+            rexp = max(rexp, 6)  # latent link scale: |sum_trees| < 64
         return cls(
             n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
             alpha=alpha, beta=beta, batch=tuple(batch), seed=int(seed), init_sum=mean,
-            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=range_exponent(Y),
+            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=rexp,
             prior_leaf=prior_leaf_table(alpha, beta),
         )
 
@@ -180,8 +183,9 @@ class PySampler:
     # -- likelihood parameters at the current point -------------------------------
     def set_likelihood(self, params) -> None:
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(params, np.float64)))
+        keep = np.zeros(1) if a.size == 0 else a  # a valid pointer even for parameter-free families
         lib = self.backend.lib
-        lib.check(lib.lib.pgb_set_likelihood(self._h, a.ctypes.data, a.size), "pgb_set_likelihood")
+        lib.check(lib.lib.pgb_set_likelihood(self._h, keep.ctypes.data, a.size), "pgb_set_likelihood")
 
     # -- one astep -----------------------------------------------------------------
     def step(self, tune: bool, fetch: bool = True):

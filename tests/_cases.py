@@ -59,6 +59,31 @@ def make_case(name: str):
         X = rng.normal(size=(n, p))
         Y = np.sin(5 * X[:, 0]) + np.cos(3 * X[:, 1]) + rng.normal(0, 0.05, n)
         c.update(m=5, P=10, steps=20, alpha=0.999, beta=0.3)
+    elif name == "probit_cfg4_small":  # BASELINE.json configs[3] at test size
+        from scipy.special import ndtr
+        n, p = 6000, 10
+        X = rng.normal(size=(n, p))
+        f = 1.5 * X[:, 0] - (X[:, 1] > 0) + 0.5 * X[:, 2] * X[:, 0]
+        Y = (rng.random(n) < ndtr(f / 1.0)).astype(float)
+        c.update(m=20, P=12, steps=30, family="bernoulli_probit")
+    elif name == "logit_nan_onehot":
+        n, p = 3000, 5
+        X = rng.normal(size=(n, p))
+        X[:, 3] = rng.integers(0, 3, n)
+        X[:, 4] = 1.0  # constant one-hot column: every split attempt on it fails
+        X[rng.random(n) < 0.15, 0] = np.nan
+        X[rng.random(n) < 0.2, 4] = np.nan
+        f = np.where(np.isnan(X[:, 0]), 0.0, 2 * X[:, 0]) + (X[:, 3] == 1) * 1.5
+        Y = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+        c.update(m=10, P=16, steps=30, family="bernoulli_logit", rules=np.array([0, 0, 0, 1, 1], np.int32))
+    elif name == "onehot_fail_nan":  # failed one-hot splits that shed NaN rows (Normal family)
+        n, p = 2500, 3
+        X = rng.normal(size=(n, p))
+        X[:, 1] = 2.0
+        X[rng.random(n) < 0.25, 1] = np.nan
+        X[:, 2] = rng.integers(0, 2, n)
+        Y = X[:, 0] + (X[:, 2] > 0) + rng.normal(0, 0.3, n)
+        c.update(m=6, P=10, steps=30, rules=np.array([0, 1, 1], np.int32), prior=np.array([1.0, 3.0, 1.0]))
     else:
         raise KeyError(name)
     c.update(X=X, Y=Y)
@@ -66,15 +91,17 @@ def make_case(name: str):
 
 
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
-         "max_particles", "duplicates", "deep_trees"]
+         "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
+         "logit_nan_onehot"]
 
 
 def run_case(c, backend, record_every: int = 1):
     """Run the case on a backend; returns everything the two backends must agree on."""
     X, Y = c["X"], c["Y"]
     p = X.shape[1]
+    family = c.get("family", "normal")
     st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
-                                  alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0))
+                                  alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family)
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
     prior = np.ones(p) if c["prior"] is None else c["prior"]
     s = PySampler(st, X, Y, rules, prior, backend=backend)
@@ -82,7 +109,8 @@ def run_case(c, backend, record_every: int = 1):
     sums, vis, trees = [], [], []
     half = c["steps"] // 2
     for it in range(c["steps"]):
-        s.set_likelihood([float(0.5 + sig_rng.random())])  # sigma moves like a Gibbs/NUTS neighbour
+        sig = float(0.5 + sig_rng.random())  # sigma moves like a Gibbs/NUTS neighbour
+        s.set_likelihood([sig] if family == "normal" else [])
         stv, vi = s.step(tune=it < half)
         if it % record_every == 0:
             sums.append(stv)
