@@ -35,10 +35,11 @@ def cpu_baseline(w, seed, budget_s=20.0):
     from pymc_bart_amd.sampler import PyBartSettings, PySampler
 
     X, Y = w["X"], w["Y"]
-    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed)
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
+                                  family=w["family"])
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]),
                   backend=oracle_backend())
-    s.set_likelihood([1.0])
+    s.set_likelihood([1.0] if w["family"] == "normal" else [])
     s.step(False, fetch=False)  # warm-up (page in)
     c0 = s.counters.as_dict()
     t0 = time.perf_counter()
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--m", type=int, default=200)
     ap.add_argument("--particles", type=int, default=40)
     ap.add_argument("--tune", type=int, default=0)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
+                    help="cfg2 (default) is the configuration the metric is quoted on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -97,13 +100,18 @@ def main():
     from pymc_bart_amd.sampler import PyBartSettings, PySampler, default_backend
 
     seed = 3415 + rank  # independent chains: SURVEY.md 8e
-    w = workloads.cfg2(seed=3415, n=args.n, p=args.p, m=args.m, num_particles=args.particles)
+    if args.workload == "cfg4":
+        w = workloads.cfg4(seed=3415, n=args.n if args.n != 100_000 else 1_000_000,
+                           p=args.p if args.p != 50 else 100, m=args.m, num_particles=args.particles)
+    else:
+        w = workloads.cfg2(seed=3415, n=args.n, p=args.p, m=args.m, num_particles=args.particles)
     X, Y = w["X"], w["Y"]
     n = X.shape[0]
-    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed)
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
+                                  family=w["family"])
     be = default_backend(local_rank)
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
-    s.set_likelihood([1.0])  # sigma fixed at 1 for the throughput run
+    s.set_likelihood([1.0] if w["family"] == "normal" else [])  # sigma fixed at 1
     tune = bool(args.tune)
 
     def barrier():
@@ -153,7 +161,8 @@ def main():
         # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); only for the default config
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40):
+        if os.path.exists(pmc) and args.workload == "cfg2" and \
+                (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40):
             traffic = json.load(open(pmc))["k_rows"]["hbm_bytes_per_launch_corrected"]
         roofline = {
             "bound": "hbm", "kernel": "k_rows", "achieved": ach, "peak": HBM_PEAK_GBS,

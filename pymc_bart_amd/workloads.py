@@ -44,3 +44,14 @@ def bytes_per_tree_update(n: int, rows_touched: float, K: int = 1, s_x: int = 8,
     """Algorithmic bytes of one tree update:
     2*(3*s_f*K*n) + (4 + s_x + 4 + s_f + 2*K*s_f) * rows_touched."""
     return 2 * (3 * s_f * K * n) + (4 + s_x + 4 + s_f + 2 * K * s_f) * rows_touched
+
+
+def cfg4(seed: int = 3415, n: int = 1_000_000, p: int = 100, m: int = 200, num_particles: int = 40):
+    """Bernoulli-probit classification, n=1M p=100 (X = 800 MB: exceeds the 256 MiB Infinity Cache)."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    f = friedman(_phi_fast(X[:, :5]))
+    f = (f - f.mean()) / 5.0
+    Y = (rng.random(n) < _phi_fast(f)).astype(np.float64)
+    return dict(X=X, Y=Y, f=f, m=m, num_particles=num_particles, family="bernoulli_probit",
+                name=f"cfg4: Bernoulli-probit n={n} p={p} m={m} P={num_particles}")

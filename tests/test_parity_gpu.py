@@ -144,3 +144,42 @@ def test_full_size_cfg2_parity_and_invariants(hip, oracle):
     assert g.counters.saturations == 0
     rmse = float(np.sqrt(np.mean((st_dev - w["f"]) ** 2)))
     assert rmse < np.std(w["f"])                        # it is actually learning the signal
+
+
+def test_full_size_cfg4_probit_parity_and_invariants(hip, oracle):
+    """BASELINE.json configs[3] at full size: Bernoulli-probit, n=1M, p=100, m=200, 40 particles.
+    The oracle needs seconds per tree at this size, so exact agreement is checked on 2 steps of
+    2 trees; size-independent properties on a longer GPU-only run."""
+    w = workloads.cfg4(seed=3415)
+    X, Y = w["X"], w["Y"]
+    n, p = X.shape
+    st = PyBartSettings.from_data(X, Y, m=200, num_particles=40, seed=3415, family="bernoulli_probit",
+                                  batch=(2, 2))
+    g = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=hip)
+    o = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=oracle)
+    for s in (g, o):
+        s.set_likelihood([])
+    for it in range(2):
+        a, va = g.step(tune=it < 1)
+        b, vb = o.step(tune=it < 1)
+        assert np.array_equal(a, b) and np.array_equal(va, vb)
+    cg, co = g.counters.as_dict(), o.counters.as_dict()
+    for k in ("particle_steps", "tree_updates", "rows_touched", "rounds", "saturations"):
+        assert cg[k] == co[k]
+    del o
+    g.step_async(False, 20)
+    st_dev, _ = g.step(False)
+    forest = g.export_trees(1)
+    roots = forest.node_off[:-1]
+    assert np.all(forest.count[roots] == n)
+    inner = np.flatnonzero(forest.var >= 0)
+    base = np.repeat(forest.node_off[:-1], np.diff(forest.node_off))
+    assert np.all(forest.count[base[inner] + forest.left[inner]] + forest.count[base[inner] + forest.right[inner]]
+                  == forest.count[inner])
+    sub = np.arange(0, n, 97)
+    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, np.zeros(p, np.int32),
+                          backend=hip)
+    pred = ps.sample_posterior(X[sub], [0])[0, 0]
+    np.testing.assert_allclose(pred, st_dev[sub], rtol=0, atol=1e-8)
+    assert g.counters.saturations == 0
+    assert np.corrcoef(st_dev, w["f"])[0, 1] > 0.3  # the latent signal is being picked up
