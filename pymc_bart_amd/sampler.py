@@ -193,6 +193,7 @@ class PySampler:
         rc = lib.lib.pgb_step(self._h, int(bool(tune)), mem.ptr(self._out), self._vi.ctypes.data,
                               C.byref(self.counters))
         lib.check(rc, "pgb_step")
+        self._check_saturation()
         st = None
         if fetch:
             st = mem.to_host(self._out)
@@ -207,7 +208,18 @@ class PySampler:
     def sync(self) -> dict:
         lib = self.backend.lib
         lib.check(lib.lib.pgb_sync(self._h, C.byref(self.counters)), "pgb_sync")
+        self._check_saturation()
         return self.counters.as_dict()
+
+    def _check_saturation(self) -> None:
+        """Fixed-point sums are exact only inside the declared range (PyBartSettings.range_exp);
+        a saturated term makes the draws invalid, so it is an error, not a statistic."""
+        if self.counters.saturations > 0:
+            raise _abi.PGBError(
+                f"{self.counters.saturations} fixed-point saturation events: |sum_trees| or the "
+                f"residuals left the range 2^{self.settings.range_exp}; re-create the sampler with "
+                "a larger PyBartSettings.range_exp"
+            )
 
     def sum_trees_device(self):
         """The device buffer the last ``step`` wrote ``sum_trees`` into."""

@@ -256,3 +256,17 @@ def test_pgbart_astep_contract(oracle):
     step.astep(None)
     base, batches = op.all_trees[0]
     assert base.n_trees == 3 and len(batches) == 2
+
+
+def test_fixed_point_saturation_is_reported(oracle):
+    # a deliberately tiny range: the sampler must refuse to return silently wrong sums
+    rng = np.random.default_rng(10)
+    X = rng.normal(size=(100, 2))
+    Y = 50.0 * X[:, 0] + rng.normal(size=100)
+    st = PyBartSettings.from_data(X, Y, m=5, num_particles=5)
+    st.range_exp = 2
+    s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    s.set_likelihood([1.0])
+    with pytest.raises(_abi.PGBError, match="saturation"):
+        for _ in range(5):
+            s.step(True)
