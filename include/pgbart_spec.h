@@ -302,6 +302,23 @@ PGB_HD double pgb_loglik1(int family, double y, double mu) {
   return ll;
 }
 
+/* Categorical-softmax over K linear predictors: mu[y] - logsumexp(mu) (serial max / sum in output
+ * order), clamped like pgb_loglik1.  y is the class index stored as a double. */
+PGB_HD double pgb_loglik_cat(int K, double y, const double* mu) {
+  double mx = mu[0];
+  for (int k = 1; k < K; ++k)
+    if (mu[k] > mx) mx = mu[k];
+  double sum = 0.0;
+  for (int k = 0; k < K; ++k) sum += pgb_exp(mu[k] - mx);
+  int c = (int)y;
+  if (c < 0) c = 0;
+  if (c > K - 1) c = K - 1;
+  double ll = (mu[c] - mx) - pgb_log(sum);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 0.0) ll = 0.0;
+  return ll;
+}
+
 /* ------------------------------------------------------------------ fixed point */
 /* q = round-to-nearest-even(x * 2^s) saturated to |q| <= 2^50, via the 1.5*2^52
  * trick (exact for |x*2^s| < 2^51).  `scale` = 2^s.  NaN -> 0.  `sat` (may be

@@ -69,7 +69,9 @@ typedef struct {
   int64_t cnt;
   int64_t q_st, q_r, q_r2; /* fixed-point sums over the node rows */
   double value, sse;
-  int64_t ll;  /* Bernoulli families: fixed-point log-likelihood of the node's rows */
+  double valx[PGB_MAX_OUTPUTS - 1];    /* leaf value of outputs 1..K-1 (K-vector leaves) */
+  int64_t q_stx[PGB_MAX_OUTPUTS - 1];  /* sum of sum_trees over the node rows, outputs 1..K-1 */
+  int64_t ll;  /* non-Normal families: fixed-point log-likelihood of the node's rows */
   int64_t seg; /* arena offset of the sorted row list (oracle only) */
 } onode;
 
@@ -97,7 +99,8 @@ struct pgb_handle {
   double* rs_mean;
   double* rs_m2;
   int64_t rs_count;
-  double leaf_sd;
+  double leaf_sd;                       /* output 0 */
+  double leaf_sdx[PGB_MAX_OUTPUTS - 1]; /* outputs 1..K-1 */
   double inv_sigma2;
   int64_t iter;
   int32_t lower;
@@ -163,28 +166,33 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
     return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
-  if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
-  if (s->family != PGB_FAMILY_NORMAL && s->family != PGB_FAMILY_BERNOULLI_PROBIT &&
-      s->family != PGB_FAMILY_BERNOULLI_LOGIT)
-    return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->family == PGB_FAMILY_CATEGORICAL) {
+    if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
+      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+  } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
+             s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
+    if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
+  } else {
+    return fail(PGB_E_UNSUPPORTED, "unknown family");
+  }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
   pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
   if (!h) return fail(PGB_E_NOMEM, "calloc");
   h->s = *s;
   h->sc = pgb_make_scales(s->n, s->range_exp);
   int64_t n = s->n;
-  int p = s->p, m = s->m, P = s->num_particles;
+  int p = s->p, m = s->m, P = s->num_particles, K = s->n_outputs;
   h->X = (double*)malloc(sizeof(double) * (size_t)n * p);
   h->y = (double*)malloc(sizeof(double) * n);
   h->rules = (int32_t*)calloc(p, sizeof(int32_t));
   h->alpha_vec = (int64_t*)malloc(sizeof(int64_t) * p);
   h->cdf = (int64_t*)malloc(sizeof(int64_t) * p);
   h->col_has_nan = (int*)calloc(p, sizeof(int));
-  h->st = (double*)malloc(sizeof(double) * n);
+  h->st = (double*)malloc(sizeof(double) * n * K); /* [K][n] */
   h->r = (double*)malloc(sizeof(double) * n);
-  h->oldv = (double*)malloc(sizeof(double) * n);
-  h->rs_mean = (double*)calloc(n, sizeof(double));
-  h->rs_m2 = (double*)calloc(n, sizeof(double));
+  h->oldv = (double*)malloc(sizeof(double) * n * K);
+  h->rs_mean = (double*)calloc((size_t)n * K, sizeof(double));
+  h->rs_m2 = (double*)calloc((size_t)n * K, sizeof(double));
   h->trees = (otree*)calloc(m, sizeof(otree));
   h->lid = (uint8_t*)calloc((size_t)m * n, 1);
   h->part = (otree*)calloc(P, sizeof(otree));
@@ -193,10 +201,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   h->arena = (int32_t*)malloc(sizeof(int32_t) * (size_t)h->arena_cap);
   h->vi = (int32_t*)calloc(p, sizeof(int32_t));
   h->last_ids = (int32_t*)calloc(m, sizeof(int32_t));
-  for (int64_t i = 0; i < n; ++i) {
-    h->st[i] = s->init_sum;
-    h->arena[i] = (int32_t)i; /* root segment: all rows, ascending */
-  }
+  for (int64_t i = 0; i < n; ++i) h->arena[i] = (int32_t)i; /* root segment: all rows, ascending */
+  for (int64_t i = 0; i < n * K; ++i) h->st[i] = s->init_sum;
   for (int t = 0; t < m; ++t) {
     otree* T = &h->trees[t];
     T->n_nodes = 1;
@@ -208,8 +214,10 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     z->left = z->right = -1;
     z->cnt = n;
     z->value = s->init_leaf;
+    for (int k = 1; k < K; ++k) z->valx[k - 1] = s->init_leaf;
   }
   h->leaf_sd = s->init_leaf_sd;
+  for (int k = 1; k < K; ++k) h->leaf_sdx[k - 1] = s->init_leaf_sd;
   h->inv_sigma2 = 1.0;
   *out = h;
   return PGB_OK;
@@ -274,21 +282,33 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
 }
 
 /* ------------------------------------------------------------------ one tree update */
+/* per-row log-likelihood of the non-Normal families at linear predictor(s) mu[0..K-1] */
+static double o_loglik(const pgb_handle* h, double y, const double* mu) {
+  return h->s.family == PGB_FAMILY_CATEGORICAL ? pgb_loglik_cat(h->s.n_outputs, y, mu)
+                                               : pgb_loglik1(h->s.family, y, mu[0]);
+}
+
 static void o_tree_begin(pgb_handle* h, int tree_id) {
   /* [U] sum_trees_noi = sum_trees - old_tree.predict(); init_particles */
   const pgb_settings* s = &h->s;
   int64_t n = s->n;
+  const int K = s->n_outputs;
   const otree* T = &h->trees[tree_id];
-  double lv[256];
-  for (int k = 0; k < 256; ++k) lv[k] = 0.0;
+  static __thread double lv[PGB_MAX_OUTPUTS][256];
+  for (int o = 0; o < K; ++o)
+    for (int k = 0; k < 256; ++k) lv[o][k] = 0.0;
   for (int k = 0; k < T->n_nodes; ++k)
-    if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].value;
+    if (T->nd[k].var < 0) {
+      lv[0][T->nd[k].label] = T->nd[k].value;
+      for (int o = 1; o < K; ++o) lv[o][T->nd[k].label] = T->nd[k].valx[o - 1];
+    }
   const uint8_t* lid = h->lid + (size_t)tree_id * n;
   unsigned sat = 0;
   int64_t A = 0, B = 0, C = 0, E0 = 0;
+  int64_t Ax[PGB_MAX_OUTPUTS - 1] = {0};
   const int normal = s->family == PGB_FAMILY_NORMAL;
   for (int64_t i = 0; i < n; ++i) {
-    double o = lv[lid[i]];
+    double o = lv[0][lid[i]];
     double noi = h->st[i] - o;
     h->oldv[i] = o;
     A += pgb_quant(h->st[i], h->sc.c1, &sat);
@@ -300,10 +320,22 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
       double e = r - o;
       E0 += pgb_quant(e * e, h->sc.c2, &sat);
     } else {
-      /* Bernoulli families: C = log-lik of a fresh stump, E0 = log-lik of the current tree */
+      /* non-Normal families: C = log-lik of a fresh stump, E0 = log-lik of the current tree */
+      double mu_stump[PGB_MAX_OUTPUTS], mu_cur[PGB_MAX_OUTPUTS];
+      mu_stump[0] = noi + s->init_leaf;
+      mu_cur[0] = h->st[i];
+      for (int k = 1; k < K; ++k) {
+        const double stk = h->st[(size_t)k * n + i];
+        const double ok = lv[k][lid[i]];
+        const double noik = stk - ok;
+        h->oldv[(size_t)k * n + i] = ok;
+        Ax[k - 1] += pgb_quant(stk, h->sc.c1, &sat);
+        mu_stump[k] = noik + s->init_leaf;
+        mu_cur[k] = stk;
+      }
       h->r[i] = 0.0;
-      C += pgb_quant(pgb_loglik1(s->family, h->y[i], noi + s->init_leaf), h->sc.cl, &sat);
-      E0 += pgb_quant(pgb_loglik1(s->family, h->y[i], h->st[i]), h->sc.cl, &sat);
+      C += pgb_quant(o_loglik(h, h->y[i], mu_stump), h->sc.cl, &sat);
+      E0 += pgb_quant(o_loglik(h, h->y[i], mu_cur), h->sc.cl, &sat);
     }
   }
   h->ctr.saturations += sat;
@@ -326,6 +358,10 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
     z->q_r = B;
     z->q_r2 = C;
     z->value = s->init_leaf;
+    for (int k = 1; k < K; ++k) {
+      z->q_stx[k - 1] = Ax[k - 1];
+      z->valx[k - 1] = s->init_leaf;
+    }
     z->sse = pgb_leaf_sse(n, B, C, z->value, h->sc.inv_c1, h->sc.inv_c2);
     z->ll = C;
     z->seg = 0;
@@ -336,15 +372,18 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
   }
 }
 
-/* Bernoulli families: fixed-point log-likelihood of `cnt` rows predicting `v` from this tree
- * ([U] update_weight restricted to the rows whose prediction changed). */
-static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, double v) {
+/* non-Normal families: fixed-point log-likelihood of `cnt` rows predicting the K-vector `v` from
+ * this tree ([U] update_weight restricted to the rows whose prediction changed). */
+static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v) {
   unsigned sat = 0;
   int64_t acc = 0;
+  const int K = h->s.n_outputs;
+  const int64_t n = h->s.n;
   for (int64_t k = 0; k < cnt; ++k) {
     int32_t i = seg[k];
-    double noi = h->st[i] - h->oldv[i];
-    acc += pgb_quant(pgb_loglik1(h->s.family, h->y[i], noi + v), h->sc.cl, &sat);
+    double mu[PGB_MAX_OUTPUTS];
+    for (int o = 0; o < K; ++o) mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + v[o];
+    acc += pgb_quant(o_loglik(h, h->y[i], mu), h->sc.cl, &sat);
   }
   h->ctr.saturations += sat;
   return acc;
@@ -390,8 +429,10 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   int32_t* sr = h->arena + offR;
   int64_t cL = 0, cR = 0, cN = 0;
   int64_t aL = 0, bL = 0, c2L = 0, aN = 0, bN = 0, c2N = 0;
+  int64_t aLx[PGB_MAX_OUTPUTS - 1] = {0}, aNx[PGB_MAX_OUTPUTS - 1] = {0};
+  const int K = s->n_outputs;
   const int normal = s->family == PGB_FAMILY_NORMAL;
-  int32_t* sn = NULL; /* NaN-dropped rows (Bernoulli families need their log-likelihood) */
+  int32_t* sn = NULL; /* NaN-dropped rows (non-Normal families need their log-likelihood) */
   if (!normal && h->col_has_nan[j]) sn = (int32_t*)malloc(sizeof(int32_t) * (size_t)nd.cnt);
   for (int64_t k = 0; k < nd.cnt; ++k) {
     int32_t i = seg[k];
@@ -403,12 +444,15 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     if (x != x) {
       if (sn) sn[cN] = i;
       cN++; aN += qa; bN += qb; c2N += qc;
+      for (int o = 1; o < K; ++o) aNx[o - 1] += pgb_quant(h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
     } else if (rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v)) {
       sl[cL++] = i; aL += qa; bL += qb; c2L += qc;
+      for (int o = 1; o < K; ++o) aLx[o - 1] += pgb_quant(h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
     } else {
       sr[cR++] = i;
     }
   }
+  double zero_v[PGB_MAX_OUTPUTS] = {0};
   /* give back the unused tail of the two segments */
   /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
   if (rule == PGB_RULE_ONEHOT && cR == 0) {
@@ -420,14 +464,18 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     T->sse_orph += (double)c2N * h->sc.inv_c2;
     T->sse_tot = (T->sse_tot - nd.sse) + new_sse;
     if (!normal) {
-      int64_t llL = o_seg_loglik(h, sl, cL, nd.value);
-      int64_t llN = sn ? o_seg_loglik(h, sn, cN, 0.0) : 0;
+      double pv[PGB_MAX_OUTPUTS];
+      pv[0] = nd.value;
+      for (int o = 1; o < K; ++o) pv[o] = nd.valx[o - 1];
+      int64_t llL = o_seg_loglik(h, sl, cL, pv);
+      int64_t llN = sn ? o_seg_loglik(h, sn, cN, zero_v) : 0;
       T->ll_orph += llN;
       T->ll_tot = (T->ll_tot - nd.ll) + llL;
       pn->ll = llL;
       free(sn);
     }
     pn->cnt = cL;
+    for (int o = 1; o < K; ++o) pn->q_stx[o - 1] = aLx[o - 1];
     pn->q_st = aL;
     pn->q_r = bL;
     pn->q_r2 = c2L;
@@ -460,15 +508,32 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   b->cnt = cR; b->q_st = aR; b->q_r = bR; b->q_r2 = c2R; b->seg = offR;
   a->value = pgb_leaf_value(cL, aL, h->sc.inv_c1, (double)s->m, z0, h->leaf_sd);
   b->value = pgb_leaf_value(cR, aR, h->sc.inv_c1, (double)s->m, z1, h->leaf_sd);
+  for (int o = 1; o < K; ++o) { /* K-vector leaves: one Box-Muller pair per output */
+    pgb_u2 uk = pgb_draw2(s->seed, it, round, (uint32_t)q, PGB_RNG_LEAF, (uint32_t)o);
+    double zk0, zk1;
+    pgb_normal2(uk.u0, uk.u1, &zk0, &zk1);
+    const int64_t aLk = aLx[o - 1], aRk = nd.q_stx[o - 1] - aLx[o - 1] - aNx[o - 1];
+    a->q_stx[o - 1] = aLk;
+    b->q_stx[o - 1] = aRk;
+    a->valx[o - 1] = pgb_leaf_value(cL, aLk, h->sc.inv_c1, (double)s->m, zk0, h->leaf_sdx[o - 1]);
+    b->valx[o - 1] = pgb_leaf_value(cR, aRk, h->sc.inv_c1, (double)s->m, zk1, h->leaf_sdx[o - 1]);
+  }
   a->sse = pgb_leaf_sse(cL, bL, c2L, a->value, h->sc.inv_c1, h->sc.inv_c2);
   b->sse = pgb_leaf_sse(cR, bR, c2R, b->value, h->sc.inv_c1, h->sc.inv_c2);
   T->sse_tot = ((T->sse_tot - nd.sse) + a->sse) + b->sse;
   if (!normal) {
     sl = h->arena + offL;
     sr = h->arena + offR;
-    a->ll = o_seg_loglik(h, sl, cL, a->value);
-    b->ll = o_seg_loglik(h, sr, cR, b->value);
-    if (sn) T->ll_orph += o_seg_loglik(h, sn, cN, 0.0);
+    double va[PGB_MAX_OUTPUTS], vb[PGB_MAX_OUTPUTS];
+    va[0] = a->value;
+    vb[0] = b->value;
+    for (int o = 1; o < K; ++o) {
+      va[o] = a->valx[o - 1];
+      vb[o] = b->valx[o - 1];
+    }
+    a->ll = o_seg_loglik(h, sl, cL, va);
+    b->ll = o_seg_loglik(h, sr, cR, vb);
+    if (sn) T->ll_orph += o_seg_loglik(h, sn, cN, zero_v);
     T->ll_tot = ((T->ll_tot - nd.ll) + a->ll) + b->ll;
     free(sn);
   }
@@ -528,19 +593,33 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   if (tune) h->rs_count += 1;
   unsigned sat = 0;
   int64_t qstd = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    double nv = lv[lid[i]];
-    double noi = h->st[i] - h->oldv[i];
-    h->st[i] = noi + nv;
-    if (tune) { /* [U] RunningSd.update (Welford) */
-      double cntf = (double)h->rs_count;
-      double delta = nv - h->rs_mean[i];
-      double mean = h->rs_mean[i] + delta / cntf;
-      double delta2 = nv - mean;
-      double m2 = h->rs_m2[i] + delta * delta2;
-      h->rs_mean[i] = mean;
-      h->rs_m2[i] = m2;
-      qstd += pgb_quant(PGB_SQRT(m2 / cntf), h->sc.c1, &sat);
+  int64_t qstdx[PGB_MAX_OUTPUTS - 1] = {0};
+  const int K = s->n_outputs;
+  for (int o = 0; o < K; ++o) {
+    double* st = h->st + (size_t)o * n;
+    double* ov = h->oldv + (size_t)o * n;
+    double* rmean = h->rs_mean + (size_t)o * n;
+    double* rm2 = h->rs_m2 + (size_t)o * n;
+    if (o > 0) { /* label -> value table of output o */
+      for (int k = 0; k < 256; ++k) lv[k] = 0.0;
+      for (int k = 0; k < T->n_nodes; ++k)
+        if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].valx[o - 1];
+    }
+    for (int64_t i = 0; i < n; ++i) {
+      double nv = lv[lid[i]];
+      double noi = st[i] - ov[i];
+      st[i] = noi + nv;
+      if (tune) { /* [U] RunningSd.update (Welford) */
+        double cntf = (double)h->rs_count;
+        double delta = nv - rmean[i];
+        double mean = rmean[i] + delta / cntf;
+        double delta2 = nv - mean;
+        double m2 = rm2[i] + delta * delta2;
+        rmean[i] = mean;
+        rm2[i] = m2;
+        int64_t qs = pgb_quant(PGB_SQRT(m2 / cntf), h->sc.c1, &sat);
+        if (o == 0) qstd += qs; else qstdx[o - 1] += qs;
+      }
     }
   }
   h->ctr.saturations += sat;
@@ -548,7 +627,10 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
     if (h->iter > s->m) build_cdf(h); /* [U] ssv rebuilt before this tree's counts are added */
     for (int k = 0; k < T->n_nodes; ++k)
       if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += h->alpha_unit;
-    if (h->iter > 2) h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
+    if (h->iter > 2) {
+      h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
+      for (int o = 1; o < K; ++o) h->leaf_sdx[o - 1] = ((double)qstdx[o - 1] * h->sc.inv_c1) / (double)n;
+    }
   } else {
     for (int k = 0; k < T->n_nodes; ++k)
       if (T->nd[k].var >= 0) h->vi[T->nd[k].var] += 1;
@@ -588,7 +670,7 @@ int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_out, int32_t* vi_out
   if (!h) return fail(PGB_E_INVALID, "null handle");
   int rc = o_step(h, tune);
   if (rc) return rc;
-  if (sum_trees_out) memcpy(sum_trees_out, h->st, sizeof(double) * h->s.n);
+  if (sum_trees_out) memcpy(sum_trees_out, h->st, sizeof(double) * h->s.n * h->s.n_outputs);
   if (vi_out) memcpy(vi_out, h->vi, sizeof(int32_t) * h->s.p);
   if (counters_out) *counters_out = h->ctr;
   return PGB_OK;
@@ -616,7 +698,7 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
   for (int t = 0; t < nt; ++t) total += h->trees[which == 0 ? h->last_ids[t] : t].n_nodes;
   if (!out->var) {
     out->n_trees = nt;
-    out->n_outputs = 1;
+    out->n_outputs = h->s.n_outputs;
     out->total_nodes = total;
     return PGB_OK;
   }
@@ -634,7 +716,9 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
       out->left[off + k] = z->left;
       out->right[off + k] = z->right;
       out->count[off + k] = z->cnt;
-      out->value[off + k] = z->var < 0 ? z->value : 0.0;
+      const int K = h->s.n_outputs;
+      out->value[(size_t)(off + k) * K] = z->var < 0 ? z->value : 0.0;
+      for (int o = 1; o < K; ++o) out->value[(size_t)(off + k) * K + o] = z->var < 0 ? z->valx[o - 1] : 0.0;
     }
     off += T->n_nodes;
   }
@@ -644,7 +728,10 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
 
 int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
-  if (leaf_sd_out) leaf_sd_out[0] = h->leaf_sd;
+  if (leaf_sd_out) {
+    leaf_sd_out[0] = h->leaf_sd;
+    for (int o = 1; o < h->s.n_outputs; ++o) leaf_sd_out[o] = h->leaf_sdx[o - 1];
+  }
   if (iter_out) *iter_out = h->iter;
   if (lower_out) *lower_out = h->lower;
   return PGB_OK;

@@ -118,6 +118,7 @@ struct Ctrl {
   int32_t alpha_cur, cdf_cur;   // current buffers of the split weights / their prefix sums
   long long iter, rs_count, pend_iter;
   double leaf_sd, inv_sigma2;
+  double leaf_sdx[PGB_MAX_OUTPUTS - 1];  // outputs 1..K-1
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
   long long steps_done;  // asteps completed since creation (mirrored to the host flag)
   long long slot_no;     // k_ctrl launches so far
@@ -127,7 +128,7 @@ struct Dev {  // kernel argument block (by value)
   long long n, n_pad;
   int32_t p, m, P, nchunks;
   int32_t batch_tune, batch_draw;
-  int32_t family, pad_family;
+  int32_t family, K;  // K = n_outputs; KX = K - 1 extension outputs live in the *x arrays below
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
@@ -156,6 +157,16 @@ struct Dev {  // kernel argument block (by value)
   double max_prior;
   const int32_t* rules;
   const int32_t* col_nan;
+  // ---- K-vector leaves (K > 1): output 0 uses the scalar fields, outputs 1..K-1 these arrays
+  double* packx;      // [KX][n_pad]            sum_trees of outputs 1.. (as of INIT, like pack.x)
+  double* pvx;        // [2][MAXP][MAXN][KX]    particle leaf values
+  long long* pqx;     // [2][MAXP][MAXN][KX]    particle node sums of sum_trees
+  double* tvx;        // [m][MAXN][KX]          accepted trees' leaf values
+  long long* accx;    // [2][MAXP][2*KX]        row-pass statistics: aL[k], aN[k]
+  long long* iax;     // [2][IA_SLOTS][2*KX]    INIT/FINAL statistics: A[k], QSTD[k]
+  double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
+  long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
+  double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
   long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
 };
@@ -298,6 +309,18 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   return x;
 }
 
+// the same for the extension outputs: lvx[label][k] from a node array + its [node][KX] values
+__device__ __forceinline__ void build_lvx(const DNode* nd, int n_nodes, const double* vx, int KX,
+                                          double* lvx /*[256][KX] global*/) {
+  for (int i = threadIdx.x; i < 256 * KX; i += BT) lvx[i] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < n_nodes * KX; e += BT) {
+    const int i = e / KX, k = e % KX;
+    if (nd[i].var < 0) lvx[(size_t)nd[i].label * KX + k] = vx[e];
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------ k_begin
 __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
   const Dev& S = *Sp;
@@ -327,14 +350,14 @@ struct ChildVals {
   double vL, vR;
 };
 __device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cnt, long long p_q_st,
-                                                  double p_value, const Acc& a, double z0, double z1,
-                                                  double leaf_sd) {
+                                                  double p_value, unsigned long long a_cnts, long long a_aL,
+                                                  long long a_aN, double z0, double z1, double leaf_sd) {
   ChildVals c;
-  c.cL = (int)(a.cnts & 0xFFFFFFFFull);
-  c.cN = (int)(a.cnts >> 32);
+  c.cL = (int)(a_cnts & 0xFFFFFFFFull);
+  c.cN = (int)(a_cnts >> 32);
   c.cR = cnt - c.cL - c.cN;
-  c.aL = a.aL;
-  c.aR = p_q_st - a.aL - a.aN;
+  c.aL = a_aL;
+  c.aR = p_q_st - a_aL - a_aN;
   if (rule == PGB_RULE_ONEHOT && c.cR == 0) {
     c.ok = -1;
     c.vL = p_value;
@@ -343,6 +366,49 @@ __device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cn
     c.ok = 1;
     c.vL = pgb_leaf_value(c.cL, c.aL, S.sc.inv_c1, S.mdouble, z0, leaf_sd);
     c.vR = pgb_leaf_value(c.cR, c.aR, S.sc.inv_c1, S.mdouble, z1, leaf_sd);
+  }
+  return c;
+}
+
+
+// ---- K-vector leaves: extension outputs 1..K-1 ------------------------------------------------
+#define KXMAX (PGB_MAX_OUTPUTS - 1)
+// leaf_sd of extension output k (0-based), with the pending update of a FINAL pass resolved the
+// same way as for output 0
+__device__ __forceinline__ double leaf_sd_x(const Dev& S, const Ctrl& c, int acc_par, int k) {
+  if (!(c.pend_leafsd && c.pend_iter > 2)) return c.leaf_sdx[k];
+  const int KX = S.K - 1;
+  long long q = 0;
+  for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + KX + k];
+  return ((double)q * S.sc.inv_c1) / (double)S.n;
+}
+__device__ __forceinline__ long long root_A_x(const Dev& S, int acc_par, int k) {
+  const int KX = S.K - 1;
+  long long q = 0;
+  for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + k];
+  return q;
+}
+// children of one particle, extension output k: values and sums ([U] draw_leaf_value per output;
+// one Box-Muller pair per output, RNG sub-index = output)
+struct ChildX {
+  double vL, vR;
+  long long aL, aR;
+};
+__device__ __forceinline__ ChildX child_values_x(const Dev& S, int ok, int cL, int cR, long long aLk,
+                                                 long long aNk, long long pq, double pv, uint32_t it,
+                                                 uint32_t round, uint32_t particle, int k, double lsd) {
+  ChildX c;
+  c.aL = aLk;
+  c.aR = pq - aLk - aNk;
+  if (ok == 1) {
+    const pgb_u2 u = pgb_draw2(S.seed, it, round, particle, PGB_RNG_LEAF, (uint32_t)(k + 1));
+    double z0, z1;
+    pgb_normal2(u.u0, u.u1, &z0, &z1);
+    c.vL = pgb_leaf_value(cL, c.aL, S.sc.inv_c1, S.mdouble, z0, lsd);
+    c.vR = pgb_leaf_value(cR, c.aR, S.sc.inv_c1, S.mdouble, z1, lsd);
+  } else {
+    c.vL = pv;  // failed one-hot split: the leaf keeps its value
+    c.vR = 0.0;
   }
   return c;
 }
@@ -424,12 +490,16 @@ __device__ __forceinline__ int sample_var_weights(const long long* A, int p, dou
   return p - 1;
 }
 
-__global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par) {
+// MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
+template <bool MK>
+__global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 2)))  // latency kernel: registers, not occupancy
+void k_ctrl(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_i[16];
   __shared__ double s_d[4];
   __shared__ double s_pre[2][PGB_SELECT_TRIES + 2];  // [set][0: coin, 1+t: row draw of try t]
+  __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
 
   TR(0);
   const Ctrl c = S.ctrl[par];
@@ -458,12 +528,20 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     S.acc[par * MAXP + p] = z;
   }
   if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, {0, 0, 0}};
+  const int KX = MK ? S.K - 1 : 0;
+  if constexpr (MK) {
+    if (tid < 2 * KX) S.accx[((size_t)par * MAXP + p) * 2 * KX + tid] = 0;
+    if (b == 0)
+      for (int i = tid; i < IA_SLOTS * 2 * KX; i += BT) S.iax[(size_t)par * IA_SLOTS * 2 * KX + i] = 0;
+  }
 
   if (c.phase == PH_IDLE) {
     if (b == 0 && tid == 0) {
       Ctrl o = c;
       o.slot_no = c.slot_no + 1;
       o.leaf_sd = leaf_sd;
+      if constexpr (MK)
+        for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
       o.pend_leafsd = 0;
       *co = o;
       cmd->kind = CMD_NOOP;
@@ -565,7 +643,7 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         f.ll_tot = j.h_ll_tot;
         f.ll_orph = j.h_ll_orph;
         if (j.active) {
-          const ChildVals cv = child_values(S, j.rule, j.cnt, j.p_q_st, j.p_value, a, z0, z1, leaf_sd);
+          const ChildVals cv = child_values(S, j.rule, j.cnt, j.p_q_st, j.p_value, a.cnts, a.aL, a.aN, z0, z1, leaf_sd);
           const int cL = cv.cL, cR = cv.cR;
           f.loc_gen = c.lid_gen;  // the row pass wrote this particle's labels here
           f.loc_slot = q;
@@ -601,6 +679,16 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
             f.ll_tot = ((j.h_ll_tot - j.p_ll) + a.llL) + a.llR;
             f.n_nodes = j.h_n_nodes + 2;
             f.n_leaves = j.h_n_leaves + 1;
+          }
+        }
+        if constexpr (MK) {
+          if (j.active)
+          for (int k = 0; k < KX; ++k) {
+            const size_t ax = ((size_t)(par ^ 1) * MAXP + q) * 2 * KX;
+            const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, S.accx[ax + k], S.accx[ax + KX + k], pq, pv, it,
+                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par ^ 1, k));
           }
         }
         s_fin[q] = f;
@@ -662,6 +750,24 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
           z.cc_row = f.ccL;
         }
         me->nd[i] = z;
+      }
+      if constexpr (MK) {  // extension outputs of the node table
+        const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX, dn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX;
+        for (int e = tid; e < nn * KX; e += BT) {
+          const int i = e / KX, k = e % KX;
+          double v = S.pvx[so + e];
+          long long qv = S.pqx[so + e];
+          if (r1 && i == 0) qv = root_A_x(S, par ^ 1, k);
+          if (f.ok == -1 && i == f.node) qv = s_finx[anc][k].aL;
+          S.pvx[dn + e] = v;
+          S.pqx[dn + e] = qv;
+        }
+        if (f.ok == 1)
+          for (int e = tid; e < 2 * KX; e += BT) {
+            const int ch = e / KX, k = e % KX;
+            S.pvx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].vR : s_finx[anc][k].vL;
+            S.pqx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].aR : s_finx[anc][k].aL;
+          }
       }
       if (f.ok == 1 && tid >= BT - 2) {
         const bool isL = tid == BT - 2;
@@ -734,8 +840,21 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         cmd->sel_slot = F.loc_slot;  // may be -1 (untouched root labels)
       }
       build_lv(me->nd, nn, cmd->lv_new);
+      if constexpr (MK) {  // extension outputs: store with the tree, publish label->value tables
+        const size_t pn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX, tn = (size_t)tree_old * MAXN * KX;
+        for (int e = tid; e < nn * KX; e += BT) S.tvx[tn + e] = S.pvx[pn + e];
+        build_lvx(me->nd, nn, S.pvx + pn, KX, S.lvx + ((size_t)par * 2 + 0) * 256 * KX);
+      }
     }
     if (b == 0) {
+      if constexpr (MK) {
+        if (sel == 0)
+          build_lvx(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tvx + (size_t)tree_old * MAXN * KX, KX,
+                    S.lvx + ((size_t)par * 2 + 0) * 256 * KX);
+        if (has_init && tree_new != tree_old)
+          build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
+                    S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+      }
       if (sel == 0) {  // the old tree is kept: nobody writes S.trees[tree_old] in this slot
         if (tid == 0) {
           cmd->sel_slot = -2;
@@ -783,6 +902,10 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       if (tree_new == tree_old && has_init) {  // m == 1 corner: next update is this very tree
         __syncthreads();
         build_lv(snd, nn, cmd->lv_next);
+        if constexpr (MK)
+          build_lvx(snd, nn, sel == 0 ? S.tvx + (size_t)tree_old * MAXN * KX
+                                      : S.pvx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
+                    KX, S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
       }
     }
     if (b == 0 && tid == 0) {
@@ -799,6 +922,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
         Ctrl o = c;
         o.slot_no = c.slot_no + 1;
         o.leaf_sd = leaf_sd;
+        if constexpr (MK)
+          for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
         o.rs_count = c.rs_count + (c.tune ? 1 : 0);
         o.pend_leafsd = c.tune ? 1 : 0;
         o.pend_iter = c.iter;
@@ -825,6 +950,9 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     }
   } else if (begin && b == 0) {
     build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+    if constexpr (MK)
+      build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
+                S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
   }
 
   // =================================================================== propose
@@ -852,6 +980,11 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       z.cnt = (int32_t)S.n;
       z.value = S.init_leaf;
       me->nd[0] = z;
+      if constexpr (MK)
+      for (int k = 0; k < KX; ++k) {
+        S.pvx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = S.init_leaf;
+        S.pqx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = 0;  // patched by the next slot
+      }
     }
     __syncthreads();
   }
@@ -1027,6 +1160,26 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
       job.p_value = nd.value;
       job.p_depth = nd.depth;
       atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
+      if constexpr (MK)
+      for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
+        long long pq;
+        double pv;
+        if (fresh) {
+          pq = 0;  // root sums are not known yet: patched by the next slot
+          pv = S.init_leaf;
+        } else if (node < F.nn_old) {
+          const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX + (size_t)node * KX + k;
+          pq = (r == 1 && node == 0) ? root_A_x(S, par ^ 1, k) : S.pqx[so];
+          pv = S.pvx[so];
+          if (F.ok == -1 && node == F.node) pq = s_finx[anc][k].aL;
+        } else {
+          const bool isL = node == F.nn_old;
+          pq = isL ? s_finx[anc][k].aL : s_finx[anc][k].aR;
+          pv = isL ? s_finx[anc][k].vL : s_finx[anc][k].vR;
+        }
+        S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
+        S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
+      }
     }
     JN[p] = job;
     me->n_nodes = F.n_nodes;
@@ -1050,6 +1203,8 @@ __global__ __launch_bounds__(BT) void k_ctrl(const Dev* __restrict__ Sp, int par
     Ctrl o = c;
     o.slot_no = c.slot_no + 1;
     o.leaf_sd = leaf_sd;
+    if constexpr (MK)
+      for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
     o.pend_leafsd = 0;
     o.lid_gen = (c.lid_gen + 1) % NGEN;
     o.sse0 = sse0;
@@ -1405,6 +1560,313 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
   }
 }
 
+// ------------------------------------------------------------------ k_rows_mk
+// K-vector leaves (K > 1, Categorical-softmax): the same slot logic as k_rows with sum_trees, leaf
+// values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
+// the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
+__device__ __forceinline__ double loglik_any(const Dev& S, double y, const double* mu) {
+  return S.family == PGB_FAMILY_CATEGORICAL ? pgb_loglik_cat(S.K, y, mu) : pgb_loglik1(S.family, y, mu[0]);
+}
+
+__global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
+  const int K = S.K, KX = K - 1;
+  __shared__ long long s_red[MAXP * (1 + 2 * PGB_MAX_OUTPUTS) * 4];
+  __shared__ double s_lv[2][256][PGB_MAX_OUTPUTS];
+  __shared__ RJob s_job[MAXP];
+  __shared__ int s_n[2];
+  const Cmd* cmd = &S.cmd[par];
+  const int kind = cmd->kind;
+  if (kind == CMD_NOOP) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
+  const bool do_part = (kind & CMD_PARTITION) != 0;
+  const int NV = 1 + 2 * K;  // per particle: counts, aL[K], aN[K]
+
+  if (do_final || do_init) {
+    const double* lx = S.lvx + (size_t)par * 2 * 256 * KX;
+    for (int i = tid; i < 256; i += BT) {
+      s_lv[0][i][0] = cmd->lv_new[i];
+      s_lv[1][i][0] = cmd->lv_next[i];
+      for (int k = 0; k < KX; ++k) {
+        s_lv[0][i][k + 1] = lx[(size_t)i * KX + k];
+        s_lv[1][i][k + 1] = lx[(size_t)256 * KX + (size_t)i * KX + k];
+      }
+    }
+  }
+  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
+  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
+  const uint8_t* sel_lid =
+      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
+  const double cntf = (double)cmd->rs_count;
+  // sum_trees buffers [2][K][n_pad]
+  const double* st_in = S.st + (size_t)cmd->st_cur * K * S.n_pad;
+  double* st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * K * S.n_pad;
+  const double c1 = S.sc.c1;
+  const long long n = S.n, n_pad = S.n_pad;
+
+  if (do_part) {
+    const Job* jobs = S.jobs + (size_t)par * MAXP;
+    if (tid < 64) {
+      Job j;
+      j.active = 0;
+      j.copy = 0;
+      if (tid >= 1 && tid < S.P) j = jobs[tid];
+      const bool has = (j.active | j.copy) != 0;
+      const unsigned long long m = __ballot(has);
+      if (has) {
+        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        RJob rj;
+        rj.p = tid;
+        rj.active = j.active;
+        rj.check_nan = j.check_nan;
+        rj.rule = j.rule;
+        rj.label = j.label;
+        rj.new_label = j.new_label;
+        rj.ccL = j.ccL;
+        rj.ccR = j.ccR;
+        rj.v = j.v;
+        rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+        rj.xoff = (long long)((size_t)j.var * S.n_pad);
+        s_job[k] = rj;
+      }
+      if (tid == 0) s_n[0] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = s_n[0];
+    if (nact == 0 && !do_init) return;
+    int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+    if (G < 1) G = 1;
+    int ngroups = (nact + G - 1) / G;
+    if (ngroups < 1) ngroups = 1;
+    const int nitems = S.nchunks * ngroups;
+    uint8_t* const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+    long long iv[2 + 2 * PGB_MAX_OUTPUTS];  // C, E0, A[K], QSTD[K]
+    for (int i = 0; i < 2 + 2 * K; ++i) iv[i] = 0;
+    unsigned sat = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      const int chunk = item % S.nchunks, grp = item / S.nchunks;
+      const long long base = (long long)chunk * CH + tid * RPT;
+      double stv[RPT][PGB_MAX_OUTPUTS];  // sum_trees of this thread's rows, per output
+      if (do_init) {
+        const bool writer = grp == 0;
+        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_sel = 0;
+        if (do_final) {
+          if (cmd->sel_slot == -2) {
+            ids_sel = *(const uint32_t*)(tl_old + base);
+          } else {
+            if (sel_lid) {
+              ids_sel = *(const uint32_t*)(sel_lid + base);
+            } else {
+              for (int e = 0; e < RPT; ++e)
+                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+            }
+            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+          }
+          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+        }
+        for (int e = 0; e < RPT; ++e) {
+          const long long row = base + e;
+          for (int k = 0; k < K; ++k) stv[e][k] = 0.0;
+          if (row >= n) continue;
+          double mu_stump[PGB_MAX_OUTPUTS], mu_cur[PGB_MAX_OUTPUTS];
+          for (int k = 0; k < K; ++k) {
+            double st = st_in[(size_t)k * n_pad + row];
+            if (do_final) {
+              const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u][k];
+              st = st + nv;
+              if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
+                const size_t ri = (size_t)k * n_pad + row;
+                const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+                const double delta = nv - mean0;
+                const double mean = mean0 + delta / cntf;
+                const double delta2 = nv - mean;
+                const double m2 = m20 + delta * delta2;
+                S.rs_mean[ri] = mean;
+                S.rs_m2[ri] = m2;
+                iv[2 + K + k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+              }
+            }
+            const double o = s_lv[1][(ids_next >> (8 * e)) & 255u][k];
+            const double noi = st - o;
+            stv[e][k] = st;
+            mu_stump[k] = noi + S.init_leaf;
+            mu_cur[k] = st;
+            if (writer) {
+              if (k == 0) S.pack[row] = make_double2(st, 0.0);
+              else S.packx[(size_t)(k - 1) * n_pad + row] = st;
+              st_out[(size_t)k * n_pad + row] = noi;
+              iv[2 + k] += pgb_quant(st, c1, &sat);
+            }
+          }
+          if (writer) {
+            const double yv = S.y[row];
+            iv[0] += pgb_quant(loglik_any(S, yv, mu_stump), S.sc.cl, &sat);  // C: fresh stump
+            iv[1] += pgb_quant(loglik_any(S, yv, mu_cur), S.sc.cl, &sat);    // E0: current tree
+          }
+        }
+      } else {
+        for (int e = 0; e < RPT; ++e) {
+          stv[e][0] = S.pack[base + e].x;
+          for (int k = 1; k < K; ++k) stv[e][k] = S.packx[(size_t)(k - 1) * n_pad + base + e];
+        }
+      }
+      uint32_t root_ids = 0;
+      for (int e = 0; e < RPT; ++e)
+        if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      for (int g = g0; g < g1; ++g) {
+        const RJob& rj = s_job[g];
+        const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + rj.src + base);
+        uint32_t out = ids;
+        uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
+        if (!rj.active) {
+          *(uint32_t*)dp = out;
+          continue;
+        }
+        const double2* xp = (const double2*)(S.XT + rj.xoff + base);
+        const double2 t0 = xp[0], t1 = xp[1];
+        const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
+        long long cnts = 0;
+        for (int e = 0; e < RPT; ++e) {
+          side[e] = 0;
+          if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+            const double xv = x[e];
+            if (xv != xv) {
+              side[e] = 3;
+              out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+              cnts += 1ll << 40;
+            } else if (go_left(rj.rule, xv, rj.v)) {
+              side[e] = 1;
+              cnts += 1;
+            } else {
+              side[e] = 2;
+              out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+              cnts += 1ll << 20;
+            }
+          }
+        }
+        *(uint32_t*)dp = out;
+        const int slot = (g - g0) * NV;
+        {
+          const long long s0 = wave_sum_dpp(cnts);
+          if (lane == 63) s_red[(slot + 0) * 4 + w] = s0;
+        }
+        for (int k = 0; k < K; ++k) {
+          long long aL = 0, aN = 0;
+          for (int e = 0; e < RPT; ++e) {
+            if (side[e] == 1 || side[e] == 3) {
+              const long long q = pgb_quant(stv[e][k], c1, nullptr);
+              if (side[e] == 1) aL += q; else aN += q;
+            }
+          }
+          const long long sL = wave_sum_dpp(aL), sN = wave_sum_dpp(aN);
+          if (lane == 63) {
+            s_red[(slot + 1 + k) * 4 + w] = sL;
+            s_red[(slot + 1 + K + k) * 4 + w] = sN;
+          }
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < (g1 - g0) * NV; t += BT) {
+        const int gi = t / NV, i = t % NV;
+        const RJob& rj = s_job[g0 + gi];
+        if (!rj.active) continue;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        Acc* a = &S.acc[(size_t)par * MAXP + rj.p];
+        long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * 2 * KX;
+        if (i == 0) {
+          const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
+          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+          if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+        } else if (s != 0) {
+          const int k = (i - 1) % K;
+          const bool isN = (i - 1) >= K;
+          long long* dst = k == 0 ? (isN ? &a->aN : &a->aL) : &ax[(isN ? KX : 0) + k - 1];
+          atomicAdd((unsigned long long*)dst, (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+    }
+    if (do_init) {
+      // C, E0, A[0] (+QSTD[0]) -> InitAcc; A[k>0], QSTD[k>0] -> iax
+      long long v5[5] = {iv[2], 0, iv[0], iv[1], iv[2 + K]};
+      block_sum<5>(v5, s_red);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (v5[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v5[0]);
+        if (v5[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)v5[2]);
+        if (v5[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v5[3]);
+        if (v5[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v5[4]);
+      }
+      for (int k = 1; k < K; ++k) {
+        long long v2[2] = {iv[2 + k], iv[2 + K + k]};
+        block_sum<2>(v2, s_red);
+        if (tid == 0) {
+          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+          if (v2[0]) atomicAdd((unsigned long long*)&ix[k - 1], (unsigned long long)v2[0]);
+          if (v2[1]) atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v2[1]);
+        }
+      }
+      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+    }
+    return;
+  }
+
+  // ---------------- lone FINAL
+  __syncthreads();
+  long long qs[PGB_MAX_OUTPUTS];
+  for (int k = 0; k < K; ++k) qs[k] = 0;
+  unsigned sat = 0;
+  const int nitems = (int)(S.n_pad / BT);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long long row = (long long)item * BT + tid;
+    if (row >= S.n) continue;
+    uint32_t id_sel;
+    if (cmd->sel_slot == -2) {
+      id_sel = tl_old[row];
+    } else {
+      id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;
+      tl_old[row] = (uint8_t)id_sel;
+    }
+    for (int k = 0; k < K; ++k) {
+      const size_t ri = (size_t)k * n_pad + row;
+      const double nv = s_lv[0][id_sel][k];
+      const double st = st_in[ri] + nv;
+      if (cmd->tune) {
+        const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+        const double delta = nv - mean0;
+        const double mean = mean0 + delta / cntf;
+        const double delta2 = nv - mean;
+        const double m2 = m20 + delta * delta2;
+        S.rs_mean[ri] = mean;
+        S.rs_m2[ri] = m2;
+        qs[k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+      }
+      st_out[ri] = st;
+    }
+  }
+  if (cmd->tune) {
+    for (int k = 0; k < K; ++k) {
+      long long v1[1] = {qs[k]};
+      block_sum<1>(v1, s_red);
+      if (tid == 0 && v1[0]) {
+        if (k == 0) {
+          InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+          atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v1[0]);
+        } else {
+          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+          atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v1[0]);
+        }
+      }
+    }
+  }
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+}
+
 // ------------------------------------------------------------------ k_loglik
 // Bernoulli families only ([U] update_weight): after the PARTITION pass of a slot, the children's
 // leaf values are known (child_values, the same routine k_ctrl uses one launch later); this pass
@@ -1414,8 +1876,10 @@ struct LJob {
   long long src, xoff;
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, pad;
+  double vLx[KXMAX], vRx[KXMAX];  // K-vector leaves: outputs 1..K-1
 };
 
+template <bool MK>
 __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 3 * 4];
@@ -1456,8 +1920,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     if (has) {
       const int k = __popcll(m & ((1ull << tid) - 1ull));
       const Acc a = S.acc[(size_t)par * MAXP + tid];
-      const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a,
-                                        z0, z1, leaf_sd);
+      const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
+                                        a.aL, a.aN, z0, z1, leaf_sd);
       LJob lj;
       lj.p = tid;
       lj.rule = j.rule;
@@ -1469,6 +1933,17 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       lj.vR = cv.vR;
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
+      if constexpr (MK)
+      for (int kx = 0; kx < S.K - 1; ++kx) {  // extension outputs: same routine as k_ctrl
+        const int KX = S.K - 1;
+        const size_t ax = ((size_t)par * MAXP + tid) * 2 * KX;
+        const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
+        const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
+        const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, S.accx[ax + kx], S.accx[ax + KX + kx], pq, pv,
+                                         it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par, kx));
+        lj.vLx[kx] = cx.vL;
+        lj.vRx[kx] = cx.vR;
+      }
       s_job[k] = lj;
     }
     if (tid == 0) s_n[0] = __popcll(m);
@@ -1480,7 +1955,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   if (G < 1) G = 1;
   const int ngroups = (nact + G - 1) / G;
   const int nitems = S.nchunks * ngroups;
-  const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * S.n_pad;
+  const int K = MK ? S.K : 1;
+  const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * K * S.n_pad;
   const double cl = S.sc.cl;
   const long long n = S.n;
   unsigned sat = 0;
@@ -1494,6 +1970,45 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       yv[e] = S.y[base + e];
       nv[e] = noi[base + e];
       if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+    }
+    if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      for (int g = g0; g < g1; ++g) {
+        const LJob& lj = s_job[g];
+        const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
+        long long v0 = 0, v1 = 0, v2 = 0;
+        for (int e = 0; e < RPT; ++e) {
+          if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+            const double xv = S.XT[lj.xoff + base + e];
+            const int side = (xv != xv) ? 2 : (go_left(lj.rule, xv, lj.v) ? 0 : 1);
+            double mu[PGB_MAX_OUTPUTS];
+            mu[0] = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);
+            for (int k = 1; k < K; ++k)
+              mu[k] = noi[(size_t)k * S.n_pad + base + e] +
+                      (side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0);
+            const long long q = pgb_quant(loglik_any(S, yv[e], mu), cl, &sat);
+            if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
+          }
+        }
+        const int slot = (g - g0) * 3;
+        v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2);
+        if (lane == 63) {
+          s_red[(slot + 0) * 4 + w] = v0;
+          s_red[(slot + 1) * 4 + w] = v1;
+          s_red[(slot + 2) * 4 + w] = v2;
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < (g1 - g0) * 3; t += BT) {
+        const int gi = t / 3, i = t % 3;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        if (s != 0) {
+          Acc* a = &S.acc[(size_t)par * MAXP + s_job[g0 + gi].p];
+          atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+      continue;
     }
     const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
     for (int g = g0; g < g1; ++g) {
@@ -1732,10 +2247,15 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->n >= (1ll << 31) - CH) return fail(PGB_E_UNSUPPORTED, "n too large");
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
     return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
-  if (s->n_outputs != 1) return fail(PGB_E_UNSUPPORTED, "n_outputs != 1 not supported yet");
-  if (s->family != PGB_FAMILY_NORMAL && s->family != PGB_FAMILY_BERNOULLI_PROBIT &&
-      s->family != PGB_FAMILY_BERNOULLI_LOGIT)
-    return fail(PGB_E_UNSUPPORTED, "family not supported yet");
+  if (s->family == PGB_FAMILY_CATEGORICAL) {
+    if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
+      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+  } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
+             s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
+    if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
+  } else {
+    return fail(PGB_E_UNSUPPORTED, "unknown family");
+  }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -1767,6 +2287,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.m = s->m;
   d.P = s->num_particles;
   d.family = s->family;
+  d.K = s->n_outputs;
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
   d.seed = s->seed;
@@ -1784,10 +2305,22 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
   DA(XT, (size_t)d.p * d.n_pad);
   DA(y, d.n_pad);
-  DA(st, 2 * d.n_pad);
+  const int K = d.K, KX = d.K - 1;
+  DA(st, (size_t)2 * K * d.n_pad);
   DA(pack, d.n_pad);
-  DA(rs_mean, d.n_pad);
-  DA(rs_m2, d.n_pad);
+  DA(rs_mean, (size_t)K * d.n_pad);
+  DA(rs_m2, (size_t)K * d.n_pad);
+  if (KX > 0) {  // K-vector leaves: extension outputs
+    DA(d.packx, (size_t)KX * d.n_pad);
+    DA(d.pvx, (size_t)2 * MAXP * MAXN * KX);
+    DA(d.pqx, (size_t)2 * MAXP * MAXN * KX);
+    DA(d.tvx, (size_t)d.m * MAXN * KX);
+    DA(d.accx, (size_t)2 * MAXP * 2 * KX);
+    DA(d.iax, (size_t)2 * IA_SLOTS * 2 * KX);
+    DA(d.lvx, (size_t)2 * 2 * 256 * KX);
+    DA(d.jqx, (size_t)2 * MAXP * KX);
+    DA(d.jvx, (size_t)2 * MAXP * KX);
+  }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
   DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
@@ -1836,8 +2369,21 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
-  HC(hipMemsetAsync(rs_mean, 0, d.n_pad * sizeof(double), sm));
-  HC(hipMemsetAsync(rs_m2, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(rs_mean, 0, (size_t)K * d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(rs_m2, 0, (size_t)K * d.n_pad * sizeof(double), sm));
+  if (KX > 0) {
+    HC(hipMemsetAsync(d.packx, 0, (size_t)KX * d.n_pad * sizeof(double), sm));
+    HC(hipMemsetAsync(d.pvx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(double), sm));
+    HC(hipMemsetAsync(d.pqx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.accx, 0, (size_t)2 * MAXP * 2 * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.iax, 0, (size_t)2 * IA_SLOTS * 2 * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.lvx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
+    HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
+    // every accepted tree starts as a stump whose K-vector leaf is init_leaf
+    hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,
+                       d.tvx, (long long)d.m * MAXN * KX, s->init_leaf);
+  }
   HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)NGEN * MAXP * d.n_pad, sm));
   HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
@@ -1852,11 +2398,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   memset(&c0, 0, sizeof c0);
   c0.phase = PH_IDLE;
   c0.leaf_sd = s->init_leaf_sd;
+  for (int k = 0; k < PGB_MAX_OUTPUTS - 1; ++k) c0.leaf_sdx[k] = s->init_leaf_sd;
   c0.inv_sigma2 = 1.0;
   Ctrl cc2[2] = {c0, c0};
   HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
-  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((2 * d.n_pad + 255) / 256)), dim3(256), 0, sm, st,
-                     2 * d.n_pad, s->init_sum);
+  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((2 * K * d.n_pad + 255) / 256)), dim3(256), 0, sm, st,
+                     2 * K * d.n_pad, s->init_sum);
   hipLaunchKernelGGL(k_init_tree_lid, dim3((unsigned)((d.n_pad * d.m + 255) / 256)), dim3(256), 0, sm,
                      tree_lid, d.n, d.n_pad, d.m);
   hipLaunchKernelGGL(k_init_trees, dim3((d.m + 63) / 64), dim3(64), 0, sm, d.trees, d.m, d.n,
@@ -1945,7 +2492,10 @@ static int enqueue_slots(pgb_handle* h, int count) {
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-    hipLaunchKernelGGL(k_ctrl, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
+    if (d.K > 1)
+      hipLaunchKernelGGL(k_ctrl<true>, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
+    else
+      hipLaunchKernelGGL(k_ctrl<false>, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
       if (h->ev_used + 2 > h->ev.size()) {
@@ -1960,10 +2510,17 @@ static int enqueue_slots(pgb_handle* h, int count) {
       h->ev_used += 2;
       (void)hipEventRecord(e0, h->stream);
     }
-    hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+    if (d.K > 1)
+      hipLaunchKernelGGL(k_rows_mk, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+    else
+      hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     if (h->prof) (void)hipEventRecord(e1, h->stream);
-    if (d.family != PGB_FAMILY_NORMAL)  // per-row log-likelihood of the rows this round re-labelled
-      hipLaunchKernelGGL(k_loglik, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+    if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
+      if (d.K > 1)
+        hipLaunchKernelGGL(k_loglik<true>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      else
+        hipLaunchKernelGGL(k_loglik<false>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+    }
     h->slot += 1;
   }
   HIPCHK(hipGetLastError());
@@ -2053,9 +2610,10 @@ extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, 
   int rc;
   if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
   if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
-  if (sum_trees_dev_out)
-    HIPCHK(hipMemcpyAsync(sum_trees_dev_out, h->d.st + (size_t)h->st_cur * h->d.n_pad, h->d.n * sizeof(double),
-                          hipMemcpyDeviceToDevice, h->stream));
+  if (sum_trees_dev_out)  // [K][n] out of the padded [K][n_pad] buffer
+    HIPCHK(hipMemcpy2DAsync(sum_trees_dev_out, h->d.n * sizeof(double),
+                            h->d.st + (size_t)h->st_cur * h->d.K * h->d.n_pad, h->d.n_pad * sizeof(double),
+                            h->d.n * sizeof(double), (size_t)h->d.K, hipMemcpyDeviceToDevice, h->stream));
   if (vi_counts_host_out)
     HIPCHK(hipMemcpyAsync(vi_counts_host_out, h->d.vi, h->d.p * sizeof(int32_t), hipMemcpyDeviceToHost,
                           h->stream));
@@ -2087,11 +2645,18 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
   }
   int total = 0;
   for (int t = 0; t < nt; ++t) total += host[t].n_nodes;
+  const int K = d.K, KX = d.K - 1;
   if (!out->var) {
     out->n_trees = nt;
-    out->n_outputs = 1;
+    out->n_outputs = K;
     out->total_nodes = total;
     return PGB_OK;
+  }
+  std::vector<double> hx;
+  if (KX > 0 && nt > 0) {
+    hx.resize((size_t)nt * MAXN * KX);
+    HIPCHK(hipMemcpy(hx.data(), d.tvx + (size_t)first * MAXN * KX, hx.size() * sizeof(double),
+                     hipMemcpyDeviceToHost));
   }
   if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
   int off = 0;
@@ -2106,7 +2671,9 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
       out->left[off + k] = z.var >= 0 ? (int32_t)z.left : -1;
       out->right[off + k] = z.var >= 0 ? (int32_t)z.right : -1;
       out->count[off + k] = z.cnt;
-      out->value[off + k] = z.var < 0 ? z.value : 0.0;
+      out->value[(size_t)(off + k) * K] = z.var < 0 ? z.value : 0.0;
+      for (int o = 1; o < K; ++o)
+        out->value[(size_t)(off + k) * K + o] = z.var < 0 ? hx[((size_t)t * MAXN + k) * KX + o - 1] : 0.0;
     }
     off += T.n_nodes;
   }
@@ -2127,7 +2694,24 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
   long long qstd = 0;
   for (int k = 0; k < IA_SLOTS; ++k) qstd += ia[k].QSTD;
   if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)qstd * d.sc.inv_c1) / (double)d.n;
-  if (leaf_sd_out) leaf_sd_out[0] = leaf_sd;
+  if (leaf_sd_out) {
+    leaf_sd_out[0] = leaf_sd;
+    const int KX = d.K - 1;
+    if (KX > 0) {
+      std::vector<long long> ix((size_t)IA_SLOTS * 2 * KX);
+      HIPCHK(hipMemcpy(ix.data(), d.iax + (size_t)((h->slot & 1) ^ 1) * IA_SLOTS * 2 * KX,
+                       ix.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      for (int k = 0; k < KX; ++k) {
+        double v = c.leaf_sdx[k];
+        if (c.pend_leafsd && c.pend_iter > 2) {
+          long long q = 0;
+          for (int sl = 0; sl < IA_SLOTS; ++sl) q += ix[(size_t)sl * 2 * KX + KX + k];
+          v = ((double)q * d.sc.inv_c1) / (double)d.n;
+        }
+        leaf_sd_out[k + 1] = v;
+      }
+    }
+  }
   if (iter_out) *iter_out = c.iter;
   if (lower_out) *lower_out = c.lower;
   return PGB_OK;

@@ -83,6 +83,21 @@ class BernoulliLikelihood:
         return []
 
 
+class CategoricalLikelihood:
+    """``y ~ Categorical(softmax(BART[0..K-1]))`` -- K-vector leaves sharing one tree structure
+    (reference ``tests/test_bart.py:140-164``: ``shape=(3, 9)``; cfg5 of BASELINE.json)."""
+
+    family = "categorical"
+
+    def __init__(self, n_outputs: int):
+        if not 2 <= int(n_outputs) <= 8:
+            raise ValueError("n_outputs must be in [2, 8]")
+        self.n_outputs = int(n_outputs)
+
+    def params(self, point=None):
+        return []
+
+
 def _op_of(var):
     owner = getattr(var, "owner", None)
     return owner.op if owner is not None and hasattr(owner, "op") else var
@@ -152,7 +167,7 @@ class PGBART(_Base):
                 X[:, j] = jitter_duplicated(X[:, j], jrng)
         self.likelihood = likelihood if likelihood is not None else NormalLikelihood(1.0)
         y_obs = Y if observed is None else np.asarray(observed, np.float64)
-        n_outputs = 1
+        n_outputs = int(getattr(self.likelihood, "n_outputs", 1))
         self.settings = PyBartSettings.from_data(
             X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
             family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
@@ -166,7 +181,7 @@ class PGBART(_Base):
         self._baseline = None
         self._batches = []
         self._registered = False
-        self.shape = (self.num_observations,)
+        self.shape = (self.num_observations,) if n_outputs == 1 else (n_outputs, self.num_observations)
         if _HAVE_PYMC and model is not None:  # pragma: no cover
             shared = {}
             super().__init__(vars, shared)

@@ -113,7 +113,7 @@ class PyBartSettings:
         leaf_sd = 3.0 / math.sqrt(m) if is_binary else float(Y.std()) / math.sqrt(m)
         rexp = range_exponent(Y)
         if family != "normal":
-            rexp = max(rexp, 6)  # latent link scale: |sum_trees| < 64
+            rexp = max(rexp, 10)  # latent link scale: |sum_trees| < 1024 (separable data drifts far)
         return cls(
             n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
             alpha=alpha, beta=beta, batch=tuple(batch), seed=int(seed), init_sum=mean,

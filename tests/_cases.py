@@ -76,6 +76,19 @@ def make_case(name: str):
         f = np.where(np.isnan(X[:, 0]), 0.0, 2 * X[:, 0]) + (X[:, 3] == 1) * 1.5
         Y = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
         c.update(m=10, P=16, steps=30, family="bernoulli_logit", rules=np.array([0, 0, 0, 1, 1], np.int32))
+    elif name == "categorical_k3_reference":  # reference tests/test_bart.py:140-164 (shape=(3, 9))
+        Y = np.array([0, 0, 0, 1, 1, 1, 2, 2, 2], float)
+        X = np.concatenate([Y[:, None], rng.integers(0, 6, size=(9, 4))], axis=1).astype(float)
+        c.update(m=2, P=10, steps=60, family="categorical", K=3, rules=np.array([1] * 5, np.int32))
+        n = 9
+    elif name == "categorical_k4_cfg5_small":  # BASELINE.json configs[4] at test size
+        n, p, K = 5000, 12, 4
+        X = rng.normal(size=(n, p))
+        X[rng.random(n) < 0.1, 2] = np.nan
+        F = np.stack([X[:, 0], -X[:, 0], 1.5 * X[:, 1], 0 * X[:, 0]])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=15, P=12, steps=24, family="categorical", K=K)
     elif name == "onehot_fail_nan":  # failed one-hot splits that shed NaN rows (Normal family)
         n, p = 2500, 3
         X = rng.normal(size=(n, p))
@@ -92,7 +105,7 @@ def make_case(name: str):
 
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
-         "logit_nan_onehot"]
+         "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small"]
 
 
 def run_case(c, backend, record_every: int = 1):
@@ -101,7 +114,8 @@ def run_case(c, backend, record_every: int = 1):
     p = X.shape[1]
     family = c.get("family", "normal")
     st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
-                                  alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family)
+                                  alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family,
+                                  n_outputs=c.get("K", 1))
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
     prior = np.ones(p) if c["prior"] is None else c["prior"]
     s = PySampler(st, X, Y, rules, prior, backend=backend)
