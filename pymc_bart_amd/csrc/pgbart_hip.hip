@@ -79,24 +79,27 @@ struct Job {  // one particle's work for a PARTITION row pass + what the next k_
   double h_sse_tot, h_sse_orph;
   int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
   int32_t pad_;
-  // Bernoulli families: fixed-point log-likelihoods instead of the SSE algebra
-  long long p_ll, h_ll_tot, h_ll_orph;
+};
+// (No unions / arrays in records that are copied by value in kernels: they defeat scalar
+//  replacement and the copies get demoted to LDS or scratch.)
+
+struct JobL {  // non-Normal families: fixed-point log-likelihoods that travel with a Job
+  long long p_ll, h_ll_tot, h_ll_orph, pad;
+};
+struct AccL {  // non-Normal families (k_loglik): log-likelihood of the left / right children and of
+  long long llL, llR, llN, pad;  // the rows dropped by a missing split value
 };
 
 struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right = parent - both)
   unsigned long long cnts;  // cntL | cntN << 32
   long long aL, bL, c2L, aN, bN, c2N;
   long long pad;
-  // Bernoulli families (k_loglik): log-likelihood of the left / right children and of the rows
-  // dropped by a missing split value (all three on their own cache line)
-  long long llL, llR, llN;
-  long long pad2[5];
 };
 
 #define IA_SLOTS 8 /* the row pass spreads its atomics over this many cache lines */
 struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;
-  long long pad[3];
+  long long pad0, pad1, pad2;
 };
 
 enum { CMD_NOOP = 0, CMD_PARTITION = 1, CMD_INIT = 2, CMD_FINAL = 4 /* FINAL|INIT = 6 */ };
@@ -117,8 +120,8 @@ struct Ctrl {
   int32_t pend_leafsd, st_cur;  // st_cur: which sum_trees buffer is current
   int32_t alpha_cur, cdf_cur;   // current buffers of the split weights / their prefix sums
   long long iter, rs_count, pend_iter;
-  double leaf_sd, inv_sigma2;
-  double leaf_sdx[PGB_MAX_OUTPUTS - 1];  // outputs 1..K-1
+  double leaf_sd, inv_sigma2;  // (leaf_sd of outputs 1..K-1: Dev::lsdx -- no arrays in this record,
+                               //  the compiler would demote a by-value copy with an indexed array to LDS)
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
   long long steps_done;  // asteps completed since creation (mirrored to the host flag)
   long long slot_no;     // k_ctrl launches so far
@@ -146,6 +149,8 @@ struct Dev {  // kernel argument block (by value)
   DPart* parts;       // [2][P]
   Job* jobs;          // [2][P]
   Acc* acc;           // [2][P]
+  AccL* accl;         // [2][P]   (non-Normal families)
+  JobL* jobl;         // [2][P]   (non-Normal families)
   InitAcc* initacc;   // [2][IA_SLOTS]
   Cmd* cmd;           // [2]
   Ctrl* ctrl;         // [2]
@@ -167,6 +172,7 @@ struct Dev {  // kernel argument block (by value)
   double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
   long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
   double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
+  double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
   long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
 };
@@ -186,6 +192,21 @@ struct Dev {  // kernel argument block (by value)
 #define TR(i) ((void)0)
 #define TRX(i, cond) ((void)0)
 #endif
+
+// A read of a wave-uniform, kernel-invariant record (written by an EARLIER launch) through the
+// constant address space: the compiler can then use scalar (SMEM) loads and keep the record in
+// SGPRs instead of issuing per-lane flat loads.
+#define PGB_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T out;
+  __builtin_memcpy(&out, (const PGB_CONST_AS void*)(unsigned long long)p, sizeof(T));
+  return out;
+#else
+  return *p;
+#endif
+}
 
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long wave_sum(long long v) {
@@ -375,8 +396,8 @@ __device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cn
 #define KXMAX (PGB_MAX_OUTPUTS - 1)
 // leaf_sd of extension output k (0-based), with the pending update of a FINAL pass resolved the
 // same way as for output 0
-__device__ __forceinline__ double leaf_sd_x(const Dev& S, const Ctrl& c, int acc_par, int k) {
-  if (!(c.pend_leafsd && c.pend_iter > 2)) return c.leaf_sdx[k];
+__device__ __forceinline__ double leaf_sd_x(const Dev& S, const Ctrl& c, int ctrl_par, int acc_par, int k) {
+  if (!(c.pend_leafsd && c.pend_iter > 2)) return S.lsdx[ctrl_par * KXMAX + k];
   const int KX = S.K - 1;
   long long q = 0;
   for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + KX + k];
@@ -492,7 +513,7 @@ __device__ __forceinline__ int sample_var_weights(const long long* A, int p, dou
 
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK>
-__global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 2)))  // latency kernel: registers, not occupancy
+__global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
 void k_ctrl(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
@@ -502,7 +523,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
 
   TR(0);
-  const Ctrl c = S.ctrl[par];
+  const Ctrl c = load_uniform(&S.ctrl[par]);
   Ctrl* co = &S.ctrl[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
   const int P = S.P, Lc = P - 1;
@@ -510,10 +531,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   InitAcc ia;  // statistics of the previous FINAL/INIT row pass (integer sums over IA_SLOTS lines)
   {
     const InitAcc* src = S.initacc + (size_t)(par ^ 1) * IA_SLOTS;
-    ia = src[0];
+    ia = load_uniform(&src[0]);
 #pragma unroll
     for (int k = 1; k < IA_SLOTS; ++k) {
-      ia.A += src[k].A; ia.B += src[k].B; ia.C += src[k].C; ia.E0 += src[k].E0; ia.QSTD += src[k].QSTD;
+      const InitAcc t = load_uniform(&src[k]);
+      ia.A += t.A; ia.B += t.B; ia.C += t.C; ia.E0 += t.E0; ia.QSTD += t.QSTD;
     }
   }
 
@@ -526,8 +548,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     Acc z;
     memset(&z, 0, sizeof z);
     S.acc[par * MAXP + p] = z;
+    if (S.family != PGB_FAMILY_NORMAL) S.accl[par * MAXP + p] = AccL{0, 0, 0, 0};
   }
-  if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, {0, 0, 0}};
+  if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, 0, 0, 0};
   const int KX = MK ? S.K - 1 : 0;
   if constexpr (MK) {
     if (tid < 2 * KX) S.accx[((size_t)par * MAXP + p) * 2 * KX + tid] = 0;
@@ -541,7 +564,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
       o.slot_no = c.slot_no + 1;
       o.leaf_sd = leaf_sd;
       if constexpr (MK)
-        for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
+        for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
       o.pend_leafsd = 0;
       *co = o;
       cmd->kind = CMD_NOOP;
@@ -596,16 +619,23 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     if (tid < 64) {
       const int q = tid;
       const bool isp = q >= 1 && q < P;
-      Fin f;
-      memset(&f, 0, sizeof f);
+      // this lane's record is built directly in LDS (a register copy with a final struct store
+      // defeats scalar replacement and ends up in scratch); slot 0 is unused in this phase
+      Fin& f = s_fin[isp ? q : 0];
       double lw = 0.0;
       bool pending = false;
       // RNG + Box-Muller do not depend on memory: they run while the loads below are in flight
       Job j;
       Acc a;
+      JobL jl = {0, 0, 0, 0};
+      AccL al = {0, 0, 0, 0};
       if (isp) {
         j = JP[q];
         a = S.acc[(par ^ 1) * MAXP + q];
+        if (!normal) {
+          jl = S.jobl[(par ^ 1) * MAXP + q];
+          al = S.accl[(par ^ 1) * MAXP + q];
+        }
       }
       // one Philox evaluation per lane: lane 0 draws the resampling offset, lane q the leaf noise
       double z0, z1, u_res;
@@ -623,10 +653,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
           j.p_sse = root_sse;
           j.h_sse_tot = root_sse;
           j.h_sse_orph = 0.0;
-          j.p_ll = ia.C;  // Bernoulli families: C carries the stump's log-likelihood
-          j.h_ll_tot = ia.C;
-          j.h_ll_orph = 0;
+          jl.p_ll = ia.C;  // non-Normal families: C carries the stump's log-likelihood
+          jl.h_ll_tot = ia.C;
+          jl.h_ll_orph = 0;
         }
+        f.ok = 0;
         f.nn_old = j.h_n_nodes;
         f.n_nodes = j.h_n_nodes;
         f.n_leaves = j.h_n_leaves;
@@ -640,8 +671,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
           f.loc_gen = c.lid_gen;
           f.loc_slot = q;
         }
-        f.ll_tot = j.h_ll_tot;
-        f.ll_orph = j.h_ll_orph;
+        f.ll_tot = jl.h_ll_tot;
+        f.ll_orph = jl.h_ll_orph;
         if (j.active) {
           const ChildVals cv = child_values(S, j.rule, j.cnt, j.p_q_st, j.p_value, a.cnts, a.aL, a.aN, z0, z1, leaf_sd);
           const int cL = cv.cL, cR = cv.cR;
@@ -653,15 +684,15 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
           f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
           f.ccL = j.ccL;
           f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
-          f.ll_orph = j.h_ll_orph + a.llN;
-          f.llL = a.llL;
+          f.ll_orph = jl.h_ll_orph + al.llN;
+          f.llL = al.llL;
           if (cv.ok == -1) {
             // [U] a one-hot split needs two distinct values: the grow fails and the node stays a
             // leaf.  No row was relabelled except rows with a missing split value, which the pass
             // dropped; the leaf sheds them (identity when there are none).
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, j.p_value, S.sc.inv_c1, S.sc.inv_c2);
             f.sse_tot = (j.h_sse_tot - j.p_sse) + f.sseL;
-            f.ll_tot = (j.h_ll_tot - j.p_ll) + a.llL;
+            f.ll_tot = (jl.h_ll_tot - jl.p_ll) + al.llL;
           } else {
             f.cR = cR;
             f.var = j.var; f.split = j.v; f.new_label = j.new_label;
@@ -675,8 +706,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
             f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
             f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
-            f.llR = a.llR;
-            f.ll_tot = ((j.h_ll_tot - j.p_ll) + a.llL) + a.llR;
+            f.llR = al.llR;
+            f.ll_tot = ((jl.h_ll_tot - jl.p_ll) + al.llL) + al.llR;
             f.n_nodes = j.h_n_nodes + 2;
             f.n_leaves = j.h_n_leaves + 1;
           }
@@ -688,10 +719,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, S.accx[ax + k], S.accx[ax + KX + k], pq, pv, it,
-                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par ^ 1, k));
+                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
           }
         }
-        s_fin[q] = f;
         pending = f.next_pop < f.n_nodes;
         lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
                     : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
@@ -923,7 +953,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         o.slot_no = c.slot_no + 1;
         o.leaf_sd = leaf_sd;
         if constexpr (MK)
-          for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
+          for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
         o.rs_count = c.rs_count + (c.tune ? 1 : 0);
         o.pend_leafsd = c.tune ? 1 : 0;
         o.pend_iter = c.iter;
@@ -998,8 +1028,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   job.h_next_pop = F.next_pop;
   job.h_sse_tot = F.sse_tot;
   job.h_sse_orph = F.sse_orph;
-  job.h_ll_tot = F.ll_tot;
-  job.h_ll_orph = F.ll_orph;
   bool attempt = false;
   int node = -1;
   DNode nd;
@@ -1155,7 +1183,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
       job.p_q_st = nd.q_st;
       job.p_q_r = nd.q_r;
       job.p_q_r2 = nd.q_r2;
-      job.p_ll = nd.q_r;  // (Bernoulli families)
       job.p_sse = nd.sse;
       job.p_value = nd.value;
       job.p_depth = nd.depth;
@@ -1182,6 +1209,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
       }
     }
     JN[p] = job;
+    if (!normal)  // the node's log-likelihood lives in q_r for these families
+      S.jobl[par * MAXP + p] = JobL{job.active ? nd.q_r : 0, F.ll_tot, F.ll_orph, 0};
     me->n_nodes = F.n_nodes;
     me->n_leaves = F.n_leaves;
     me->next_pop = job.h_next_pop;
@@ -1204,7 +1233,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     o.slot_no = c.slot_no + 1;
     o.leaf_sd = leaf_sd;
     if constexpr (MK)
-      for (int k = 0; k < KX; ++k) o.leaf_sdx[k] = leaf_sd_x(S, c, par ^ 1, k);
+      for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
     o.pend_leafsd = 0;
     o.lid_gen = (c.lid_gen + 1) % NGEN;
     o.sse0 = sse0;
@@ -1940,7 +1969,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
         const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
         const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, S.accx[ax + kx], S.accx[ax + KX + kx], pq, pv,
-                                         it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par, kx));
+                                         it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
       }
@@ -2003,7 +2032,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         const int gi = t / 3, i = t % 3;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
         if (s != 0) {
-          Acc* a = &S.acc[(size_t)par * MAXP + s_job[g0 + gi].p];
+          AccL* a = &S.accl[(size_t)par * MAXP + s_job[g0 + gi].p];
           atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
         }
       }
@@ -2044,7 +2073,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       const int gi = t / 3, i = t % 3;
       const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
       if (s != 0) {
-        Acc* a = &S.acc[(size_t)par * MAXP + s_job[g0 + gi].p];
+        AccL* a = &S.accl[(size_t)par * MAXP + s_job[g0 + gi].p];
         atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
       }
     }
@@ -2320,6 +2349,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.lvx, (size_t)2 * 2 * 256 * KX);
     DA(d.jqx, (size_t)2 * MAXP * KX);
     DA(d.jvx, (size_t)2 * MAXP * KX);
+    DA(d.lsdx, (size_t)2 * KXMAX);
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
@@ -2328,6 +2358,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
   DA(d.acc, 2 * MAXP);
+  DA(d.accl, 2 * MAXP);
+  DA(d.jobl, 2 * MAXP);
   DA(d.initacc, 2 * IA_SLOTS);
   DA(d.cmd, 2);
   DA(d.ctrl, 2);
@@ -2380,6 +2412,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipMemsetAsync(d.lvx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
     HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
+    hipLaunchKernelGGL(k_fill_f64, dim3(1), dim3(256), 0, sm, d.lsdx, (long long)2 * KXMAX, s->init_leaf_sd);
     // every accepted tree starts as a stump whose K-vector leaf is init_leaf
     hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,
                        d.tvx, (long long)d.m * MAXN * KX, s->init_leaf);
@@ -2389,6 +2422,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
   HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * sizeof(AccL), sm));
+  HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
   HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
   HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
   HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
@@ -2398,7 +2433,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   memset(&c0, 0, sizeof c0);
   c0.phase = PH_IDLE;
   c0.leaf_sd = s->init_leaf_sd;
-  for (int k = 0; k < PGB_MAX_OUTPUTS - 1; ++k) c0.leaf_sdx[k] = s->init_leaf_sd;
   c0.inv_sigma2 = 1.0;
   Ctrl cc2[2] = {c0, c0};
   HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
@@ -2701,8 +2735,10 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
       std::vector<long long> ix((size_t)IA_SLOTS * 2 * KX);
       HIPCHK(hipMemcpy(ix.data(), d.iax + (size_t)((h->slot & 1) ^ 1) * IA_SLOTS * 2 * KX,
                        ix.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double lsdx[2 * KXMAX];
+      HIPCHK(hipMemcpy(lsdx, d.lsdx, sizeof lsdx, hipMemcpyDeviceToHost));
       for (int k = 0; k < KX; ++k) {
-        double v = c.leaf_sdx[k];
+        double v = lsdx[(h->slot & 1) * KXMAX + k];
         if (c.pend_leafsd && c.pend_iter > 2) {
           long long q = 0;
           for (int sl = 0; sl < IA_SLOTS; ++sl) q += ix[(size_t)sl * 2 * KX + KX + k];
