@@ -36,7 +36,7 @@ def cpu_baseline(w, seed, budget_s=20.0):
 
     X, Y = w["X"], w["Y"]
     st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
-                                  family=w["family"])
+                                  family=w["family"], n_outputs=w.get("K", 1))
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]),
                   backend=oracle_backend())
     s.set_likelihood([1.0] if w["family"] == "normal" else [])
@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--m", type=int, default=200)
     ap.add_argument("--particles", type=int, default=40)
     ap.add_argument("--tune", type=int, default=0)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default) is the configuration the metric is quoted on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -103,12 +103,14 @@ def main():
     if args.workload == "cfg4":
         w = workloads.cfg4(seed=3415, n=args.n if args.n != 100_000 else 1_000_000,
                            p=args.p if args.p != 50 else 100, m=args.m, num_particles=args.particles)
+    elif args.workload == "cfg5":
+        w = workloads.cfg5(seed=3415, num_particles=args.particles)
     else:
         w = workloads.cfg2(seed=3415, n=args.n, p=args.p, m=args.m, num_particles=args.particles)
     X, Y = w["X"], w["Y"]
     n = X.shape[0]
     st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
-                                  family=w["family"])
+                                  family=w["family"], n_outputs=w.get("K", 1))
     be = default_backend(local_rank)
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
     s.set_likelihood([1.0] if w["family"] == "normal" else [])  # sigma fixed at 1
@@ -154,7 +156,7 @@ def main():
         ms, launches = s.profile(False)
         tu = cp1["tree_updates"] - cp0["tree_updates"]
         rt = cp1["rows_touched"] - cp0["rows_touched"]
-        alg = workloads.bytes_per_tree_update(n, rt / max(tu, 1)) * tu
+        alg = workloads.bytes_per_tree_update(n, rt / max(tu, 1), K=w.get("K", 1)) * tu
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM traffic per launch cannot be measured inside this process: it comes from the PMC
         # passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command,
@@ -179,7 +181,7 @@ def main():
     # end-of-run gather of the draws (the only collective; outside the timed region)
     gather_ms = None
     if dist is not None:
-        draw = s.sum_trees_device().clone()
+        draw = s.sum_trees_device().clone()  # (K*n,) of the last step
         outs = [torch.empty_like(draw) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         g0 = time.perf_counter()

@@ -55,3 +55,15 @@ def cfg4(seed: int = 3415, n: int = 1_000_000, p: int = 100, m: int = 200, num_p
     Y = (rng.random(n) < _phi_fast(f)).astype(np.float64)
     return dict(X=X, Y=Y, f=f, m=m, num_particles=num_particles, family="bernoulli_probit",
                 name=f"cfg4: Bernoulli-probit n={n} p={p} m={m} P={num_particles}")
+
+
+def cfg5(seed: int = 3415, n: int = 250_000, p: int = 200, K: int = 4, m: int = 100, num_particles: int = 40):
+    """Multi-output (shape=(K, n)) BART with a Categorical-softmax likelihood, all ContinuousSplit."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    F = np.stack([X[:, 0], -X[:, 0] + 0.5 * X[:, 1], 1.5 * X[:, 2] * X[:, 3], np.zeros(n)])[:K]
+    pr = np.exp(F - F.max(axis=0))
+    pr /= pr.sum(axis=0)
+    Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(axis=0).clip(0, K - 1).astype(np.float64)
+    return dict(X=X, Y=Y, f=F, m=m, num_particles=num_particles, family="categorical", K=K,
+                name=f"cfg5: Categorical-softmax K={K} n={n} p={p} m={m} P={num_particles}")

@@ -183,3 +183,36 @@ def test_full_size_cfg4_probit_parity_and_invariants(hip, oracle):
     np.testing.assert_allclose(pred, st_dev[sub], rtol=0, atol=1e-8)
     assert g.counters.saturations == 0
     assert np.corrcoef(st_dev, w["f"])[0, 1] > 0.3  # the latent signal is being picked up
+
+
+def test_full_size_cfg5_categorical_parity_and_invariants(hip, oracle):
+    """BASELINE.json configs[4] at full size: shape=(4, n) BART, n=250k, p=200, m=100, softmax."""
+    w = workloads.cfg5(seed=3415)
+    X, Y = w["X"], w["Y"]
+    n, p = X.shape
+    st = PyBartSettings.from_data(X, Y, m=100, num_particles=40, seed=3415, family="categorical",
+                                  n_outputs=4, batch=(1, 1))
+    g = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=hip)
+    o = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=oracle)
+    for s in (g, o):
+        s.set_likelihood([])
+    for it in range(2):
+        a, va = g.step(tune=it < 1)
+        b, vb = o.step(tune=it < 1)
+        assert a.shape == (4, n)
+        assert np.array_equal(a, b) and np.array_equal(va, vb)
+    cg, co = g.counters.as_dict(), o.counters.as_dict()
+    for k in ("particle_steps", "tree_updates", "rows_touched", "rounds", "saturations"):
+        assert cg[k] == co[k]
+    assert np.array_equal(g.state()["leaf_sd"], o.state()["leaf_sd"])
+    del o
+    g.step_async(False, 30)
+    st_dev, _ = g.step(False)
+    forest = g.export_trees(1)
+    assert forest.n_outputs == 4 and forest.value.shape[1] == 4
+    sub = np.arange(0, n, 53)
+    ps = PosteriorSampler(forest, np.arange(100, dtype=np.int32)[None, :], 100, 4, np.zeros(p, np.int32),
+                          backend=hip)
+    pred = ps.sample_posterior(X[sub], [0])[0]
+    np.testing.assert_allclose(pred, st_dev[:, sub], rtol=0, atol=1e-8)
+    assert g.counters.saturations == 0
