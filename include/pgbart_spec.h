@@ -58,6 +58,7 @@
 #define PGB_FAMILY_BERNOULLI_PROBIT 1 /* y ~ Bern(Phi(mu))                   */
 #define PGB_FAMILY_BERNOULLI_LOGIT 2  /* y ~ Bern(expit(mu))                 */
 #define PGB_FAMILY_CATEGORICAL 3      /* y ~ Cat(softmax(mu[0..K-1]))        */
+#define PGB_FAMILY_NORMAL_MEANSCALE 4 /* y ~ N(mu[0], |mu[1]|), K = 2        */
 
 /* RNG purposes (high half of counter word 3) */
 #define PGB_RNG_PROPOSE 1u  /* u0: prior coin, u1: split variable            */
@@ -317,6 +318,26 @@ PGB_HD double pgb_loglik_cat(int K, double y, const double* mu) {
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 0.0) ll = 0.0;
   return ll;
+}
+
+/* Normal with BART mean and BART scale (reference tests/test_bart.py:118: Normal(w[0], |w[1]|)):
+ * -log|s| - 0.5 ((y - m)/s)^2 (the constant -0.5 log 2pi cancels in the particle weights).
+ * |s| is floored at 1e-8; clamped to [-2047, 2047]. */
+PGB_HD double pgb_loglik_meanscale(double y, const double* mu) {
+  double sd = mu[1] < 0.0 ? -mu[1] : mu[1];
+  if (sd < 1e-8) sd = 1e-8;
+  const double z = (y - mu[0]) / sd;
+  double ll = -pgb_log(sd) - 0.5 * (z * z);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 2047.0) ll = 2047.0;
+  return ll;
+}
+
+/* Per-row log-likelihood of every non-Normal(sigma) family at the K linear predictors mu. */
+PGB_HD double pgb_loglik(int family, int K, double y, const double* mu) {
+  if (family == PGB_FAMILY_CATEGORICAL) return pgb_loglik_cat(K, y, mu);
+  if (family == PGB_FAMILY_NORMAL_MEANSCALE) return pgb_loglik_meanscale(y, mu);
+  return pgb_loglik1(family, y, mu[0]);
 }
 
 /* ------------------------------------------------------------------ fixed point */

@@ -169,6 +169,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
       return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+  } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
+    if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
@@ -284,8 +286,7 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
 /* ------------------------------------------------------------------ one tree update */
 /* per-row log-likelihood of the non-Normal families at linear predictor(s) mu[0..K-1] */
 static double o_loglik(const pgb_handle* h, double y, const double* mu) {
-  return h->s.family == PGB_FAMILY_CATEGORICAL ? pgb_loglik_cat(h->s.n_outputs, y, mu)
-                                               : pgb_loglik1(h->s.family, y, mu[0]);
+  return pgb_loglik(h->s.family, h->s.n_outputs, y, mu);
 }
 
 static void o_tree_begin(pgb_handle* h, int tree_id) {

@@ -6,12 +6,13 @@ Public names mirror what the reference imports from the external ``bartrs`` whee
 """
 
 from . import _abi
-from .pgbart import PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NormalLikelihood
+from .pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NormalLikelihood,
+                     NormalMeanScaleLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
 
 __version__ = "0.1.0"
 __all__ = [
-    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood",
+    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood",
     "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "_abi",
 ]

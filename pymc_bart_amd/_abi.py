@@ -32,11 +32,13 @@ FAMILY_NORMAL = 0
 FAMILY_BERNOULLI_PROBIT = 1
 FAMILY_BERNOULLI_LOGIT = 2
 FAMILY_CATEGORICAL = 3
+FAMILY_NORMAL_MEANSCALE = 4
 FAMILIES = {
     "normal": FAMILY_NORMAL,
     "bernoulli_probit": FAMILY_BERNOULLI_PROBIT,
     "bernoulli_logit": FAMILY_BERNOULLI_LOGIT,
     "categorical": FAMILY_CATEGORICAL,
+    "normal_meanscale": FAMILY_NORMAL_MEANSCALE,
 }
 
 #: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)

@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
 // values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
 // the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
 __device__ __forceinline__ double loglik_any(const Dev& S, double y, const double* mu) {
-  return S.family == PGB_FAMILY_CATEGORICAL ? pgb_loglik_cat(S.K, y, mu) : pgb_loglik1(S.family, y, mu[0]);
+  return pgb_loglik(S.family, S.K, y, mu);
 }
 
 __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
@@ -2279,6 +2279,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
       return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+  } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
+    if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");

@@ -98,6 +98,17 @@ class CategoricalLikelihood:
         return []
 
 
+class NormalMeanScaleLikelihood:
+    """``y ~ Normal(BART[0], |BART[1]|)`` -- the ``shape=(2, n)`` model of reference
+    ``tests/test_bart.py:107-123``."""
+
+    family = "normal_meanscale"
+    n_outputs = 2
+
+    def params(self, point=None):
+        return []
+
+
 def _op_of(var):
     owner = getattr(var, "owner", None)
     return owner.op if owner is not None and hasattr(owner, "op") else var

@@ -89,6 +89,11 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=15, P=12, steps=24, family="categorical", K=K)
+    elif name == "meanscale_k2_reference":  # reference tests/test_bart.py:107-123 (shape=(2, 250))
+        n, p = 250, 3
+        X = rng.normal(0, 1, size=(n, p))
+        Y = rng.normal(0, 1, size=n) * (0.5 + (X[:, 0] > 0)) + X[:, 1]
+        c.update(m=2, P=10, steps=60, family="normal_meanscale", K=2)
     elif name == "onehot_fail_nan":  # failed one-hot splits that shed NaN rows (Normal family)
         n, p = 2500, 3
         X = rng.normal(size=(n, p))
@@ -105,7 +110,8 @@ def make_case(name: str):
 
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
-         "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small"]
+         "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
+         "meanscale_k2_reference"]
 
 
 def run_case(c, backend, record_every: int = 1):

@@ -304,3 +304,29 @@ def test_categorical_model_recovers_classes(oracle, split_rule):
     # X was jittered for the continuous rule inside PGBART: compare on the sampler's own matrix
     if split_rule == "OneHotSplit":
         np.testing.assert_allclose(pred[0], lo, atol=1e-9)
+
+
+def test_shape_two_outputs_mean_and_scale(oracle):
+    # reference tests/test_bart.py:107-123: w = BART(shape=(2, 250)); y ~ Normal(w[0], |w[1]|):
+    # astep returns (2, n); the scale output must pick up heteroscedasticity
+    from pymc_bart_amd.pgbart import NormalMeanScaleLikelihood
+
+    rng = np.random.default_rng(3)
+    X = rng.normal(0, 1, size=(250, 3))
+    sd = np.where(X[:, 0] > 0, 2.0, 0.3)
+    Y = X[:, 1] + sd * rng.normal(0, 1, size=250)
+    op = BARTOp(X, Y, m=10)
+    step = PGBART([op], num_particles=10, likelihood=NormalMeanScaleLikelihood(), random_seed=3415,
+                  backend=oracle)
+    assert step.shape == (2, 250)
+    acc = np.zeros((2, 250))
+    for it in range(400):
+        if it == 200:
+            step.stop_tuning()
+        w, _ = step.astep(None)
+        assert w.shape == (2, 250)
+        if it >= 250:
+            acc += np.abs(w) if False else np.stack([w[0], np.abs(w[1])])
+    acc /= 150
+    assert np.corrcoef(acc[0], X[:, 1])[0, 1] > 0.7
+    assert acc[1][X[:, 0] > 0].mean() > 1.5 * acc[1][X[:, 0] <= 0].mean()
