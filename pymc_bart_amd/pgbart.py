@@ -178,6 +178,7 @@ class PGBART(_Base):
                 X[:, j] = jitter_duplicated(X[:, j], jrng)
         self.likelihood = likelihood if likelihood is not None else NormalLikelihood(1.0)
         y_obs = Y if observed is None else np.asarray(observed, np.float64)
+        self._y_obs = np.array(y_obs, np.float64, copy=True)
         n_outputs = int(getattr(self.likelihood, "n_outputs", 1))
         self.settings = PyBartSettings.from_data(
             X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
@@ -210,8 +211,17 @@ class PGBART(_Base):
     def stop_tuning(self):
         self.tune = False
 
-    def astep(self, _q=None, point=None):
-        """Re-sample the next batch of trees; returns ``(sum_trees, [stats])``."""
+    def astep(self, _q=None, point=None, offset=None):
+        """Re-sample the next batch of trees; returns ``(sum_trees, [stats])``.
+
+        ``offset``: contribution of the *other* additive terms of a Normal model at the current
+        point (e.g. a second BART variable, reference ``tests/test_bart.py:211-241``): this step
+        method then fits ``observed - offset``.
+        """
+        if offset is not None:
+            if self.likelihood.family != "normal":
+                raise NotImplementedError("offsets are implemented for the Normal family only")
+            self.sampler.set_response(self._y_obs - np.asarray(offset, np.float64))
         self.sampler.set_likelihood(self.likelihood.params(point))
         if not self.tune and self._baseline is None:
             # first draw: freeze the forest the per-draw batches are deltas of (utils.py:124-127)

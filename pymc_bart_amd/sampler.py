@@ -180,6 +180,12 @@ class PySampler:
         except Exception:
             pass
 
+    # -- observed response (e.g. y minus the other additive terms of the model) --------
+    def set_response(self, y_obs) -> None:
+        lib, mem = self.backend.lib, self.backend.mem
+        self._y = mem.from_host(np.ascontiguousarray(y_obs, dtype=np.float64))
+        lib.check(lib.lib.pgb_set_response(self._h, mem.ptr(self._y)), "pgb_set_response")
+
     # -- likelihood parameters at the current point -------------------------------
     def set_likelihood(self, params) -> None:
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(params, np.float64)))

@@ -330,3 +330,38 @@ def test_shape_two_outputs_mean_and_scale(oracle):
     acc /= 150
     assert np.corrcoef(acc[0], X[:, 1])[0, 1] > 0.7
     assert acc[1][X[:, 0] > 0].mean() > 1.5 * acc[1][X[:, 0] <= 0].mean()
+
+
+def test_multiple_bart_variables_manual_step(oracle):
+    # reference tests/test_bart.py:211-241: two BART variables with their own PGBART step methods
+    # (num_particles=5) in one additive Normal model; both are sampled, shapes (draws, n), separate
+    # all_trees objects
+    rng = np.random.default_rng(0)
+    X1 = rng.normal(0, 1, size=(60, 2))
+    X2 = rng.normal(0, 1, size=(60, 2))
+    Y = 2.0 * X1[:, 0] - 1.5 * X2[:, 1] + rng.normal(0, 0.1, size=60)
+    mu1 = BARTOp(X1, Y, m=8, name="mu1")
+    mu2 = BARTOp(X2, Y, m=8, name="mu2")
+    lik = NormalLikelihood("sigma")
+    step1 = PGBART([mu1], num_particles=5, likelihood=lik, random_seed=3415, backend=oracle)
+    step2 = PGBART([mu2], num_particles=5, likelihood=lik, random_seed=3416, backend=oracle)
+    cur1 = np.full(60, Y.mean() / 2)
+    cur2 = np.full(60, Y.mean() / 2)
+    d1, d2 = [], []
+    for it in range(200):
+        if it == 100:
+            step1.stop_tuning()
+            step2.stop_tuning()
+        point = {"sigma": 0.3}
+        cur1, _ = step1.astep(None, point, offset=cur2)
+        cur2, _ = step2.astep(None, point, offset=cur1)
+        if it >= 100:
+            d1.append(cur1)
+            d2.append(cur2)
+    d1, d2 = np.array(d1), np.array(d2)
+    assert d1.shape == (100, 60) and d2.shape == (100, 60)
+    assert mu1.all_trees is not mu2.all_trees and len(mu1.all_trees) == 1 and len(mu2.all_trees) == 1
+    # each variable picks up ITS covariate's effect; the sum explains Y
+    assert np.corrcoef(d1.mean(0), X1[:, 0])[0, 1] > 0.8
+    assert np.corrcoef(d2.mean(0), -X2[:, 1])[0, 1] > 0.8
+    assert np.sqrt(np.mean((d1.mean(0) + d2.mean(0) - Y) ** 2)) < 0.6
