@@ -85,7 +85,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -181,13 +181,16 @@ def main():
     # end-of-run gather of the draws (the only collective; outside the timed region)
     gather_ms = None
     if dist is not None:
-        draw = s.sum_trees_device().clone()  # (K*n,) of the last step
-        outs = [torch.empty_like(draw) for _ in range(world)] if rank == 0 else None
+        s.step(tune)  # one synchronous step so that the output buffer holds this chain's last draw
+        draw = s.sum_trees_device().clone()  # (K*n,)
+        outs = [torch.empty_like(draw) for _ in range(world)]
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.gather(draw, outs, dst=0)
+        dist.all_gather(outs, draw)  # direct all-gather over xGMI: every rank's shard moves in parallel
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0 and world > 1:
+            assert not torch.equal(outs[0], outs[1]), "chains must be independent"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
