@@ -132,6 +132,7 @@ struct Dev {  // kernel argument block (by value)
   int32_t p, m, P, nchunks;
   int32_t batch_tune, batch_draw;
   int32_t family, K;  // K = n_outputs; KX = K - 1 extension outputs live in the *x arrays below
+  int32_t rows_target, rows_target_init;  // work items the row passes aim for (tuning knobs)
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
@@ -1283,7 +1284,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
 // work in this round are not touched at all: their labels stay where they are (NGEN generations).
 // FINAL/INIT item = 256 rows.
 
-#define ROWS_TARGET_ITEMS 1024
+// Work items a row pass aims for (measured on cfg2: 640 for plain rounds, 512 for the fused
+// FINAL+INIT+round-0 pass whose INIT part is repeated by every particle group).
+#define ROWS_TARGET_ITEMS 640
+#define ROWS_TARGET_ITEMS_INIT 512
 #define PB 4 /* particles processed per batch inside a work item */
 
 struct RJob {  // the fields of a Job the row pass needs, cached in LDS
@@ -1355,7 +1359,8 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
     __syncthreads();
     const int nact = s_n[0];
     if (nact == 0 && !do_init) return;
-    int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+    const int target = do_init ? S.rows_target_init : S.rows_target;
+    int G = (nact * S.nchunks + target - 1) / target;
     if (G < 1) G = 1;
     int ngroups = (nact + G - 1) / G;
     if (ngroups < 1) ngroups = 1;  // an INIT must run even if no particle splits
@@ -1664,7 +1669,8 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
     __syncthreads();
     const int nact = s_n[0];
     if (nact == 0 && !do_init) return;
-    int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+    const int target = do_init ? S.rows_target_init : S.rows_target;
+    int G = (nact * S.nchunks + target - 1) / target;
     if (G < 1) G = 1;
     int ngroups = (nact + G - 1) / G;
     if (ngroups < 1) ngroups = 1;
@@ -1980,7 +1986,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   __syncthreads();
   const int nact = s_n[0];
   if (nact == 0) return;
-  int G = (nact * S.nchunks + ROWS_TARGET_ITEMS - 1) / ROWS_TARGET_ITEMS;
+  int G = (nact * S.nchunks + S.rows_target - 1) / S.rows_target;
   if (G < 1) G = 1;
   const int ngroups = (nact + G - 1) / G;
   const int nitems = S.nchunks * ngroups;
@@ -2319,6 +2325,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.P = s->num_particles;
   d.family = s->family;
   d.K = s->n_outputs;
+  d.rows_target = ROWS_TARGET_ITEMS;
+  d.rows_target_init = ROWS_TARGET_ITEMS_INIT;
+  if (const char* e = getenv("PGB_ROWS_TARGET")) d.rows_target = atoi(e) > 0 ? atoi(e) : d.rows_target;
+  if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
   d.seed = s->seed;
