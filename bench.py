@@ -73,6 +73,11 @@ def main():
     ap.add_argument("--tune", type=int, default=0)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default) is the configuration the metric is quoted on")
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="independent chains run concurrently on each GPU (own stream + host thread "
+                         "each); the headline is quoted at 1, as north_star shards one chain per GPU")
+    ap.add_argument("--no-multichain", action="store_true",
+                    help="skip the informational 4-chains-on-one-GPU leg (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -121,19 +126,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        s.step_async(tune, args.warmup)
-    s.sync()
-    c0 = s.counters.as_dict()
-    barrier()
-    t0 = time.perf_counter()
-    s.step_async(tune, args.steps)  # returns when the device state machine is idle again
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = s.sync()
-    dps = c1["particle_steps"] - c0["particle_steps"]
-    dtu = c1["tree_updates"] - c0["tree_updates"]
-    drt = c1["rows_touched"] - c0["rows_touched"]
+    def extra_chains(count, first_chain):
+        """More independent chains on this GPU, each on its own HIP stream."""
+        out = []
+        for c in range(count):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                stc = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"],
+                                               seed=seed + 1000 * (first_chain + c), family=w["family"],
+                                               n_outputs=w.get("K", 1))
+                sc = PySampler(stc, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
+                sc.set_likelihood([1.0] if w["family"] == "normal" else [])
+                out.append(sc)
+        torch.cuda.synchronize()
+        return out
+
+    def run_all(samplers, k):
+        """k steps of every sampler; concurrent host threads when there is more than one chain
+        (step_async returns when that chain's device state machine is idle again)."""
+        if len(samplers) == 1:
+            samplers[0].step_async(tune, k)
+            return
+        import threading
+
+        th = [threading.Thread(target=lambda q=q: q.step_async(tune, k)) for q in samplers]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    def counters_sum(samplers):
+        tot = {}
+        for q in samplers:
+            for key, v in q.sync().items():
+                tot[key] = tot.get(key, 0) + v
+        return tot
+
+    def timed(samplers, warmup, steps):
+        if warmup > 0:
+            run_all(samplers, warmup)
+        a = counters_sum(samplers)
+        barrier()
+        t0 = time.perf_counter()
+        run_all(samplers, steps)
+        barrier()
+        el = time.perf_counter() - t0
+        b = counters_sum(samplers)
+        return el, {key: b[key] - a[key] for key in b}
+
+    ss = [s] + extra_chains(args.chains_per_gpu - 1, 1)
+    dt, dc = timed(ss, args.warmup, args.steps)
+    dps, dtu, drt = dc["particle_steps"], dc["tree_updates"], dc["rows_touched"]
 
     # whole-job aggregate: max time over ranks, sum of units over ranks
     if dist is not None:
@@ -192,6 +234,16 @@ def main():
         if rank == 0 and world > 1:
             assert not torch.equal(outs[0], outs[1]), "chains must be independent"
 
+    # informational: PyMC's default of 4 chains, run concurrently on ONE GPU (never the headline)
+    multichain = None
+    if world == 1 and dist is None and args.chains_per_gpu == 1 and not args.no_multichain:
+        ss4 = [s] + extra_chains(3, 1)
+        el4, d4 = timed(ss4, 1, args.steps)
+        multichain = {"chains_per_gpu": 4, "value": d4["particle_steps"] / el4,
+                      "unit": "particle-steps/s", "ms_per_step": el4 * 1e3 / args.steps,
+                      "note": "4 independent chains on one GPU, one HIP stream + host thread each"}
+        del ss4
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, seed)
@@ -213,7 +265,8 @@ def main():
             "config": {
                 "workload": w["name"] + f", sigma=1 fixed, tune={int(tune)}, "
                             f"{st.batch_sizes()[0 if tune else 1]} trees per step",
-                "chains": world, "parallelism": f"chains{world}",
+                "chains": world * args.chains_per_gpu, "chains_per_gpu": args.chains_per_gpu,
+                "parallelism": f"chains{world * args.chains_per_gpu}",
             },
             "tree_updates_per_s": tot_tu / dt_max,
             "rows_touched_per_tree": tot_rt / max(tot_tu, 1.0),
@@ -222,6 +275,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if multichain is not None:
+            line["concurrent_chains"] = multichain
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
         if cpu:

@@ -216,3 +216,20 @@ def test_full_size_cfg5_categorical_parity_and_invariants(hip, oracle):
     pred = ps.sample_posterior(X[sub], [0])[0]
     np.testing.assert_allclose(pred, st_dev[:, sub], rtol=0, atol=1e-8)
     assert g.counters.saturations == 0
+
+
+def test_concurrent_chains_on_one_gpu_equal_the_chains_run_alone(hip):
+    """pm.sample(chains=4) on one GPU: every chain on its own HIP stream and host thread.  Chains
+    share nothing, so each must reproduce, bit for bit, what it draws when it runs alone."""
+    from pymc_bart_amd.chains import sample_chains
+
+    w = workloads.cfg2(seed=5, n=20_000, p=10, m=20, num_particles=10)
+    kw = dict(num_particles=10, random_seed=11, backend=hip)
+    together = sample_chains(BARTOp(w["X"], w["Y"], m=20), chains=4, tune=3, draws=3, **kw)
+    assert [r["chain"] for r in together] == [0, 1, 2, 3]
+    for c in (0, 3):
+        alone = sample_chain(BARTOp(w["X"], w["Y"], m=20), 3, 3, chain=c, **kw)
+        assert np.array_equal(alone["mu"], together[c]["mu"])
+        assert np.array_equal(alone["sigma"], together[c]["sigma"])
+        assert alone["variable_inclusion"] == together[c]["variable_inclusion"]
+    assert not np.array_equal(together[0]["mu"], together[1]["mu"])
