@@ -148,6 +148,17 @@ int pgb_predict(const pgb_tree_arrays* trees_host, const int32_t* forest_tree_id
  * its dominant kernel with events on its stream and accumulates their duration. */
 int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out);
 
+/* Checkpoint / resume of one chain (what pickling the reference's step method into a PyMC worker
+ * process carries: reference SURVEY 8b "must be picklable"; tree hand-off bart.py:134-135).
+ * The blob is an opaque image of the sampler state at an idle point (between asteps); it is
+ * specific to the backend that wrote it.  To resume: pgb_create with the SAME settings,
+ * pgb_set_data / pgb_set_response with the same data, then pgb_checkpoint_load; the chain then
+ * continues bit-identically (the random numbers are addressed by (seed, iter, ...), so the image
+ * carries no generator state beyond the iteration counter). */
+int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out);
+int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes);
+int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

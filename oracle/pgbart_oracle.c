@@ -808,6 +808,111 @@ int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* l
   return PGB_OK;
 }
 
+/* ------------------------------------------------------------------ checkpoint / resume
+ * (same ABI as the HIP backend; the image layout is this backend's own) */
+typedef struct {
+  char magic[8];
+  char backend[16];
+  pgb_settings s;
+  int64_t payload_bytes;
+  int64_t rs_count, iter;
+  int32_t lower, n_last;
+  double leaf_sd, leaf_sdx[PGB_MAX_OUTPUTS - 1], inv_sigma2;
+  pgb_counters ctr;
+} ockpt;
+
+typedef struct { void* p; size_t bytes; } oblk;
+
+static int o_blocks(pgb_handle* h, oblk* b) {
+  const pgb_settings* s = &h->s;
+  size_t n = (size_t)s->n, K = (size_t)s->n_outputs, p = (size_t)s->p, m = (size_t)s->m;
+  int k = 0;
+  b[k++] = (oblk){h->st, sizeof(double) * n * K};
+  b[k++] = (oblk){h->rs_mean, sizeof(double) * n * K};
+  b[k++] = (oblk){h->rs_m2, sizeof(double) * n * K};
+  b[k++] = (oblk){h->trees, sizeof(otree) * m};
+  b[k++] = (oblk){h->lid, m * n};
+  b[k++] = (oblk){h->alpha_vec, sizeof(int64_t) * p};
+  b[k++] = (oblk){h->cdf, sizeof(int64_t) * p};
+  b[k++] = (oblk){h->vi, sizeof(int32_t) * p};
+  b[k++] = (oblk){h->last_ids, sizeof(int32_t) * m};
+  return k;
+}
+
+int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out) {
+  if (!h || !bytes_out) return fail(PGB_E_INVALID, "null argument");
+  oblk b[16];
+  int nb = o_blocks(h, b);
+  int64_t tot = (int64_t)sizeof(ockpt);
+  for (int i = 0; i < nb; ++i) tot += (int64_t)b[i].bytes;
+  *bytes_out = tot;
+  return PGB_OK;
+}
+
+int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes) {
+  if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  int64_t need;
+  pgb_checkpoint_size(h, &need);
+  if (bytes < need) return fail(PGB_E_INVALID, "checkpoint buffer too small");
+  ockpt hd;
+  memset(&hd, 0, sizeof hd);
+  memcpy(hd.magic, "PGBCKPT1", 8);
+  snprintf(hd.backend, sizeof hd.backend, "%s", pgb_backend_name());
+  hd.s = h->s;
+  hd.payload_bytes = need - (int64_t)sizeof hd;
+  hd.rs_count = h->rs_count;
+  hd.iter = h->iter;
+  hd.lower = h->lower;
+  hd.n_last = h->n_last;
+  hd.leaf_sd = h->leaf_sd;
+  memcpy(hd.leaf_sdx, h->leaf_sdx, sizeof hd.leaf_sdx);
+  hd.inv_sigma2 = h->inv_sigma2;
+  hd.ctr = h->ctr;
+  memcpy(host_buf, &hd, sizeof hd);
+  char* o = (char*)host_buf + sizeof hd;
+  oblk b[16];
+  int nb = o_blocks(h, b);
+  for (int i = 0; i < nb; ++i) {
+    memcpy(o, b[i].p, b[i].bytes);
+    o += b[i].bytes;
+  }
+  return PGB_OK;
+}
+
+int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
+  if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  if (bytes < (int64_t)sizeof(ockpt)) return fail(PGB_E_INVALID, "checkpoint truncated");
+  ockpt hd;
+  memcpy(&hd, host_buf, sizeof hd);
+  if (memcmp(hd.magic, "PGBCKPT1", 8) != 0) return fail(PGB_E_INVALID, "not a pgbart checkpoint");
+  if (strncmp(hd.backend, pgb_backend_name(), sizeof hd.backend) != 0)
+    return fail(PGB_E_INVALID, "checkpoint was written by a different backend");
+  if (memcmp(&hd.s, &h->s, sizeof(pgb_settings)) != 0)
+    return fail(PGB_E_INVALID, "checkpoint settings differ from this sampler's settings");
+  int64_t need;
+  pgb_checkpoint_size(h, &need);
+  if (hd.payload_bytes != need - (int64_t)sizeof hd || bytes < need)
+    return fail(PGB_E_INVALID, "checkpoint layout does not match this build");
+  const char* o = (const char*)host_buf + sizeof hd;
+  oblk b[16];
+  int nb = o_blocks(h, b);
+  for (int i = 0; i < nb; ++i) {
+    memcpy(b[i].p, o, b[i].bytes);
+    o += b[i].bytes;
+  }
+  h->rs_count = hd.rs_count;
+  h->iter = hd.iter;
+  h->lower = hd.lower;
+  h->n_last = hd.n_last;
+  h->leaf_sd = hd.leaf_sd;
+  memcpy(h->leaf_sdx, hd.leaf_sdx, sizeof hd.leaf_sdx);
+  h->inv_sigma2 = hd.inv_sigma2;
+  h->ctr = hd.ctr;
+  return PGB_OK;
+}
+
 /* ------------------------------------------------------------------ test hooks
  * (pgbo_*: exported only by the oracle so that tests can pin the numeric primitives of
  * pgbart_spec.h against known-answer vectors and libm) */

@@ -2246,6 +2246,8 @@ struct pgb_handle {
   long long bundles;
   hipStream_t stream;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;     // per allocation: payload size ...
+  std::vector<char> alloc_persist;     // ... and whether a checkpoint carries it
   long long slot;  // next slot index (parity = slot & 1)
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
@@ -2269,9 +2271,13 @@ static int dalloc(pgb_handle* h, T** p, size_t count) {
   hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
   if (e != hipSuccess) return fail_hip(e, "hipMalloc");
   h->allocs.push_back(q);
+  h->alloc_bytes.push_back(count * sizeof(T));
+  h->alloc_persist.push_back(1);
   *p = (T*)q;
   return PGB_OK;
 }
+// data, per-tree scratch and pointer tables are rebuilt by create/set_data: not part of a checkpoint
+static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
 
 extern "C" const char* pgb_last_error(void) { return g_err; }
 extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
@@ -2345,7 +2351,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
 #define DA(ptr, cnt) \
   if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
   DA(XT, (size_t)d.p * d.n_pad);
+  transient(h);
   DA(y, d.n_pad);
+  transient(h);
   const int K = d.K, KX = d.K - 1;
   DA(st, (size_t)2 * K * d.n_pad);
   DA(pack, d.n_pad);
@@ -2365,6 +2373,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
+  transient(h);  // particle labels live for one tree update only
   DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
@@ -2400,9 +2409,11 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     d.host_flag = (unsigned long long*)dp;
 #ifdef PGB_TRACE
     if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * 16)) != PGB_OK) { pgb_destroy(h); return rc; }
+    transient(h);
     HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * 16 * sizeof(long long), sm));
 #endif
     if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
+    transient(h);  // holds device pointers
     HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
     for (int i = 0; i < 4; ++i) {
       hipEvent_t ev;
@@ -2829,6 +2840,104 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   (void)hipFree(db);
   if (e != hipSuccess) return fail_hip(e, "k_predict launch");
   if (e2 != hipSuccess) return fail_hip(e2, "k_predict");
+  return PGB_OK;
+}
+
+// ---- checkpoint / resume ------------------------------------------------------------------
+struct CkptHeader {
+  char magic[8];       // "PGBCKPT1"
+  char backend[16];    // pgb_backend_name()
+  pgb_settings s;      // must equal the loading handle's settings
+  long long n_allocs, payload_bytes;
+  // host mirrors at the idle point
+  long long slot, steps_target, flag;
+  int32_t st_cur, alpha_cur, lower_host, last_lower, last_n, sigma_dirty;
+  double inv_sigma2;
+  pgb_counters ctr;
+};
+
+static long long ckpt_payload(const pgb_handle* h, long long* n_allocs) {
+  long long tot = 0, cnt = 0;
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (h->alloc_persist[i]) {
+      tot += (long long)((h->alloc_bytes[i] + 7) & ~(size_t)7);
+      cnt += 1;
+    }
+  if (n_allocs) *n_allocs = cnt;
+  return tot;
+}
+
+extern "C" int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out) {
+  if (!h || !bytes_out) return fail(PGB_E_INVALID, "null argument");
+  *bytes_out = (int64_t)sizeof(CkptHeader) + ckpt_payload(h, nullptr);
+  return PGB_OK;
+}
+
+extern "C" int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes) {
+  if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  CkptHeader hd;
+  memset(&hd, 0, sizeof hd);
+  memcpy(hd.magic, "PGBCKPT1", 8);
+  snprintf(hd.backend, sizeof hd.backend, "%s", pgb_backend_name());
+  hd.s = h->s;
+  hd.payload_bytes = ckpt_payload(h, &hd.n_allocs);
+  if (bytes < (int64_t)sizeof hd + hd.payload_bytes) return fail(PGB_E_INVALID, "checkpoint buffer too small");
+  HIPCHK(hipStreamSynchronize(h->stream));  // step calls return idle; this also covers set_* uploads
+  hd.slot = h->slot;
+  hd.steps_target = h->steps_target;
+  hd.flag = (long long)*h->flag;
+  hd.st_cur = h->st_cur;
+  hd.alpha_cur = h->alpha_cur;
+  hd.lower_host = h->lower_host;
+  hd.last_lower = h->last_lower;
+  hd.last_n = h->last_n;
+  hd.sigma_dirty = h->sigma_dirty;
+  hd.inv_sigma2 = h->inv_sigma2;
+  hd.ctr = h->ctr;
+  memcpy(host_buf, &hd, sizeof hd);
+  char* o = (char*)host_buf + sizeof hd;
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (h->alloc_persist[i]) {
+      HIPCHK(hipMemcpy(o, h->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToHost));
+      o += (h->alloc_bytes[i] + 7) & ~(size_t)7;
+    }
+  return PGB_OK;
+}
+
+extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
+  if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  if (bytes < (int64_t)sizeof(CkptHeader)) return fail(PGB_E_INVALID, "checkpoint truncated");
+  CkptHeader hd;
+  memcpy(&hd, host_buf, sizeof hd);
+  if (memcmp(hd.magic, "PGBCKPT1", 8) != 0) return fail(PGB_E_INVALID, "not a pgbart checkpoint");
+  if (strncmp(hd.backend, pgb_backend_name(), sizeof hd.backend) != 0)
+    return fail(PGB_E_INVALID, "checkpoint was written by a different backend");
+  if (memcmp(&hd.s, &h->s, sizeof(pgb_settings)) != 0)
+    return fail(PGB_E_INVALID, "checkpoint settings differ from this sampler's settings");
+  long long n_allocs = 0;
+  const long long payload = ckpt_payload(h, &n_allocs);
+  if (hd.n_allocs != n_allocs || hd.payload_bytes != payload || bytes < (int64_t)sizeof hd + payload)
+    return fail(PGB_E_INVALID, "checkpoint layout does not match this build");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const char* o = (const char*)host_buf + sizeof hd;
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (h->alloc_persist[i]) {
+      HIPCHK(hipMemcpy(h->allocs[i], o, h->alloc_bytes[i], hipMemcpyHostToDevice));
+      o += (h->alloc_bytes[i] + 7) & ~(size_t)7;
+    }
+  h->slot = hd.slot;
+  h->steps_target = hd.steps_target;
+  *h->flag = (unsigned long long)hd.flag;
+  h->st_cur = hd.st_cur;
+  h->alpha_cur = hd.alpha_cur;
+  h->lower_host = hd.lower_host;
+  h->last_lower = hd.last_lower;
+  h->last_n = hd.last_n;
+  h->sigma_dirty = hd.sigma_dirty;
+  h->inv_sigma2 = hd.inv_sigma2;
+  h->ctr = hd.ctr;
   return PGB_OK;
 }
 

@@ -185,6 +185,7 @@ class PGBART(_Base):
             family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
             batch=batch, seed=seed,
         )
+        self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
         self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
         # the op is a mailbox: utils.py:125 reads op.n_outputs, which the step method sets
         op.n_outputs = n_outputs
@@ -197,6 +198,22 @@ class PGBART(_Base):
         if _HAVE_PYMC and model is not None:  # pragma: no cover
             shared = {}
             super().__init__(vars, shared)
+
+    # -- pickling: PyMC sends the step method to its worker processes ----------
+    def __getstate__(self):
+        """Everything but the native handle; the chain itself travels as a checkpoint image, so
+        a step method pickled mid-run resumes bit-identically in the process that unpickles it
+        (on that process's current GPU)."""
+        d = dict(self.__dict__)
+        d["_checkpoint"] = d.pop("sampler").checkpoint()
+        return d
+
+    def __setstate__(self, d):
+        blob = d.pop("_checkpoint")
+        self.__dict__.update(d)
+        self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
+                                 self._split_prior, backend=None)
+        self.sampler.restore(blob)
 
     # -- PyMC step-method surface ---------------------------------------------------
     @staticmethod

@@ -256,6 +256,23 @@ class PySampler:
         lib.check(lib.lib.pgb_get_split_weights(self._h, a.ctypes.data), "pgb_get_split_weights")
         return a
 
+    # -- checkpoint / resume ---------------------------------------------------------
+    def checkpoint(self) -> bytes:
+        """Opaque image of the chain at this idle point (see ``pgb_checkpoint_save``)."""
+        lib = self.backend.lib
+        nb = C.c_int64()
+        lib.check(lib.lib.pgb_checkpoint_size(self._h, C.byref(nb)), "pgb_checkpoint_size")
+        buf = np.empty(int(nb.value), np.uint8)
+        lib.check(lib.lib.pgb_checkpoint_save(self._h, buf.ctypes.data, buf.size), "pgb_checkpoint_save")
+        return buf.tobytes()
+
+    def restore(self, blob: bytes) -> None:
+        """Continue a chain from :meth:`checkpoint`.  This sampler must have been built with the
+        same settings and data; the continuation is bit-identical to the uninterrupted chain."""
+        lib = self.backend.lib
+        buf = np.frombuffer(blob, np.uint8)
+        lib.check(lib.lib.pgb_checkpoint_load(self._h, buf.ctypes.data, buf.size), "pgb_checkpoint_load")
+
     def profile(self, enable: bool) -> tuple[float, int]:
         lib = self.backend.lib
         ms = C.c_double()

@@ -114,8 +114,10 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
          "meanscale_k2_reference"]
 
 
-def run_case(c, backend, record_every: int = 1):
-    """Run the case on a backend; returns everything the two backends must agree on."""
+def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
+    """Run the case on a backend; returns everything the two backends must agree on.
+    ``checkpoint_at``: step indices before which the chain is checkpointed, its sampler destroyed
+    and a freshly built sampler restored from the image (must not change anything)."""
     X, Y = c["X"], c["Y"]
     p = X.shape[1]
     family = c.get("family", "normal")
@@ -129,6 +131,11 @@ def run_case(c, backend, record_every: int = 1):
     sums, vis, trees = [], [], []
     half = c["steps"] // 2
     for it in range(c["steps"]):
+        if it in checkpoint_at:
+            blob = s.checkpoint()
+            del s
+            s = PySampler(st, X, Y, rules, prior, backend=backend)
+            s.restore(blob)
         sig = float(0.5 + sig_rng.random())  # sigma moves like a Gibbs/NUTS neighbour
         s.set_likelihood([sig] if family == "normal" else [])
         stv, vi = s.step(tune=it < half)

@@ -365,3 +365,56 @@ def test_multiple_bart_variables_manual_step(oracle):
     assert np.corrcoef(d1.mean(0), X1[:, 0])[0, 1] > 0.8
     assert np.corrcoef(d2.mean(0), -X2[:, 1])[0, 1] > 0.8
     assert np.sqrt(np.mean((d1.mean(0) + d2.mean(0) - Y) ** 2)) < 0.6
+
+
+def test_checkpoint_rejects_foreign_images(oracle):
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(200, 3))
+    Y = X[:, 0] + rng.normal(0, 0.1, 200)
+    mk = lambda m: PySampler(PyBartSettings.from_data(X, Y, m=m, num_particles=5, seed=1), X, Y,  # noqa: E731
+                             np.zeros(3, np.int32), np.ones(3), backend=oracle)
+    a, b = mk(5), mk(6)
+    a.set_likelihood([1.0])
+    a.step(True)
+    blob = a.checkpoint()
+    with pytest.raises(_abi.PGBError, match="settings differ"):
+        b.restore(blob)
+    with pytest.raises(_abi.PGBError, match="not a pgbart checkpoint"):
+        a.restore(b"x" * len(blob))
+    with pytest.raises(_abi.PGBError, match="truncated"):
+        a.restore(blob[:16])
+    a.restore(blob)  # its own image is fine
+
+
+def test_pgbart_pickle_round_trip_resumes_the_chain(oracle, monkeypatch):
+    """the step method must be picklable (PyMC sends it to worker processes).  A
+    step method pickled mid-run continues exactly where it was."""
+    import pickle
+
+    from pymc_bart_amd import sampler as sampler_mod
+
+    monkeypatch.setattr(sampler_mod, "_DEFAULT_BACKEND", oracle)  # what default_backend() returns
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(400, 4))
+    Y = np.sin(2 * X[:, 0]) + rng.normal(0, 0.2, 400)
+
+    def run(pickle_at):
+        step = PGBART([BARTOp(X, Y, m=10)], num_particles=6, likelihood=NormalLikelihood("sigma"),
+                      random_seed=9, backend=oracle)
+        out = []
+        for it in range(12):
+            if it == 6:
+                step.stop_tuning()
+            if it in pickle_at:
+                step = pickle.loads(pickle.dumps(step))
+            mu, stats = step.astep(None, {"sigma": 0.7})
+            out.append((mu, stats[0]["variable_inclusion"]))
+        return out, step
+
+    a, sa = run(())
+    b, sb = run((0, 3, 9))
+    for (m1, v1), (m2, v2) in zip(a, b):
+        assert np.array_equal(m1, m2) and v1 == v2
+    # the tree history travels with the pickle too
+    assert len(sb._batches) == len(sa._batches) == 6
+    assert np.array_equal(sa._batches[-1].value, sb._batches[-1].value)

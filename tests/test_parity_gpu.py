@@ -233,3 +233,35 @@ def test_concurrent_chains_on_one_gpu_equal_the_chains_run_alone(hip):
         assert np.array_equal(alone["sigma"], together[c]["sigma"])
         assert alone["variable_inclusion"] == together[c]["variable_inclusion"]
     assert not np.array_equal(together[0]["mu"], together[1]["mu"])
+
+
+@pytest.mark.parametrize("name", ["nan_onehot_prior", "ragged_1025", "max_particles",
+                                  "categorical_k4_cfg5_small", "probit_cfg4_small"])
+def test_checkpoint_resume_does_not_change_the_chain_gpu(hip, name):
+    """A chain resumed from pgb_checkpoint_load on a fresh handle reproduces the committed
+    fingerprint of the uninterrupted chain (cuts in tuning, at the boundary and in the draws)."""
+    c = make_case(name)
+    cuts = (1, c["steps"] // 2 - 1, c["steps"] // 2 + 2)
+    assert digest(run_case(c, hip, checkpoint_at=cuts)) == GOLD[name]
+
+
+def test_pgbart_pickle_round_trip_on_gpu(hip):
+    import pickle
+
+    from pymc_bart_amd.pgbart import PGBART, NormalLikelihood
+
+    w = workloads.cfg2(seed=8, n=30_000, p=8, m=20, num_particles=12)
+
+    def run(pickle_at):
+        step = PGBART([BARTOp(w["X"], w["Y"], m=20)], num_particles=12,
+                      likelihood=NormalLikelihood("sigma"), random_seed=3)
+        out = []
+        for it in range(8):
+            if it == 4:
+                step.stop_tuning()
+            if it in pickle_at:
+                step = pickle.loads(pickle.dumps(step))
+            out.append(step.astep(None, {"sigma": 1.1})[0])
+        return np.array(out)
+
+    assert np.array_equal(run(()), run((2, 5)))
