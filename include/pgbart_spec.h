@@ -52,6 +52,8 @@
 /* split rules (reference names: tests/test_bart.py:143-145, bart.py:100-103) */
 #define PGB_RULE_CONTINUOUS 0 /* go left iff x <= v  */
 #define PGB_RULE_ONEHOT 1     /* go left iff x == v  */
+#define PGB_RULE_SUBSET 2     /* go left iff category x is in the set v (bart.py:100-103)   */
+#define PGB_SUBSET_BITS 52    /* categories are integer codes 0..51; the set is a bit mask  */
 
 /* likelihood families (closed family; SURVEY.md 7 "Hard parts") */
 #define PGB_FAMILY_NORMAL 0           /* y ~ N(mu, sigma)      params: sigma */
@@ -130,6 +132,29 @@ PGB_HD double pgb_u2d(uint64_t u) {
 }
 
 PGB_HD double pgb_pow2(int e) { return pgb_u2d((uint64_t)(e + 1023) << 52); }
+
+/* ------------------------------------------------------------------ split rules */
+/* SubsetSplit: the column holds integer category codes; every non-NaN value maps to a code
+ * in [0, 52) (out-of-range values clamp -- callers validate).  The split "value" is the set of
+ * categories that go left, stored as the integer bit mask M < 2^52 converted to double (exact).
+ *   proposal ([U] SubsetSplitRule.get_split_value: each available category joins the set with
+ *   probability 1/2): the category of the uniformly chosen row always goes left, every other
+ *   category independently with probability 1/2 (52 bits of the unused second uniform of the
+ *   SELECT draw).  If no row of the leaf falls outside the set the grow fails, exactly like a
+ *   one-hot split on a leaf with a single category (upstream redraws until the subset is
+ *   proper; the difference is a failure probability of 2^(1-k) with k categories present). */
+PGB_HD int pgb_subset_code(double x) { return x >= 51.0 ? 51 : (x > 0.0 ? (int)x : 0); }
+PGB_HD double pgb_subset_value(double u1, double x) {
+  uint64_t M = (uint64_t)(u1 * 4503599627370496.0); /* 2^52 */
+  M |= (uint64_t)1 << pgb_subset_code(x);
+  return (double)M;
+}
+/* x is not NaN */
+PGB_HD int pgb_go_left(int rule, double x, double v) {
+  if (rule == PGB_RULE_CONTINUOUS) return x <= v;
+  if (rule == PGB_RULE_ONEHOT) return x == v;
+  return (int)(((uint64_t)v >> pgb_subset_code(x)) & 1u);
+}
 
 /* ------------------------------------------------------------------ exp */
 /* exp(x) for the softmax of particle weights: x is clamped to [-700, 700].

@@ -248,7 +248,7 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
   h->max_prior = mx;
   h->alpha_unit = pgb_alpha_unit(mx);
   for (int j = 0; j < p; ++j) {
-    if (rules[j] != PGB_RULE_CONTINUOUS && rules[j] != PGB_RULE_ONEHOT)
+    if (rules[j] != PGB_RULE_CONTINUOUS && rules[j] != PGB_RULE_ONEHOT && rules[j] != PGB_RULE_SUBSET)
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
     h->rules[j] = rules[j];
     h->alpha_vec[j] = pgb_alpha_init(split_prior[j], mx);
@@ -415,7 +415,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     if (k > nd.cnt - 1) k = nd.cnt - 1;
     double x = xc[seg[k]];
     if (x == x) {
-      v = x;
+      v = h->rules[j] == PGB_RULE_SUBSET ? pgb_subset_value(us.u1, x) : x;
       found = 1;
     }
   }
@@ -446,7 +446,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
       if (sn) sn[cN] = i;
       cN++; aN += qa; bN += qb; c2N += qc;
       for (int o = 1; o < K; ++o) aNx[o - 1] += pgb_quant(h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
-    } else if (rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v)) {
+    } else if (pgb_go_left(rule, x, v)) {
       sl[cL++] = i; aL += qa; bL += qb; c2L += qc;
       for (int o = 1; o < K; ++o) aLx[o - 1] += pgb_quant(h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
     } else {
@@ -456,8 +456,8 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   double zero_v[PGB_MAX_OUTPUTS] = {0};
   /* give back the unused tail of the two segments */
   /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
-  if (rule == PGB_RULE_ONEHOT && cR == 0) {
-    /* [U] a one-hot split needs two distinct values: the grow fails and the node stays a leaf.
+  if (rule != PGB_RULE_CONTINUOUS && cR == 0) {
+    /* [U] a one-hot / subset split needs two distinct values: the grow fails and the node stays a leaf.
        Rows with a missing split value have been dropped by the partition; the leaf sheds them
        (an identity when there are none).  Same arithmetic as the HIP backend. */
     onode* pn = &T->nd[l];
@@ -770,7 +770,7 @@ static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const doubl
       return;
     }
     int rule = rules[j];
-    int go_left = rule == PGB_RULE_CONTINUOUS ? (xv <= T->split[g]) : (xv == T->split[g]);
+    int go_left = pgb_go_left(rule, xv, T->split[g]);
     k = go_left ? T->left[g] : T->right[g];
   }
 }

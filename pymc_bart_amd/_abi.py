@@ -21,11 +21,15 @@ MAX_NODES = 255
 
 RULE_CONTINUOUS = 0
 RULE_ONEHOT = 1
+RULE_SUBSET = 2
+SUBSET_BITS = 52
 RULES = {
     "ContinuousSplit": RULE_CONTINUOUS,
     "ContinuousSplitRule": RULE_CONTINUOUS,
     "OneHotSplit": RULE_ONEHOT,
     "OneHotSplitRule": RULE_ONEHOT,
+    "SubsetSplit": RULE_SUBSET,
+    "SubsetSplitRule": RULE_SUBSET,
 }
 
 FAMILY_NORMAL = 0

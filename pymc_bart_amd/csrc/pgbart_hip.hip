@@ -276,6 +276,13 @@ __device__ __forceinline__ int block_excl_scan(int x, int* sm /* [8] */, int* to
 }
 
 __device__ __forceinline__ bool go_left(int rule, double x, double v) {
+  return pgb_go_left(rule, x, v) != 0;
+}
+// the two-rule form for data without SubsetSplit columns (the Normal-family row pass is compiled
+// both ways: it has no registers to spare for the set-membership test)
+template <bool SUB>
+__device__ __forceinline__ bool go_left_t(int rule, double x, double v) {
+  if (SUB) return pgb_go_left(rule, x, v) != 0;
   return rule == PGB_RULE_CONTINUOUS ? (x <= v) : (x == v);
 }
 
@@ -380,7 +387,7 @@ __device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cn
   c.cR = cnt - c.cL - c.cN;
   c.aL = a_aL;
   c.aR = p_q_st - a_aL - a_aN;
-  if (rule == PGB_RULE_ONEHOT && c.cR == 0) {
+  if (rule != PGB_RULE_CONTINUOUS && c.cR == 0) {
     c.ok = -1;
     c.vL = p_value;
     c.vR = 0.0;
@@ -521,6 +528,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   __shared__ int s_i[16];
   __shared__ double s_d[4];
   __shared__ double s_pre[2][PGB_SELECT_TRIES + 2];  // [set][0: coin, 1+t: row draw of try t]
+  __shared__ double s_pre1[2][PGB_SELECT_TRIES + 2]; // second uniform of the same draws (subset masks)
   __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
 
   TR(0);
@@ -596,7 +604,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     const int set = (tid >> 6) - 1, l = tid & 63;
     const pgb_u2 u = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p,
                                l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
-    if (l <= PGB_SELECT_TRIES) s_pre[set][l] = u.u0;
+    if (l <= PGB_SELECT_TRIES) {
+      s_pre[set][l] = u.u0;
+      s_pre1[set][l] = u.u1;
+    }
     const double u1 = readlane_d(u.u1, 0);
     const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
     if (l == 0) s_i[8 + set] = jj;
@@ -1083,6 +1094,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     if (tid < 64) {
       const int j = s_i[8 + set];
       const double* xc = S.XT + (size_t)j * S.n_pad;
+      const bool subset_rule = S.rules[j] == PGB_RULE_SUBSET;
       const uint8_t* lid =
           job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
       const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
@@ -1150,6 +1162,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         const double x = xc[row];
         found = (x == x) ? 1 : 0;
         v = x;
+        if (found && subset_rule) v = pgb_subset_value(s_pre1[set][1 + tr], x);
       }
       if (tid == 0) {
         s_i[0] = found;
@@ -1297,6 +1310,7 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
 };
 
+template <bool SUB>
 __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 7 * 4];
@@ -1477,7 +1491,7 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
             if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
-              if (go_left(rj.rule, x[e], rj.v)) {
+              if (go_left_t<SUB>(rj.rule, x[e], rj.v)) {
                 v0 += 1;
                 v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
               } else {
@@ -1504,7 +1518,7 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
                 out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
                 v[0] += 1ll << 40;
                 v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
-              } else if (go_left(rj.rule, xv, rj.v)) {
+              } else if (go_left_t<SUB>(rj.rule, xv, rj.v)) {
                 v[0] += 1;
                 v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
               } else {
@@ -2212,7 +2226,7 @@ __global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* fore
           w = w * (cl / tot);
           continue;
         }
-        const bool gl = rules[j] == PGB_RULE_CONTINUOUS ? (xv <= T.split[g]) : (xv == T.split[g]);
+        const bool gl = pgb_go_left(rules[j], xv, T.split[g]) != 0;
         k = gl ? T.left[g] : T.right[g];
       }
     }
@@ -2251,6 +2265,7 @@ struct pgb_handle {
   long long slot;  // next slot index (parity = slot & 1)
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
+  int has_subset;  // any SubsetSplit column: selects the row-pass instance
   int sigma_dirty;
   double inv_sigma2;
   int lower_host;      // mirror of the batch cursor
@@ -2311,6 +2326,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->s = *s;
   h->stream = (hipStream_t)stream;
   h->slot = 0;
+  h->has_subset = 0;
   h->st_cur = 0;
   h->alpha_cur = 0;
   h->d_dev = nullptr;
@@ -2488,8 +2504,11 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   Dev& d = h->d;
   if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
   double mx = 0.0;
+  h->has_subset = 0;
   for (int j = 0; j < d.p; ++j) {
-    if (rules_host[j] != PGB_RULE_CONTINUOUS && rules_host[j] != PGB_RULE_ONEHOT)
+    if (rules_host[j] == PGB_RULE_SUBSET) h->has_subset = 1;
+    if (rules_host[j] != PGB_RULE_CONTINUOUS && rules_host[j] != PGB_RULE_ONEHOT &&
+        rules_host[j] != PGB_RULE_SUBSET)
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
     if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
     if (split_prior_host[j] > mx) mx = split_prior_host[j];
@@ -2570,7 +2589,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
     if (d.K > 1)
       hipLaunchKernelGGL(k_rows_mk, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     else
-      hipLaunchKernelGGL(k_rows, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      if (h->has_subset) hipLaunchKernelGGL(k_rows<true>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      else hipLaunchKernelGGL(k_rows<false>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     if (h->prof) (void)hipEventRecord(e1, h->stream);
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
       if (d.K > 1)

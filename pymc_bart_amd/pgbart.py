@@ -176,6 +176,13 @@ class PGBART(_Base):
         for j in range(self.num_variates):
             if rule_ids[j] == _abi.RULE_CONTINUOUS:
                 X[:, j] = jitter_duplicated(X[:, j], jrng)
+            elif rule_ids[j] == _abi.RULE_SUBSET:
+                col = X[:, j][~np.isnan(X[:, j])]
+                if col.size and (np.any(col != np.floor(col)) or col.min() < 0
+                                 or col.max() >= _abi.SUBSET_BITS):
+                    raise ValueError(
+                        f"SubsetSplit column {j}: categories must be integer codes in "
+                        f"[0, {_abi.SUBSET_BITS}) (NaN = missing)")
         self.likelihood = likelihood if likelihood is not None else NormalLikelihood(1.0)
         y_obs = Y if observed is None else np.asarray(observed, np.float64)
         self._y_obs = np.array(y_obs, np.float64, copy=True)

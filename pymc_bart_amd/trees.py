@@ -121,7 +121,13 @@ def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rule
                 rec(base, l, x, w * (cl / tot), acc)
                 rec(base, r, x, w * (cr / tot), acc)
                 return
-            go_left = x[j] <= trees.split[g] if rules[j] == _abi.RULE_CONTINUOUS else x[j] == trees.split[g]
+            if rules[j] == _abi.RULE_CONTINUOUS:
+                go_left = x[j] <= trees.split[g]
+            elif rules[j] == _abi.RULE_ONEHOT:
+                go_left = x[j] == trees.split[g]
+            else:  # subset: the split value is the bit mask of the categories that go left
+                code = min(max(int(x[j]), 0), _abi.SUBSET_BITS - 1)
+                go_left = bool((int(trees.split[g]) >> code) & 1)
             k = trees.left[g] if go_left else trees.right[g]
             g = base + k
         acc += w * trees.value[g]

@@ -102,6 +102,18 @@ def make_case(name: str):
         X[:, 2] = rng.integers(0, 2, n)
         Y = X[:, 0] + (X[:, 2] > 0) + rng.normal(0, 0.3, n)
         c.update(m=6, P=10, steps=30, rules=np.array([0, 1, 1], np.int32), prior=np.array([1.0, 3.0, 1.0]))
+    elif name == "subset_rule":  # SubsetSplitRule (bart.py:100-103): categorical codes, set-valued splits
+        n, p = 4000, 5
+        X = rng.normal(size=(n, p))
+        X[:, 2] = rng.integers(0, 7, n)       # 7 categories, effect of the set {1, 4, 6}
+        X[:, 3] = rng.integers(0, 2, n)       # binary category
+        X[:, 4] = 3.0                         # a single category: every subset split on it fails
+        X[rng.random(n) < 0.1, 2] = np.nan
+        X[rng.random(n) < 0.2, 4] = np.nan
+        Y = (np.isin(X[:, 2], [1, 4, 6]) * 3.0 + (X[:, 3] > 0) * 1.0 + 0.5 * X[:, 0]
+             + rng.normal(0, 0.3, n))
+        c.update(m=12, P=14, steps=30, rules=np.array([0, 0, 2, 2, 2], np.int32),
+                 prior=np.array([1.0, 1.0, 3.0, 1.0, 1.0]))
     else:
         raise KeyError(name)
     c.update(X=X, Y=Y)
@@ -111,7 +123,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference"]
+         "meanscale_k2_reference", "subset_rule"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):

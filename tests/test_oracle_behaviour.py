@@ -222,7 +222,9 @@ def test_error_paths(oracle):
     with pytest.raises(NotImplementedError):
         BARTOp(X, Y, response="linear")
     with pytest.raises(NotImplementedError):
-        PGBART([BARTOp(X, Y, split_rules=["SubsetSplit", "SubsetSplit"])], backend=oracle)
+        PGBART([BARTOp(X, Y, split_rules=["NoSuchSplit", "ContinuousSplit"])], backend=oracle)
+    with pytest.raises(_abi.PGBError, match="unknown split rule"):
+        PySampler(st, X, Y, np.array([0, 7], np.int32), np.ones(2), backend=oracle)
 
 
 def test_constant_response_and_duplicate_rows(oracle):
@@ -418,3 +420,42 @@ def test_pgbart_pickle_round_trip_resumes_the_chain(oracle, monkeypatch):
     # the tree history travels with the pickle too
     assert len(sb._batches) == len(sa._batches) == 6
     assert np.array_equal(sa._batches[-1].value, sb._batches[-1].value)
+
+
+def test_subset_rule_recovers_a_set_valued_effect(oracle):
+    # bart.py:100-103 names SubsetSplitRule next to OneHotSplitRule: the split sends a SET of
+    # categories left.  The effect below is constant on {1, 4, 6} vs the rest: one subset split
+    # captures it, one-hot splits need several.
+    rng = np.random.default_rng(77)
+    cat = rng.integers(0, 7, size=400)
+    X = np.column_stack([cat, rng.integers(0, 5, size=400), rng.normal(size=400)]).astype(float)
+    f = np.where(np.isin(cat, [1, 4, 6]), 2.0, -1.0)
+    Y = f + rng.normal(0, 0.2, 400)
+    op = BARTOp(X, Y, m=10, split_rules=["SubsetSplit", "SubsetSplit", "ContinuousSplit"])
+    res = sample_chain(op, tune=100, draws=40, random_seed=3415, backend=oracle)
+    assert np.sqrt(np.mean((res["mu"].mean(axis=0) - f) ** 2)) < 0.3
+    vi = res["vi_counts"].sum(axis=0)
+    assert vi[0] > vi[1] + vi[2]
+    # set-valued split values: integer masks below 2^52, no empty child, and the history
+    # evaluated on the training rows reproduces astep's output
+    base, batches = res["history"]
+    rules = np.array([2, 2, 0], np.int32)
+    for ta in [base] + batches:
+        sub = (ta.var == 0) | (ta.var == 1)
+        assert np.all(ta.split[sub] == np.floor(ta.split[sub])) and np.all(ta.split[sub] < 2.0 ** 52)
+        assert np.all(ta.split[sub] >= 1)
+        off = np.repeat(ta.node_off[:-1], np.diff(ta.node_off))
+        inner = ta.var >= 0
+        assert np.all(ta.count[ta.left[inner] + off[inner]] > 0)
+        assert np.all(ta.count[ta.right[inner] + off[inner]] > 0)
+    ps = PosteriorSampler.from_history(batches, base, 10, 1, rules=rules, backend=oracle)
+    pred = ps.sample_posterior(X, list(range(40)))
+    np.testing.assert_allclose(pred[:, 0, :], res["mu"], rtol=0, atol=1e-9)
+    ref = predict_numpy(ps.pool, ps.forest_idx[[7]], X, rules)
+    np.testing.assert_allclose(pred[7], ref[0], atol=1e-12)
+    # invalid category codes are rejected up front
+    Xbad = X.copy()
+    Xbad[0, 0] = 60.0
+    with pytest.raises(ValueError, match="SubsetSplit column 0"):
+        PGBART([BARTOp(Xbad, Y, m=2, split_rules=["SubsetSplit"] * 2 + ["ContinuousSplit"])],
+               backend=oracle)
