@@ -1310,8 +1310,8 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
 };
 
-template <bool SUB>
-__global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int par) {
+template <bool SUB, bool NORMAL>
+__global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 7 * 4];
   __shared__ double s_lv[2][256];
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(BT, 3) void k_rows(const Dev* __restrict__ Sp, int 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
   const bool do_part = (kind & CMD_PARTITION) != 0;
-  const bool normal = S.family == PGB_FAMILY_NORMAL;
+  constexpr bool normal = NORMAL;  // compiled per family class: the Normal instance carries no log-likelihood code
 
   if (do_final || do_init) {
     for (int i = tid; i < 256; i += BT) {
@@ -2070,14 +2070,15 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+          // ONE evaluation per row: the side only selects the leaf value and the accumulator
+          // (separate calls per side would run one after the other on a divergent wave)
           const double xv = x[e];
-          if (xv != xv) {
-            v2 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e]), cl, &sat);  // dropped: predicts 0
-          } else if (go_left(lj.rule, xv, lj.v)) {
-            v0 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e] + lj.vL), cl, &sat);
-          } else {
-            v1 += pgb_quant(pgb_loglik1(S.family, yv[e], nv[e] + lj.vR), cl, &sat);
-          }
+          const int side = (xv != xv) ? 2 : (go_left(lj.rule, xv, lj.v) ? 0 : 1);
+          const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
+          const long long q = pgb_quant(pgb_loglik1(S.family, yv[e], mu), cl, &sat);
+          v0 += side == 0 ? q : 0;
+          v1 += side == 1 ? q : 0;
+          v2 += side == 2 ? q : 0;
         }
       }
       const int slot = (g - g0) * 3;
@@ -2588,9 +2589,16 @@ static int enqueue_slots(pgb_handle* h, int count) {
     }
     if (d.K > 1)
       hipLaunchKernelGGL(k_rows_mk, grows, dim3(BT), 0, h->stream, h->d_dev, par);
-    else
-      if (h->has_subset) hipLaunchKernelGGL(k_rows<true>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
-      else hipLaunchKernelGGL(k_rows<false>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+    else {
+      const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
+      if (h->has_subset) {
+        if (nrm) hipLaunchKernelGGL((k_rows<true, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        else hipLaunchKernelGGL((k_rows<true, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else {
+        if (nrm) hipLaunchKernelGGL((k_rows<false, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        else hipLaunchKernelGGL((k_rows<false, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      }
+    }
     if (h->prof) (void)hipEventRecord(e1, h->stream);
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
       if (d.K > 1)

@@ -154,3 +154,31 @@ def test_weight_pick_follows_inverse_cdf(oracle):
     # overwhelming weight differences (the n=100k regime): never NaN, picks the heavy particle
     lw[1:6] = [-1e6, -3.0, -1e5, -2e6, -1e9]
     assert [f(lw.ctypes.data, 1, 5, u, None) for u in (0.01, 0.5, 0.99)] == [2, 2, 2]
+
+
+def test_log_ndtr_against_scipy(oracle):
+    # pgb_log_ndtr: table-driven scaled-tail form (tools/fit_log_ndtr.py); the likelihood sums
+    # are fixed point, so the bar is absolute error (1 ulp of log Phi(-38) = -726 is 1.1e-13)
+    from scipy.special import log_ndtr
+
+    f = _lib(oracle).pgbo_log_ndtr
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    f.restype = None
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.linspace(-38, 38, 100001), rng.normal(0, 2, 50000),
+                        [0.0, -0.0, 1e-300, -1e-300, 2.0 * 15 / 1 - 1e-9, 30.0, -30.0]])
+    out = np.empty_like(x)
+    f(x.ctypes.data, x.size, out.ctypes.data)
+    ref = log_ndtr(x)
+    assert np.max(np.abs(out - ref)) < 4e-13
+    body = np.abs(x) < 5
+    assert np.max(np.abs(out[body] - ref[body])) < 1e-14  # 3 ulp of 15
+    assert np.all(out <= 0.0) and np.all(np.diff(out[:100001]) >= -1e-15)  # a log-probability, monotone
+    # far tails stay finite and follow -x^2/2 - log(|x| sqrt(2 pi))
+    far = np.array([-1e3, -1e5, -1e8, 1e3, 1e8])
+    o2 = np.empty_like(far)
+    f(far.ctypes.data, far.size, o2.ctypes.data)
+    assert np.allclose(o2[:3], log_ndtr(far[:3]), rtol=1e-14) and np.all(o2[3:] == 0.0)
+    nan = np.array([np.nan])
+    f(nan.ctypes.data, 1, nan.ctypes.data)
+    assert np.isnan(nan[0])
