@@ -214,7 +214,8 @@ def main():
             "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
             "algorithmic_bytes_per_launch": alg / max(launches, 1),
             "note": "achieved = algorithmic bytes (sum over tree updates of 48 n + 40 rows_touched, "
-                    "SURVEY.md 8d) / total k_rows time from HIP events on the sampler's stream; "
+                    "SURVEY.md 8d) / total k_rows time from HIP events attached to each k_rows dispatch "
+                    "(hipExtLaunchKernelGGL start/stop on the sampler's stream); "
                     "traffic = HBM bytes per k_rows launch from profiles/r01_pmc_traffic.json: well "
                     "BELOW the algorithmic bytes because the 39 particles share the X columns and "
                     "{sum_trees, r} through L2 / Infinity Cache at this size",

@@ -21,6 +21,7 @@
 //   * No MFMA: the path is gather / partition / reduce (HBM / L2 bound).
 //
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -2585,21 +2586,28 @@ static int enqueue_slots(pgb_handle* h, int count) {
       e0 = h->ev[h->ev_used];
       e1 = h->ev[h->ev_used + 1];
       h->ev_used += 2;
-      (void)hipEventRecord(e0, h->stream);
     }
-    if (d.K > 1)
-      hipLaunchKernelGGL(k_rows_mk, grows, dim3(BT), 0, h->stream, h->d_dev, par);
-    else {
+    // Profiling: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. they
+    // carry the start / end timestamps of the kernel's own AQL packet -- the interval rocprofv3
+    // reports -- rather than bracketing the launch with two extra barrier packets.
+#define LAUNCH_ROWS(KERN)                                                                         \
+  do {                                                                                            \
+    if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par); \
+    else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par);    \
+  } while (0)
+    if (d.K > 1) {
+      LAUNCH_ROWS(k_rows_mk);
+    } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (h->has_subset) {
-        if (nrm) hipLaunchKernelGGL((k_rows<true, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
-        else hipLaunchKernelGGL((k_rows<true, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        if (nrm) LAUNCH_ROWS((k_rows<true, true>));
+        else LAUNCH_ROWS((k_rows<true, false>));
       } else {
-        if (nrm) hipLaunchKernelGGL((k_rows<false, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
-        else hipLaunchKernelGGL((k_rows<false, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        if (nrm) LAUNCH_ROWS((k_rows<false, true>));
+        else LAUNCH_ROWS((k_rows<false, false>));
       }
     }
-    if (h->prof) (void)hipEventRecord(e1, h->stream);
+#undef LAUNCH_ROWS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
       if (d.K > 1)
         hipLaunchKernelGGL(k_loglik<true>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
