@@ -98,6 +98,16 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
 };
 
 #define IA_SLOTS 8 /* the row pass spreads its atomics over this many cache lines */
+// Per-particle split statistics: every work item of a particle adds to the particle's record, and
+// atomics on ONE cache line serialise (~12 ns each: 98 chunks x 4 values = 4.7 us at cfg2).  The
+// record is therefore kept ACC_SLOTS times (item -> slot by chunk); readers sum the copies.
+#ifndef ACC_SLOTS
+#define ACC_SLOTS 4 /* measured at cfg2: 1 -> 1.52 M, 4 -> 1.62 M, 8 -> 1.58 M, 16 -> 1.51 M particle-steps/s */
+#endif
+#ifndef ACC_STRIDE
+#define ACC_STRIDE 2 /* distance between copies, in records of 64 B: one 128-B line each */
+#endif
+#define ACC_PER (ACC_SLOTS * ACC_STRIDE)
 struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;
   long long pad0, pad1, pad2;
@@ -150,7 +160,7 @@ struct Dev {  // kernel argument block (by value)
   DTree* trees;       // [m]
   DPart* parts;       // [2][P]
   Job* jobs;          // [2][P]
-  Acc* acc;           // [2][P]
+  Acc* acc;           // [2][P][ACC_SLOTS]
   AccL* accl;         // [2][P]   (non-Normal families)
   JobL* jobl;         // [2][P]   (non-Normal families)
   InitAcc* initacc;   // [2][IA_SLOTS]
@@ -190,9 +200,16 @@ struct Dev {  // kernel argument block (by value)
   do {                                                                                     \
     if (cond) S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64(); \
   } while (0)
+// stamps of the row pass (entries 12..15 of the slot's record), taken by one chosen workgroup
+#define TRR(i, blk)                                                                                  \
+  do {                                                                                               \
+    if (blockIdx.x == (blk) && threadIdx.x == 0)                                                     \
+      S.trace[(size_t)((S.ctrl[par ^ 1].slot_no - 1) % TRACE_SLOTS) * 16 + (i)] = wall_clock64();    \
+  } while (0)
 #else
 #define TR(i) ((void)0)
 #define TRX(i, cond) ((void)0)
+#define TRR(i, blk) ((void)0)
 #endif
 
 // A read of a wave-uniform, kernel-invariant record (written by an EARLIER launch) through the
@@ -238,6 +255,66 @@ __device__ __forceinline__ long long wave_sum_dpp(long long v) {
   PGB_DPP_STEP(0x143, 0xc)  // row_bcast:31
 #undef PGB_DPP_STEP
   return ((long long)hi << 32) | (unsigned)lo;
+}
+
+// Wave-wide sums of FOUR 64-bit values at once ("transposed" butterfly): the first two exchange
+// steps halve the number of live values instead of carrying all four through every step, so the
+// whole reduction costs ~42 VALU instructions instead of 4 x 24.  Integer adds: any order gives
+// the same bits.  Exchanges: quad_perm (xor 1, xor 2), masked row shifts (xor 4), row_ror:8
+// (xor 8) and the gfx950 v_permlane16_swap / v_permlane32_swap (xor 16, xor 32).
+// Returns, in EVERY lane, the wave total of value number (lane & 3).
+template <int CTRL>
+__device__ __forceinline__ long long dpp_mov64(long long x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, 0);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, 0xf, 0xf, 0);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int dpp_xor4(int x) {
+  int t = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, 0);  // lanes 4-7, 12-15 <- lane - 4
+  return __builtin_amdgcn_update_dpp(t, x, 0x104, 0xf, 0x5, 0);   // lanes 0-3, 8-11  <- lane + 4
+}
+__device__ __forceinline__ long long wave_sum4(long long v0, long long v1, long long v2, long long v3) {
+  const int lane = (int)(threadIdx.x & 63);
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  // xor 1: even lanes keep (v0, v2), odd lanes keep (v1, v3)
+  long long k0 = b0 ? v1 : v0, k1 = b0 ? v3 : v2;
+  const long long s0 = b0 ? v0 : v1, s1 = b0 ? v2 : v3;
+  k0 += dpp_mov64<0xB1>(s0);  // quad_perm [1,0,3,2]
+  k1 += dpp_mov64<0xB1>(s1);
+  // xor 2: lanes with bit 1 clear keep the first (v0 | v1), the others the second (v2 | v3)
+  long long k = b1 ? k1 : k0;
+  const long long s = b1 ? k0 : k1;
+  k += dpp_mov64<0x4E>(s);  // quad_perm [2,3,0,1]
+  // from here on lane l carries value (l & 3)
+  {
+    const int lo = dpp_xor4((int)k), hi = dpp_xor4((int)(k >> 32));
+    k += ((long long)hi << 32) | (unsigned)lo;
+  }
+  k += dpp_mov64<0x128>(k);  // row_ror:8
+  {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    k = (long long)(((unsigned long long)h[0] << 32) | l[0]) + (long long)(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    k = (long long)(((unsigned long long)h[0] << 32) | l[0]) + (long long)(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  return k;
+}
+
+// sum of the ACC_SLOTS copies of a particle's split statistics
+__device__ __forceinline__ Acc load_acc(const Acc* __restrict__ base) {
+  Acc a = base[0];
+#pragma unroll
+  for (int k = 1; k < ACC_SLOTS; ++k) {
+    const Acc t = base[k * ACC_STRIDE];
+    a.cnts += t.cnts;
+    a.aL += t.aL; a.bL += t.bL; a.c2L += t.c2L;
+    a.aN += t.aN; a.bN += t.bN; a.c2N += t.c2N;
+  }
+  return a;
 }
 
 // block-wide sum of NV long long values; result valid in thread 0
@@ -554,11 +631,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
 
   if (b == 0 && tid == 0 && c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
-  if (tid == 0) {
+  if (tid < ACC_SLOTS) {
     Acc z;
     memset(&z, 0, sizeof z);
-    S.acc[par * MAXP + p] = z;
-    if (S.family != PGB_FAMILY_NORMAL) S.accl[par * MAXP + p] = AccL{0, 0, 0, 0};
+    S.acc[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = z;
+    if (tid == 0 && S.family != PGB_FAMILY_NORMAL) S.accl[par * MAXP + p] = AccL{0, 0, 0, 0};
   }
   if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, 0, 0, 0};
   const int KX = MK ? S.K - 1 : 0;
@@ -644,7 +721,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
       AccL al = {0, 0, 0, 0};
       if (isp) {
         j = JP[q];
-        a = S.acc[(par ^ 1) * MAXP + q];
+        a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
         if (!normal) {
           jl = S.jobl[(par ^ 1) * MAXP + q];
           al = S.accl[(par ^ 1) * MAXP + q];
@@ -1320,6 +1397,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
   __shared__ int s_n[2];
   const Cmd* cmd = &S.cmd[par];
   const int kind = cmd->kind;
+  TRR(12, 0);
   if (kind == CMD_NOOP) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
@@ -1372,6 +1450,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
       if (tid == 0) s_n[0] = __popcll(m);
     }
     __syncthreads();
+    TRR(13, 0);
     const int nact = s_n[0];
     if (nact == 0 && !do_init) return;
     const int target = do_init ? S.rows_target_init : S.rows_target;
@@ -1474,17 +1553,38 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
       for (int e = 0; e < RPT; ++e)
         if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
       const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      // software pipeline over the particles of the group: the labels and split-column values of
+      // particle g + 1 are requested before particle g is relabelled and reduced
+      uint32_t nx_ids = root_ids;
+      double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
+      if (g0 < g1) {
+        const RJob& rn = s_job[g0];
+        if (rn.src >= 0) nx_ids = *(const uint32_t*)(lid0 + rn.src + base);
+        if (rn.active) {
+          const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+          nx0 = xn[0];
+          nx1 = xn[1];
+        }
+      }
       for (int g = g0; g < g1; ++g) {
         const RJob& rj = s_job[g];
-        const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rj.src + base);
+        const uint32_t ids = nx_ids;
+        const double2 t0 = nx0, t1 = nx1;
+        if (g + 1 < g1) {
+          const RJob& rn = s_job[g + 1];
+          nx_ids = rn.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rn.src + base);
+          if (rn.active) {
+            const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+            nx0 = xn[0];
+            nx1 = xn[1];
+          }
+        }
         uint32_t out = ids;
         uint8_t* __restrict__ const dp = dst0 + (size_t)rj.p * n_pad + base;
         if (!rj.active) {  // forced refresh only
           *(uint32_t*)dp = out;
           continue;
         }
-        const double2* __restrict__ xp = (const double2*)(XT + rj.xoff + base);
-        const double2 t0 = xp[0], t1 = xp[1];
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
         const int slot = (g - g0) * 7;
         if (!rj.check_nan) {  // common case: the split column has no missing values
@@ -1502,13 +1602,8 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
             }
           }
           *(uint32_t*)dp = out;
-          v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2); v3 = wave_sum_dpp(v3);
-          if (lane == 63) {
-            s_red[(slot + 0) * 4 + w] = v0;
-            s_red[(slot + 1) * 4 + w] = v1;
-            s_red[(slot + 2) * 4 + w] = v2;
-            s_red[(slot + 3) * 4 + w] = v3;
-          }
+          const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
+          if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
         } else {
           long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
 #pragma unroll
@@ -1529,10 +1624,10 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
             }
           }
           *(uint32_t*)dp = out;
-          for (int i = 0; i < 7; ++i) {
-            const long long s = wave_sum_dpp(v[i]);
-            if (lane == 63) s_red[(slot + i) * 4 + w] = s;
-          }
+          const long long ta = wave_sum4(v[0], v[1], v[2], v[3]);
+          const long long tb = wave_sum4(v[4], v[5], v[6], 0);
+          if (lane < 4) s_red[(slot + lane) * 4 + w] = ta;
+          else if (lane < 7) s_red[(slot + lane) * 4 + w] = tb;  // lane 4..6: value (lane & 3) of the second set
         }
       }
       __syncthreads();
@@ -1542,7 +1637,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
         const RJob& rj = s_job[g0 + gi];
         if (!rj.active || (i >= 4 && !rj.check_nan)) continue;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
-        Acc* a = &S.acc[(size_t)par * MAXP + rj.p];
+        Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
           S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
@@ -1825,7 +1920,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
         const RJob& rj = s_job[g0 + gi];
         if (!rj.active) continue;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
-        Acc* a = &S.acc[(size_t)par * MAXP + rj.p];
+        Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
         long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * 2 * KX;
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
@@ -1969,7 +2064,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     }
     if (has) {
       const int k = __popcll(m & ((1ull << tid) - 1ull));
-      const Acc a = S.acc[(size_t)par * MAXP + tid];
+      const Acc a = load_acc(&S.acc[((size_t)par * MAXP + tid) * ACC_PER]);
       const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
                                         a.aL, a.aN, z0, z1, leaf_sd);
       LJob lj;
@@ -2268,6 +2363,7 @@ struct pgb_handle {
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
+  int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int sigma_dirty;
   double inv_sigma2;
   int lower_host;      // mirror of the batch cursor
@@ -2329,6 +2425,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->stream = (hipStream_t)stream;
   h->slot = 0;
   h->has_subset = 0;
+  h->rows_grid = 1024;
+  if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
   h->st_cur = 0;
   h->alpha_cur = 0;
   h->d_dev = nullptr;
@@ -2396,7 +2494,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
-  DA(d.acc, 2 * MAXP);
+  DA(d.acc, 2 * MAXP * ACC_PER);
   DA(d.accl, 2 * MAXP);
   DA(d.jobl, 2 * MAXP);
   DA(d.initacc, 2 * IA_SLOTS);
@@ -2462,7 +2560,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
-  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
   HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * sizeof(AccL), sm));
   HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
   HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
@@ -2566,7 +2664,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
   Dev& d = h->d;
   long long want = (long long)d.nchunks * (d.P - 1);
   if (want < d.n_pad / BT) want = d.n_pad / BT;
-  if (want > 1024) want = 1024;
+  if (want > h->rows_grid) want = h->rows_grid;
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
