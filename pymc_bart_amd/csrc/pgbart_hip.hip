@@ -108,6 +108,10 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
 #define ACC_STRIDE 2 /* distance between copies, in records of 64 B: one 128-B line each */
 #endif
 #define ACC_PER (ACC_SLOTS * ACC_STRIDE)
+// the same for the log-likelihood sums of k_loglik (32-byte records): 8 copies, 128 B apart
+#define LL_SLOTS 8
+#define LL_STRIDE 4
+#define LL_PER (LL_SLOTS * LL_STRIDE)
 struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;
   long long pad0, pad1, pad2;
@@ -161,7 +165,7 @@ struct Dev {  // kernel argument block (by value)
   DPart* parts;       // [2][P]
   Job* jobs;          // [2][P]
   Acc* acc;           // [2][P][ACC_SLOTS]
-  AccL* accl;         // [2][P]   (non-Normal families)
+  AccL* accl;         // [2][P][LL_SLOTS]   (non-Normal families)
   JobL* jobl;         // [2][P]   (non-Normal families)
   InitAcc* initacc;   // [2][IA_SLOTS]
   Cmd* cmd;           // [2]
@@ -635,8 +639,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
     Acc z;
     memset(&z, 0, sizeof z);
     S.acc[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = z;
-    if (tid == 0 && S.family != PGB_FAMILY_NORMAL) S.accl[par * MAXP + p] = AccL{0, 0, 0, 0};
   }
+  if (tid < LL_SLOTS && S.family != PGB_FAMILY_NORMAL)
+    S.accl[((size_t)par * MAXP + p) * LL_PER + tid * LL_STRIDE] = AccL{0, 0, 0, 0};
   if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, 0, 0, 0};
   const int KX = MK ? S.K - 1 : 0;
   if constexpr (MK) {
@@ -724,7 +729,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
         if (!normal) {
           jl = S.jobl[(par ^ 1) * MAXP + q];
-          al = S.accl[(par ^ 1) * MAXP + q];
+          al = AccL{0, 0, 0, 0};
+          for (int k = 0; k < LL_SLOTS; ++k) {
+            const AccL t = S.accl[((size_t)(par ^ 1) * MAXP + q) * LL_PER + k * LL_STRIDE];
+            al.llL += t.llL; al.llR += t.llR; al.llN += t.llN;
+          }
         }
       }
       // one Philox evaluation per lane: lane 0 draws the resampling offset, lane q the leaf noise
@@ -2148,7 +2157,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         const int gi = t / 3, i = t % 3;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
         if (s != 0) {
-          AccL* a = &S.accl[(size_t)par * MAXP + s_job[g0 + gi].p];
+          AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
           atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
         }
       }
@@ -2190,7 +2199,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       const int gi = t / 3, i = t % 3;
       const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
       if (s != 0) {
-        AccL* a = &S.accl[(size_t)par * MAXP + s_job[g0 + gi].p];
+        AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
         atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
       }
     }
@@ -2495,7 +2504,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
   DA(d.acc, 2 * MAXP * ACC_PER);
-  DA(d.accl, 2 * MAXP);
+  DA(d.accl, 2 * MAXP * LL_PER);
   DA(d.jobl, 2 * MAXP);
   DA(d.initacc, 2 * IA_SLOTS);
   DA(d.cmd, 2);
@@ -2561,7 +2570,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
   HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
-  HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * sizeof(AccL), sm));
+  HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * LL_PER * sizeof(AccL), sm));
   HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
   HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
   HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
