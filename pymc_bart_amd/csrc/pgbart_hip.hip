@@ -112,6 +112,10 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
 #define LL_SLOTS 8
 #define LL_STRIDE 4
 #define LL_PER (LL_SLOTS * LL_STRIDE)
+// ... and for the extension-output sums of the multi-output row pass: 4 copies of 16 longs (128 B)
+#define AX_SLOTS 4
+#define AX_REC 16
+#define AX_PER (AX_SLOTS * AX_REC)
 struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;
   long long pad0, pad1, pad2;
@@ -183,7 +187,7 @@ struct Dev {  // kernel argument block (by value)
   double* pvx;        // [2][MAXP][MAXN][KX]    particle leaf values
   long long* pqx;     // [2][MAXP][MAXN][KX]    particle node sums of sum_trees
   double* tvx;        // [m][MAXN][KX]          accepted trees' leaf values
-  long long* accx;    // [2][MAXP][2*KX]        row-pass statistics: aL[k], aN[k]
+  long long* accx;    // [2][MAXP][AX_SLOTS][AX_REC]  row-pass statistics: aL[k], aN[k] (copies, see AX_SLOTS)
   long long* iax;     // [2][IA_SLOTS][2*KX]    INIT/FINAL statistics: A[k], QSTD[k]
   double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
   long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
@@ -319,6 +323,15 @@ __device__ __forceinline__ Acc load_acc(const Acc* __restrict__ base) {
     a.aN += t.aN; a.bN += t.bN; a.c2N += t.c2N;
   }
   return a;
+}
+
+// extension-output statistic `idx` (aL[k]: k, aN[k]: KX + k) of a particle, summed over its copies
+__device__ __forceinline__ long long load_accx(const long long* __restrict__ accx, int par, int q, int idx) {
+  const long long* b = accx + ((size_t)par * MAXP + q) * AX_PER + idx;
+  long long s = 0;
+#pragma unroll
+  for (int k = 0; k < AX_SLOTS; ++k) s += b[k * AX_REC];
+  return s;
 }
 
 // block-wide sum of NV long long values; result valid in thread 0
@@ -645,7 +658,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, 0, 0, 0};
   const int KX = MK ? S.K - 1 : 0;
   if constexpr (MK) {
-    if (tid < 2 * KX) S.accx[((size_t)par * MAXP + p) * 2 * KX + tid] = 0;
+    if (tid < AX_PER) S.accx[((size_t)par * MAXP + p) * AX_PER + tid] = 0;
     if (b == 0)
       for (int i = tid; i < IA_SLOTS * 2 * KX; i += BT) S.iax[(size_t)par * IA_SLOTS * 2 * KX + i] = 0;
   }
@@ -814,10 +827,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         if constexpr (MK) {
           if (j.active)
           for (int k = 0; k < KX; ++k) {
-            const size_t ax = ((size_t)(par ^ 1) * MAXP + q) * 2 * KX;
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
-            s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, S.accx[ax + k], S.accx[ax + KX + k], pq, pv, it,
+            s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, load_accx(S.accx, par ^ 1, q, k),
+                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
                                           (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
           }
         }
@@ -1721,11 +1734,15 @@ __device__ __forceinline__ double loglik_any(const Dev& S, double y, const doubl
   return pgb_loglik(S.family, S.K, y, mu);
 }
 
+// KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay
+// in registers), 0: any K <= PGB_MAX_OUTPUTS.
+template <int KT>
 __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
-  const int K = S.K, KX = K - 1;
-  __shared__ long long s_red[MAXP * (1 + 2 * PGB_MAX_OUTPUTS) * 4];
-  __shared__ double s_lv[2][256][PGB_MAX_OUTPUTS];
+  const int K = KT > 0 ? KT : S.K, KX = K - 1;
+  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops
+  __shared__ long long s_red[MAXP * (1 + 2 * KB) * 4];
+  __shared__ double s_lv[2][256][KB];
   __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
   const Cmd* cmd = &S.cmd[par];
@@ -1801,7 +1818,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
       const int chunk = item % S.nchunks, grp = item / S.nchunks;
       const long long base = (long long)chunk * CH + tid * RPT;
-      double stv[RPT][PGB_MAX_OUTPUTS];  // sum_trees of this thread's rows, per output
+      double stv[RPT][KB];  // sum_trees of this thread's rows, per output
       if (do_init) {
         const bool writer = grp == 0;
         uint32_t ids_next = *(const uint32_t*)(tl_new + base);
@@ -1824,7 +1841,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
           const long long row = base + e;
           for (int k = 0; k < K; ++k) stv[e][k] = 0.0;
           if (row >= n) continue;
-          double mu_stump[PGB_MAX_OUTPUTS], mu_cur[PGB_MAX_OUTPUTS];
+          double mu_stump[KB], mu_cur[KB];
           for (int k = 0; k < K; ++k) {
             double st = st_in[(size_t)k * n_pad + row];
             if (do_final) {
@@ -1856,8 +1873,8 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
           }
           if (writer) {
             const double yv = S.y[row];
-            iv[0] += pgb_quant(loglik_any(S, yv, mu_stump), S.sc.cl, &sat);  // C: fresh stump
-            iv[1] += pgb_quant(loglik_any(S, yv, mu_cur), S.sc.cl, &sat);    // E0: current tree
+            iv[0] += pgb_quant(pgb_loglik(S.family, K, yv, mu_stump), S.sc.cl, &sat);  // C: fresh stump
+            iv[1] += pgb_quant(pgb_loglik(S.family, K, yv, mu_cur), S.sc.cl, &sat);    // E0: current tree
           }
         }
       } else {
@@ -1869,6 +1886,11 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
       uint32_t root_ids = 0;
       for (int e = 0; e < RPT; ++e)
         if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+      long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) qst[e][k] = k < K ? pgb_quant(stv[e][k], c1, nullptr) : 0;
       const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
       for (int g = g0; g < g1; ++g) {
         const RJob& rj = s_job[g];
@@ -1904,22 +1926,32 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
         }
         *(uint32_t*)dp = out;
         const int slot = (g - g0) * NV;
-        {
-          const long long s0 = wave_sum_dpp(cnts);
-          if (lane == 63) s_red[(slot + 0) * 4 + w] = s0;
-        }
-        for (int k = 0; k < K; ++k) {
-          long long aL = 0, aN = 0;
-          for (int e = 0; e < RPT; ++e) {
-            if (side[e] == 1 || side[e] == 3) {
-              const long long q = pgb_quant(stv[e][k], c1, nullptr);
-              if (side[e] == 1) aL += q; else aN += q;
+        // values of this particle: [0] counts, [1 + k] aL[k], [1 + K + k] aN[k]; reduced four at a
+        // time (wave_sum4); a column without missing values has no aN part
+        long long vals[1 + 2 * KB + 3];
+#pragma unroll
+        for (int i = 0; i < 1 + 2 * KB + 3; ++i) vals[i] = 0;
+        vals[0] = cnts;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          if (k < K) {
+            long long aL = 0, aN = 0;
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              const long long q = qst[e][k];
+              aL += side[e] == 1 ? q : 0;
+              aN += side[e] == 3 ? q : 0;
             }
+            vals[1 + k] = aL;
+            vals[1 + K + k] = aN;
           }
-          const long long sL = wave_sum_dpp(aL), sN = wave_sum_dpp(aN);
-          if (lane == 63) {
-            s_red[(slot + 1 + k) * 4 + w] = sL;
-            s_red[(slot + 1 + K + k) * 4 + w] = sN;
+        }
+        const int nv = rj.check_nan ? NV : 1 + K;
+#pragma unroll
+        for (int c4 = 0; c4 < (1 + 2 * KB + 3) / 4; ++c4) {
+          if (c4 * 4 < nv) {
+            const long long tot = wave_sum4(vals[c4 * 4], vals[c4 * 4 + 1], vals[c4 * 4 + 2], vals[c4 * 4 + 3]);
+            if (lane < 4 && c4 * 4 + lane < nv) s_red[(slot + c4 * 4 + lane) * 4 + w] = tot;
           }
         }
       }
@@ -1927,10 +1959,10 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
       for (int t = tid; t < (g1 - g0) * NV; t += BT) {
         const int gi = t / NV, i = t % NV;
         const RJob& rj = s_job[g0 + gi];
-        if (!rj.active) continue;
+        if (!rj.active || (i > K && !rj.check_nan)) continue;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
         Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
-        long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * 2 * KX;
+        long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
           S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
@@ -2090,10 +2122,10 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       if constexpr (MK)
       for (int kx = 0; kx < S.K - 1; ++kx) {  // extension outputs: same routine as k_ctrl
         const int KX = S.K - 1;
-        const size_t ax = ((size_t)par * MAXP + tid) * 2 * KX;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
         const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
-        const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, S.accx[ax + kx], S.accx[ax + KX + kx], pq, pv,
+        const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
+                                         load_accx(S.accx, par, tid, KX + kx), pq, pv,
                                          it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
@@ -2489,7 +2521,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.pvx, (size_t)2 * MAXP * MAXN * KX);
     DA(d.pqx, (size_t)2 * MAXP * MAXN * KX);
     DA(d.tvx, (size_t)d.m * MAXN * KX);
-    DA(d.accx, (size_t)2 * MAXP * 2 * KX);
+    DA(d.accx, (size_t)2 * MAXP * AX_PER);
     DA(d.iax, (size_t)2 * IA_SLOTS * 2 * KX);
     DA(d.lvx, (size_t)2 * 2 * 256 * KX);
     DA(d.jqx, (size_t)2 * MAXP * KX);
@@ -2555,7 +2587,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipMemsetAsync(d.packx, 0, (size_t)KX * d.n_pad * sizeof(double), sm));
     HC(hipMemsetAsync(d.pvx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.pqx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(long long), sm));
-    HC(hipMemsetAsync(d.accx, 0, (size_t)2 * MAXP * 2 * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.accx, 0, (size_t)2 * MAXP * AX_PER * sizeof(long long), sm));
     HC(hipMemsetAsync(d.iax, 0, (size_t)2 * IA_SLOTS * 2 * KX * sizeof(long long), sm));
     HC(hipMemsetAsync(d.lvx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
@@ -2702,8 +2734,14 @@ static int enqueue_slots(pgb_handle* h, int count) {
     if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par); \
     else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par);    \
   } while (0)
-    if (d.K > 1) {
-      LAUNCH_ROWS(k_rows_mk);
+    if (d.K == 2) {
+      LAUNCH_ROWS(k_rows_mk<2>);
+    } else if (d.K == 3) {
+      LAUNCH_ROWS(k_rows_mk<3>);
+    } else if (d.K == 4) {
+      LAUNCH_ROWS(k_rows_mk<4>);
+    } else if (d.K > 1) {
+      LAUNCH_ROWS(k_rows_mk<0>);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (h->has_subset) {
