@@ -2065,9 +2065,12 @@ struct LJob {
   double vLx[KXMAX], vRx[KXMAX];  // K-vector leaves: outputs 1..K-1
 };
 
-template <bool MK>
+// KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
+template <int KT>
 __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
+  constexpr bool MK = KT != 1;
+  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
@@ -2120,8 +2123,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
       if constexpr (MK)
-      for (int kx = 0; kx < S.K - 1; ++kx) {  // extension outputs: same routine as k_ctrl
-        const int KX = S.K - 1;
+      for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
+        const int KX = (KT > 0 ? KT : S.K) - 1;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
         const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
         const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
@@ -2141,7 +2144,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   if (G < 1) G = 1;
   const int ngroups = (nact + G - 1) / G;
   const int nitems = S.nchunks * ngroups;
-  const int K = MK ? S.K : 1;
+  const int K = KT > 0 ? KT : S.K;
   const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * K * S.n_pad;
   const double cl = S.sc.cl;
   const long long n = S.n;
@@ -2167,12 +2170,13 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
             const double xv = S.XT[lj.xoff + base + e];
             const int side = (xv != xv) ? 2 : (go_left(lj.rule, xv, lj.v) ? 0 : 1);
-            double mu[PGB_MAX_OUTPUTS];
+            double mu[KB];
             mu[0] = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);
-            for (int k = 1; k < K; ++k)
-              mu[k] = noi[(size_t)k * S.n_pad + base + e] +
+#pragma unroll
+            for (int k = 1; k < KB; ++k)
+              if (k < K) mu[k] = noi[(size_t)k * S.n_pad + base + e] +
                       (side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0);
-            const long long q = pgb_quant(loglik_any(S, yv[e], mu), cl, &sat);
+            const long long q = pgb_quant(pgb_loglik(S.family, K, yv[e], mu), cl, &sat);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
         }
@@ -2755,9 +2759,14 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef LAUNCH_ROWS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
       if (d.K > 1)
-        hipLaunchKernelGGL(k_loglik<true>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        switch (d.K) {
+          case 2: hipLaunchKernelGGL(k_loglik<2>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
+          case 3: hipLaunchKernelGGL(k_loglik<3>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
+          case 4: hipLaunchKernelGGL(k_loglik<4>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
+          default: hipLaunchKernelGGL(k_loglik<0>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        }
       else
-        hipLaunchKernelGGL(k_loglik<false>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        hipLaunchKernelGGL(k_loglik<1>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
     }
     h->slot += 1;
   }

@@ -89,6 +89,14 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=15, P=12, steps=24, family="categorical", K=K)
+    elif name == "categorical_k6_generic":  # more than 4 outputs: the run-time-K kernel instances
+        n, p, K = 3000, 6, 6
+        X = rng.normal(size=(n, p))
+        X[rng.random(n) < 0.1, 1] = np.nan
+        F = np.stack([X[:, 0], -X[:, 0], X[:, 2], -X[:, 2], 0.5 * X[:, 3], 0 * X[:, 0]])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=8, P=10, steps=20, family="categorical", K=K)
     elif name == "meanscale_k2_reference":  # reference tests/test_bart.py:107-123 (shape=(2, 250))
         n, p = 250, 3
         X = rng.normal(0, 1, size=(n, p))
@@ -123,7 +131,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
