@@ -10,9 +10,10 @@ from .pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood,
                      NormalMeanScaleLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
+from .importance import compute_variable_importance
 
 __version__ = "0.1.0"
 __all__ = [
     "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood",
-    "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "_abi",
+    "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "_abi",
 ]

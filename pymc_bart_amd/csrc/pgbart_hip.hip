@@ -1397,10 +1397,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
 // work in this round are not touched at all: their labels stay where they are (NGEN generations).
 // FINAL/INIT item = 256 rows.
 
-// Work items a row pass aims for (measured on cfg2: 640 for plain rounds, 512 for the fused
+// Work items a row pass aims for (measured on cfg2: 640 for plain rounds, 768 for the fused
 // FINAL+INIT+round-0 pass whose INIT part is repeated by every particle group).
 #define ROWS_TARGET_ITEMS 640
-#define ROWS_TARGET_ITEMS_INIT 512
+#define ROWS_TARGET_ITEMS_INIT 768
 #define PB 4 /* particles processed per batch inside a work item */
 
 struct RJob {  // the fields of a Job the row pass needs, cached in LDS

@@ -1,0 +1,159 @@
+"""Variable importance from the posterior of trees.
+
+Counterpart of reference ``pymc_bart/utils.py:868-1090`` (``compute_variable_importance``) and its
+helpers ``generate_sequences`` (``:1330-1336``) and ``pearsonr2`` (``:1340-1346``).  The expensive
+part -- posterior predictions with a set of covariates marginalised out (``excluded``), O(p) sweeps
+for "VI" and O(p^2) for the backward search -- runs in the ``k_predict`` kernel through
+``PosteriorSampler.sample_posterior``; the correlations are a few n-vectors of NumPy per sweep.
+
+The ranking logic is restated from the reference's documented behaviour:
+
+* ``"VI"``: variables ordered by how often they were used for splitting; prediction j keeps only the
+  j + 1 most used variables (the rest are excluded), the last keeps them all.
+* ``"backward"``: greedy elimination -- at every stage the variable whose additional exclusion
+  hurts the squared correlation with the full prediction least joins the excluded set.
+* ``"backward_VI"``: the ``fixed`` least used variables are eliminated by inclusion counts, the
+  others by the backward search.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .utils import _decode_vi, _get_posterior_sampler, _sample_posterior
+
+CI_PROB = 0.94  # ArviZ's default rcParams["stats.ci_prob"], used by the reference for the r2 interval
+
+
+def pearsonr2(a, b) -> float:
+    """Squared Pearson correlation of two arrays (flattened)."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    da, db = a - a.mean(), b - b.mean()
+    return float((da @ db) ** 2 / ((da @ da) * (db @ db)))
+
+
+def generate_sequences(n_vars: int, i_var: int, include: list) -> list:
+    """Candidate exclusion sets of stage ``i_var``: ``include`` plus one variable not yet in it
+    (the empty set at stage 0)."""
+    if not i_var:
+        return [()]
+    return [tuple(include + [v]) for v in range(n_vars) if v not in include]
+
+
+def hdi(x, prob: float = CI_PROB) -> np.ndarray:
+    """Narrowest interval holding ``prob`` of the sample (what ArviZ's ``hdi`` returns for a
+    unimodal sample)."""
+    x = np.sort(np.asarray(x, np.float64).ravel())
+    n = x.size
+    k = max(int(np.floor(prob * n)), 1)
+    if k >= n:
+        return np.array([x[0], x[-1]])
+    widths = x[k:] - x[: n - k]
+    i = int(np.argmin(widths))
+    return np.array([x[i], x[i + k]])
+
+
+def inclusion_counts(vi, n_vars: int) -> np.ndarray:
+    """Total split-variable counts from whatever carries them: an InferenceData-like mapping
+    (``idata["sample_stats"]["variable_inclusion"]``), a sequence of the base64 stat strings the
+    step method emits, or an array of counts ``(draws, p)`` / ``(p,)``."""
+    if hasattr(vi, "__getitem__") and not isinstance(vi, (list, tuple, np.ndarray)):
+        vi = vi["sample_stats"]["variable_inclusion"]
+        vi = getattr(vi, "values", vi)
+    arr = np.asarray(vi)
+    if arr.dtype.kind in "OUS":
+        return np.array([_decode_vi(str(s), n_vars) for s in arr.ravel()], dtype=np.int64).sum(axis=0)
+    arr = arr.astype(np.int64)
+    return arr.reshape(-1, n_vars).sum(axis=0)
+
+
+def _r2_against(full: np.ndarray, part: np.ndarray) -> np.ndarray:
+    return np.array([pearsonr2(full[j], part[j]) for j in range(full.shape[0])])
+
+
+def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0, samples: int = 50,
+                                random_seed=None, backend=None) -> dict:
+    """Rank the covariates of a fitted BART variable and report how well the model restricted to
+    the top-k of them reproduces the full posterior predictions.
+
+    ``vi``: see :func:`inclusion_counts` (ignored by ``method="backward"``).  ``bart``: the BART
+    variable or its op (needs ``all_trees``).  Returns the reference's dictionary: ``indices``
+    (most important first), ``labels``, ``r2_mean``, ``r2_hdi``, ``preds`` and ``preds_all``.
+    """
+    if method not in ("VI", "backward", "backward_VI"):
+        raise ValueError("method must be 'VI', 'backward' or 'backward_VI'")
+    op = bart.owner.op if getattr(bart, "owner", None) is not None else bart
+    sampler = _get_posterior_sampler(op, backend=backend)
+    rng = np.random.default_rng(random_seed)
+    if hasattr(X, "columns") and hasattr(X, "to_numpy"):
+        names = np.asarray(X.columns).astype(str)
+        X = X.to_numpy()
+    else:
+        X = np.asarray(X, np.float64)
+        names = np.arange(X.shape[1]).astype(str)
+    p = X.shape[1]
+    if method == "backward_VI" and not 1 <= fixed < p:
+        raise ValueError("fixed must be greater than 0 and less than the number of variables")
+
+    def predict(excluded):
+        return _sample_posterior(sampler, X=X, rng=rng, size=samples,
+                                 excluded=None if excluded is None else list(excluded))
+
+    full = predict(None)
+    # stage results, least restrictive model last: (excluded set) -> r2 sample, predictions
+    order: list[int] = []       # variables, least important first
+    stages: list[tuple] = []    # (r2 sample, predictions) once the variables of `order` so far are excluded
+
+    if method in ("VI", "backward_VI"):
+        by_use = np.argsort(inclusion_counts(vi, p), kind="stable")  # least used first
+        n_by_vi = p if method == "VI" else fixed
+        order = [int(v) for v in by_use[:n_by_vi]]
+    n_seed = len(order)
+
+    if method == "VI":
+        # model k keeps the k + 1 most used variables; the last one keeps all of them
+        for keep in range(1, p + 1):
+            excl = order[: p - keep]
+            pred = predict(excl if excl else None)
+            stages.append((_r2_against(full, pred), pred))
+        ranked = order[::-1]
+    else:
+        # backward_VI: the `fixed` least used variables are eliminated by inclusion counts; their
+        # models run from "all of them excluded" to "none excluded"
+        vi_stages = []
+        for j in range(n_seed, 0, -1):
+            pred = predict(order[:j])
+            vi_stages.append((_r2_against(full, pred), pred))
+        if n_seed:
+            pred = predict(None)
+            vi_stages.append((_r2_against(full, pred), pred))
+        # greedy backward search over the remaining variables
+        excluded = order[::-1]  # (the reference seeds its list in this order, utils.py:1012)
+        back = []
+        for stage in range(n_seed + (1 if n_seed else 0), p):
+            best = None
+            for cand in generate_sequences(p, stage, excluded):
+                pred = predict(cand if cand else None)
+                r2 = _r2_against(full, pred)
+                if best is None or r2.mean() > best[0]:
+                    best = (float(r2.mean()), cand, r2, pred)
+            back.append((best[2], best[3]))
+            for v in best[1]:
+                if v not in excluded:
+                    excluded.append(int(v))
+        excluded += [v for v in range(p) if v not in excluded]
+        ranked = excluded[::-1]
+        stages = back[::-1] + vi_stages
+    r2_mean = np.array([s[0].mean() for s in stages])
+    r2_hdi = np.array([hdi(s[0]) for s in stages]).reshape(-1, 2)
+    preds = np.array([s[1] for s in stages])
+    labels = np.array([names[v] if k == 0 else "+ " + names[v] for k, v in enumerate(ranked)])
+    return {
+        "indices": np.asarray(ranked),
+        "labels": labels,
+        "r2_mean": r2_mean,
+        "r2_hdi": r2_hdi,
+        "preds": preds.squeeze(),
+        "preds_all": full.squeeze(),
+    }

@@ -2,7 +2,7 @@
 
 Only the pieces on or next to the hot path are here:
 the variable-inclusion wire format the step method emits and the posterior-sampling
-dispatch.  Plotting / PDP / variable-importance analytics are out of scope.
+dispatch.  Variable importance lives in ``importance.py``; plotting / PDP are out of scope.
 """
 
 from __future__ import annotations

@@ -459,3 +459,52 @@ def test_subset_rule_recovers_a_set_valued_effect(oracle):
     with pytest.raises(ValueError, match="SubsetSplit column 0"):
         PGBART([BARTOp(Xbad, Y, m=2, split_rules=["SubsetSplit"] * 2 + ["ContinuousSplit"])],
                backend=oracle)
+
+
+def test_variable_importance_ranks_the_informative_covariates(oracle):
+    # SURVEY.md 8f f4 / reference utils.py:868-1090: "VI" follows the inclusion counts, "backward"
+    # the greedy elimination by squared correlation with the full prediction
+    from pymc_bart_amd.importance import (compute_variable_importance, generate_sequences, hdi,
+                                          inclusion_counts, pearsonr2)
+
+    rng = np.random.default_rng(21)
+    X = rng.normal(size=(300, 5))
+    Y = 3.0 * X[:, 1] + 1.5 * np.sin(2 * X[:, 3]) + rng.normal(0, 0.2, 300)
+    op = BARTOp(X, Y, m=20)
+    res = sample_chain(op, tune=120, draws=60, random_seed=5, backend=oracle)
+    stats = res["variable_inclusion"]
+    counts = inclusion_counts(stats, 5)
+    assert np.array_equal(counts, res["vi_counts"].sum(axis=0))
+    assert np.array_equal(inclusion_counts({"sample_stats": {"variable_inclusion": np.array(stats)}}, 5), counts)
+
+    out = compute_variable_importance(stats, op, X, method="VI", samples=20, random_seed=1, backend=oracle)
+    assert set(out) == {"indices", "labels", "r2_mean", "r2_hdi", "preds", "preds_all"}
+    assert list(out["indices"]) == list(np.argsort(counts, kind="stable")[::-1])
+    assert set(out["indices"][:2]) == {1, 3}
+    assert out["r2_mean"].shape == (5,) and out["r2_hdi"].shape == (5, 2)
+    assert out["preds"].shape == (5, 20, 300) and out["preds_all"].shape == (20, 300)
+    assert out["labels"][0] == str(out["indices"][0]) and out["labels"][1].startswith("+ ")
+    assert out["r2_mean"][1] > 0.9 and out["r2_mean"][1] > out["r2_mean"][0]   # top-2 model explains the fit
+    assert np.all(out["r2_hdi"][:, 0] <= out["r2_mean"] + 1e-12) and np.all(out["r2_mean"] <= out["r2_hdi"][:, 1] + 1e-12)
+
+    back = compute_variable_importance(None, op, X, method="backward", samples=15, random_seed=2, backend=oracle)
+    assert set(back["indices"][:2]) == {1, 3} and sorted(back["indices"]) == [0, 1, 2, 3, 4]
+    assert back["r2_mean"].shape == (5,) and back["r2_mean"][-1] > 0.8
+    assert np.all(np.diff(back["r2_mean"][:3]) > -0.05)  # adding variables back does not hurt
+
+    bvi = compute_variable_importance(stats, op, X, method="backward_VI", fixed=2, samples=10,
+                                      random_seed=3, backend=oracle)
+    assert sorted(bvi["indices"]) == [0, 1, 2, 3, 4] and bvi["r2_mean"].shape == (5,)
+    assert set(bvi["indices"][-2:]) == set(np.argsort(counts, kind="stable")[:2])  # the fixed, least used ones
+    with pytest.raises(ValueError):
+        compute_variable_importance(stats, op, X, method="nope", backend=oracle)
+    with pytest.raises(ValueError):
+        compute_variable_importance(stats, op, X, method="backward_VI", fixed=5, backend=oracle)
+
+    # helpers (reference utils.py:1330-1346)
+    assert generate_sequences(4, 0, []) == [()]
+    assert generate_sequences(4, 2, [1]) == [(1, 0), (1, 2), (1, 3)]
+    a = rng.normal(size=50)
+    assert abs(pearsonr2(a, 2 * a + 1) - 1.0) < 1e-12 and pearsonr2(a, rng.normal(size=50)) < 0.3
+    lo, hi = hdi(rng.normal(size=4000), 0.94)
+    assert -2.2 < lo < -1.6 and 1.6 < hi < 2.2

@@ -265,3 +265,25 @@ def test_pgbart_pickle_round_trip_on_gpu(hip):
         return np.array(out)
 
     assert np.array_equal(run(()), run((2, 5)))
+
+
+def test_variable_importance_on_gpu_matches_the_oracle(hip, oracle):
+    """the O(p) / O(p^2) prediction sweeps with excluded covariates run in
+    k_predict; the chain, its history and every sweep agree with the CPU oracle."""
+    from pymc_bart_amd.importance import compute_variable_importance
+
+    rng = np.random.default_rng(21)
+    X = rng.normal(size=(2000, 6))
+    Y = 3.0 * X[:, 1] + 1.5 * np.sin(2 * X[:, 3]) + rng.normal(0, 0.2, 2000)
+    outs = []
+    for be in (hip, oracle):
+        op = BARTOp(X, Y, m=20)
+        res = sample_chain(op, tune=40, draws=20, random_seed=5, backend=be)
+        for method, kw in (("VI", {}), ("backward", {}), ("backward_VI", {"fixed": 2})):
+            outs.append(compute_variable_importance(res["variable_inclusion"], op, X, method=method,
+                                                    samples=8, random_seed=1, backend=be, **kw))
+    for g, o in zip(outs[:3], outs[3:]):
+        assert np.array_equal(g["indices"], o["indices"])
+        np.testing.assert_allclose(g["preds_all"], o["preds_all"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(g["r2_mean"], o["r2_mean"], rtol=0, atol=1e-9)
+    assert set(outs[0]["indices"][:2]) == {1, 3}
