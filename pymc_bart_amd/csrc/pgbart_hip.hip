@@ -625,8 +625,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
   __shared__ double s_pre[2][PGB_SELECT_TRIES + 2];  // [set][0: coin, 1+t: row draw of try t]
   __shared__ double s_pre1[2][PGB_SELECT_TRIES + 2]; // second uniform of the same draws (subset masks)
   __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
+  __shared__ double s_prior[PGB_MAX_DEPTH];           // P(leaf | depth): read once by the idle wave 3
+  __shared__ DNode s_pop[MAXP];                       // node each OLD particle would pop next (prefetched)
 
   TR(0);
+  if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
   const Ctrl c = load_uniform(&S.ctrl[par]);
   Ctrl* co = &S.ctrl[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
@@ -737,9 +740,13 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
       Acc a;
       JobL jl = {0, 0, 0, 0};
       AccL al = {0, 0, 0, 0};
+      DNode popn;  // the node this particle pops next if it is an old node (children: from Fin)
+      memset(&popn, 0, sizeof popn);
       if (isp) {
         j = JP[q];
         a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
+        // requested as soon as the job header is here; consumed at the end of this phase
+        if (j.h_next_pop < j.h_n_nodes) popn = OT[q].nd[j.h_next_pop];
         if (!normal) {
           jl = S.jobl[(par ^ 1) * MAXP + q];
           al = AccL{0, 0, 0, 0};
@@ -834,6 +841,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
                                           (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
           }
         }
+        s_pop[q] = popn;
         pending = f.next_pop < f.n_nodes;
         lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
                     : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
@@ -1157,7 +1165,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         nd.cnt = (int32_t)S.n;
         nd.value = S.init_leaf;
       } else if (np < F.nn_old) {
-        nd = OT[anc].nd[np];
+        nd = s_pop[anc];
         if (r == 1 && np == 0) nd.q_st = ia.A, nd.q_r = normal ? ia.B : ia.C, nd.q_r2 = ia.C,
             nd.sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
       } else {
@@ -1173,7 +1181,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
         nd.value = isL ? F.vL : F.vR;
         nd.cc_row = isL ? F.ccL : F.ccR;
       }
-      double pl = nd.depth < PGB_MAX_DEPTH ? S.prior_leaf[nd.depth] : 1.0;
+      double pl = nd.depth < PGB_MAX_DEPTH ? s_prior[nd.depth] : 1.0;
       attempt = (pl < s_pre[set][0]) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
       s_i[5] = nd.cnt;
       s_i[6] = nd.cc_row;
