@@ -617,7 +617,8 @@ __device__ __forceinline__ int sample_var_weights(const long long* A, int p, dou
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
-void k_ctrl(const Dev* __restrict__ Sp, int par) {
+void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias) {
+  // ctrls / ias repeat S.ctrl / S.initacc as kernel arguments (see k_rows)
   const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_i[16];
@@ -630,14 +631,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par) {
 
   TR(0);
   if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
-  const Ctrl c = load_uniform(&S.ctrl[par]);
-  Ctrl* co = &S.ctrl[par ^ 1];
+  const Ctrl c = load_uniform(&ctrls[par]);
+  Ctrl* co = &ctrls[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
   const int P = S.P, Lc = P - 1;
   Cmd* cmd = &S.cmd[par];
   InitAcc ia;  // statistics of the previous FINAL/INIT row pass (integer sums over IA_SLOTS lines)
   {
-    const InitAcc* src = S.initacc + (size_t)(par ^ 1) * IA_SLOTS;
+    const InitAcc* src = ias + (size_t)(par ^ 1) * IA_SLOTS;
     ia = load_uniform(&src[0]);
 #pragma unroll
     for (int k = 1; k < IA_SLOTS; ++k) {
@@ -1419,13 +1420,17 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
 };
 
 template <bool SUB, bool NORMAL>
-__global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par) {
+__global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
+                                                              const Cmd* __restrict__ cmds,
+                                                              const Job* __restrict__ jobs_all) {
+  // cmds / jobs_all repeat S.cmd / S.jobs as kernel arguments: their first loads then do not wait
+  // for the load of the argument block S itself (one dependent memory round trip less)
   const Dev& S = *Sp;
   __shared__ long long s_red[MAXP * 7 * 4];
   __shared__ double s_lv[2][256];
   __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
-  const Cmd* cmd = &S.cmd[par];
+  const Cmd* cmd = &cmds[par];
   const int kind = cmd->kind;
   TRR(12, 0);
   if (kind == CMD_NOOP) return;
@@ -1451,7 +1456,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
   double* const st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad;
 
   if (do_part) {
-    const Job* jobs = S.jobs + (size_t)par * MAXP;
+    const Job* jobs = jobs_all + (size_t)par * MAXP;
     // list of particles with work in this pass (split or forced label refresh); their job
     // fields are cached in LDS once per workgroup
     if (tid < 64) {
@@ -2722,9 +2727,9 @@ static int enqueue_slots(pgb_handle* h, int count) {
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
     if (d.K > 1)
-      hipLaunchKernelGGL(k_ctrl<true>, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
+      hipLaunchKernelGGL(k_ctrl<true>, gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
     else
-      hipLaunchKernelGGL(k_ctrl<false>, gctrl, dim3(BT), 0, h->stream, h->d_dev, par);
+      hipLaunchKernelGGL(k_ctrl<false>, gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
       if (h->ev_used + 2 > h->ev.size()) {
@@ -2741,11 +2746,12 @@ static int enqueue_slots(pgb_handle* h, int count) {
     // Profiling: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. they
     // carry the start / end timestamps of the kernel's own AQL packet -- the interval rocprofv3
     // reports -- rather than bracketing the launch with two extra barrier packets.
-#define LAUNCH_ROWS(KERN)                                                                         \
+#define LAUNCH_ROWS(KERN, ...)                                                                    \
   do {                                                                                            \
-    if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par); \
-    else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par);    \
+    if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par, ##__VA_ARGS__); \
+    else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, ##__VA_ARGS__);    \
   } while (0)
+#define ROWS_PTRS (const Cmd*)d.cmd, (const Job*)d.jobs
     if (d.K == 2) {
       LAUNCH_ROWS(k_rows_mk<2>);
     } else if (d.K == 3) {
@@ -2757,14 +2763,15 @@ static int enqueue_slots(pgb_handle* h, int count) {
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (h->has_subset) {
-        if (nrm) LAUNCH_ROWS((k_rows<true, true>));
-        else LAUNCH_ROWS((k_rows<true, false>));
+        if (nrm) LAUNCH_ROWS((k_rows<true, true>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<true, false>), ROWS_PTRS);
       } else {
-        if (nrm) LAUNCH_ROWS((k_rows<false, true>));
-        else LAUNCH_ROWS((k_rows<false, false>));
+        if (nrm) LAUNCH_ROWS((k_rows<false, true>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<false, false>), ROWS_PTRS);
       }
     }
 #undef LAUNCH_ROWS
+#undef ROWS_PTRS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
       if (d.K > 1)
         switch (d.K) {
