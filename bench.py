@@ -218,7 +218,10 @@ def main():
                     "(hipExtLaunchKernelGGL start/stop on the sampler's stream); "
                     "traffic = HBM bytes per k_rows launch from profiles/r01_pmc_traffic.json: well "
                     "BELOW the algorithmic bytes because the 39 particles share the X columns and "
-                    "{sum_trees, r} through L2 / Infinity Cache at this size",
+                    "{sum_trees, r} through L2 / Infinity Cache at this size; the algorithmic figure is the "
+                    "traffic of the reference's index-list layout (40 B per touched row) -- this layout "
+                    "moves ~10 B per touched row plus 16 B per row and particle GROUP, so frac can "
+                    "exceed 1 at large n: it measures work per second, not HBM utilisation",
         }
 
     # end-of-run gather of the draws (the only collective; outside the timed region)
