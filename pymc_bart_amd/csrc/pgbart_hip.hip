@@ -1527,18 +1527,35 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           }
           if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
         }
+        // every input of the thread's four rows is requested BEFORE the first result is stored:
+        // the stores below may alias the loads as far as the compiler knows, so loads left inside
+        // the loop would be issued one row (one memory round trip) at a time
+        double st4[RPT], y4[RPT], mean4[RPT], m24[RPT];
+        {
+          const double2* __restrict__ sp = (const double2*)(st_in + base);
+          const double2* __restrict__ yp = (const double2*)(S.y + base);
+          const double2 s01 = sp[0], s23 = sp[1], y01 = yp[0], y23 = yp[1];
+          st4[0] = s01.x; st4[1] = s01.y; st4[2] = s23.x; st4[3] = s23.y;
+          y4[0] = y01.x; y4[1] = y01.y; y4[2] = y23.x; y4[3] = y23.y;
+          const bool upd = do_final && cmd->tune && writer;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
+            m24[e] = upd ? S.rs_m2[base + e] : 0.0;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
           const long long row = base + e;
           qa[e] = qb[e] = qc[e] = 0;
           if (row >= n) continue;
-          double st = st_in[row];  // sum_trees at a step boundary, sum_trees_noi inside an update
+          double st = st4[e];  // sum_trees at a step boundary, sum_trees_noi inside an update
           if (do_final) {
             // [U] sum_trees = sum_trees_noi + new_tree.predict()
             const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
             st = st + nv;
             if (cmd->tune && writer) {  // [U] RunningSd.update (Welford)
-              const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+              const double mean0 = mean4[e], m20 = m24[e];
               const double delta = nv - mean0;
               const double mean = mean0 + delta / cntf;
               const double delta2 = nv - mean;
@@ -1551,7 +1568,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           // [U] sum_trees_noi = sum_trees - old_tree.predict()
           const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
           const double noi = st - o;
-          const double yv = S.y[row];
+          const double yv = y4[e];
           const double r = normal ? yv - noi : 0.0;  // Bernoulli families: no residual algebra
           unsigned sat1 = 0;
           qa[e] = pgb_quant(st, c1, &sat1);
@@ -1583,6 +1600,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
         }
       }
+      TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
       uint32_t root_ids = 0;
 #pragma unroll
       for (int e = 0; e < RPT; ++e)
@@ -1685,6 +1703,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
       }
       __syncthreads();
     }
+    TRR(15, 0);  // item loop done
     if (do_init) {  // statistics of the INIT (+FINAL) part, accumulated by the writer groups only
       block_sum<5>(iv, s_red);
       if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
