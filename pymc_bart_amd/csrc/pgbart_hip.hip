@@ -1510,23 +1510,6 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
         // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
         // residuals (INIT) on the fly; the first group of each chunk also writes them back
         const bool writer = grp == 0;
-        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
-        uint32_t ids_sel = 0;
-        if (do_final) {
-          if (cmd->sel_slot == -2) {
-            ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
-          } else {
-            if (sel_lid) {
-              ids_sel = *(const uint32_t*)(sel_lid + base);
-            } else {  // untouched root: label 0 (pad rows: orphan)
-#pragma unroll
-              for (int e = 0; e < RPT; ++e)
-                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
-            }
-            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
-          }
-          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
-        }
         // every input of the thread's four rows is requested BEFORE the first result is stored:
         // the stores below may alias the loads as far as the compiler knows, so loads left inside
         // the loop would be issued one row (one memory round trip) at a time
@@ -1543,6 +1526,23 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
             mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
             m24[e] = upd ? S.rs_m2[base + e] : 0.0;
           }
+        }
+        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_sel = 0;
+        if (do_final) {
+          if (cmd->sel_slot == -2) {
+            ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
+          } else {
+            if (sel_lid) {
+              ids_sel = *(const uint32_t*)(sel_lid + base);
+            } else {  // untouched root: label 0 (pad rows: orphan)
+#pragma unroll
+              for (int e = 0; e < RPT; ++e)
+                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+            }
+            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+          }
+          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
         }
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {

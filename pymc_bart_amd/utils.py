@@ -108,16 +108,25 @@ class _MultiChainSampler:
         return out
 
 
-_posterior_sampler_cache: dict[int, tuple[int, _MultiChainSampler]] = {}
+_posterior_sampler_cache: dict[int, tuple] = {}
 
 
 def _get_posterior_sampler(op, backend=None) -> _MultiChainSampler:
     """Rebuild (and cache) the per-chain samplers from ``op.all_trees``
-    (reference ``utils.py:110-130``)."""
+    (reference ``utils.py:110-130``).
+
+    The reference keys its cache on ``id(op)`` and the number of chains alone; an ``id`` can be
+    reused by a later object and a chain can grow, so the entry here also pins the op itself
+    (weakly), the number of stored draws and the backend."""
+    import weakref
+
     n_chains = len(op.all_trees)
+    n_batches = sum(len(batches) for _, batches in op.all_trees)
     cached = _posterior_sampler_cache.get(id(op))
-    if cached is not None and cached[0] == n_chains:
-        return cached[1]
+    if cached is not None:
+        ref, c_chains, c_batches, c_backend, sampler = cached
+        if ref() is op and c_chains == n_chains and c_batches == n_batches and c_backend is backend:
+            return sampler
     rules = getattr(op, "_rule_ids", None)
     chain_samplers = [
         PosteriorSampler.from_history(batches, baseline, op.m, op.n_outputs, rules=rules,
@@ -125,5 +134,11 @@ def _get_posterior_sampler(op, backend=None) -> _MultiChainSampler:
         for baseline, batches in op.all_trees
     ]
     sampler = _MultiChainSampler(chain_samplers)
-    _posterior_sampler_cache[id(op)] = (n_chains, sampler)
+    try:
+        ref = weakref.ref(op)
+    except TypeError:  # not weak-referenceable: never trust the cache for it
+        return sampler
+    for key in [k for k, v in _posterior_sampler_cache.items() if v[0]() is None]:
+        del _posterior_sampler_cache[key]  # entries of ops that are gone
+    _posterior_sampler_cache[id(op)] = (ref, n_chains, n_batches, backend, sampler)
     return sampler

@@ -508,3 +508,33 @@ def test_variable_importance_ranks_the_informative_covariates(oracle):
     assert abs(pearsonr2(a, 2 * a + 1) - 1.0) < 1e-12 and pearsonr2(a, rng.normal(size=50)) < 0.3
     lo, hi = hdi(rng.normal(size=4000), 0.94)
     assert -2.2 < lo < -1.6 and 1.6 < hi < 2.2
+
+
+def test_posterior_sampler_cache_is_not_fooled_by_reused_ids_or_growing_chains(oracle):
+    # the reference caches on id(op) + number of chains (utils.py:110-130); ids are reused by later
+    # objects and chains grow, so the cache here must notice both
+    import gc
+
+    rng = np.random.default_rng(8)
+    X = rng.normal(size=(60, 2))
+    seen = {}
+    for k in range(40):  # many short-lived ops: some will reuse an earlier id
+        Y = (k + 1) * 10.0 + X[:, 0]
+        op = BARTOp(X, Y, m=3)
+        sample_chain(op, tune=2, draws=2, random_seed=k, backend=oracle)
+        s = _get_posterior_sampler(op, backend=oracle)
+        pred = _sample_posterior(s, X=X, rng=np.random.default_rng(0), size=2)
+        assert abs(pred.mean() - Y.mean()) < 5.0, "stale sampler of an earlier op"
+        seen[id(op)] = seen.get(id(op), 0) + 1
+        del op, s
+        gc.collect()
+    assert max(seen.values()) > 1, "the loop is meant to recycle ids"
+    # a chain that grows invalidates the entry
+    Y = X[:, 0]
+    op = BARTOp(X, Y, m=3)
+    step = PGBART([op], num_particles=4, likelihood=NormalLikelihood(1.0), backend=oracle)
+    step.stop_tuning()
+    step.astep(None, {})
+    assert _get_posterior_sampler(op, backend=oracle).n_draws == 1
+    step.astep(None, {})
+    assert _get_posterior_sampler(op, backend=oracle).n_draws == 2
