@@ -1510,23 +1510,6 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
         // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
         // residuals (INIT) on the fly; the first group of each chunk also writes them back
         const bool writer = grp == 0;
-        // every input of the thread's four rows is requested BEFORE the first result is stored:
-        // the stores below may alias the loads as far as the compiler knows, so loads left inside
-        // the loop would be issued one row (one memory round trip) at a time
-        double st4[RPT], y4[RPT], mean4[RPT], m24[RPT];
-        {
-          const double2* __restrict__ sp = (const double2*)(st_in + base);
-          const double2* __restrict__ yp = (const double2*)(S.y + base);
-          const double2 s01 = sp[0], s23 = sp[1], y01 = yp[0], y23 = yp[1];
-          st4[0] = s01.x; st4[1] = s01.y; st4[2] = s23.x; st4[3] = s23.y;
-          y4[0] = y01.x; y4[1] = y01.y; y4[2] = y23.x; y4[3] = y23.y;
-          const bool upd = do_final && cmd->tune && writer;
-#pragma unroll
-          for (int e = 0; e < RPT; ++e) {
-            mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
-            m24[e] = upd ? S.rs_m2[base + e] : 0.0;
-          }
-        }
         uint32_t ids_next = *(const uint32_t*)(tl_new + base);
         uint32_t ids_sel = 0;
         if (do_final) {
@@ -1543,6 +1526,23 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
             if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
           }
           if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+        }
+        // every input of the thread's four rows is requested BEFORE the first result is stored:
+        // the stores below may alias the loads as far as the compiler knows, so loads left inside
+        // the loop would be issued one row (one memory round trip) at a time
+        double st4[RPT], y4[RPT], mean4[RPT], m24[RPT];
+        {
+          const double2* __restrict__ sp = (const double2*)(st_in + base);
+          const double2* __restrict__ yp = (const double2*)(S.y + base);
+          const double2 s01 = sp[0], s23 = sp[1], y01 = yp[0], y23 = yp[1];
+          st4[0] = s01.x; st4[1] = s01.y; st4[2] = s23.x; st4[3] = s23.y;
+          y4[0] = y01.x; y4[1] = y01.y; y4[2] = y23.x; y4[3] = y23.y;
+          const bool upd = do_final && cmd->tune && writer;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
+            m24[e] = upd ? S.rs_m2[base + e] : 0.0;
+          }
         }
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
