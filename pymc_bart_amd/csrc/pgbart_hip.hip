@@ -1410,7 +1410,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
 // FINAL+INIT+round-0 pass whose INIT part is repeated by every particle group).
 #define ROWS_TARGET_ITEMS 640
 #define ROWS_TARGET_ITEMS_INIT 768
-#define PB 4 /* particles processed per batch inside a work item */
 
 struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   long long src;   // byte offset of the source labels in S.lid, -1: implicit root labels
