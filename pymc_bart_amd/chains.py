@@ -71,7 +71,7 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
     pass -> control kernel ...), so a single chain is latency-bound at cfg2 sizes.  Chains are
     independent, hence each gets its own HIP stream and a host thread that feeds its state machine
     (the ctypes calls release the GIL); the row pass of one chain overlaps the control kernel of
-    another.  Measured on MI355X at cfg2: 1 chain 1.68 M, 2 chains 2.86 M, 4 chains 4.26 M
+    another.  Measured on MI355X at cfg2: 1 chain 1.74 M, 2 chains 2.98 M, 4 chains 4.47 M
     particle-steps/s aggregate.  The draws of every chain are bit-identical to the ones it
     produces when run alone (``tests/test_parity_gpu.py``)."""
     import threading
