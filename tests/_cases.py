@@ -187,7 +187,7 @@ def digest(res) -> dict:
     return {
         "sha256": h.hexdigest(),
         "counters": {k: int(v) for k, v in res["counters"].items()},
-        "last_sum_trees_head": res["sum_trees"][-1][:8].tolist(),
+        "last_sum_trees_head": np.asarray(res["sum_trees"][-1]).ravel()[:8].tolist(),
         "leaf_sd": float(res["state"]["leaf_sd"][0]),
         "iter": int(res["state"]["iter"]),
     }
