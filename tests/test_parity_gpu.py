@@ -287,3 +287,28 @@ def test_variable_importance_on_gpu_matches_the_oracle(hip, oracle):
         np.testing.assert_allclose(g["preds_all"], o["preds_all"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(g["r2_mean"], o["r2_mean"], rtol=0, atol=1e-9)
     assert set(outs[0]["indices"][:2]) == {1, 3}
+
+
+def test_full_size_cfg2_recovers_the_regression_function(hip):
+    """Not parity but purpose: at the headline size (n=100k, p=50, m=200, P=40) a short run must
+    fit the synthetic regression function.  f has standard deviation ~4.9, the noise is N(0, 1);
+    ten sweeps over the trees bring the posterior mean inside the noise level and most of the
+    sampler's splits onto the five informative columns."""
+    w = workloads.cfg2(seed=3415)
+    X, Y, f = w["X"], w["Y"], w["f"]
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=11)
+    s = PySampler(st, X, Y, np.zeros(50, np.int32), np.ones(50), backend=hip)
+    s.set_likelihood([1.0])
+    s.step_async(True, 100)   # 10 sweeps while tuning
+    s.sync()
+    draws, vi = [], np.zeros(50, np.int64)
+    for _ in range(30):
+        mu, v = s.step(False)
+        draws.append(mu)
+        vi += v
+    post = np.mean(draws, axis=0)
+    rmse = float(np.sqrt(np.mean((post - f) ** 2)))
+    assert rmse < float(np.std(Y - f)), rmse                         # inside the noise level (measured: 0.71)
+    assert rmse < 0.2 * float(np.std(f))                             # and far from a constant fit
+    assert vi[:5].sum() > 0.5 * vi.sum()                             # 5 of 50 columns draw most splits (0.68)
+    assert s.counters.saturations == 0
