@@ -290,36 +290,126 @@ PGB_HD void pgb_normal2(double u0, double u1, double* z0, double* z1) {
 }
 
 /* ------------------------------------------------------------------ log-likelihoods */
-/* log Phi(x) (standard normal CDF), deterministic, one polynomial evaluation for either sign.
+/* log Phi(x) (standard normal CDF), deterministic: one table row, one degree-8 Horner chain.
  * z = |x|.
- *   x <  0: log Phi(-z) = -z^2/2 - log((z + 2) / 2) + LG(t),  t = z / (z + 2) in [0, 1);
- *           LG(t) = log(Phi(-z) exp(z^2/2) / (1 - t)) is smooth and bounded: 16 degree-8 pieces
- *           on equal intervals of t (table tn).  No exp: exact far into the tail.
- *   x >= 0: log Phi(z) itself, 34 degree-8 pieces of width 1/4 on [0, 8.5) (table tp); 0 beyond
- *           (|log Phi(8.5)| < 1e-17).
+ *   x <  0: log Phi(-z) = -z^2/2 + F(z),  F(z) = log(Phi(-z) exp(z^2/2)) (smooth, ~ -log z).
+ *           F is tabulated on dyadic intervals -- [0, 1/8) and [2^e (1 + s/8), 2^e (1 + (s+1)/8))
+ *           for e = -3..9, s = 0..7 -- so the row index and the local variable come straight from
+ *           the exponent and the top three mantissa bits of z: no division, no exp, no log.
+ *           z >= 1024: -log z - log sqrt(2 pi) - w + 2.5 w^2, w = z^-2 (next term < 1e-17).
+ *   x >= 0: log Phi(z) itself, 34 pieces of width 1/4 on [0, 8.5); 0 beyond (|.| < 1e-17).
  * Both signs share ONE Horner evaluation (the sign only selects the table row and the local
- * variable), so a wave with mixed signs does not run two polynomial paths; the x < 0 lanes add
- * one pgb_log.  Tables: tools/fit_log_ndtr.py (Chebyshev-node interpolation against mpmath at 50
- * digits; absolute error 4e-16 / 5e-16).  Absolute error of the function < 4e-13 against
- * scipy.special.log_ndtr on [-38, 38], < 1e-14 on [-5, 5] (tests/test_spec.py). */
+ * variable), so a wave with mixed signs runs one polynomial path.  Tables: tools/fit_log_ndtr.py
+ * (Chebyshev-node interpolation against mpmath at 60 digits; absolute error 4e-15 / 5e-16).
+ * Absolute error of the function < 4e-13 against scipy.special.log_ndtr on [-38, 38] (the
+ * rounding of z^2 at |x| ~ 38), < 1e-14 on [-5, 5] (tests/test_spec.py). */
 PGB_HD double pgb_log_ndtr(double x) {
-  static const double tn[16][9] = {
-    {-0x1.6c9c157b3b477p-1, -0x1.3cfd24ebe10dcp-6, -0x1.832b258771687p-12, -0x1.80e3c3bf73935p-19, 0x1.a54e8c8c6458dp-25, 0x1.5ced36570cb4dp-29, 0x1.e850a2f45761bp-35, 0x1.27fb972265d12p-41, -0x1.be282ab840064p-47},
-    {-0x1.813061f66fc65p-1, -0x1.55b8b1b075af4p-6, -0x1.93bfa88feec9fp-12, -0x1.3d5e3efe0d003p-19, 0x1.4e8f47c595531p-24, 0x1.bd9517f493ad6p-29, 0x1.0c00759bae9c5p-34, 0x1.bbcf7c479c9a7p-43, -0x1.0f52d0d96db94p-45},
-    {-0x1.97581a3384203p-1, -0x1.6f6017fa58958p-6, -0x1.a060ab306a625p-12, -0x1.ae03b3b61fb23p-20, 0x1.e9947f0f4d597p-24, 0x1.111549263dae7p-28, 0x1.056f5877dfcdep-34, -0x1.13dd3453762dfp-41, -0x1.02a416e17fc2ep-44},
-    {-0x1.af1fb8758e046p-1, -0x1.89a6156c82328p-6, -0x1.a73d55bd2188dp-12, -0x1.1836047a00f82p-21, 0x1.51575494c458dp-23, 0x1.3d44605db935ap-28, 0x1.8b1d8451af6eep-35, -0x1.dc389c3c2d9bdp-40, -0x1.a78f1e25735a5p-44},
-    {-0x1.c88deb30b0f8fp-1, -0x1.a41d8576fe21bp-6, -0x1.a62c41cc2b5dap-12, 0x1.f0df230b82755p-21, 0x1.b903d8af3fa82p-23, 0x1.555e133c3552dp-28, 0x1.4644ec353f7fap-37, -0x1.eebcc79347ac5p-39, -0x1.2bdfaefacbd15p-43},
-    {-0x1.e3a16da2176ebp-1, -0x1.be3479a30797bp-6, -0x1.9ac405a6c4a8fp-12, 0x1.734befde729e9p-19, 0x1.1138548614803p-22, 0x1.4467878114807p-28, -0x1.ebe7d9a621d34p-35, -0x1.9c9e2aef53f6ep-38, -0x1.5d03b1f2af4cep-43},
-    {-0x1.0027518f7da15p+0, -0x1.d731cf7c91c8ap-6, -0x1.82948032efe68p-12, 0x1.4e174c5d350afp-18, 0x1.3e5b939648324p-22, 0x1.df7a5008f3a87p-29, -0x1.549ba4c9694f2p-33, -0x1.1fb9f1ac835d2p-37, -0x1.108026aec59d1p-43},
-    {-0x1.0f3e97b5a9e3ep+0, -0x1.ee37b2e549e3ap-6, -0x1.5b8cc26cd7500p-12, 0x1.f4a6b1c64606cp-18, 0x1.574105d058ee0p-22, 0x1.ee5129443239cp-31, -0x1.32dcceb7dc608p-32, -0x1.420cf1e620bc1p-37, 0x1.756d84f3a9214p-46},
-    {-0x1.1f02f935ebe92p+0, -0x1.0127054794a79p-5, -0x1.2491e8b677883p-12, 0x1.4fadb8f8aa814p-17, 0x1.4c3fc9b24574ap-22, -0x1.b5c8698b1b9acp-29, -0x1.b3998b2acb512p-32, -0x1.db649f16cf05ep-38, 0x1.5203b7b230769p-42},
-    {-0x1.2f58fe63c7ce1p+0, -0x1.093bc15ced211p-5, -0x1.bc6da6b47a7c3p-13, 0x1.9c3b877ed11ecp-17, 0x1.0eecc44d16018p-22, -0x1.1e7499fcc1f63p-27, -0x1.e8ebe66bed359p-32, 0x1.ddeb4463359d1p-41, 0x1.6c2455d8eeac6p-41},
-    {-0x1.401d9877f90aep+0, -0x1.0ee8efdb3f2eep-5, -0x1.16c2a3440412ap-13, 0x1.d2719f49864f5p-17, 0x1.33b30782bf583p-23, -0x1.c873e82bb699dp-27, -0x1.8234436a82fbep-32, 0x1.c95e60bb2dae2p-37, 0x1.ca220c8b49f34p-41},
-    {-0x1.512797078b338p+0, -0x1.11dee2cc97cffp-5, -0x1.8c10c84f13cc0p-15, 0x1.e57b88d69aa72p-17, -0x1.a3f038bd98429p-28, -0x1.13e2790cc912dp-26, -0x1.7461bce5c2d07p-34, 0x1.a799355c2ace1p-36, 0x1.0793c4290e0abp-41},
-    {-0x1.624a5a19095f5p+0, -0x1.1201f4562e06dp-5, 0x1.401f59852b54ap-15, 0x1.ce4f1880ee6dbp-17, -0x1.6196e1bc902e7p-23, -0x1.005201a637877p-26, 0x1.3073ec9269221p-32, 0x1.b7b1246270d04p-36, -0x1.c9b870813670ep-42},
-    {-0x1.7359730352325p+0, -0x1.0f7484e419ec7p-5, 0x1.e58ebfa27d1bep-14, 0x1.90027d7407dfdp-17, -0x1.385207572daa2p-22, -0x1.4fcc281d30515p-27, 0x1.2e016f15cd238p-31, 0x1.9bc579d2bc99cp-37, -0x1.4577afa4c1b24p-40},
-    {-0x1.842c751330986p+0, -0x1.0a92539b273dap-5, 0x1.78ca958bd1a6ep-13, 0x1.37e90cd2f2f3ep-17, -0x1.7bc7f202cbd79p-22, -0x1.77bfcab1c6b8fp-29, 0x1.3e68315e452adp-31, -0x1.ef8db05c32455p-38, -0x1.20077de85c726p-40},
-    {-0x1.94a201257a7ecp+0, -0x1.03dd32ed393cbp-5, 0x1.dbc659b25a226p-13, 0x1.b06ee41e93671p-18, -0x1.7707827460cf7p-22, 0x1.bd0cc8b3129ffp-29, 0x1.aee567e9c475cp-32, -0x1.3176193e2486ap-36, -0x1.05bb65b475210p-42},
+  static const double tn[105][9] = {
+    {-0x1.7c1095dd2ee18p-1, -0x1.8d1ab6a7490c2p-5, 0x1.6660cbdea201bp-11, -0x1.1fdd292b99f46p-17, 0x1.395f6bb4173c0p-24, -0x1.41183ee9009fcp-35, -0x1.8d47d27c3c90bp-37, 0x1.ab76140dcca81p-43, -0x1.99c0bcea901d1p-51},
+    {-0x1.978ca807aaec6p-1, -0x1.80c4c05863cebp-8, 0x1.577ce4a842339p-17, -0x1.14df722e48797p-26, 0x1.379c44e0c7e71p-36, -0x1.d9d51d68b3605p-49, -0x1.59ae71e770c59p-55, 0x1.9a1101d9fa280p-64, -0x1.22075289065abp-74},
+    {-0x1.9d8a616688a75p-1, -0x1.7e1902be7d586p-8, 0x1.5441ec8d6b7a0p-17, -0x1.1270d4698c3bcp-26, 0x1.36fe2d9f67ba5p-36, -0x1.0cccdc442a87ep-48, -0x1.4e881dbbbf3fcp-55, 0x1.95696a43fbe72p-64, -0x1.3194ff623f4e9p-74},
+    {-0x1.a37d78b12600dp-1, -0x1.7b73b3ca3955ep-8, 0x1.510e3e5dd977ap-17, -0x1.100386892cb9cp-26, 0x1.364c7c3a83404p-36, -0x1.2ba51f9efd232p-48, -0x1.438333722b4a8p-55, 0x1.9085db1b7b31ap-64, -0x1.40046f11cdae0p-74},
+    {-0x1.a9660784f73c2p-1, -0x1.78d4c4ebd7cc2p-8, 0x1.4de1d5efb6739p-17, -0x1.0d97af1bd3b13p-26, 0x1.3587d5f9db849p-36, -0x1.49768de2d3f3ap-48, -0x1.38a1474c92720p-55, 0x1.8b6abd06cdcb8p-64, -0x1.4d5dce9e1a66fp-74},
+    {-0x1.af44274542dcdp-1, -0x1.763c279c5ece1p-8, 0x1.4abcaea76e87fp-17, -0x1.0b2d7367a44f8p-26, 0x1.34b0de18737b1p-36, -0x1.664480a51eb7fp-48, -0x1.2de3cf23539e3p-55, 0x1.861c57b58c46ap-64, -0x1.59a96b24ca01bp-74},
+    {-0x1.b517f11b4680fp-1, -0x1.73a9cd5e7a235p-8, 0x1.479ec37b82f90p-17, -0x1.08c4f76e6ae1ap-26, 0x1.33c835aea7302p-36, -0x1.82127323b4df9p-48, -0x1.234c234dae8bdp-55, 0x1.809ed16ef45e3p-64, -0x1.64efaa8c67a25p-74},
+    {-0x1.bae17df65f2a6p-1, -0x1.711da7bf53556p-8, 0x1.44880ef850bd3p-17, -0x1.065e5df1f698ap-26, 0x1.32ce7b9dfd859p-36, -0x1.9ce3ff8bbb02dp-48, -0x1.18db7f8cda226p-55, 0x1.7af62ebcb1bfdp-64, -0x1.6f39049f4da4dp-74},
+    {-0x1.c0a0e68c34d99p-1, -0x1.6e97a857623c8p-8, 0x1.41788b43c9bd1p-17, -0x1.03f9c87899fbfp-26, 0x1.31c44c7ea6b87p-36, -0x1.b6bcdc56ab6e3p-48, -0x1.0e9303f910949p-55, 0x1.752652306b0f8p-64, -0x1.788dfc8e5d792p-74},
+    {-0x1.c92d34eaf340ap-1, -0x1.6ada117e750edp-7, 0x1.3ceeb3796230dp-15, -0x1.0066f62261ff0p-23, 0x1.30177b13337d3p-32, -0x1.dbb83c29b5db5p-43, -0x1.fee795344d074p-50, 0x1.6c2c7211ce8ecp-57, -0x1.84d1b467f9324p-66},
+    {-0x1.d47056729a44cp-1, -0x1.65f2488c1b51cp-7, 0x1.36fa8148ce22ap-15, -0x1.f756c94de1a35p-24, 0x1.2da7aab29a5dcp-32, -0x1.04e2aa0aff3cbp-42, -0x1.d7bece205128dp-50, 0x1.5fce514e94d42p-57, -0x1.922a1efb0faf3p-66},
+    {-0x1.df8c985eaeba7p-1, -0x1.612217bf91bccp-7, 0x1.31229661a75aep-15, -0x1.edf4050aba21cp-24, 0x1.2b008e864e9e1p-32, -0x1.1a1b807d4bad8p-42, -0x1.b1f5b44a930fdp-50, 0x1.53127b8dddc5ap-57, -0x1.9c49f31b0feb7p-66},
+    {-0x1.ea82b5ad37440p-1, -0x1.5c690e794da5dp-7, 0x1.2b66b32224c2dp-15, -0x1.e4a74807e7e3dp-24, 0x1.282694092dae5p-32, -0x1.2d975580fbecap-42, -0x1.8d95280b448cfp-50, 0x1.4611aa33285ebp-57, -0x1.a373cceadf865p-66},
+    {-0x1.f55365db52476p-1, -0x1.57c6bd21f8a32p-7, 0x1.25c693235133ap-15, -0x1.db72180e7fb41p-24, 0x1.251dfe7bf7891p-32, -0x1.3f6737e9c54e2p-42, -0x1.6aa372647ffe5p-50, 0x1.38e287b6f4311p-57, -0x1.a7e8b85b5eb0ap-66},
+    {-0x1.ffff5cedc1bbbp-1, -0x1.533ab53cb74d0p-7, 0x1.2041ed9f580f1p-15, -0x1.d255d97907b19p-24, 0x1.21eae62832308p-32, -0x1.4f9c7388afdb4p-42, -0x1.49247de5b6270p-50, 0x1.2b99bdd5e87eep-57, -0x1.a9e7c903d7d57p-66},
+    {-0x1.0543a5bd016eep+0, -0x1.4ec48977ded62p-7, 0x1.1ad875d3cb387p-15, -0x1.c953d08d36704p-24, 0x1.1e9137ea22e94p-32, -0x1.5e48760b9b0d6p-42, -0x1.291a0dd716436p-50, 0x1.1e4a06b40c5f8p-57, -0x1.a9adc5023f409p-66},
+    {-0x1.0a75ef57f2c15p+0, -0x1.4a63cdbc29ac9p-7, 0x1.1589db5fd750ep-15, -0x1.c06d22d85b964p-24, 0x1.1b14b4fb66d7bp-32, -0x1.6b7cb666fe6f3p-42, -0x1.0a83f36258ad8p-50, 0x1.1104406242baap-57, -0x1.a774e14614c97p-66},
+    {-0x1.1220f16b3718ep+0, -0x1.43f9fceb7ce00p-6, 0x1.0dc59aed923b5p-13, -0x1.b348a38c67f73p-21, 0x1.15a06d2f35531p-28, -0x1.7cb09a8ba2095p-37, -0x1.beb08a9a327c4p-45, 0x1.fa9fa56f8229ep-51, -0x1.a0d30d2438b6bp-58},
+    {-0x1.1c1f745d3dd24p+0, -0x1.3bb415039ffcfp-6, 0x1.03c57ca737789p-13, -0x1.a22b1e89d385ep-21, 0x1.0e00d95ce1a9cp-28, -0x1.8f1e9430979f4p-37, -0x1.558294cad0ea5p-45, 0x1.c7558617c2854p-51, -0x1.92f7168d213bep-58},
+    {-0x1.25dd03d41e61dp+0, -0x1.33bc9724315cdp-6, 0x1.f4553862b4dadp-14, -0x1.918a33f448e1fp-21, 0x1.061103dc28a7bp-28, -0x1.9ce0e61377de9p-37, -0x1.eeadf29a9e4aep-46, 0x1.9611e0cb47871p-51, -0x1.80a424757559dp-58},
+    {-0x1.2f5c0697d4713p+0, -0x1.2c1065326d3f3p-6, 0x1.e1e4009909353p-14, -0x1.816a33e347736p-21, 0x1.fbce02cb3cf84p-29, -0x1.a678c99c3b69bp-37, -0x1.475c42d7b0a73p-46, 0x1.674eef839e1cdp-51, -0x1.6b1c97d991c74p-58},
+    {-0x1.389ecadfabec1p+0, -0x1.24ac793a536d7p-6, 0x1.d03133a95f15fp-14, -0x1.71ce210017166p-21, 0x1.eb2ce0f8bb44bp-29, -0x1.ac60edbe305f0p-37, -0x1.67c7b1b3bf28ep-47, 0x1.3b61a12cb7547p-51, -0x1.537319463fc41p-58},
+    {-0x1.41a78715e2c28p+0, -0x1.1d8de5ffc049ap-6, 0x1.bf36963b9e04fp-14, -0x1.62b7d6d6a32b2p-21, 0x1.da6138f0455d8p-29, -0x1.af0c96ddb6325p-37, -0x1.97d33a9ce63c2p-49, 0x1.127f6838e1f56p-51, -0x1.3a8d4fba11cf0p-58},
+    {-0x1.4a785a9ef152ep+0, -0x1.16b1d758271a1p-6, 0x1.aeeddce28e51ep-14, -0x1.54282dd7302b3p-21, 0x1.c9894835e4270p-29, -0x1.aee711713151bp-37, 0x1.e5debe98d2026p-49, 0x1.d98745699911fp-52, -0x1.21277fb565947p-58},
+    {-0x1.53134ea2d9d05p+0, -0x1.10159253ad32fp-6, 0x1.9f50b77576064p-14, -0x1.461f1cdc5f7fbp-21, 0x1.b8bf44711b2f6p-29, -0x1.ac53693075967p-37, 0x1.3943a681c47dep-47, 0x1.94690a7dfa114p-52, -0x1.07d8afa23844ap-58},
+    {-0x1.5f9af900426eap+0, -0x1.069d09fceb65fp-5, 0x1.8918f3ff32ac8p-12, -0x1.320bf4774920dp-18, 0x1.9fdaa5d680c25p-25, -0x1.a4aba2887abd6p-32, 0x1.11d856e3efb96p-40, 0x1.38916e7e1a1dep-45, -0x1.c61a475838261p-51},
+    {-0x1.6fa4dab0716c3p+0, -0x1.f587aeeca7bccp-6, 0x1.6d979343d2cbap-12, -0x1.191239556f4ffp-18, 0x1.7f9119412b68dp-25, -0x1.94ffb15c37c6ep-32, 0x1.836148cbe83e2p-40, 0x1.a52ae0c4fa0dbp-46, -0x1.6b688a1fd83f7p-51},
+    {-0x1.7ef7d89d2b969p+0, -0x1.df7b2477a8cdfp-6, 0x1.5455b96bf7f30p-12, -0x1.02124a59fb2cdp-18, 0x1.60af9c40b153bp-25, -0x1.80f9b7f0c93ccp-32, 0x1.cd12c8b1e588bp-40, 0x1.03dcfeddb0689p-46, -0x1.1bbc71455de82p-51},
+    {-0x1.8da095a14fbe7p+0, -0x1.caf1f195a6a34p-6, 0x1.3d251ce7a4eb4p-12, -0x1.d9e6986633c63p-19, 0x1.437bf3776ba3fp-25, -0x1.6a424bfafa315p-32, 0x1.f7a1a9b995673p-40, 0x1.0ed126e0ce400p-47, -0x1.b019656dafb0fp-52},
+    {-0x1.9baaabde4541ap+0, -0x1.b7cc643e71df2p-6, 0x1.27d9f53dd17e2p-12, -0x1.b331f75922dcep-19, 0x1.281e98ed52a71p-25, -0x1.52214f21574e3p-32, 0x1.053ae2aedf26ap-39, 0x1.4eb3cb9154f28p-49, -0x1.402c0a12c7af5p-52},
+    {-0x1.a920c29dad3a6p+0, -0x1.a5ed713560ea4p-6, 0x1.144b38a1a9158p-12, -0x1.8fca9255146d7p-19, 0x1.0ea9adf7258b6p-25, -0x1.398d7fcd24e6ep-32, 0x1.05d81ca711f09p-39, -0x1.a7cfdfba56a9dp-50, -0x1.cb8050392fe80p-53},
+    {-0x1.b60ca2d523c3bp+0, -0x1.953a871887aaep-6, 0x1.0252b7dc865f0p-12, -0x1.6f731d43be685p-19, 0x1.ee3d78b7e45d7p-26, -0x1.213b39fb51b5ep-32, 0x1.0022e4904dfd7p-39, -0x1.2a80e326439efp-48, -0x1.3c699d4136cfap-53},
+    {-0x1.c2774a3dc0351p+0, -0x1.859b6083e6de5p-6, 0x1.e39a4262e308cp-13, -0x1.51eee4d9b2f36p-19, 0x1.c2e6bd51b40edp-26, -0x1.09a9b7b2c6639p-32, 0x1.ec232885441ddp-40, -0x1.abc2a9c50f3a7p-48, -0x1.9acc112dd231ep-54},
+    {-0x1.d436e13388a73p+0, -0x1.7001c9c13fa66p-5, 0x1.b6eba906997b7p-11, -0x1.2a749d3eda535p-16, 0x1.889671b0b057fp-22, -0x1.d0d61730fddafp-28, 0x1.c40c70f30eb79p-34, -0x1.0ac49e8c6b4efp-40, -0x1.5dc0f08f88c11p-47},
+    {-0x1.ea647d005a2c5p+0, -0x1.563b4cdeb189ep-5, 0x1.834a269ce14d2p-11, -0x1.fb4f37713098fp-17, 0x1.4648e705f68bbp-22, -0x1.81c29ffec1c7bp-28, 0x1.86cc20ff2cb9bp-34, -0x1.1cd5e0d672dd7p-40, 0x1.4de1a56907b74p-51},
+    {-0x1.ff0e2b51417a1p+0, -0x1.3f6fa97f0aa74p-5, 0x1.5754132b0733ap-11, -0x1.b0d0839374661p-17, 0x1.0f6e9c0d1de8ep-22, -0x1.3e440580903cep-28, 0x1.49b7c2248b1b4p-34, -0x1.0d8c3e2470fd9p-40, 0x1.90294e1d9db2cp-48},
+    {-0x1.092ffed73ad20p+1, -0x1.2b2ecd2fa392dp-5, 0x1.31bf6c807d3a9p-11, -0x1.72c9ab3a0c5b5p-17, 0x1.c481234461dedp-23, -0x1.05c841f295aecp-28, 0x1.11e120ac115bap-34, -0x1.dedaf1a225a63p-41, 0x1.0caa7455e3f79p-47},
+    {-0x1.123fcfae50152p+1, -0x1.191b670420d8fp-5, 0x1.117c4d3670f85p-11, -0x1.3f04d383437c4p-17, 0x1.7a3a603cd26cep-23, -0x1.ae36582d54646p-29, 0x1.c287212b758e8p-35, -0x1.99b98b29363edp-41, 0x1.159b3078c6e1cp-47},
+    {-0x1.1ac6b30967b45p+1, -0x1.08e795517c23ap-5, 0x1.eb56557a27dfap-12, -0x1.13ae0c52fc8d0p-17, 0x1.3d3008f74ef2ap-23, -0x1.61ac050f89ee9p-29, 0x1.705bc11b64651p-35, -0x1.5678b26c34f01p-41, 0x1.015e4cb3e79e7p-47},
+    {-0x1.22d2991d9ac9ep+1, -0x1.f4a44c0f8ba79p-6, 0x1.bb2897d774fc3p-12, -0x1.de8af8afbad50p-18, 0x1.0af92b1c66cefp-23, -0x1.23332c9d61bc8p-29, 0x1.2c372b66d29d5p-35, -0x1.1a04d087ee44cp-41, 0x1.c27f6400a4812p-48},
+    {-0x1.2a6f93a34f22ep+1, -0x1.da48aa6c8b26fp-6, 0x1.91411890723c2p-12, -0x1.a1237e1566fd6p-18, 0x1.c32b3acdb56eap-24, -0x1.e0a4a7bc969f9p-30, 0x1.e8c302479423ap-36, -0x1.cc1c43fa219fap-42, 0x1.7d0423845c42ap-48},
+    {-0x1.3521a931372ffp+1, -0x1.b73db57ef13c1p-5, 0x1.5c1498e54b348p-10, -0x1.562bf9e45cf5bp-15, 0x1.61174ac909615p-20, -0x1.6a59b0f03fb39p-25, 0x1.673a86b2dcb62p-30, -0x1.4fff42352c5d9p-35, 0x1.1d91efc390878p-40},
+    {-0x1.4237980e0a9f5p+1, -0x1.8f6bf62d4a980p-5, 0x1.2363df2f03bd9p-10, -0x1.0a76d9b1ec999p-15, 0x1.0251add7aa40fp-20, -0x1.f7453a01060bdp-26, 0x1.df79d540abb35p-31, -0x1.b664acf5d7247p-36, 0x1.76a7ca7a73d65p-41},
+    {-0x1.4e291fc988c3cp+1, -0x1.6de2e052face6p-5, 0x1.edd675a563441p-11, -0x1.a54d4ead4461cp-16, 0x1.8016426bb6360p-21, -0x1.62c5cbf530703p-26, 0x1.4387fbf58b80dp-31, -0x1.1e9950b14697ap-36, 0x1.e3421fc45f15ap-42},
+    {-0x1.5922fb9cd60eap+1, -0x1.5150a81c01a4bp-5, 0x1.a70c56f477c59p-11, -0x1.51b31cf0f011ap-16, 0x1.21f7ef5548e90p-21, -0x1.fbeb2265e3d09p-27, 0x1.ba75ec6d365b7p-32, -0x1.79cbf94aaee02p-37, 0x1.36dfb412d3af1p-42},
+    {-0x1.6348bfd9c6287p+1, -0x1.38b88434a0bccp-5, 0x1.6df3e67a03215p-11, -0x1.1223ffa785bd9p-16, 0x1.bc37f94fe7c55p-22, -0x1.71201b7a35b2fp-27, 0x1.32e87cdb12811p-32, -0x1.f7b71c0aefca5p-38, 0x1.920318557bd97p-43},
+    {-0x1.6cb71ac88e7e1p+1, -0x1.235a6a8faa114p-5, 0x1.3f56d7806a28bp-11, -0x1.c24573fe4451ep-17, 0x1.58e5d6a4938ffp-22, -0x1.1031a31daaf30p-27, 0x1.affcde2d7ce50p-33, -0x1.543154e70ee6ep-38, 0x1.065d0eec1b74fp-43},
+    {-0x1.758573dc00849p+1, -0x1.10a263e930f5ap-5, 0x1.18dbe1d8c60d2p-11, -0x1.75b57e7fe540ap-17, 0x1.0f2ba1a96108ap-22, -0x1.9706ca9b70b5ep-28, 0x1.34649ad0dd66ep-33, -0x1.d1d43ce8e8521p-39, 0x1.5a6d6835539b7p-44},
+    {-0x1.7dc71b0cfb7dap+1, -0x1.001cebe13e518p-5, 0x1.f18a08d7f1d63p-12, -0x1.392bc530e75aap-17, 0x1.af65d51d91ba1p-23, -0x1.3451c1110be40p-28, 0x1.be6f8050eda1fp-34, -0x1.4359c29a6fef6p-39, 0x1.cf405fcc98cf2p-45},
+    {-0x1.89444941c5639p+1, -0x1.d561e70624c15p-5, 0x1.a3aeb3676e872p-10, -0x1.e861b26223c98p-15, 0x1.3833c8136a69dp-19, -0x1.9fdb7c92b4f63p-24, 0x1.19bafb54b9646p-28, -0x1.80b4aa6dd035ap-33, 0x1.04500e9770001p-37},
+    {-0x1.972ba3f08010cp+1, -0x1.a617da00ce00ap-5, 0x1.54f1f54903bc7p-10, -0x1.67fcb571196eap-15, 0x1.a3595d666eb32p-20, -0x1.ff0f88597c24ap-25, 0x1.3e1fd7c973937p-29, -0x1.90b968e29f14bp-34, 0x1.f7079828219b2p-39},
+    {-0x1.a3bc66d06351dp+1, -0x1.7f51dbe2b799dp-5, 0x1.1a28d48d18992p-10, -0x1.10629cc220221p-15, 0x1.2309114ed7ec9p-20, -0x1.465b80e3fff2cp-25, 0x1.770e9a598d9b2p-30, -0x1.b5602b5a23425p-35, 0x1.fe5f3f41cef38p-40},
+    {-0x1.af31dc5999bf7p+1, -0x1.5efb05097d7e3p-5, 0x1.da610944f1caep-11, -0x1.a580e9e5a8cf3p-16, 0x1.9f8e7f1c2d99bp-21, -0x1.af09ea24857fap-26, 0x1.cb591ef120aa8p-31, -0x1.f1d21c1f0c53ap-36, 0x1.0ec5ea3a71bb3p-40},
+    {-0x1.b9b950b032245p+1, -0x1.439d29c92b4f8p-5, 0x1.942162e83abf7p-11, -0x1.4c72afc450166p-16, 0x1.300adbe005ef2p-21, -0x1.251fa30225528p-26, 0x1.22e9a1e488669p-31, -0x1.261d7eb030f88p-36, 0x1.2b33dea845269p-41},
+    {-0x1.c3761bbdddbd3p+1, -0x1.2c2a6847d01ecp-5, 0x1.5c4497f9b1bcdp-11, -0x1.0a9bf7928415ep-16, 0x1.c687c1c637be5p-22, -0x1.9914cf8355a58p-27, 0x1.7b9c5f9953a04p-32, -0x1.6754a7e59b740p-37, 0x1.56eaeeb99d999p-42},
+    {-0x1.cc84527e5f0e8p+1, -0x1.17db7e4e7328bp-5, 0x1.2f255f674a1afp-11, -0x1.b1e309375fc67p-17, 0x1.5a3353edb654dp-22, -0x1.240744ca2a968p-27, 0x1.fc9eee2fc710bp-33, -0x1.c44da12be336bp-38, 0x1.9627b4af7bbbap-43},
+    {-0x1.d4fa9fc291064p+1, -0x1.061a460e9e014p-5, 0x1.0a3257beb44a5p-11, -0x1.659ce9919adcbp-17, 0x1.0c1c26536afa1p-22, -0x1.a973405e2ca31p-28, 0x1.5cdd7a1991b9bp-33, -0x1.24611d9bc7913p-38, 0x1.ef83edb17ca4ap-44},
+    {-0x1.e0b6eeabb1608p+1, -0x1.de9a9225075d4p-5, 0x1.bc61ed1c07b04p-10, -0x1.113e5a10266b1p-14, 0x1.77883b622489ap-19, -0x1.1171bc4c0e685p-23, 0x1.9c1447c628721p-28, -0x1.3efb564a1b8f2p-32, 0x1.f216ce7053a92p-37},
+    {-0x1.eedd4de216516p+1, -0x1.accd37be4b86ap-5, 0x1.652e6292995e7p-10, -0x1.8a91dfba55a57p-15, 0x1.e7bd5c0d880fap-20, -0x1.3fd690c92a866p-24, 0x1.b29fed3655ab9p-29, -0x1.2f75c24ad827ep-33, 0x1.ac63baed6da9dp-38},
+    {-0x1.fb9c938c93ca1p+1, -0x1.8458882658651p-5, 0x1.253f1002bbd60p-10, -0x1.25f16deeb52c0p-15, 0x1.4a03a083a2d37p-20, -0x1.8979f9d80ac89p-25, 0x1.e68c03eb71fabp-30, -0x1.352fcc51ee9dap-34, 0x1.8dedce83d9301p-39},
+    {-0x1.039aa71ce1a35p+2, -0x1.62d701e46738bp-5, 0x1.ea03398731ddap-11, -0x1.c17363150a8dap-16, 0x1.ce11943135c52p-21, -0x1.f8d8579d0d933p-26, 0x1.1e39dce0542c6p-30, -0x1.4da290e2a68dbp-35, 0x1.8a5363032275bp-40},
+    {-0x1.08ec0f90cfd75p+2, -0x1.46a3c458f7bc4p-5, 0x1.9f74e923839c8p-11, -0x1.5f2d2cfe2806ep-16, 0x1.4ce6d1abac0ddp-21, -0x1.4f90393609269p-26, 0x1.5f3d38b13b98ap-31, -0x1.79f865a566b38p-36, 0x1.9cd47a70ddd3cp-41},
+    {-0x1.0dd5473889f7ap+2, -0x1.2e94a68568d09p-5, 0x1.64aaee8a786a8p-11, -0x1.1786809f54677p-16, 0x1.eb936ad1386a9p-22, -0x1.cbd21b39019c1p-27, 0x1.bed5982159fd1p-32, -0x1.be71129a296b8p-37, 0x1.c51842ce79ddap-42},
+    {-0x1.1265167a20a92p+2, -0x1.19d09fe09f3d2p-5, 0x1.3580c8bf6c0f6p-11, -0x1.c427155aed134p-17, 0x1.72b09466a1d83p-22, -0x1.4367f6e60eebdp-27, 0x1.25393fc067ce8p-32, -0x1.115c51e8b60bcp-37, 0x1.03090d90b3dfbp-42},
+    {-0x1.16a7570ead596p+2, -0x1.07b6001f4209fp-5, 0x1.0f18113bae992p-11, -0x1.72d087ebd6de7p-17, 0x1.1cb963cf6b32cp-22, -0x1.d16f6a59ca341p-28, 0x1.8b75b01f6c4ccp-33, -0x1.5980d19ce4341p-38, 0x1.32fc1db6c12d5p-43},
+    {-0x1.1c8dec18c1856p+2, -0x1.e10d5eea71bfep-5, 0x1.c332fbe813098p-10, -0x1.19a63bddc6219p-14, 0x1.8ae6c328dcdfep-19, -0x1.26cb8b23949efp-23, 0x1.c9b0e7970faf1p-28, -0x1.6efc2e4100601p-32, 0x1.2a26b17db7a72p-36},
+    {-0x1.23a96d6068f22p+2, -0x1.ae90125ffa64fp-5, 0x1.699490b128ef3p-10, -0x1.944f73fa10872p-15, 0x1.fbe752fd81037p-20, -0x1.53d1aa8e72c42p-24, 0x1.d90533adcf30ep-29, -0x1.53c48e0c46502p-33, 0x1.ef4b63c2790c3p-38},
+    {-0x1.2a0f248f25e12p+2, -0x1.85a779c27ccc4p-5, 0x1.283590235ed20p-10, -0x1.2be4c2f8a2654p-15, 0x1.55314a1b58133p-20, -0x1.9d9708857a4c2p-25, 0x1.04d3b7b3590afp-29, -0x1.53510c9dc41e4p-34, 0x1.c0686db46298ep-39},
+    {-0x1.2fe01556963acp+2, -0x1.63d68aeec9c41p-5, 0x1.ee258cd002983p-11, -0x1.c90bbaf8c62ebp-16, 0x1.db20127a90ac5p-21, -0x1.072d0509e407cp-25, 0x1.2f6a17bf58befp-30, -0x1.68a2dde78c46fp-35, 0x1.b3c86acf688b0p-40},
+    {-0x1.3535055a3e525p+2, -0x1.476b1ade86354p-5, 0x1.a26d56fe02b29p-11, -0x1.643459f104a3cp-16, 0x1.54de2248e0327p-21, -0x1.5ba8eb3840dbap-26, 0x1.71119fc19b267p-31, -0x1.93c90c4aa0422p-36, 0x1.c16684c4c5d69p-41},
+    {-0x1.3a210473e9474p+2, -0x1.2f331d3e495e4p-5, 0x1.66db2db32f1f7p-11, -0x1.1af59a0ad23eap-16, 0x1.f5aa39831f261p-22, -0x1.da076db4006ffp-27, 0x1.d242d27bfbc72p-32, -0x1.d885eac9b2dcep-37, 0x1.e7624e8c15071p-42},
+    {-0x1.3eb30dd25ad51p+2, -0x1.1a50a7fa283b7p-5, 0x1.3726893bf504ap-11, -0x1.c8f884425e5a5p-17, 0x1.79496baac6905p-22, -0x1.4c112c2923499p-27, 0x1.3043dfec373a9p-32, -0x1.1f2d9e89722dfp-37, 0x1.13facaec6fd74p-42},
+    {-0x1.42f71e3f24e31p+2, -0x1.081ee99769c82p-5, 0x1.105b8f946eb62p-11, -0x1.76463cdb9ae3fp-17, 0x1.2128e8032699ap-22, -0x1.dc578c483d65cp-28, 0x1.987b9d8c17632p-33, -0x1.68c37fd12ac4cp-38, 0x1.44847cc178fc5p-43},
+    {-0x1.48dfd831b6df2p+2, -0x1.e1ac952e85cf9p-5, 0x1.c4f2ea90f189ap-10, -0x1.1bd5d63eb8a32p-14, 0x1.9004700886da2p-19, -0x1.2c89733b3431dp-23, 0x1.d63603fddede4p-28, -0x1.7c792bec2806ap-32, 0x1.384da01e7e311p-36},
+    {-0x1.4ffd759594e01p+2, -0x1.af023c3050ab4p-5, 0x1.6ab426a36f2b1p-10, -0x1.96d2f2c7263ccp-15, 0x1.00961ee0d3e8cp-19, -0x1.591df16658a00p-24, 0x1.e35ef935e0574p-29, -0x1.5dbdf7af5c0b8p-33, 0x1.01071630565bfp-37},
+    {-0x1.5664b6689a4d7p+2, -0x1.85fc184223a2cp-5, 0x1.28f68613a8a57p-10, -0x1.2d6ba8984d99dp-15, 0x1.58173ca4930c9p-20, -0x1.a2de2885628b2p-25, 0x1.097f19b0230f7p-29, -0x1.5b74fcab18c0bp-34, 0x1.ce47870f0d606p-39},
+    {-0x1.5c36cee1a865ep+2, -0x1.6416fd2cbbce3p-5, 0x1.ef3204088d0fdp-11, -0x1.cafc88cd906b3p-16, 0x1.de7d8b0e52c07p-21, -0x1.09f9b17ead1d2p-25, 0x1.33f0d88937e1fp-30, -0x1.6fd6f8653c07dp-35, 0x1.bf006c4292d4bp-40},
+    {-0x1.618ca29f78f13p+2, -0x1.479d4fa899f9bp-5, 0x1.a32dcfbfe9784p-11, -0x1.657c27b65a4bbp-16, 0x1.56e950d4bd7ebp-21, -0x1.5eca30ddff3dfp-26, 0x1.75ba3ad81df29p-31, -0x1.9a9af4b034be4p-36, 0x1.cb2dfb73ed0e9p-41},
+    {-0x1.667954d123a20p+2, -0x1.2f5afbd4363e4p-5, 0x1.6768bc178626cp-11, -0x1.1bd4e5c3026cap-16, 0x1.f83e6e1fe15f4p-22, -0x1.ddb00c066d1c2p-27, 0x1.d74e388ad21a4p-32, -0x1.df5c3a89bc28ap-37, 0x1.f0779359dc0b8p-42},
+    {-0x1.6b0bed90d2b1dp+2, -0x1.1a70d77cb219fp-5, 0x1.3790f32997c04p-11, -0x1.ca3128b9615dep-17, 0x1.7af7da7fb197ap-22, -0x1.4e49e49fafb15p-27, 0x1.331e376f23ca1p-32, -0x1.22c726b3d3820p-37, 0x1.186f282ceb952p-42},
+    {-0x1.6f50728e3524ap+2, -0x1.08394497b8f00p-5, 0x1.10ad16ed01c5bp-11, -0x1.77265b8cdf8f0p-17, 0x1.22499febe5cd6p-22, -0x1.df2178916af83p-28, 0x1.9bd589ced10b9p-33, -0x1.6cb81a06e2887p-38, 0x1.49192a87f0c6cp-43},
+    {-0x1.7539b65749285p+2, -0x1.e1d48bf17c81ap-5, 0x1.c563a771d9f65p-10, -0x1.1c6327200b13fp-14, 0x1.91507f617bc7cp-19, -0x1.2dffe16782699p-23, 0x1.d96ad1be0951bp-28, -0x1.7ff2e2d6aad32p-32, 0x1.3bf95b7858d6cp-36},
+    {-0x1.7c57db400dad9p+2, -0x1.af1ede4dc43b7p-5, 0x1.6afc6f7c95a47p-10, -0x1.97752020e6e26p-15, 0x1.0140a62c3b743p-19, -0x1.5a76260f26e97p-24, 0x1.e60255e261edcp-29, -0x1.604bf6aae77a7p-33, 0x1.037170b22a3a1p-37},
+    {-0x1.82bf7ec658a86p+2, -0x1.86114e3ef3cdbp-5, 0x1.2926fa284dc0cp-10, -0x1.2dce07f6cffe5p-15, 0x1.58d2728e74bcfp-20, -0x1.a43420d84e9d8p-25, 0x1.0aaeb74089b22p-29, -0x1.5d8868ef5624cp-34, 0x1.d1d51135102fdp-39},
+    {-0x1.8891e159d3d63p+2, -0x1.642722db7a345p-5, 0x1.ef75612e46bc0p-11, -0x1.cb796c2451a28p-16, 0x1.df56946426f05p-21, -0x1.0aaeb6c7cd2eep-25, 0x1.3516634f5ec3cp-30, -0x1.71abb09d8a4d1p-35, 0x1.c1dd154280ae2p-40},
+    {-0x1.8de7ee23f17d7p+2, -0x1.47a9e2df53885p-5, 0x1.a35e146272e48p-11, -0x1.65ce7d65e923ap-16, 0x1.576cf814261c2p-21, -0x1.5f9442fe53f7fp-26, 0x1.76e7bcef59f70p-31, -0x1.9c5598032c6a1p-36, 0x1.cdaaa77e1450cp-41},
+    {-0x1.92d4cd2f8ad7bp+2, -0x1.2f64f79282949p-5, 0x1.678c37ef91c2fp-11, -0x1.1c0cf2131477fp-16, 0x1.f8e468e3bf9c8p-22, -0x1.de9bf54993803p-27, 0x1.d8942fba80b87p-32, -0x1.e11719609acb1p-37, 0x1.f2c57e0596e91p-42},
+    {-0x1.976789d54a2cap+2, -0x1.1a78e63b5f237p-5, 0x1.37ab9d7238e08p-11, -0x1.ca7f977dee844p-17, 0x1.7b63fc8004516p-22, -0x1.4ed8ff6d01d8ep-27, 0x1.33d65451b488fp-32, -0x1.23aff2d43f152p-37, 0x1.198fe6def5397p-42},
+    {-0x1.9bac2c008f546p+2, -0x1.083fdd65e32b8p-5, 0x1.10c1835bb47a9p-11, -0x1.775e8eec40690p-17, 0x1.22921cbbd6a92p-22, -0x1.dfd4f7a77ec16p-28, 0x1.9cad96cd537b1p-33, -0x1.6db792bb825b9p-38, 0x1.4a419f65aa47bp-43},
+    {-0x1.a19592491b611p+2, -0x1.e1de8c397dd91p-5, 0x1.c57fe2d8b4b1fp-10, -0x1.1c869240fe6d4p-14, 0x1.91a3ce98e552cp-19, -0x1.2e5dee4f0bd9dp-23, 0x1.da3944d0cbfb7p-28, -0x1.80d303db55b9ep-32, 0x1.3ce67c3e36b3ep-36},
+    {-0x1.a8b3d91b0286ap+2, -0x1.af2608519ee9ap-5, 0x1.6b0e87f3dd8c2p-10, -0x1.979dc083effe0p-15, 0x1.016b66fd11f78p-19, -0x1.5acc86a6c2245p-24, 0x1.e6abff9522f5dp-29, -0x1.60f07648d7999p-33, 0x1.040d2f0360d71p-37},
+    {-0x1.af1b9552c78fdp+2, -0x1.86169ca4e8c83p-5, 0x1.29331a9c0b112p-10, -0x1.2de6aa424b7f1p-15, 0x1.59015be34fe8ap-20, -0x1.a489e2c6ad964p-25, 0x1.0afaec1d93fddp-29, -0x1.5e0dee10c1ec2p-34, 0x1.d2b9d77ef4c0cp-39},
+    {-0x1.b4ee0a6fc127ep+2, -0x1.642b2cd99e5ebp-5, 0x1.ef863c720f6f5p-11, -0x1.cb98b00a2b606p-16, 0x1.df8cf1a5183edp-21, -0x1.0adc160b270a6p-25, 0x1.356004716a5d2p-30, -0x1.72215ba445fd9p-35, 0x1.c2952e43c4e2fp-40},
+    {-0x1.ba44257ecfc9ep+2, -0x1.47ad080d8cee1p-5, 0x1.a36a27f4b7ea0p-11, -0x1.65e318fe3b2b0p-16, 0x1.578defb655cb2p-21, -0x1.5fc6e3d094699p-26, 0x1.773353bd2b5d9p-31, -0x1.9cc4a4b00ec26p-36, 0x1.ce4a820766f62p-41},
+    {-0x1.bf310fc224973p+2, -0x1.2f6776c3cc9cdp-5, 0x1.6795186adf083p-11, -0x1.1c1af8c180871p-16, 0x1.f90df68549ef1p-22, -0x1.ded70beb2dc70p-27, 0x1.d8e5dfd615c05p-32, -0x1.e18626b3aaf97p-37, 0x1.f3598412e8de0p-42},
+    {-0x1.c3c3d562448f2p+2, -0x1.1a7aea190477cp-5, 0x1.37b24901f8bdfp-11, -0x1.ca93378dfefcep-17, 0x1.7b7f0d6ff3d1bp-22, -0x1.4efcd503e9bd3p-27, 0x1.3404742c233eap-32, -0x1.23ea4cdc284afp-37, 0x1.19d851aa86d37p-42},
+    {-0x1.c8087ed99e7efp+2, -0x1.084183ba5f11dp-5, 0x1.10c69f215d16bp-11, -0x1.776c9e81c264ep-17, 0x1.22a440e2eaed0p-22, -0x1.e001e7c4e5ae4p-28, 0x1.9ce3b35881452p-33, -0x1.6df7965a8a6cfp-38, 0x1.4a8bf1b8cdfd4p-43},
+    {-0x1.cdf1edc2a64c6p+2, -0x1.e1e10c75031eap-5, 0x1.c586f275c3671p-10, -0x1.1c8f6e78d8fbep-14, 0x1.91b8a721616d6p-19, -0x1.2e7578a74779ap-23, 0x1.da6cf5ad329e1p-28, -0x1.810b2781aec80p-32, 0x1.3d21e7d8b0201p-36},
+    {-0x1.d5103d0f54d82p+2, -0x1.af27d2ea651e5p-5, 0x1.6b130e75ec9f8p-10, -0x1.97a7e9ee46b7ep-15, 0x1.01761922a781bp-19, -0x1.5ae224088c114p-24, 0x1.e6d67739e0e6dp-29, -0x1.6119a64516eedp-33, 0x1.04343131e328dp-37},
+    {-0x1.db77ff73c3058p+2, -0x1.8617f04cd5e52p-5, 0x1.293622eff7f50p-10, -0x1.2decd37cba888p-15, 0x1.590d17f7477aap-20, -0x1.a49f57833c2f9p-25, 0x1.0b0dfe3116d17p-29, -0x1.5e2f5a068abd2p-34, 0x1.d2f31f6c1ded3p-39},
+    {-0x1.e14a79334a75ap+2, -0x1.642c2f6250b67p-5, 0x1.ef8a7382bae0dp-11, -0x1.cba081b4ed2e5p-16, 0x1.df9a8aa4f00c1p-21, -0x1.0ae76fbc4b3b2p-25, 0x1.357270a41c757p-30, -0x1.723ece3d17e57p-35, 0x1.c2c343814fc76p-40},
+    {-0x1.e6a097d3b337ap+2, -0x1.47add15f25179p-5, 0x1.a36d2cffed695p-11, -0x1.65e8404738f24p-16, 0x1.57962e7c6a04cp-21, -0x1.5fd38dcac46d4p-26, 0x1.77463cd771b8ep-31, -0x1.9ce06e1debe23p-36, 0x1.ce7283acd2331p-41},
+    {-0x1.eb8d84e50ae1cp+2, -0x1.2f6816943b362p-5, 0x1.679750a20c713p-11, -0x1.1c1e7aa6d3374p-16, 0x1.f9185add1164cp-22, -0x1.dee5d3597aab5p-27, 0x1.d8fa4f03cd7e3p-32, -0x1.e1a1ef660a5e4p-37, 0x1.f37e8e53a5868p-42},
+    {-0x1.f0204cc3d0cdap+2, -0x1.1a7b6b134dd3ep-5, 0x1.37b3f3f5c541bp-11, -0x1.ca981fd804048p-17, 0x1.7b85d2331a439p-22, -0x1.4f05cb583ff53p-27, 0x1.340ffdada3d96p-32, -0x1.23f8e5cf9cbbcp-37, 0x1.19ea7012071bap-42},
+    {-0x1.f464f80e39b26p+2, -0x1.0841ed518d60cp-5, 0x1.10c7e61d68ca6p-11, -0x1.77702293076d6p-17, 0x1.22a8ca3bf88b4p-22, -0x1.e00d24d21cac0p-28, 0x1.9cf13c10b9855p-33, -0x1.6e07999aaab5cp-38, 0x1.4a9e89a16afefp-43},
   };
   static const double tp[34][9] = {
     {-0x1.3256172f7f1bep-1, 0x1.70aa14147e559p-4, -0x1.3789f7df5bd50p-8, 0x1.3d21436888496p-14, 0x1.3464f17fbfa71p-20, -0x1.bf1c1c2260febp-28, -0x1.0e61fb5735579p-30, -0x1.b296e7a7e0028p-36, 0x1.3482c461d6327p-43},
@@ -360,17 +450,21 @@ PGB_HD double pgb_log_ndtr(double x) {
   if (!(x == x)) return x;
   const int neg = x < 0.0;
   const double z = neg ? -x : x;
-  const double zp2 = z + 2.0;
-  const double t = z / zp2;
-  int in = (int)(t * 16.0);
-  if (in > 15) in = 15;
+  /* x >= 0: equal intervals of z */
   const double zc = z < 8.5 ? z : 8.5; /* keeps the conversion below in range */
   int ip = (int)(zc * 4.0);
   if (ip > 33) ip = 33;
-  const double un = t * 32.0 - (double)(2 * in + 1); /* local variables in [-1, 1] */
   const double up = zc * 8.0 - (double)(2 * ip + 1);
+  /* x < 0: dyadic intervals from the bits of z (every step below is exact) */
+  const uint64_t zb = pgb_d2u(z);
+  const int e = (int)((zb >> 52) & 0x7FF) - 1023;
+  const int ec = e > 9 ? 9 : e;
+  const int sub = (int)((zb >> 49) & 7);
+  const double m = pgb_u2d((zb & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1, 2) */
+  const int in = e < -3 ? 0 : 1 + (ec + 3) * 8 + sub;
+  const double un = e < -3 ? z * 16.0 - 1.0 : (m - (1.0 + (double)sub * 0.125)) * 16.0 - 1.0;
   const double* c = neg ? tn[in] : tp[ip];
-  const double u = neg ? un : up;
+  const double u = neg ? un : up; /* local variable in [-1, 1] */
   double g = c[8];
   g = PGB_FMA(g, u, c[7]);
   g = PGB_FMA(g, u, c[6]);
@@ -380,7 +474,13 @@ PGB_HD double pgb_log_ndtr(double x) {
   g = PGB_FMA(g, u, c[2]);
   g = PGB_FMA(g, u, c[1]);
   g = PGB_FMA(g, u, c[0]);
-  if (neg) return -0.5 * (z * z) + (g - pgb_log(0.5 * zp2));
+  if (neg) {
+    if (e > 9) { /* far tail: asymptotic series of the Mills ratio */
+      const double w = 1.0 / (z * z);
+      g = (-pgb_log(z) - 0.91893853320467274178) + (2.5 * w * w - w);
+    }
+    return -0.5 * (z * z) + g;
+  }
   return z < 8.5 ? g : 0.0;
 }
 
