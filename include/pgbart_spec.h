@@ -303,8 +303,10 @@ PGB_HD void pgb_normal2(double u0, double u1, double* z0, double* z1) {
  * (Chebyshev-node interpolation against mpmath at 60 digits; absolute error 4e-15 / 5e-16).
  * Absolute error of the function < 4e-13 against scipy.special.log_ndtr on [-38, 38] (the
  * rounding of z^2 at |x| ~ 38), < 1e-14 on [-5, 5] (tests/test_spec.py). */
-PGB_HD double pgb_log_ndtr(double x) {
-  static const double tn[105][9] = {
+/* the tables live in accessor functions so that a kernel can stage them in LDS (per-lane rows
+ * through the vector L1 cost one cache-line access per distinct row and instruction) */
+PGB_HD const double* pgb_ln_tn(void) {
+  static const double t[105][9] = {
     {-0x1.7c1095dd2ee18p-1, -0x1.8d1ab6a7490c2p-5, 0x1.6660cbdea201bp-11, -0x1.1fdd292b99f46p-17, 0x1.395f6bb4173c0p-24, -0x1.41183ee9009fcp-35, -0x1.8d47d27c3c90bp-37, 0x1.ab76140dcca81p-43, -0x1.99c0bcea901d1p-51},
     {-0x1.978ca807aaec6p-1, -0x1.80c4c05863cebp-8, 0x1.577ce4a842339p-17, -0x1.14df722e48797p-26, 0x1.379c44e0c7e71p-36, -0x1.d9d51d68b3605p-49, -0x1.59ae71e770c59p-55, 0x1.9a1101d9fa280p-64, -0x1.22075289065abp-74},
     {-0x1.9d8a616688a75p-1, -0x1.7e1902be7d586p-8, 0x1.5441ec8d6b7a0p-17, -0x1.1270d4698c3bcp-26, 0x1.36fe2d9f67ba5p-36, -0x1.0cccdc442a87ep-48, -0x1.4e881dbbbf3fcp-55, 0x1.95696a43fbe72p-64, -0x1.3194ff623f4e9p-74},
@@ -411,7 +413,10 @@ PGB_HD double pgb_log_ndtr(double x) {
     {-0x1.f0204cc3d0cdap+2, -0x1.1a7b6b134dd3ep-5, 0x1.37b3f3f5c541bp-11, -0x1.ca981fd804048p-17, 0x1.7b85d2331a439p-22, -0x1.4f05cb583ff53p-27, 0x1.340ffdada3d96p-32, -0x1.23f8e5cf9cbbcp-37, 0x1.19ea7012071bap-42},
     {-0x1.f464f80e39b26p+2, -0x1.0841ed518d60cp-5, 0x1.10c7e61d68ca6p-11, -0x1.77702293076d6p-17, 0x1.22a8ca3bf88b4p-22, -0x1.e00d24d21cac0p-28, 0x1.9cf13c10b9855p-33, -0x1.6e07999aaab5cp-38, 0x1.4a9e89a16afefp-43},
   };
-  static const double tp[34][9] = {
+  return &t[0][0];
+}
+PGB_HD const double* pgb_ln_tp(void) {
+  static const double t[34][9] = {
     {-0x1.3256172f7f1bep-1, 0x1.70aa14147e559p-4, -0x1.3789f7df5bd50p-8, 0x1.3d21436888496p-14, 0x1.3464f17fbfa71p-20, -0x1.bf1c1c2260febp-28, -0x1.0e61fb5735579p-30, -0x1.b296e7a7e0028p-36, 0x1.3482c461d6327p-43},
     {-0x1.bf2c740535475p-2, 0x1.26a4c52e2ce76p-4, -0x1.180d396af5f9ap-8, 0x1.61df01422a853p-14, 0x1.114d199b40162p-20, -0x1.5c1a53d31f0afp-26, -0x1.6326c23229253p-30, -0x1.30a16f2adb08bp-36, 0x1.d4dfaa4cdd552p-41},
     {-0x1.3ca5e181de6b4p-2, 0x1.c9ce8bd89f145p-5, -0x1.eacddce394bc3p-9, 0x1.7fbbd102ff368p-14, 0x1.8a2f50dc14b01p-21, -0x1.3bc8a3053e538p-25, -0x1.83d5038031323p-30, 0x1.8cd24374cc4f0p-39, 0x1.d897ff6a1f8bap-40},
@@ -447,6 +452,11 @@ PGB_HD double pgb_log_ndtr(double x) {
     {-0x1.01e30a1d54c78p-52, 0x1.09c5972f5074ep-52, -0x1.0decae900b470p-53, 0x1.67fce4ea8ea40p-55, -0x1.625d50c385d1ep-57, 0x1.124ee1cc13d16p-59, -0x1.5be8a1ae7023cp-62, 0x1.7cdb7df3dbf96p-65, -0x1.5a7c048cf453fp-68},
     {-0x1.fd59ae3f7142ep-56, 0x1.0e5011ed79d14p-55, -0x1.1afbd42aa4a19p-56, 0x1.855e848815345p-58, -0x1.8bd3fed38282ap-60, 0x1.3cc0b1c690573p-62, -0x1.9fd8b74267e10p-65, 0x1.d8cccd4785191p-68, -0x1.be4ce2cee174dp-71},
   };
+  return &t[0][0];
+}
+#define PGB_LN_TN_ROWS 105
+#define PGB_LN_TP_ROWS 34
+PGB_HD double pgb_log_ndtr_t(double x, const double* tn, const double* tp) {
   if (!(x == x)) return x;
   const int neg = x < 0.0;
   const double z = neg ? -x : x;
@@ -463,7 +473,7 @@ PGB_HD double pgb_log_ndtr(double x) {
   const double m = pgb_u2d((zb & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1, 2) */
   const int in = e < -3 ? 0 : 1 + (ec + 3) * 8 + sub;
   const double un = e < -3 ? z * 16.0 - 1.0 : (m - (1.0 + (double)sub * 0.125)) * 16.0 - 1.0;
-  const double* c = neg ? tn[in] : tp[ip];
+  const double* c = neg ? tn + in * 9 : tp + ip * 9;
   const double u = neg ? un : up; /* local variable in [-1, 1] */
   double g = c[8];
   g = PGB_FMA(g, u, c[7]);
@@ -484,6 +494,8 @@ PGB_HD double pgb_log_ndtr(double x) {
   return z < 8.5 ? g : 0.0;
 }
 
+PGB_HD double pgb_log_ndtr(double x) { return pgb_log_ndtr_t(x, pgb_ln_tn(), pgb_ln_tp()); }
+
 /* log(1 + e^t) */
 PGB_HD double pgb_softplus(double t) {
   if (t > 36.0) return t;
@@ -493,12 +505,15 @@ PGB_HD double pgb_softplus(double t) {
 /* Per-row log-likelihood of the closed families with one linear predictor mu (K = 1).
  * y is the observed response (0/1 for the Bernoulli families).  Clamped to [-2047, 0] so that
  * n terms fit the fixed-point accumulator (scale cl). */
-PGB_HD double pgb_loglik1(int family, double y, double mu) {
+PGB_HD double pgb_loglik1_t(int family, double y, double mu, const double* tn, const double* tp) {
   const double smu = y > 0.5 ? mu : -mu;
-  double ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr(smu) : -pgb_softplus(-smu);
+  double ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 0.0) ll = 0.0;
   return ll;
+}
+PGB_HD double pgb_loglik1(int family, double y, double mu) {
+  return pgb_loglik1_t(family, y, mu, pgb_ln_tn(), pgb_ln_tp());
 }
 
 /* Categorical-softmax over K linear predictors: mu[y] - logsumexp(mu) (serial max / sum in output

@@ -2092,7 +2092,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
 struct LJob {
   long long src, xoff;
   double v, vL, vR;
-  int32_t p, rule, label, check_nan, ok, pad;
+  int32_t p, rule, label, check_nan, ok, new_label;
   double vLx[KXMAX], vRx[KXMAX];  // K-vector leaves: outputs 1..K-1
 };
 
@@ -2105,8 +2105,18 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
+  // log Phi tables in LDS (single-output Bernoulli path): a per-lane row through the vector L1
+  // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
+  __shared__ double s_ln[KT == 1 ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
   const Cmd* cmd = &S.cmd[par];
   if (!(cmd->kind & CMD_PARTITION)) return;
+  if constexpr (KT == 1) {
+    const double* gtn = pgb_ln_tn();
+    const double* gtp = pgb_ln_tp();
+    for (int i = threadIdx.x; i < PGB_LN_TN_ROWS * 9; i += BT) s_ln[i] = gtn[i];
+    for (int i = threadIdx.x; i < PGB_LN_TP_ROWS * 9; i += BT) s_ln[PGB_LN_TN_ROWS * 9 + i] = gtp[i];
+    // (the barrier after the job list below also publishes the tables)
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const Ctrl cn = S.ctrl[par ^ 1];  // the state this slot's k_ctrl produced
   const int round = cn.round - 1;   // round of the proposals of this slot
@@ -2146,6 +2156,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       lj.p = tid;
       lj.rule = j.rule;
       lj.label = j.label;
+      lj.new_label = j.new_label;
       lj.check_nan = j.check_nan;
       lj.ok = cv.ok;
       lj.v = j.v;
@@ -2178,6 +2189,10 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   const int K = KT > 0 ? KT : S.K;
   const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * K * S.n_pad;
   const double cl = S.sc.cl;
+  // The row pass of this slot has already sorted the rows of every split leaf: left rows kept the
+  // leaf's label, right rows carry the new one, dropped rows the orphan label.  Reading those
+  // bytes back (1 B per row) replaces a second read of the split column (8 B per row).
+  const uint8_t* __restrict__ const newl = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
   const long long n = S.n;
   unsigned sat = 0;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -2196,11 +2211,12 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
         const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
+        const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
         long long v0 = 0, v1 = 0, v2 = 0;
         for (int e = 0; e < RPT; ++e) {
           if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
-            const double xv = S.XT[lj.xoff + base + e];
-            const int side = (xv != xv) ? 2 : (go_left(lj.rule, xv, lj.v) ? 0 : 1);
+            const uint32_t nl = (nid >> (8 * e)) & 255u;
+            const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
             double mu[KB];
             mu[0] = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);
 #pragma unroll
@@ -2235,19 +2251,17 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     for (int g = g0; g < g1; ++g) {
       const LJob& lj = s_job[g];
       const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
-      const double2* __restrict__ xp = (const double2*)(S.XT + lj.xoff + base);
-      const double2 t0 = xp[0], t1 = xp[1];
-      const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+      const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
       long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
           // ONE evaluation per row: the side only selects the leaf value and the accumulator
           // (separate calls per side would run one after the other on a divergent wave)
-          const double xv = x[e];
-          const int side = (xv != xv) ? 2 : (go_left(lj.rule, xv, lj.v) ? 0 : 1);
+          const uint32_t nl = (nid >> (8 * e)) & 255u;
+          const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
           const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
-          const long long q = pgb_quant(pgb_loglik1(S.family, yv[e], mu), cl, &sat);
+          const long long q = pgb_quant(pgb_loglik1_t(S.family, yv[e], mu, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
           v0 += side == 0 ? q : 0;
           v1 += side == 1 ? q : 0;
           v2 += side == 2 ? q : 0;
