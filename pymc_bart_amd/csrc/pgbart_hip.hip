@@ -6,18 +6,23 @@
 //
 // Design:
 //   * The whole astep is a DEVICE-RESIDENT STATE MACHINE.  The host only enqueues identical
-//     "slots" = { k_ctrl ; k_rows } on one HIP stream; it never waits for the device inside
-//     a tree update.  k_ctrl (one 256-thread workgroup per particle) finishes the previous
-//     SMC round from the integer statistics the row pass produced -- leaf values, particle
-//     weights, systematic resampling on one wave, the next growth proposal incl. the exact
-//     "k-th row of the leaf" selection -- and writes one job per particle.  k_rows streams the
-//     rows: every workgroup owns a 1024-row chunk of one particle, relabels the rows of the
-//     leaf being split and reduces the children's sufficient statistics.
+//     "slots" = { k_ctrl ; k_rows [; k_loglik] } on one HIP stream and polls a pinned progress
+//     word; it never waits for the device inside a tree update.  k_ctrl (one 256-thread
+//     workgroup per particle) finishes the previous SMC round from the integer statistics the
+//     row pass produced -- leaf values, particle weights, systematic resampling on one wave, the
+//     next growth proposal incl. the exact "k-th row of the leaf" selection -- and writes one
+//     job per particle.  k_rows streams the rows on a persistent grid: a work item is a 1024-row
+//     chunk times a group of particles with work; it relabels the rows of the leaves being split
+//     and reduces the children's sufficient statistics (four values per butterfly, wave_sum4).
+//     The slot that starts a tree fuses FINAL(previous tree) + INIT + round 0 into one pass.
 //   * HBM layout: X column-major (coalesced column streams), {sum_trees, residual} packed as
-//     double2 per row, one BYTE leaf label per row per particle (3 generations, so a failed
-//     split rolls back for free and resampling copies are fused into the next row pass).
+//     double2 per row, one BYTE leaf label per row per particle in an 8-generation ring (idle
+//     particles are never copied; a pass writes only particles that split).
 //   * All row reductions are integer (fixed point) => bit-reproducible, independent of
 //     launch geometry and atomics order, and identical to the CPU oracle.
+//   * Kernel instances are compiled per data set where the hot loop has no registers or
+//     instructions to spare: k_rows<SubsetSplit columns?, Normal family?>, k_rows_mk<K>,
+//     k_loglik<K>, k_ctrl<multi-output?>.
 //   * No MFMA: the path is gather / partition / reduce (HBM / L2 bound).
 //
 #include <hip/hip_runtime.h>
