@@ -191,3 +191,40 @@ def digest(res) -> dict:
         "leaf_sd": float(res["state"]["leaf_sd"][0]),
         "iter": int(res["state"]["iter"]),
     }
+
+
+def random_case(seed):
+    """A random configuration for the fuzz parity test: sizes around the chunk / wave boundaries,
+    every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta."""
+    rng = np.random.default_rng(seed)
+    fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale"])
+    n = int(rng.choice([3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 5000, 20000]))
+    p = int(rng.integers(1, 9))
+    m = int(rng.integers(1, 12))
+    P = int(rng.choice([2, 3, 5, 10, 20, 40, 64]))
+    X = rng.normal(size=(n, p))
+    rules = np.zeros(p, np.int32)
+    for j in range(p):
+        r = rng.random()
+        if r < 0.2:
+            X[:, j] = rng.integers(0, int(rng.integers(1, 6)), n); rules[j] = 1
+        elif r < 0.35:
+            X[:, j] = rng.integers(0, int(rng.integers(1, 9)), n); rules[j] = 2
+        elif r < 0.45:
+            X[:, j] = np.round(X[:, j])  # heavy ties, continuous rule
+        if rng.random() < 0.3:
+            X[rng.random(n) < rng.uniform(0.01, 0.5), j] = np.nan
+    f = np.nan_to_num(X[:, 0]) * 1.5 + (np.nan_to_num(X[:, -1]) > 0)
+    K = 1
+    if fam == "normal":
+        Y = f + rng.normal(0, 0.5, n)
+    elif fam.startswith("bernoulli"):
+        Y = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+    elif fam == "categorical":
+        K = int(rng.integers(2, 8)); Y = rng.integers(0, K, n).astype(float)
+    else:
+        K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
+    batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
+    return dict(name=f"fuzz{seed}", X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
+                prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
+                alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))
