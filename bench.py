@@ -53,11 +53,19 @@ def cpu_baseline(w, seed, budget_s=20.0):
     c1 = s.counters.as_dict()
     ps = c1["particle_steps"] - c0["particle_steps"]
     tu = c1["tree_updates"] - c0["tree_updates"]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), model)
+    except OSError:
+        pass
     return {
         "value": ps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{steps} asteps ({tu} tree updates, {dt:.1f} s) of the same cfg2 data after 1 "
-                  "warm-up astep; restated CPU baseline (oracle/), not the reference binary",
+        "sample": f"{steps} asteps ({tu} tree updates, {dt:.1f} s) of the same {w['name'].split(':')[0]} data "
+                  "after 1 warm-up astep; restated CPU baseline (oracle/), not the reference binary; one "
+                  "chain on one core, as upstream runs a chain (chains are processes)",
         "tree_updates_per_s": tu / dt,
+        "host": {"nproc": os.cpu_count(), "cpu_model": model},
     }
 
 
