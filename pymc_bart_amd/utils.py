@@ -15,97 +15,95 @@ from .trees import PosteriorSampler
 
 
 def _encode_vi(vec) -> str:
-    """LEB128 varints of the per-draw split-variable counts, base64 encoded.
+    """Per-draw split-variable counts -> the string stored in ``sample_stats["variable_inclusion"]``.
 
-    Wire format of ``sample_stats["variable_inclusion"]`` (reference
-    ``utils.py:1387-1398``); golden vectors in ``tests/golden/vi_codec.json``.
-    """
-    out = bytearray()
-    for num in vec:
-        n = int(num)
-        if n < 0:
-            raise ValueError("variable inclusion counts must be non-negative")
-        while n > 127:
-            out.append((n & 0x7F) | 0x80)
-            n >>= 7
-        out.append(n & 0x7F)
-    return base64.b64encode(bytes(out)).decode("ascii")
+    Wire format (reference ``utils.py:1387-1398``): every count as an unsigned LEB128 varint --
+    7 value bits per byte, least significant group first, bit 7 set on all but the last byte of a
+    count -- and the byte string base64-encoded.  Golden vectors: ``tests/golden/vi_codec.json``."""
+    counts = np.asarray(vec, dtype=np.int64).ravel()
+    if counts.size and int(counts.min()) < 0:
+        raise ValueError("variable inclusion counts must be non-negative")
+    payload = bytearray()
+    for value in counts.tolist():
+        groups = [(value >> shift) & 0x7F for shift in range(0, max(value.bit_length(), 1), 7)]
+        payload.extend(g | 0x80 for g in groups[:-1])
+        payload.append(groups[-1])
+    return base64.b64encode(bytes(payload)).decode("ascii")
 
 
 def _decode_vi(s: str, length: int) -> list[int]:
-    """Inverse of :func:`_encode_vi` (reference ``utils.py:1368-1384``)."""
-    data = base64.b64decode(s)
-    result: list[int] = []
-    i = 0
-    while len(result) < length and i < len(data):
-        num = 0
-        shift = 0
-        while i < len(data):
-            byte = data[i]
-            i += 1
-            num |= (byte & 0x7F) << shift
-            if not byte & 0x80:
-                break
-            shift += 7
-        result.append(num)
-    return result
+    """Inverse of :func:`_encode_vi` (reference ``utils.py:1368-1384``): at most ``length`` counts;
+    a truncated trailing varint yields the bits that are there, as upstream does."""
+    raw = np.frombuffer(base64.b64decode(s), dtype=np.uint8)
+    last_bytes = np.flatnonzero(raw < 0x80)  # bytes that close a varint
+    bounds = [0] + (last_bytes + 1).tolist()
+    if bounds[-1] < raw.size:
+        bounds.append(int(raw.size))  # unterminated tail
+    out: list[int] = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        if len(out) == length:
+            break
+        septets = (raw[lo:hi] & 0x7F).tolist()
+        out.append(sum(v << (7 * k) for k, v in enumerate(septets)))
+    return out
 
 
 def _sample_posterior(sampler, X, rng: np.random.Generator, size=None, excluded=None) -> np.ndarray:
-    """Draw posterior predictions; same contract as reference ``utils.py:26-71``:
-    result shape ``(*size, n_rows, n_outputs)``; draw indices depend only on ``rng``."""
-    if size is None:
-        size_iter: tuple[int, ...] | list[int] = ()
-    elif isinstance(size, int):
-        size_iter = [size]
-    else:
-        size_iter = size
-    flatten_size = 1
-    for s in size_iter:
-        flatten_size *= s
+    """Posterior predictions at the rows of ``X`` for randomly chosen stored draws.
 
-    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
-    excl = list(excluded) if excluded is not None else None
-    first = sampler[0] if isinstance(sampler, list) else sampler
-    draw_indices = rng.integers(0, first.n_draws, size=flatten_size).tolist()
-    if isinstance(sampler, list):
-        pred = np.concatenate([s.sample_posterior(X, draw_indices, excl) for s in sampler], axis=1)
+    Contract of reference ``utils.py:26-71``: the draw indices come from ONE
+    ``rng.integers(0, n_draws, size=prod(size))`` call (so equal generators give equal draws for
+    any ``X``), a list of samplers contributes its outputs side by side, and the result has shape
+    ``(*size, n_rows, n_outputs)``."""
+    if size is None:
+        lead: tuple[int, ...] = ()
+    elif np.isscalar(size):
+        lead = (int(size),)
     else:
-        pred = sampler.sample_posterior(X, draw_indices, excl)
-    return pred.transpose((0, 2, 1)).reshape((*size_iter, -1, pred.shape[1]))
+        lead = tuple(int(v) for v in size)
+    n_pred = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    group = sampler if isinstance(sampler, list) else [sampler]
+    rows = np.ascontiguousarray(X, dtype=np.float64)
+    picks = rng.integers(0, group[0].n_draws, size=n_pred).tolist()
+    drop = None if excluded is None else [int(v) for v in excluded]
+    blocks = [np.asarray(g.sample_posterior(rows, picks, drop)) for g in group]  # (n_pred, K_g, n_rows)
+    stacked = blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=1)
+    return np.moveaxis(stacked, 1, 2).reshape(lead + (stacked.shape[2], stacked.shape[1]))
 
 
 class _MultiChainSampler:
-    """Dispatch each draw to the chain it came from (reference ``utils.py:74-107``)."""
+    """All chains of one BART variable behind one draw index (reference ``utils.py:74-107``):
+    draw ``d`` belongs to the chain whose range of the concatenated history contains it."""
 
     def __init__(self, chain_samplers: list):
-        if not chain_samplers:
+        self._parts = list(chain_samplers)
+        if not self._parts:
             raise ValueError("No posterior draws available yet: run the sampler first.")
-        self._chain_samplers = chain_samplers
-        self._offsets = np.cumsum([0] + [s.n_draws for s in chain_samplers])
+        self._starts = np.concatenate([[0], np.cumsum([part.n_draws for part in self._parts])]).astype(np.int64)
+
+    @property
+    def _chain_samplers(self):  # name used by callers that reach into the chains
+        return self._parts
 
     @property
     def n_draws(self) -> int:
-        return int(self._offsets[-1])
+        return int(self._starts[-1])
 
     @property
     def n_outputs(self) -> int:
-        return self._chain_samplers[0].n_outputs
+        return self._parts[0].n_outputs
 
     def sample_posterior(self, X, draw_indices, excluded):
-        draw_indices = np.asarray(draw_indices)
-        chain_of_draw = np.searchsorted(self._offsets, draw_indices, side="right") - 1
-        out = None
-        for chain_idx, sampler in enumerate(self._chain_samplers):
-            mask = chain_of_draw == chain_idx
-            if not np.any(mask):
-                continue
-            local = (draw_indices[mask] - self._offsets[chain_idx]).tolist()
-            preds = sampler.sample_posterior(X, local, excluded)
-            if out is None:
-                out = np.empty((len(draw_indices), *preds.shape[1:]), dtype=preds.dtype)
-            out[mask] = preds
-        return out
+        want = np.asarray(draw_indices, dtype=np.int64).ravel()
+        owner = np.digitize(want, self._starts[1:])  # chain of every requested draw
+        result = None
+        for c in np.unique(owner).tolist():
+            where = np.flatnonzero(owner == c)
+            part = self._parts[c].sample_posterior(X, (want[where] - self._starts[c]).tolist(), excluded)
+            if result is None:
+                result = np.empty((want.size,) + part.shape[1:], dtype=part.dtype)
+            result[where] = part
+        return result
 
 
 _posterior_sampler_cache: dict[int, tuple] = {}
