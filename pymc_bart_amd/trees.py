@@ -97,6 +97,58 @@ class TreeArrays:
         )
 
 
+_HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value")
+
+
+def save_history(path, all_trees, m: int, rules=None) -> None:
+    """Write the per-chain tree histories ``[(baseline_forest, batches), ...]`` -- the list the
+    step method keeps on ``op.all_trees`` (reference ``bart.py:134-135``, ``utils.py:124-127``) --
+    to ONE ``.npz`` file (the reference has no on-disk format).
+
+    Layout: every chain's forests are concatenated (baseline first, then the per-draw batches);
+    ``c<i>_<field>`` holds the SoA arrays of chain ``i`` and ``c<i>_sizes`` the number of trees of
+    each forest, which is all that is needed to cut the concatenation apart again."""
+    out = {"format": np.array("pgbart-history-1"), "n_chains": np.array(len(all_trees)), "m": np.array(int(m)),
+           "rules": np.asarray([] if rules is None else rules, np.int32)}
+    for i, (baseline, batches) in enumerate(all_trees):
+        parts = [baseline] + list(batches)
+        cat = TreeArrays.concat(parts)
+        out[f"c{i}_n_outputs"] = np.array(cat.n_outputs)
+        out[f"c{i}_sizes"] = np.array([p.n_trees for p in parts], np.int64)
+        for f in _HISTORY_FIELDS:
+            out[f"c{i}_{f}"] = getattr(cat, f)
+    np.savez_compressed(path, **out)
+
+
+def load_history(path):
+    """Inverse of :func:`save_history`: returns ``(all_trees, m, rules)`` with ``all_trees`` in the
+    layout ``PosteriorSampler.from_history`` / ``_get_posterior_sampler`` consume."""
+    z = np.load(path, allow_pickle=False)
+    if str(z["format"]) != "pgbart-history-1":
+        raise ValueError("not a pgbart tree-history file")
+    all_trees = []
+    for i in range(int(z["n_chains"])):
+        K = int(z[f"c{i}_n_outputs"])
+        arrs = {f: z[f"c{i}_{f}"] for f in _HISTORY_FIELDS}
+        sizes = z[f"c{i}_sizes"].tolist()
+        forests, t0 = [], 0
+        for nt in sizes:
+            a, b = int(arrs["node_off"][t0]), int(arrs["node_off"][t0 + nt])
+            forests.append(TreeArrays(
+                n_outputs=K,
+                tree_id=arrs["tree_id"][t0:t0 + nt].astype(np.int32),
+                node_off=(arrs["node_off"][t0:t0 + nt + 1] - a).astype(np.int32),
+                var=arrs["var"][a:b].astype(np.int32), split=arrs["split"][a:b].astype(np.float64),
+                left=arrs["left"][a:b].astype(np.int32), right=arrs["right"][a:b].astype(np.int32),
+                count=arrs["count"][a:b].astype(np.int64),
+                value=arrs["value"][a:b].reshape(b - a, K).astype(np.float64),
+            ))
+            t0 += nt
+        all_trees.append((forests[0], forests[1:]))
+    rules = z["rules"]
+    return all_trees, int(z["m"]), (rules if rules.size else None)
+
+
 def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rules: np.ndarray,
                   excluded=None) -> np.ndarray:
     """Slow host restatement of ``pgb_predict`` used by tests only (tiny inputs)."""

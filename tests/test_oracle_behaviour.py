@@ -538,3 +538,34 @@ def test_posterior_sampler_cache_is_not_fooled_by_reused_ids_or_growing_chains(o
     assert _get_posterior_sampler(op, backend=oracle).n_draws == 1
     step.astep(None, {})
     assert _get_posterior_sampler(op, backend=oracle).n_draws == 2
+
+
+def test_tree_history_round_trips_through_a_file(oracle, tmp_path):
+    # an on-disk format for (baseline_forest, batches) per chain
+    from pymc_bart_amd.trees import load_history, save_history
+
+    rng = np.random.default_rng(31)
+    X = rng.normal(size=(150, 3))
+    X[:, 2] = rng.integers(0, 4, 150)
+    Y = X[:, 0] + (X[:, 2] == 1) + rng.normal(0, 0.2, 150)
+    op = BARTOp(X, Y, m=6, split_rules=["ContinuousSplit", "ContinuousSplit", "OneHotSplit"])
+    for c in range(2):
+        sample_chain(op, tune=10, draws=7, random_seed=3, chain=c, backend=oracle)
+    assert len(op.all_trees) == 2
+    ref = _sample_posterior(_get_posterior_sampler(op, backend=oracle), X, np.random.default_rng(5), size=9)
+    path = tmp_path / "history.npz"
+    save_history(path, op.all_trees, m=6, rules=op._rule_ids)
+    all_trees, m, rules = load_history(path)
+    assert m == 6 and np.array_equal(rules, [0, 0, 1]) and len(all_trees) == 2
+    for (b0, bs0), (b1, bs1) in zip(op.all_trees, all_trees):
+        assert len(bs0) == len(bs1) == 7
+        for t0, t1 in zip([b0] + list(bs0), [b1] + list(bs1)):
+            for f in ("tree_id", "node_off", "var", "split", "left", "right", "count", "value"):
+                assert np.array_equal(getattr(t0, f), getattr(t1, f)), f
+    op2 = BARTOp(X, Y, m=6, split_rules=["ContinuousSplit", "ContinuousSplit", "OneHotSplit"], all_trees=all_trees)
+    op2.n_outputs, op2._rule_ids = 1, rules
+    again = _sample_posterior(_get_posterior_sampler(op2, backend=oracle), X, np.random.default_rng(5), size=9)
+    assert np.array_equal(ref, again)
+    with pytest.raises(ValueError):
+        np.savez(tmp_path / "bad.npz", format=np.array("x"))
+        load_history(tmp_path / "bad.npz")
