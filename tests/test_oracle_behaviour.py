@@ -219,8 +219,8 @@ def test_error_paths(oracle):
     s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
     with pytest.raises(_abi.PGBError, match="sigma"):
         s.set_likelihood([-1.0])
-    with pytest.raises(NotImplementedError):
-        BARTOp(X, Y, response="linear")
+    with pytest.raises(ValueError):
+        BARTOp(X, Y, response="quadratic")
     with pytest.raises(NotImplementedError):
         PGBART([BARTOp(X, Y, split_rules=["NoSuchSplit", "ContinuousSplit"])], backend=oracle)
     with pytest.raises(_abi.PGBError, match="unknown split rule"):
