@@ -38,6 +38,11 @@ class BARTOp:
                  split_prior=None, name="mu", all_trees=None):
         if response not in ("constant", "linear", "mix"):
             raise ValueError("response must be 'constant', 'linear' or 'mix'")
+        if response != "constant":  # same caveat as the reference (bart.py:128-132)
+            import warnings
+
+            warnings.warn(f"response={response!r} is experimental (upstream flags it the same way); "
+                          "check the fit before relying on it", stacklevel=2)
         self.name = name
         self.X = np.asarray(X, dtype=float)
         self.Y = np.asarray(Y, dtype=float)

@@ -236,6 +236,9 @@ def random_case(seed):
     else:
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
-    return dict(name=f"fuzz{seed}", X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
+    response = "constant"
+    if fam == "normal" and not rules.any():  # linear / mix need the Normal family and continuous columns
+        response = str(rng.choice(["constant", "linear", "mix"]))
+    return dict(name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))
