@@ -49,6 +49,8 @@ typedef struct {
   int32_t batch_tune;     /* trees updated per step while tuning                */
   int32_t batch_draw;     /* trees updated per step after tuning                */
   int32_t range_exp;      /* fixed-point range: |sum_trees|,|y - mu| < 2^range_exp */
+  int32_t response;       /* PGB_RESPONSE_*: how leaf values are computed (bart.py:88-90)   */
+  int32_t reserved0;
   uint64_t seed;          /* Philox key                                         */
   double init_sum;        /* initial sum_trees value = mean(Y)   (bart.py:148)  */
   double init_leaf;       /* initial leaf value      = mean(Y)/m                */
@@ -85,6 +87,11 @@ typedef struct {
   int32_t* right;     /* [total_nodes]                                          */
   int64_t* count;     /* [total_nodes]                                          */
   double* value;      /* [total_nodes * n_outputs]                              */
+  /* linear response (NULL = not wanted): a leaf predicts value + slope * (x[svar] - xbar);
+   * svar = -1 (slope 0) for constant leaves                                              */
+  double* slope;      /* [total_nodes]                                          */
+  double* xbar;       /* [total_nodes]                                          */
+  int32_t* svar;      /* [total_nodes]                                          */
 } pgb_tree_arrays;
 
 const char* pgb_last_error(void);

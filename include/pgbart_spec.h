@@ -48,6 +48,11 @@
 #define PGB_FMA(a, b, c) fma((a), (b), (c))
 #endif
 
+/* leaf responses (bart.py:88-90; "linear" and "mix" are flagged experimental upstream) */
+#define PGB_RESPONSE_CONSTANT 0
+#define PGB_RESPONSE_LINEAR 1 /* per-leaf OLS of sum_trees/m on the parent's split variable */
+#define PGB_RESPONSE_MIX 2    /* a fair coin per new leaf between the two                   */
+
 /* ------------------------------------------------------------------ limits */
 #define PGB_MAX_NODES 255     /* nodes per tree (127 splits + 128 leaves)        */
 #define PGB_MAX_LEAVES 128
@@ -76,6 +81,7 @@
 #define PGB_RNG_LEAF 3u     /* Box-Muller pair -> (left, right) leaf noise   */
 #define PGB_RNG_RESAMPLE 4u /* u0: systematic-resampling offset              */
 #define PGB_RNG_FINAL 5u    /* u0: final particle choice                     */
+#define PGB_RNG_MIX 6u      /* response = mix: u0 / u1 < 1/2 => the left / right child is linear */
 
 /* ------------------------------------------------------------------ Philox */
 typedef struct {
@@ -669,6 +675,60 @@ PGB_HD double pgb_leaf_sse(int64_t cnt, int64_t q_r, int64_t q_r2, double v, dou
   double a = (double)q_r2 * inv_c2;
   double b = (double)q_r * inv_c1;
   return (a - (2.0 * v) * b) + ((double)cnt * v) * v;
+}
+
+/* ------------------------------------------------------------------ linear response */
+/* [U] draw_leaf_value / fast_linear_fit with response = "linear": a new leaf predicts
+ *     value + slope * (x - xbar),   x = its rows' value of the PARENT's split variable,
+ * value being the constant-response leaf value (mean(sum_trees)/m + noise) and slope the OLS
+ * slope of sum_trees/m on x over the leaf's rows (0 with fewer than 3 rows or no spread).
+ * The row pass works with u = x * 2^-ex (ex: exponent bound of the column, |u| <= 1) and
+ * reduces, next to the usual sums, the fixed-point sums
+ *     q_u = sum q(u R), q_uu = sum q(u^2 R), q_us = sum q(u sum_trees), q_ur = sum q(u r)
+ * all at scale c1 (R = 2^(range_exp - 1) lifts u and u^2 to the resolution of the others). */
+typedef struct {
+  double slope_u; /* slope with respect to u            */
+  double ubar;    /* mean of u over the leaf's rows     */
+  double var_u;   /* sum (u - ubar)^2                   */
+} pgb_linfit;
+
+PGB_HD pgb_linfit pgb_lin_fit(int64_t cnt, int64_t q_u, int64_t q_uu, int64_t q_us, int64_t q_st,
+                              double inv_c1, double inv_R, double m) {
+  pgb_linfit f;
+  f.slope_u = 0.0;
+  f.ubar = 0.0;
+  f.var_u = 0.0;
+  if (cnt < 3) return f;
+  const double nn = (double)cnt;
+  const double su = ((double)q_u * inv_c1) * inv_R;
+  const double suu = ((double)q_uu * inv_c1) * inv_R;
+  const double sus = (double)q_us * inv_c1;
+  const double sst = (double)q_st * inv_c1;
+  f.ubar = su / nn;
+  const double var = suu - su * f.ubar;
+  const double cov = sus - sst * f.ubar;
+  if (!(var > 1.0e-12)) return f; /* no spread (or cancellation noise): constant leaf */
+  f.var_u = var;
+  f.slope_u = (cov / var) / m;
+  return f;
+}
+/* SSE of the leaf's rows under the linear prediction, from the constant-leaf SSE:
+ * sum (r - value - b (u - ubar))^2 = sse_const - 2 b sum r (u - ubar) + b^2 var  (sum (u - ubar) = 0) */
+PGB_HD double pgb_lin_sse(double sse_const, pgb_linfit f, int64_t q_ur, int64_t q_r, double inv_c1) {
+  const double cru = (double)q_ur * inv_c1 - f.ubar * ((double)q_r * inv_c1);
+  double sse = (sse_const - (2.0 * f.slope_u) * cru) + (f.slope_u * f.slope_u) * f.var_u;
+  return sse;
+}
+/* exponent bound of a column: smallest ex >= 0... any integer ex with max|x| <= 2^ex */
+PGB_HD int pgb_col_exponent(double amax) {
+  if (!(amax > 0.0)) return 0;
+  int e = (int)((pgb_d2u(amax) >> 52) & 0x7FF) - 1023 + 1; /* amax < 2^e */
+  if (e < -1000) e = -1000;
+  return e;
+}
+/* per-row prediction of a leaf */
+PGB_HD double pgb_leaf_pred(double value, double slope, double xbar, double x) {
+  return value + slope * (x - xbar);
 }
 
 /* Leaf value: mean of sum_trees over the leaf rows / m + noise (upstream

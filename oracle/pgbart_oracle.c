@@ -72,6 +72,8 @@ typedef struct {
   double valx[PGB_MAX_OUTPUTS - 1];    /* leaf value of outputs 1..K-1 (K-vector leaves) */
   int64_t q_stx[PGB_MAX_OUTPUTS - 1];  /* sum of sum_trees over the node rows, outputs 1..K-1 */
   int64_t ll;  /* non-Normal families: fixed-point log-likelihood of the node's rows */
+  double slope, xbar; /* linear response: the leaf predicts value + slope (x[svar] - xbar) */
+  int32_t svar;       /* ... svar = -1: constant leaf                                       */
   int64_t seg; /* arena offset of the sorted row list (oracle only) */
 } onode;
 
@@ -93,6 +95,8 @@ struct pgb_handle {
   int64_t alpha_unit;
   double max_prior;
   int* col_has_nan;
+  int* col_ex;       /* linear response: exponent bound of every column (u = x 2^-ex) */
+  double lin_R, inv_R;
   double* st; /* sum_trees n */
   double* r;  /* y - noi */
   double* oldv;
@@ -178,6 +182,12 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  if (s->response != PGB_RESPONSE_CONSTANT) {
+    if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
+      return fail(PGB_E_UNSUPPORTED, "unknown response");
+    if (s->family != PGB_FAMILY_NORMAL)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for the Normal family only");
+  }
   pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
   if (!h) return fail(PGB_E_NOMEM, "calloc");
   h->s = *s;
@@ -190,6 +200,9 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   h->alpha_vec = (int64_t*)malloc(sizeof(int64_t) * p);
   h->cdf = (int64_t*)malloc(sizeof(int64_t) * p);
   h->col_has_nan = (int*)calloc(p, sizeof(int));
+  h->col_ex = (int*)calloc(p, sizeof(int));
+  h->lin_R = pgb_pow2(s->range_exp - 1);
+  h->inv_R = pgb_pow2(1 - s->range_exp);
   h->st = (double*)malloc(sizeof(double) * n * K); /* [K][n] */
   h->r = (double*)malloc(sizeof(double) * n);
   h->oldv = (double*)malloc(sizeof(double) * n * K);
@@ -216,6 +229,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     z->left = z->right = -1;
     z->cnt = n;
     z->value = s->init_leaf;
+    z->svar = -1;
     for (int k = 1; k < K; ++k) z->valx[k - 1] = s->init_leaf;
   }
   h->leaf_sd = s->init_leaf_sd;
@@ -227,7 +241,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
 
 int pgb_destroy(pgb_handle* h) {
   if (!h) return PGB_OK;
-  free(h->X); free(h->y); free(h->rules); free(h->alpha_vec); free(h->cdf); free(h->col_has_nan);
+  free(h->X); free(h->y); free(h->rules); free(h->alpha_vec); free(h->cdf); free(h->col_has_nan); free(h->col_ex);
   free(h->st); free(h->r); free(h->oldv); free(h->rs_mean); free(h->rs_m2); free(h->trees);
   free(h->lid); free(h->part); free(h->part2); free(h->arena); free(h->vi); free(h->last_ids);
   free(h);
@@ -259,6 +273,15 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
       if (x != x) has = 1;
     }
     h->col_has_nan[j] = has;
+    double amax = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      double a = h->X[(size_t)j * n + i];
+      a = a < 0.0 ? -a : a;
+      if (a > amax) amax = a; /* NaN compares false */
+    }
+    h->col_ex[j] = pgb_col_exponent(amax);
+    if (h->s.response != PGB_RESPONSE_CONSTANT && rules[j] != PGB_RULE_CONTINUOUS)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix needs ContinuousSplit columns");
   }
   build_cdf(h);
   h->have_data = 1;
@@ -304,12 +327,24 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
       for (int o = 1; o < K; ++o) lv[o][T->nd[k].label] = T->nd[k].valx[o - 1];
     }
   const uint8_t* lid = h->lid + (size_t)tree_id * n;
+  /* linear response: label -> (slope, xbar, column) of the tree being replaced */
+  static __thread double lb[256], lx[256];
+  static __thread int lj[256];
+  for (int k = 0; k < 256; ++k) { lb[k] = 0.0; lx[k] = 0.0; lj[k] = -1; }
+  if (s->response != PGB_RESPONSE_CONSTANT)
+    for (int k = 0; k < T->n_nodes; ++k)
+      if (T->nd[k].var < 0) {
+        lb[T->nd[k].label] = T->nd[k].slope;
+        lx[T->nd[k].label] = T->nd[k].xbar;
+        lj[T->nd[k].label] = T->nd[k].svar;
+      }
   unsigned sat = 0;
   int64_t A = 0, B = 0, C = 0, E0 = 0;
   int64_t Ax[PGB_MAX_OUTPUTS - 1] = {0};
   const int normal = s->family == PGB_FAMILY_NORMAL;
   for (int64_t i = 0; i < n; ++i) {
     double o = lv[0][lid[i]];
+    if (lj[lid[i]] >= 0) o = pgb_leaf_pred(o, lb[lid[i]], lx[lid[i]], h->X[(size_t)lj[lid[i]] * n + i]);
     double noi = h->st[i] - o;
     h->oldv[i] = o;
     A += pgb_quant(h->st[i], h->sc.c1, &sat);
@@ -354,6 +389,7 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
     z->left = z->right = -1;
     z->depth = 0;
     z->label = 0;
+    z->svar = -1;
     z->cnt = n;
     z->q_st = A;
     z->q_r = B;
@@ -435,6 +471,10 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   const int normal = s->family == PGB_FAMILY_NORMAL;
   int32_t* sn = NULL; /* NaN-dropped rows (non-Normal families need their log-likelihood) */
   if (!normal && h->col_has_nan[j]) sn = (int32_t*)malloc(sizeof(int32_t) * (size_t)nd.cnt);
+  /* linear response: sums of u = x 2^-ex over the two children (see pgb_lin_fit) */
+  const int lin = s->response != PGB_RESPONSE_CONSTANT;
+  const double uscale = pgb_pow2(-h->col_ex[j]);
+  int64_t uL[4] = {0, 0, 0, 0}, uR[4] = {0, 0, 0, 0}; /* q_u, q_uu, q_us, q_ur */
   for (int64_t k = 0; k < nd.cnt; ++k) {
     int32_t i = seg[k];
     double x = xc[i];
@@ -449,8 +489,22 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     } else if (pgb_go_left(rule, x, v)) {
       sl[cL++] = i; aL += qa; bL += qb; c2L += qc;
       for (int o = 1; o < K; ++o) aLx[o - 1] += pgb_quant(h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
+      if (lin) {
+        const double uu = x * uscale;
+        uL[0] += pgb_quant(uu * h->lin_R, h->sc.c1, NULL);
+        uL[1] += pgb_quant((uu * uu) * h->lin_R, h->sc.c1, NULL);
+        uL[2] += pgb_quant(uu * h->st[i], h->sc.c1, NULL);
+        uL[3] += pgb_quant(uu * h->r[i], h->sc.c1, NULL);
+      }
     } else {
       sr[cR++] = i;
+      if (lin) {
+        const double uu = x * uscale;
+        uR[0] += pgb_quant(uu * h->lin_R, h->sc.c1, NULL);
+        uR[1] += pgb_quant((uu * uu) * h->lin_R, h->sc.c1, NULL);
+        uR[2] += pgb_quant(uu * h->st[i], h->sc.c1, NULL);
+        uR[3] += pgb_quant(uu * h->r[i], h->sc.c1, NULL);
+      }
     }
   }
   double zero_v[PGB_MAX_OUTPUTS] = {0};
@@ -521,6 +575,34 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   }
   a->sse = pgb_leaf_sse(cL, bL, c2L, a->value, h->sc.inv_c1, h->sc.inv_c2);
   b->sse = pgb_leaf_sse(cR, bR, c2R, b->value, h->sc.inv_c1, h->sc.inv_c2);
+  a->svar = b->svar = -1;
+  if (lin) { /* [U] fast_linear_fit on the split variable; "mix": a fair coin per child */
+    int linL = 1, linR = 1;
+    if (s->response == PGB_RESPONSE_MIX) {
+      pgb_u2 um = pgb_draw2(s->seed, it, round, (uint32_t)q, PGB_RNG_MIX, 0);
+      linL = um.u0 < 0.5;
+      linR = um.u1 < 0.5;
+    }
+    const double xs = pgb_pow2(h->col_ex[j]);
+    if (linL) {
+      pgb_linfit f = pgb_lin_fit(cL, uL[0], uL[1], uL[2], aL, h->sc.inv_c1, h->inv_R, (double)s->m);
+      if (f.slope_u != 0.0) {
+        a->svar = j;
+        a->slope = f.slope_u * uscale; /* per unit of x */
+        a->xbar = f.ubar * xs;
+        a->sse = pgb_lin_sse(a->sse, f, uL[3], bL, h->sc.inv_c1);
+      }
+    }
+    if (linR) {
+      pgb_linfit f = pgb_lin_fit(cR, uR[0], uR[1], uR[2], aR, h->sc.inv_c1, h->inv_R, (double)s->m);
+      if (f.slope_u != 0.0) {
+        b->svar = j;
+        b->slope = f.slope_u * uscale;
+        b->xbar = f.ubar * xs;
+        b->sse = pgb_lin_sse(b->sse, f, uR[3], bR, h->sc.inv_c1);
+      }
+    }
+  }
   T->sse_tot = ((T->sse_tot - nd.sse) + a->sse) + b->sse;
   if (!normal) {
     sl = h->arena + offL;
@@ -590,6 +672,16 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   for (int k = 0; k < 256; ++k) lv[k] = 0.0;
   for (int k = 0; k < T->n_nodes; ++k)
     if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].value;
+  static __thread double lb[256], lx[256];
+  static __thread int lj[256];
+  for (int k = 0; k < 256; ++k) { lb[k] = 0.0; lx[k] = 0.0; lj[k] = -1; }
+  if (s->response != PGB_RESPONSE_CONSTANT)
+    for (int k = 0; k < T->n_nodes; ++k)
+      if (T->nd[k].var < 0) {
+        lb[T->nd[k].label] = T->nd[k].slope;
+        lx[T->nd[k].label] = T->nd[k].xbar;
+        lj[T->nd[k].label] = T->nd[k].svar;
+      }
   /* [U] sum_trees = sum_trees_noi + new_tree.predict() */
   if (tune) h->rs_count += 1;
   unsigned sat = 0;
@@ -608,6 +700,7 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
     }
     for (int64_t i = 0; i < n; ++i) {
       double nv = lv[lid[i]];
+      if (o == 0 && lj[lid[i]] >= 0) nv = pgb_leaf_pred(nv, lb[lid[i]], lx[lid[i]], h->X[(size_t)lj[lid[i]] * n + i]);
       double noi = st[i] - ov[i];
       st[i] = noi + nv;
       if (tune) { /* [U] RunningSd.update (Welford) */
@@ -719,6 +812,12 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
       out->count[off + k] = z->cnt;
       const int K = h->s.n_outputs;
       out->value[(size_t)(off + k) * K] = z->var < 0 ? z->value : 0.0;
+      if (out->slope && out->xbar && out->svar) {
+        const int islin = z->var < 0 && h->s.response != PGB_RESPONSE_CONSTANT && z->svar >= 0;
+        out->slope[off + k] = islin ? z->slope : 0.0;
+        out->xbar[off + k] = islin ? z->xbar : 0.0;
+        out->svar[off + k] = islin ? z->svar : -1;
+      }
       for (int o = 1; o < K; ++o) out->value[(size_t)(off + k) * K + o] = z->var < 0 ? z->valx[o - 1] : 0.0;
     }
     off += T->n_nodes;
@@ -755,7 +854,14 @@ static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const doubl
   for (;;) {
     int g = base + k;
     if (T->var[g] < 0) {
-      for (int o = 0; o < K; ++o) acc[o] += w * T->value[(size_t)g * K + o];
+      double v0 = T->value[(size_t)g * K];
+      if (T->svar && T->svar[g] >= 0) { /* linear leaf; a missing / excluded regressor: the mean */
+        const int js = T->svar[g];
+        const double xs = x[js];
+        if (!excl[js] && xs == xs) v0 = pgb_leaf_pred(v0, T->slope[g], T->xbar[g], xs);
+      }
+      acc[0] += w * v0;
+      for (int o = 1; o < K; ++o) acc[o] += w * T->value[(size_t)g * K + o];
       return;
     }
     int j = T->var[g];

@@ -23,6 +23,7 @@ RULE_CONTINUOUS = 0
 RULE_ONEHOT = 1
 RULE_SUBSET = 2
 SUBSET_BITS = 52
+RESPONSES = {"constant": 0, "linear": 1, "mix": 2}
 RULES = {
     "ContinuousSplit": RULE_CONTINUOUS,
     "ContinuousSplitRule": RULE_CONTINUOUS,
@@ -81,6 +82,8 @@ class Settings(C.Structure):
         ("batch_tune", C.c_int32),
         ("batch_draw", C.c_int32),
         ("range_exp", C.c_int32),
+        ("response", C.c_int32),
+        ("reserved0", C.c_int32),
         ("seed", C.c_uint64),
         ("init_sum", C.c_double),
         ("init_leaf", C.c_double),
@@ -118,6 +121,9 @@ class TreeArraysC(C.Structure):
         ("right", C.POINTER(C.c_int32)),
         ("count", C.POINTER(C.c_int64)),
         ("value", C.POINTER(C.c_double)),
+        ("slope", C.POINTER(C.c_double)),
+        ("xbar", C.POINTER(C.c_double)),
+        ("svar", C.POINTER(C.c_int32)),
     ]
 
 

@@ -129,6 +129,17 @@ struct InitAcc {   // one 64-byte line
 enum { CMD_NOOP = 0, CMD_PARTITION = 1, CMD_INIT = 2, CMD_FINAL = 4 /* FINAL|INIT = 6 */ };
 enum { PH_IDLE = 0, PH_BEGIN = 1, PH_ROUND = 2 };
 
+// linear response: what a leaf adds to its constant value: slope * (x[svar] - xbar); svar < 0: nothing
+struct LinP {
+  double slope, xbar;
+  long long svar;
+};
+// linear response: sums of u = x 2^-ex over the left / right child of a split (see pgb_lin_fit):
+// q_u, q_uu, q_us, q_ur each
+struct AccU {
+  long long uL[4], uR[4];
+};
+
 struct Cmd {
   int32_t kind;
   int32_t tree_old, tree_new;
@@ -198,6 +209,14 @@ struct Dev {  // kernel argument block (by value)
   long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
   double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
   double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
+  // ---- linear response (Normal family, K = 1, continuous columns)
+  int32_t response, pad_resp;
+  double lin_R, inv_R;
+  const int32_t* col_ex;  // [p] exponent bound of every column
+  LinP* plin;             // [2][MAXP][MAXN]  particle leaves
+  LinP* tlin;             // [m][MAXN]        accepted trees' leaves
+  LinP* lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
+  AccU* accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
   long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
 };
@@ -394,6 +413,14 @@ __device__ __forceinline__ void build_lv(const DNode* nd, int n_nodes, double* l
     if (nd[i].var < 0) lv[nd[i].label] = nd[i].value;
   __syncthreads();
 }
+// linear response: label -> linear part of the leaf
+__device__ __forceinline__ void build_lvl(const DNode* nd, int n_nodes, const LinP* lin, LinP* lv /*[256] global*/) {
+  for (int i = threadIdx.x; i < 256; i += BT) lv[i] = LinP{0.0, 0.0, -1};
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_nodes; i += BT)
+    if (nd[i].var < 0) lv[nd[i].label] = lin[i];
+  __syncthreads();
+}
 
 
 __device__ __forceinline__ double readlane_d(double v, int lane /* wave-uniform */) {
@@ -553,6 +580,9 @@ struct Fin {  // result of finishing the pending split of an old particle (kept 
   long long aL, aR, bL, bR, c2L, c2R;
   long long llL, llR, ll_tot, ll_orph;  // Bernoulli families
   double split, vL, vR, sseL, sseR, sse_tot, sse_orph;
+  // linear response: the children's linear parts (svar < 0: constant leaf)
+  double slopeL, xbarL, slopeR, xbarR;
+  int svarL, svarR;
 };
 
 // [U] normalize + inverse-CDF pick on ONE wave, one particle per lane: lanes [first, first+cnt)
@@ -620,7 +650,7 @@ __device__ __forceinline__ int sample_var_weights(const long long* A, int p, dou
 }
 
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
-template <bool MK>
+template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
 void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias) {
   // ctrls / ias repeat S.ctrl / S.initacc as kernel arguments (see k_rows)
@@ -661,6 +691,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     Acc z;
     memset(&z, 0, sizeof z);
     S.acc[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = z;
+    if constexpr (LIN) {
+      AccU zu;
+      memset(&zu, 0, sizeof zu);
+      S.accu[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = zu;
+    }
   }
   if (tid < LL_SLOTS && S.family != PGB_FAMILY_NORMAL)
     S.accl[((size_t)par * MAXP + p) * LL_PER + tid * LL_STRIDE] = AccL{0, 0, 0, 0};
@@ -830,6 +865,41 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             f.vR = cv.vR;
             f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
             f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
+            f.svarL = f.svarR = -1;
+            f.slopeL = f.xbarL = f.slopeR = f.xbarR = 0.0;
+            if constexpr (LIN) {  // [U] fast_linear_fit on the split variable; "mix": a fair coin per child
+              long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+              for (int k = 0; k < ACC_SLOTS; ++k) {
+                const AccU t = S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER + k * ACC_STRIDE];
+                for (int i2 = 0; i2 < 4; ++i2) { ul[i2] += t.uL[i2]; ur[i2] += t.uR[i2]; }
+              }
+              bool linL = true, linR = true;
+              if (S.response == PGB_RESPONSE_MIX) {
+                const pgb_u2 um = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_MIX, 0);
+                linL = um.u0 < 0.5;
+                linR = um.u1 < 0.5;
+              }
+              const int ex = S.col_ex[j.var];
+              const double uscale = pgb_pow2(-ex), xs = pgb_pow2(ex);
+              if (linL) {
+                const pgb_linfit lf = pgb_lin_fit(cL, ul[0], ul[1], ul[2], f.aL, S.sc.inv_c1, S.inv_R, S.mdouble);
+                if (lf.slope_u != 0.0) {
+                  f.svarL = j.var;
+                  f.slopeL = lf.slope_u * uscale;
+                  f.xbarL = lf.ubar * xs;
+                  f.sseL = pgb_lin_sse(f.sseL, lf, ul[3], f.bL, S.sc.inv_c1);
+                }
+              }
+              if (linR) {
+                const pgb_linfit lf = pgb_lin_fit(cR, ur[0], ur[1], ur[2], f.aR, S.sc.inv_c1, S.inv_R, S.mdouble);
+                if (lf.slope_u != 0.0) {
+                  f.svarR = j.var;
+                  f.slopeR = lf.slope_u * uscale;
+                  f.xbarR = lf.ubar * xs;
+                  f.sseR = pgb_lin_sse(f.sseR, lf, ur[3], f.bR, S.sc.inv_c1);
+                }
+              }
+            }
             f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
             f.llR = al.llR;
             f.ll_tot = ((jl.h_ll_tot - jl.p_ll) + al.llL) + al.llR;
@@ -906,6 +976,15 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           z.cc_row = f.ccL;
         }
         me->nd[i] = z;
+      }
+      if constexpr (LIN) {  // linear parts of the leaves
+        const LinP* la = S.plin + ((size_t)par * MAXP + anc) * MAXN;
+        LinP* lm = S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN;
+        for (int i = tid; i < nn; i += BT) lm[i] = la[i];
+        if (f.ok == 1 && tid < 2) {
+          lm[nn + tid] = tid == 0 ? LinP{f.slopeL, f.xbarL, (long long)f.svarL}
+                                  : LinP{f.slopeR, f.xbarR, (long long)f.svarR};
+        }
       }
       if constexpr (MK) {  // extension outputs of the node table
         const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX, dn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX;
@@ -996,6 +1075,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         cmd->sel_slot = F.loc_slot;  // may be -1 (untouched root labels)
       }
       build_lv(me->nd, nn, cmd->lv_new);
+      if constexpr (LIN) {
+        const LinP* lm = S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN;
+        for (int i = tid; i < nn; i += BT) S.tlin[(size_t)tree_old * MAXN + i] = lm[i];
+        build_lvl(me->nd, nn, lm, S.lvl + ((size_t)par * 2 + 0) * 256);
+      }
       if constexpr (MK) {  // extension outputs: store with the tree, publish label->value tables
         const size_t pn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX, tn = (size_t)tree_old * MAXN * KX;
         for (int e = tid; e < nn * KX; e += BT) S.tvx[tn + e] = S.pvx[pn + e];
@@ -1003,6 +1087,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       }
     }
     if (b == 0) {
+      if constexpr (LIN) {
+        if (sel == 0)
+          build_lvl(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tlin + (size_t)tree_old * MAXN,
+                    S.lvl + ((size_t)par * 2 + 0) * 256);
+        if (has_init && tree_new != tree_old)
+          build_lvl(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tlin + (size_t)tree_new * MAXN,
+                    S.lvl + ((size_t)par * 2 + 1) * 256);
+      }
       if constexpr (MK) {
         if (sel == 0)
           build_lvx(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tvx + (size_t)tree_old * MAXN * KX, KX,
@@ -1058,6 +1150,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       if (tree_new == tree_old && has_init) {  // m == 1 corner: next update is this very tree
         __syncthreads();
         build_lv(snd, nn, cmd->lv_next);
+        if constexpr (LIN)
+          build_lvl(snd, nn, sel == 0 ? S.tlin + (size_t)tree_old * MAXN
+                                      : S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN,
+                    S.lvl + ((size_t)par * 2 + 1) * 256);
         if constexpr (MK)
           build_lvx(snd, nn, sel == 0 ? S.tvx + (size_t)tree_old * MAXN * KX
                                       : S.pvx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
@@ -1106,6 +1202,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     }
   } else if (begin && b == 0) {
     build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+    if constexpr (LIN)
+      build_lvl(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tlin + (size_t)tree_new * MAXN,
+                S.lvl + ((size_t)par * 2 + 1) * 256);
     if constexpr (MK)
       build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
                 S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
@@ -1136,6 +1235,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       z.cnt = (int32_t)S.n;
       z.value = S.init_leaf;
       me->nd[0] = z;
+      if constexpr (LIN) S.plin[((size_t)(par ^ 1) * MAXP + p) * MAXN] = LinP{0.0, 0.0, -1};
       if constexpr (MK)
       for (int k = 0; k < KX; ++k) {
         S.pvx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = S.init_leaf;
@@ -1420,18 +1520,23 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   long long src;   // byte offset of the source labels in S.lid, -1: implicit root labels
   long long xoff;  // element offset of the split column in S.XT
   double v;
+  double uscale;  // linear response: 2^-ex of the split column
   int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
 };
 
-template <bool SUB, bool NORMAL>
-__global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
+// LIN: linear response (Normal family only): leaves predict value + slope (x[svar] - xbar); the
+// partition additionally reduces the sums pgb_lin_fit needs for both children.
+template <bool SUB, bool NORMAL, bool LIN>
+__global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
                                                               const Cmd* __restrict__ cmds,
                                                               const Job* __restrict__ jobs_all) {
   // cmds / jobs_all repeat S.cmd / S.jobs as kernel arguments: their first loads then do not wait
   // for the load of the argument block S itself (one dependent memory round trip less)
   const Dev& S = *Sp;
-  __shared__ long long s_red[MAXP * 7 * 4];
+  constexpr int NRED = LIN ? 15 : 7;  // values reduced per particle
+  __shared__ long long s_red[MAXP * NRED * 4];
   __shared__ double s_lv[2][256];
+  __shared__ LinP s_ll[LIN ? 2 : 1][LIN ? 256 : 1];  // label -> linear part: [0 new | 1 next]
   __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
   const Cmd* cmd = &cmds[par];
@@ -1447,6 +1552,10 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
     for (int i = tid; i < 256; i += BT) {
       s_lv[0][i] = cmd->lv_new[i];
       s_lv[1][i] = cmd->lv_next[i];
+      if constexpr (LIN) {
+        s_ll[0][i] = S.lvl[((size_t)par * 2 + 0) * 256 + i];
+        s_ll[1][i] = S.lvl[((size_t)par * 2 + 1) * 256 + i];
+      }
     }
   }
   uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
@@ -1484,6 +1593,8 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
         rj.v = j.v;
         rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
         rj.xoff = (long long)((size_t)j.var * S.n_pad);
+        rj.uscale = 1.0;
+        if constexpr (LIN) rj.uscale = j.active ? pgb_pow2(-S.col_ex[j.var]) : 1.0;
         s_job[k] = rj;
       }
       if (tid == 0) s_n[0] = __popcll(m);
@@ -1510,6 +1621,9 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
       const long long base = (long long)chunk * CH + tid * RPT;
       // rows of this thread: {sum_trees, r} quantised once, reused for every particle of the group
       long long qa[RPT], qb[RPT], qc[RPT];
+      double strow[RPT], rrow[RPT];  // linear response: the unquantised {sum_trees, r} of the rows
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) strow[e] = rrow[e] = 0.0;
       if (do_init) {
         // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
         // residuals (INIT) on the fly; the first group of each chunk also writes them back
@@ -1556,7 +1670,11 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           double st = st4[e];  // sum_trees at a step boundary, sum_trees_noi inside an update
           if (do_final) {
             // [U] sum_trees = sum_trees_noi + new_tree.predict()
-            const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+            double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+            if constexpr (LIN) {
+              const LinP lp = s_ll[0][(ids_sel >> (8 * e)) & 255u];
+              if (lp.svar >= 0) nv = pgb_leaf_pred(nv, lp.slope, lp.xbar, XT[(size_t)lp.svar * n_pad + row]);
+            }
             st = st + nv;
             if (cmd->tune && writer) {  // [U] RunningSd.update (Welford)
               const double mean0 = mean4[e], m20 = m24[e];
@@ -1570,7 +1688,11 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
             }
           }
           // [U] sum_trees_noi = sum_trees - old_tree.predict()
-          const double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+          double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+          if constexpr (LIN) {
+            const LinP lp = s_ll[1][(ids_next >> (8 * e)) & 255u];
+            if (lp.svar >= 0) o = pgb_leaf_pred(o, lp.slope, lp.xbar, XT[(size_t)lp.svar * n_pad + row]);
+          }
           const double noi = st - o;
           const double yv = y4[e];
           const double r = normal ? yv - noi : 0.0;  // Bernoulli families: no residual algebra
@@ -1578,6 +1700,8 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           qa[e] = pgb_quant(st, c1, &sat1);
           qb[e] = pgb_quant(r, c1, &sat1);
           qc[e] = pgb_quant(r * r, c2, &sat1);
+          strow[e] = st;
+          rrow[e] = r;
           if (writer) {  // saturation is counted where the values are produced, once
             S.pack[row] = make_double2(st, r);
             st_out[row] = noi;
@@ -1599,6 +1723,8 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
           const double2 sr = S.pack[base + e];
+          strow[e] = sr.x;
+          rrow[e] = sr.y;
           qa[e] = pgb_quant(sr.x, c1, nullptr);
           qb[e] = pgb_quant(sr.y, c1, nullptr);
           qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
@@ -1643,7 +1769,7 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           continue;
         }
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
-        const int slot = (g - g0) * 7;
+        const int slot = (g - g0) * NRED;
         if (!rj.check_nan) {  // common case: the split column has no missing values
           long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
@@ -1686,14 +1812,44 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
           if (lane < 4) s_red[(slot + lane) * 4 + w] = ta;
           else if (lane < 7) s_red[(slot + lane) * 4 + w] = tb;  // lane 4..6: value (lane & 3) of the second set
         }
+        if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit)
+          long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            const double xv = x[e];
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label && xv == xv) {
+              const double uu = xv * rj.uscale;
+              const long long q0 = pgb_quant(uu * S.lin_R, c1, nullptr);
+              const long long q1 = pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
+              const long long q2 = pgb_quant(uu * strow[e], c1, nullptr);
+              const long long q3 = pgb_quant(uu * rrow[e], c1, nullptr);
+              const bool gl = go_left_t<SUB>(rj.rule, xv, rj.v);
+              ul[0] += gl ? q0 : 0; ul[1] += gl ? q1 : 0; ul[2] += gl ? q2 : 0; ul[3] += gl ? q3 : 0;
+              ur[0] += gl ? 0 : q0; ur[1] += gl ? 0 : q1; ur[2] += gl ? 0 : q2; ur[3] += gl ? 0 : q3;
+            }
+          }
+          const long long tl = wave_sum4(ul[0], ul[1], ul[2], ul[3]);
+          const long long tr = wave_sum4(ur[0], ur[1], ur[2], ur[3]);
+          if (lane < 4) {
+            s_red[(slot + 7 + lane) * 4 + w] = tl;
+            s_red[(slot + 11 + lane) * 4 + w] = tr;
+          }
+        }
       }
       __syncthreads();
       // one thread per (particle of the group, statistic): combine the 4 waves, publish
-      for (int t = tid; t < (g1 - g0) * 7; t += BT) {
-        const int gi = t / 7, i = t % 7;
+      for (int t = tid; t < (g1 - g0) * NRED; t += BT) {
+        const int gi = t / NRED, i = t % NRED;
         const RJob& rj = s_job[g0 + gi];
-        if (!rj.active || (i >= 4 && !rj.check_nan)) continue;
+        if (!rj.active || (i >= 4 && i < 7 && !rj.check_nan)) continue;
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        if constexpr (LIN) {
+          if (i >= 7) {
+            AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+            if (s != 0) atomicAdd((unsigned long long*)(i < 11 ? &au->uL[i - 7] : &au->uR[i - 11]), (unsigned long long)s);
+            continue;
+          }
+        }
         Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
@@ -1740,7 +1896,11 @@ __global__ __launch_bounds__(BT, NORMAL ? 3 : 2) void k_rows(const Dev* __restri
       tl_old[row] = (uint8_t)id_sel;
     }
     // [U] sum_trees = sum_trees_noi + new_tree.predict()
-    const double nv = s_lv[0][id_sel];
+    double nv = s_lv[0][id_sel];
+    if constexpr (LIN) {
+      const LinP lp = s_ll[0][id_sel];
+      if (lp.svar >= 0) nv = pgb_leaf_pred(nv, lp.slope, lp.xbar, S.XT[(size_t)lp.svar * S.n_pad + row]);
+    }
     st = st + nv;
     if (cmd->tune) {  // [U] RunningSd.update (Welford)
       const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
@@ -2321,6 +2481,29 @@ __global__ __launch_bounds__(BT) void k_transpose(const double* __restrict__ X, 
   }
 }
 
+__global__ void k_init_linp(LinP* p, long long n) {  // constant leaves everywhere
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = LinP{0.0, 0.0, -1};
+}
+// per-column max |x| (NaN ignored) of the column-major copy: one workgroup per column
+__global__ __launch_bounds__(BT) void k_colmax(const double* __restrict__ XT, long long n, long long n_pad,
+                                               double* __restrict__ amax) {
+  __shared__ double sm[BT];
+  const double* c = XT + (size_t)blockIdx.x * n_pad;
+  double a = 0.0;
+  for (long long i = threadIdx.x; i < n; i += BT) {
+    double v = c[i];
+    v = v < 0.0 ? -v : v;
+    if (v > a) a = v;
+  }
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = BT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o && sm[threadIdx.x + o] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) amax[blockIdx.x] = sm[0];
+}
 __global__ void k_fill_f64(double* a, long long n, double v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -2372,6 +2555,10 @@ struct PredTrees {
   const int32_t* right;
   const long long* count;
   const double* value;
+  // linear leaves (svar == nullptr: none)
+  const double* slope;
+  const double* xbar;
+  const int32_t* svar;
 };
 
 __global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* forest_idx, int n_forests,
@@ -2401,7 +2588,16 @@ __global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* fore
         const int g = base + k;
         const int j = T.var[g];
         if (j < 0) {
-          for (int o = 0; o < K; ++o) acc[o] += w * T.value[(size_t)g * K + o];
+          double v0 = T.value[(size_t)g * K];
+          if (T.svar != nullptr) {  // linear leaf; a missing / excluded regressor: the mean
+            const int js = T.svar[g];
+            if (js >= 0) {
+              const double xs = x[js];
+              if (!excl[js] && xs == xs) v0 = pgb_leaf_pred(v0, T.slope[g], T.xbar[g], xs);
+            }
+          }
+          acc[0] += w * v0;
+          for (int o = 1; o < K; ++o) acc[o] += w * T.value[(size_t)g * K + o];
           break;
         }
         const double xv = x[j];
@@ -2508,6 +2704,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  if (s->response != PGB_RESPONSE_CONSTANT) {
+    if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
+      return fail(PGB_E_UNSUPPORTED, "unknown response");
+    if (s->family != PGB_FAMILY_NORMAL)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for the Normal family only");
+  }
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
   if (e0 != hipSuccess || ndev < 1) {
@@ -2542,6 +2744,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.P = s->num_particles;
   d.family = s->family;
   d.K = s->n_outputs;
+  d.response = s->response;
+  d.lin_R = pgb_pow2(s->range_exp - 1);
+  d.inv_R = pgb_pow2(1 - s->range_exp);
   d.rows_target = ROWS_TARGET_ITEMS;
   d.rows_target_init = ROWS_TARGET_ITEMS_INIT;
   if (const char* e = getenv("PGB_ROWS_TARGET")) d.rows_target = atoi(e) > 0 ? atoi(e) : d.rows_target;
@@ -2602,6 +2807,15 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(prior_leaf, PGB_MAX_DEPTH);
   DA(rules, d.p);
   DA(col_nan, d.p);
+  int32_t* col_ex;
+  DA(col_ex, d.p);
+  d.col_ex = col_ex;
+  if (d.response != PGB_RESPONSE_CONSTANT) {
+    DA(d.plin, (size_t)2 * MAXP * MAXN);
+    DA(d.tlin, (size_t)d.m * MAXN);
+    DA(d.lvl, (size_t)2 * 2 * 256);
+    DA(d.accu, (size_t)2 * MAXP * ACC_PER);
+  }
 #undef DA
   d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
   d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha = alpha; d.cdfS = cdfS;
@@ -2663,6 +2877,14 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
   HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
   HC(hipMemsetAsync(col_nan, 0, d.p * sizeof(int32_t), sm));
+  HC(hipMemsetAsync(col_ex, 0, d.p * sizeof(int32_t), sm));
+  if (d.response != PGB_RESPONSE_CONSTANT) {
+    const long long n1 = (long long)2 * MAXP * MAXN, n2 = (long long)d.m * MAXN, n3 = 2 * 2 * 256;
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, sm, d.plin, n1);
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, sm, d.tlin, n2);
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, sm, d.lvl, n3);
+    HC(hipMemsetAsync(d.accu, 0, (size_t)2 * MAXP * ACC_PER * sizeof(AccU), sm));
+  }
   Ctrl c0;
   memset(&c0, 0, sizeof c0);
   c0.phase = PH_IDLE;
@@ -2707,6 +2929,8 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
     if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
     if (split_prior_host[j] > mx) mx = split_prior_host[j];
+    if (d.response != PGB_RESPONSE_CONSTANT && rules_host[j] != PGB_RULE_CONTINUOUS)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix needs ContinuousSplit columns");
   }
   d.max_prior = mx;
   d.alpha_unit = pgb_alpha_unit(mx);
@@ -2726,6 +2950,19 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   }
   hipLaunchKernelGGL(k_init_alpha, dim3(1), dim3(64), 0, sm, prior_stage ? prior_stage : d.rs_mean, mx,
                      d.alpha, d.cdfS, d.p);
+  if (d.response != PGB_RESPONSE_CONSTANT) {  // exponent bound of every column (u = x 2^-ex)
+    double* amax_dev = nullptr;
+    HIPCHK(hipMalloc((void**)&amax_dev, d.p * sizeof(double)));
+    hipLaunchKernelGGL(k_colmax, dim3((unsigned)d.p), dim3(BT), 0, sm, d.XT, d.n, d.n_pad, amax_dev);
+    std::vector<double> amax(d.p);
+    HIPCHK(hipMemcpyAsync(amax.data(), amax_dev, d.p * sizeof(double), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+    (void)hipFree(amax_dev);
+    std::vector<int32_t> ex(d.p);
+    for (int j = 0; j < d.p; ++j) ex[j] = pgb_col_exponent(amax[j]);
+    HIPCHK(hipMemcpyAsync((void*)d.col_ex, ex.data(), d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+  }
   HIPCHK(hipMemsetAsync(d.rs_mean, 0, d.n_pad * sizeof(double), sm));
   HIPCHK(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));  // alpha_unit, max_prior
   HIPCHK(hipGetLastError());
@@ -2764,9 +3001,12 @@ static int enqueue_slots(pgb_handle* h, int count) {
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
     if (d.K > 1)
-      hipLaunchKernelGGL(k_ctrl<true>, gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+      hipLaunchKernelGGL((k_ctrl<true, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
     else
-      hipLaunchKernelGGL(k_ctrl<false>, gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+      if (d.response != PGB_RESPONSE_CONSTANT)
+        hipLaunchKernelGGL((k_ctrl<false, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+      else
+        hipLaunchKernelGGL((k_ctrl<false, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
       if (h->ev_used + 2 > h->ev.size()) {
@@ -2799,12 +3039,14 @@ static int enqueue_slots(pgb_handle* h, int count) {
       LAUNCH_ROWS(k_rows_mk<0>);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
-      if (h->has_subset) {
-        if (nrm) LAUNCH_ROWS((k_rows<true, true>), ROWS_PTRS);
-        else LAUNCH_ROWS((k_rows<true, false>), ROWS_PTRS);
+      if (d.response != PGB_RESPONSE_CONSTANT) {
+        LAUNCH_ROWS((k_rows<false, true, true>), ROWS_PTRS);
+      } else if (h->has_subset) {
+        if (nrm) LAUNCH_ROWS((k_rows<true, true, false>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<true, false, false>), ROWS_PTRS);
       } else {
-        if (nrm) LAUNCH_ROWS((k_rows<false, true>), ROWS_PTRS);
-        else LAUNCH_ROWS((k_rows<false, false>), ROWS_PTRS);
+        if (nrm) LAUNCH_ROWS((k_rows<false, true, false>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<false, false, false>), ROWS_PTRS);
       }
     }
 #undef LAUNCH_ROWS
@@ -2958,6 +3200,12 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
                      hipMemcpyDeviceToHost));
   }
   if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
+  std::vector<LinP> hl;
+  const bool want_lin = out->slope && out->xbar && out->svar;
+  if (want_lin && d.response != PGB_RESPONSE_CONSTANT && nt > 0) {
+    hl.resize((size_t)nt * MAXN);
+    HIPCHK(hipMemcpy(hl.data(), d.tlin + (size_t)first * MAXN, hl.size() * sizeof(LinP), hipMemcpyDeviceToHost));
+  }
   int off = 0;
   for (int t = 0; t < nt; ++t) {
     const DTree& T = host[t];
@@ -2971,6 +3219,12 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
       out->right[off + k] = z.var >= 0 ? (int32_t)z.right : -1;
       out->count[off + k] = z.cnt;
       out->value[(size_t)(off + k) * K] = z.var < 0 ? z.value : 0.0;
+      if (want_lin) {
+        const bool islin = z.var < 0 && !hl.empty() && hl[(size_t)t * MAXN + k].svar >= 0;
+        out->slope[off + k] = islin ? hl[(size_t)t * MAXN + k].slope : 0.0;
+        out->xbar[off + k] = islin ? hl[(size_t)t * MAXN + k].xbar : 0.0;
+        out->svar[off + k] = islin ? (int32_t)hl[(size_t)t * MAXN + k].svar : -1;
+      }
       for (int o = 1; o < K; ++o)
         out->value[(size_t)(off + k) * K + o] = z.var < 0 ? hx[((size_t)t * MAXN + k) * KX + o - 1] : 0.0;
     }
@@ -3045,7 +3299,10 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   // one upload buffer: [node_off | var | left | right | rules | fidx] int32, then 8-byte arrays
   size_t n_i32 = (size_t)(NT + 1) + 3 * (size_t)N + p + (size_t)n_forests * m;
   size_t off8 = ((n_i32 * 4 + 7) / 8) * 8;
-  size_t bytes = off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p;
+  const bool lin = trees->slope && trees->xbar && trees->svar;
+  // ... then, for linear leaves, slope / xbar (8-byte) and svar (int32) after the exclusion flags
+  const size_t off_lin = ((off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p + 7) / 8) * 8;
+  size_t bytes = lin ? off_lin + (size_t)N * 20 : off8 + (size_t)N * 16 + (size_t)N * K * 8 + p;
   std::vector<uint8_t> hb(bytes);
   int32_t* hi = (int32_t*)hb.data();
   size_t o = 0;
@@ -3060,6 +3317,11 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   memcpy(h8 + (size_t)N * 8, trees->count, (size_t)N * 8);
   memcpy(h8 + (size_t)N * 16, trees->value, (size_t)N * K * 8);
   memcpy(h8 + (size_t)N * 16 + (size_t)N * K * 8, excl.data(), p);
+  if (lin) {
+    memcpy(hb.data() + off_lin, trees->slope, (size_t)N * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * 8, trees->xbar, (size_t)N * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * 16, trees->svar, (size_t)N * 4);
+  }
   uint8_t* db = nullptr;
   HIPCHK(hipMalloc((void**)&db, bytes));
   hipError_t e = hipMemcpyAsync(db, hb.data(), bytes, hipMemcpyHostToDevice, sm);
@@ -3073,6 +3335,9 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   T.split = (const double*)(db + off8);
   T.count = (const long long*)(db + off8 + (size_t)N * 8);
   T.value = (const double*)(db + off8 + (size_t)N * 16);
+  T.slope = lin ? (const double*)(db + off_lin) : nullptr;
+  T.xbar = lin ? (const double*)(db + off_lin + (size_t)N * 8) : nullptr;
+  T.svar = lin ? (const int32_t*)(db + off_lin + (size_t)N * 16) : nullptr;
   const uint8_t* dexcl = db + off8 + (size_t)N * 16 + (size_t)N * K * 8;
   dim3 grid((unsigned)((n_rows + BT - 1) / BT), (unsigned)n_forests);
   hipLaunchKernelGGL(k_predict, grid, dim3(BT), 0, sm, T, di + o_f, n_forests, m, K, X_dev,

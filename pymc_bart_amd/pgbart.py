@@ -36,11 +36,13 @@ class BARTOp:
 
     def __init__(self, X, Y, m=50, alpha=0.95, beta=2.0, response="constant", split_rules=None,
                  split_prior=None, name="mu", all_trees=None):
-        if response != "constant":
-            raise NotImplementedError(
-                "response='linear'/'mix' are experimental upstream (bart.py:128-132) and not "
-                "implemented by the MI355X backend"
-            )
+        if response not in ("constant", "linear", "mix"):
+            raise ValueError("response must be 'constant', 'linear' or 'mix'")
+        if response != "constant":  # same caveat as the reference (bart.py:128-132)
+            import warnings
+
+            warnings.warn(f"response={response!r} is experimental (upstream flags it the same way); "
+                          "check the fit before relying on it", stacklevel=2)
         self.name = name
         self.X = np.asarray(X, dtype=float)
         self.Y = np.asarray(Y, dtype=float)
@@ -152,8 +154,9 @@ class PGBART(_Base):
             raise ValueError("X must be 2-dimensional")
         self.num_observations, self.num_variates = X.shape
         self.m = int(op.m)
-        if getattr(op, "response", "constant") != "constant":
-            raise NotImplementedError("only response='constant' is implemented")
+        self.response = getattr(op, "response", "constant")
+        if self.response not in ("constant", "linear", "mix"):
+            raise ValueError("response must be 'constant', 'linear' or 'mix'")
         split_prior = np.asarray(getattr(op, "split_prior", np.array([])), dtype=np.float64)
         if split_prior.size == 0:  # bart.py:139 -> all covariates equally likely
             split_prior = np.ones(self.num_variates)
@@ -190,7 +193,7 @@ class PGBART(_Base):
         self.settings = PyBartSettings.from_data(
             X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
             family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
-            batch=batch, seed=seed,
+            batch=batch, seed=seed, response=self.response,
         )
         self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
         self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)

@@ -100,11 +100,12 @@ class PyBartSettings:
     init_leaf: float = 0.0
     init_leaf_sd: float = 1.0
     range_exp: int = 4
+    response: str = "constant"
     prior_leaf: np.ndarray = field(default_factory=lambda: np.ones(_abi.MAX_DEPTH))
 
     @classmethod
     def from_data(cls, X, Y, m=50, num_particles=10, n_outputs=1, family="normal", alpha=0.95,
-                  beta=2.0, batch=(0.1, 0.1), seed=0) -> "PyBartSettings":
+                  beta=2.0, batch=(0.1, 0.1), seed=0, response="constant") -> "PyBartSettings":
         Y = np.asarray(Y, np.float64)
         n, p = X.shape
         mean = float(Y.mean())
@@ -117,7 +118,7 @@ class PyBartSettings:
         return cls(
             n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
             alpha=alpha, beta=beta, batch=tuple(batch), seed=int(seed), init_sum=mean,
-            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=rexp,
+            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=rexp, response=response,
             prior_leaf=prior_leaf_table(alpha, beta),
         )
 
@@ -136,6 +137,7 @@ class PyBartSettings:
         s.family = _abi.FAMILIES[self.family]
         s.batch_tune, s.batch_draw = self.batch_sizes()
         s.range_exp = self.range_exp
+        s.response = _abi.RESPONSES[self.response]
         s.seed = self.seed & 0xFFFFFFFFFFFFFFFF
         s.init_sum = self.init_sum
         s.init_leaf = self.init_leaf

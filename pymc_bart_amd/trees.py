@@ -32,6 +32,19 @@ class TreeArrays:
     right: np.ndarray     # int32 [nodes]
     count: np.ndarray     # int64 [nodes]
     value: np.ndarray     # float64 [nodes, n_outputs]
+    # linear response: a leaf predicts value + slope * (x[svar] - xbar); svar = -1: constant leaf
+    slope: np.ndarray = None  # float64 [nodes]
+    xbar: np.ndarray = None   # float64 [nodes]
+    svar: np.ndarray = None   # int32 [nodes]
+
+    def __post_init__(self):
+        nn = int(np.asarray(self.var).shape[0])
+        if self.slope is None:
+            self.slope = np.zeros(nn, np.float64)
+        if self.xbar is None:
+            self.xbar = np.zeros(nn, np.float64)
+        if self.svar is None:
+            self.svar = np.full(nn, -1, np.int32)
 
     @property
     def n_trees(self) -> int:
@@ -53,6 +66,9 @@ class TreeArrays:
             right=np.zeros(total_nodes, np.int32),
             count=np.zeros(total_nodes, np.int64),
             value=np.zeros((total_nodes, n_outputs), np.float64),
+            slope=np.zeros(total_nodes, np.float64),
+            xbar=np.zeros(total_nodes, np.float64),
+            svar=np.full(total_nodes, -1, np.int32),
         )
 
     def as_c(self) -> _abi.TreeArraysC:
@@ -68,6 +84,9 @@ class TreeArrays:
         c.right = _abi._ptr(self.right, C.c_int32)
         c.count = _abi._ptr(self.count, C.c_int64)
         c.value = _abi._ptr(self.value, C.c_double)
+        c.slope = _abi._ptr(self.slope, C.c_double)
+        c.xbar = _abi._ptr(self.xbar, C.c_double)
+        c.svar = _abi._ptr(self.svar, C.c_int32)
         return c
 
     def split_variables(self, t: int) -> np.ndarray:
@@ -94,10 +113,13 @@ class TreeArrays:
             right=np.concatenate([p.right for p in parts]).astype(np.int32),
             count=np.concatenate([p.count for p in parts]).astype(np.int64),
             value=np.concatenate([p.value for p in parts], axis=0),
+            slope=np.concatenate([p.slope for p in parts]).astype(np.float64),
+            xbar=np.concatenate([p.xbar for p in parts]).astype(np.float64),
+            svar=np.concatenate([p.svar for p in parts]).astype(np.int32),
         )
 
 
-_HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value")
+_HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "slope", "xbar", "svar")
 
 
 def save_history(path, all_trees, m: int, rules=None) -> None:
@@ -142,6 +164,8 @@ def load_history(path):
                 left=arrs["left"][a:b].astype(np.int32), right=arrs["right"][a:b].astype(np.int32),
                 count=arrs["count"][a:b].astype(np.int64),
                 value=arrs["value"][a:b].reshape(b - a, K).astype(np.float64),
+                slope=arrs["slope"][a:b].astype(np.float64), xbar=arrs["xbar"][a:b].astype(np.float64),
+                svar=arrs["svar"][a:b].astype(np.int32),
             ))
             t0 += nt
         all_trees.append((forests[0], forests[1:]))
@@ -182,7 +206,11 @@ def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rule
                 go_left = bool((int(trees.split[g]) >> code) & 1)
             k = trees.left[g] if go_left else trees.right[g]
             g = base + k
-        acc += w * trees.value[g]
+        leaf = np.array(trees.value[g], dtype=np.float64)
+        js = int(trees.svar[g])
+        if js >= 0 and not excl[js] and not np.isnan(x[js]):  # linear leaf (a missing regressor: the mean)
+            leaf[0] = leaf[0] + trees.slope[g] * (x[js] - trees.xbar[g])
+        acc += w * leaf
 
     for d in range(forest_idx.shape[0]):
         for i in range(n_rows):

@@ -97,6 +97,14 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=8, P=10, steps=20, family="categorical", K=K)
+    elif name in ("linear_response", "mix_response"):  # reference tests parametrise response=["constant","linear"]
+        n, p = 3000, 4
+        X = rng.uniform(-2, 2, size=(n, p))
+        X[:, 3] = np.round(X[:, 3])            # ties
+        X[rng.random(n) < 0.1, 1] = np.nan     # missing values in a regressor
+        f = np.where(X[:, 0] < 0, 2 * X[:, 0] + 1, -1.5 * X[:, 0] + 1) + 0.5 * np.nan_to_num(X[:, 1])
+        Y = f + rng.normal(0, 0.1, n)
+        c.update(m=8, P=12, steps=30, response="linear" if name == "linear_response" else "mix")
     elif name == "meanscale_k2_reference":  # reference tests/test_bart.py:107-123 (shape=(2, 250))
         n, p = 250, 3
         X = rng.normal(0, 1, size=(n, p))
@@ -131,7 +139,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -143,7 +151,7 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
     family = c.get("family", "normal")
     st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
                                   alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family,
-                                  n_outputs=c.get("K", 1))
+                                  n_outputs=c.get("K", 1), response=c.get("response", "constant"))
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
     prior = np.ones(p) if c["prior"] is None else c["prior"]
     s = PySampler(st, X, Y, rules, prior, backend=backend)
@@ -163,8 +171,11 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
             sums.append(stv)
             vis.append(vi)
             ta = s.export_trees(0)
-            trees.append(np.concatenate([ta.tree_id, ta.node_off, ta.var, ta.left, ta.right,
-                                         ta.count, ta.split.view(np.int64), ta.value.ravel().view(np.int64)]))
+            parts = [ta.tree_id, ta.node_off, ta.var, ta.left, ta.right, ta.count, ta.split.view(np.int64),
+                     ta.value.ravel().view(np.int64)]
+            if c.get("response", "constant") != "constant":  # linear leaves are part of the fingerprint
+                parts += [ta.slope.view(np.int64), ta.xbar.view(np.int64), ta.svar]
+            trees.append(np.concatenate(parts))
     forest = s.export_trees(1)
     ctr = s.counters.as_dict()
     ctr.pop("slots")
@@ -225,6 +236,9 @@ def random_case(seed):
     else:
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
-    return dict(name=f"fuzz{seed}", X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
+    response = "constant"
+    if fam == "normal" and not rules.any():  # linear / mix need the Normal family and continuous columns
+        response = str(rng.choice(["constant", "linear", "mix"]))
+    return dict(name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

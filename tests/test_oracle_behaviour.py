@@ -219,8 +219,8 @@ def test_error_paths(oracle):
     s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
     with pytest.raises(_abi.PGBError, match="sigma"):
         s.set_likelihood([-1.0])
-    with pytest.raises(NotImplementedError):
-        BARTOp(X, Y, response="linear")
+    with pytest.raises(ValueError):
+        BARTOp(X, Y, response="quadratic")
     with pytest.raises(NotImplementedError):
         PGBART([BARTOp(X, Y, split_rules=["NoSuchSplit", "ContinuousSplit"])], backend=oracle)
     with pytest.raises(_abi.PGBError, match="unknown split rule"):
@@ -569,3 +569,64 @@ def test_tree_history_round_trips_through_a_file(oracle, tmp_path):
     with pytest.raises(ValueError):
         np.savez(tmp_path / "bad.npz", format=np.array("x"))
         load_history(tmp_path / "bad.npz")
+
+
+@pytest.mark.parametrize("response", ["linear", "mix"])
+def test_linear_response_fits_slopes_and_stays_consistent(oracle, response):
+    # reference tests parametrise response=["constant", "linear"] (tests/test_bart.py:44-123); leaves
+    # then predict value + slope * (x[split variable of the parent] - xbar)  ([U] fast_linear_fit)
+    rng = np.random.default_rng(0)
+    n = 600
+    X = rng.uniform(-2, 2, size=(n, 3))
+    f = np.where(X[:, 0] < 0, 2 * X[:, 0] + 1, -1.5 * X[:, 0] + 1) + 0.5 * X[:, 1]
+    Y = f + rng.normal(0, 0.1, n)
+
+    def run(resp):
+        st = PyBartSettings.from_data(X, Y, m=10, num_particles=10, seed=3, response=resp)
+        s = PySampler(st, X, Y, np.zeros(3, np.int32), np.ones(3), backend=oracle)
+        s.set_likelihood([0.1])
+        for it in range(120):
+            mu, _ = s.step(it < 60)
+        return s, mu
+
+    s, mu = run(response)
+    _, mu_const = run("constant")
+    rmse = lambda a: float(np.sqrt(np.mean((a - f) ** 2)))  # noqa: E731
+    assert rmse(mu) < 0.9 * rmse(mu_const)        # piecewise-linear target: slopes help
+    forest = s.export_trees(1)
+    leaves = forest.var < 0
+    assert (forest.svar[leaves] >= 0).sum() > 5 and np.all(forest.svar[~leaves] == -1)
+    assert np.all(forest.slope[forest.svar < 0] == 0.0)
+    # the running sum is the sum of the stored trees evaluated WITH their linear parts ...
+    rules = np.zeros(3, np.int32)
+    pred = predict_numpy(forest, np.arange(10)[None, :], X, rules)[0, 0]
+    np.testing.assert_allclose(pred, mu, rtol=0, atol=1e-9)
+    # ... and the prediction entry point agrees with the host restatement, incl. excluded / missing
+    ps = PosteriorSampler(forest, np.arange(10, dtype=np.int32)[None, :], 10, 1, rules, backend=oracle)
+    np.testing.assert_allclose(ps.sample_posterior(X, [0])[0, 0], pred, atol=1e-12)
+    Xn = X[:50].copy()
+    Xn[::3, 0] = np.nan
+    np.testing.assert_allclose(ps.sample_posterior(Xn, [0], excluded=[1])[0, 0],
+                               predict_numpy(forest, np.arange(10)[None, :], Xn, rules, excluded=[1])[0, 0],
+                               atol=1e-12)
+    assert s.counters.saturations == 0
+
+
+def test_linear_response_through_the_step_method_and_its_limits(oracle):
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(200, 2))
+    Y = 1.5 * X[:, 0] + rng.normal(0, 0.2, 200)
+    op = BARTOp(X, Y, m=5, response="linear")
+    res = sample_chain(op, tune=40, draws=10, random_seed=2, backend=oracle)
+    base, batches = res["history"]
+    assert any((ta.svar >= 0).any() for ta in [base] + batches)
+    ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
+    np.testing.assert_allclose(ps.sample_posterior(X, list(range(10)))[:, 0, :], res["mu"], rtol=0, atol=1e-9)
+    assert res["vi_counts"].sum(axis=0)[0] > res["vi_counts"].sum(axis=0)[1]
+    # not every combination exists: categorical rules and non-Normal families are rejected
+    with pytest.raises(_abi.PGBError, match="ContinuousSplit"):
+        PGBART([BARTOp(X, Y, m=2, response="linear", split_rules=["OneHotSplit", "ContinuousSplit"])], backend=oracle)
+    st = PyBartSettings.from_data(X, (Y > 0).astype(float), m=2, num_particles=4, family="bernoulli_probit",
+                                  response="linear")
+    with pytest.raises(_abi.PGBError, match="Normal family"):
+        PySampler(st, X, (Y > 0).astype(float), np.zeros(2, np.int32), np.ones(2), backend=oracle)

@@ -322,3 +322,26 @@ def test_fuzz_parity_over_random_configurations(hip, oracle):
         c = random_case(seed)
         g, o = digest(run_case(c, hip)), digest(run_case(c, oracle))
         assert g == o, (seed, c["family"], c["X"].shape, c["m"], c["P"], c["K"], c["rules"].tolist())
+
+
+def test_linear_leaves_predict_the_same_on_gpu_and_host(hip, oracle):
+    """response="linear": the chain, its exported slopes and the prediction kernel (with excluded and
+    missing regressors) agree with the oracle / the host restatement."""
+    rng = np.random.default_rng(12)
+    X = rng.uniform(-2, 2, size=(5000, 4))
+    X[rng.random(5000) < 0.05, 2] = np.nan
+    Y = np.where(X[:, 0] < 0, 2 * X[:, 0], -X[:, 0]) + 0.3 * X[:, 1] + rng.normal(0, 0.1, 5000)
+    res = {}
+    for name, be in (("hip", hip), ("oracle", oracle)):
+        op = BARTOp(X, Y, m=12, response="linear")
+        r = sample_chain(op, tune=20, draws=6, num_particles=12, random_seed=4, sigma=0.2, backend=be)
+        s = _get_posterior_sampler(op, backend=be)
+        Xn = X[:300].copy()
+        Xn[::5, 0] = np.nan
+        res[name] = (r["mu"], _sample_posterior(s, Xn, np.random.default_rng(1), size=4, excluded=[1]), r["history"])
+    assert np.array_equal(res["hip"][0], res["oracle"][0])
+    np.testing.assert_allclose(res["hip"][1], res["oracle"][1], rtol=0, atol=1e-12)
+    base, batches = res["hip"][2]
+    assert any((ta.svar >= 0).any() for ta in [base] + batches)
+    for a, b in zip([base] + batches, [res["oracle"][2][0]] + res["oracle"][2][1]):
+        assert np.array_equal(a.slope, b.slope) and np.array_equal(a.xbar, b.xbar) and np.array_equal(a.svar, b.svar)
