@@ -22,13 +22,16 @@ def _sampler(oracle, X, Y, m=10, P=10, seed=3415, rules=None, batch=(0.1, 0.1), 
                      np.ones(p) if prior is None else prior, backend=oracle)
 
 
-def test_bart_vi_important_variable_dominates(oracle):
+@pytest.mark.filterwarnings("ignore:response=")
+@pytest.mark.parametrize("response", ["constant", "linear"])  # as the reference parametrises it
+def test_bart_vi_important_variable_dominates(oracle, response):
     # reference tests/test_bart.py:44-64: X[:,0] ~ Y, m=10, tune=draws=200 -> var_imp[0] > rest
     rng = np.random.default_rng(3415)
     X = rng.normal(0, 1, size=(250, 3))
     Y = rng.normal(0, 1, size=250)
     X[:, 0] = rng.normal(Y, 0.1)
-    res = sample_chain(BARTOp(X, Y, m=10), tune=200, draws=200, random_seed=3415, backend=oracle)
+    res = sample_chain(BARTOp(X, Y, m=10, response=response), tune=200, draws=200, random_seed=3415,
+                       backend=oracle)
     vi_vals = res["variable_inclusion"]
     var_imp = np.array([_decode_vi(v, 3) for v in vi_vals]).sum(axis=0)
     var_imp = var_imp / var_imp.sum()
@@ -37,13 +40,16 @@ def test_bart_vi_important_variable_dominates(oracle):
     assert res["mu"].shape == (200, 250)
 
 
-def test_missing_data_samples_without_error(oracle):
+@pytest.mark.filterwarnings("ignore:response=")
+@pytest.mark.parametrize("response", ["constant", "linear"])
+def test_missing_data_samples_without_error(oracle, response):
     # reference tests/test_bart.py:67-81
     rng = np.random.default_rng(0)
     X = rng.normal(0, 1, size=(50, 2))
     Y = rng.normal(0, 1, size=50)
     X[10:20, 0] = np.nan
-    res = sample_chain(BARTOp(X, Y, m=10), tune=100, draws=100, random_seed=3415, backend=oracle)
+    res = sample_chain(BARTOp(X, Y, m=10, response=response), tune=100, draws=100, random_seed=3415,
+                       backend=oracle)
     assert np.all(np.isfinite(res["mu"]))
     assert res["counters"]["saturations"] == 0
 
@@ -612,6 +618,7 @@ def test_linear_response_fits_slopes_and_stays_consistent(oracle, response):
     assert s.counters.saturations == 0
 
 
+@pytest.mark.filterwarnings("ignore:response=")
 def test_linear_response_through_the_step_method_and_its_limits(oracle):
     rng = np.random.default_rng(5)
     X = rng.normal(size=(200, 2))

@@ -324,6 +324,7 @@ def test_fuzz_parity_over_random_configurations(hip, oracle):
         assert g == o, (seed, c["family"], c["X"].shape, c["m"], c["P"], c["K"], c["rules"].tolist())
 
 
+@pytest.mark.filterwarnings("ignore:response=")
 def test_linear_leaves_predict_the_same_on_gpu_and_host(hip, oracle):
     """response="linear": the chain, its exported slopes and the prediction kernel (with excluded and
     missing regressors) agree with the oracle / the host restatement."""
