@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(w, seed, budget_s=20.0):
+def cpu_baseline(w, seed, budget_s=20.0, response="constant"):
     """The CPU oracle (oracle/, a single-threaded C restatement) on a bounded sample of the
     same workload.  Reported baseline, not the target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,7 +36,7 @@ def cpu_baseline(w, seed, budget_s=20.0):
 
     X, Y = w["X"], w["Y"]
     st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
-                                  family=w["family"], n_outputs=w.get("K", 1))
+                                  family=w["family"], n_outputs=w.get("K", 1), response=response)
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]),
                   backend=oracle_backend())
     s.set_likelihood([1.0] if w["family"] == "normal" else [])
@@ -86,6 +86,8 @@ def main():
                          "each); the headline is quoted at 1, as north_star shards one chain per GPU")
     ap.add_argument("--no-multichain", action="store_true",
                     help="skip the informational 4-chains-on-one-GPU leg (N=1 only)")
+    ap.add_argument("--response", default="constant", choices=["constant", "linear", "mix"],
+                    help="leaf response (cfg2 only; the metric is quoted on 'constant')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -123,7 +125,9 @@ def main():
     X, Y = w["X"], w["Y"]
     n = X.shape[0]
     st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=seed,
-                                  family=w["family"], n_outputs=w.get("K", 1))
+                                  family=w["family"], n_outputs=w.get("K", 1), response=args.response)
+    if args.response != "constant":
+        w["name"] += f", response={args.response}"
     be = default_backend(local_rank)
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
     s.set_likelihood([1.0] if w["family"] == "normal" else [])  # sigma fixed at 1
@@ -141,7 +145,7 @@ def main():
             with torch.cuda.stream(torch.cuda.Stream()):
                 stc = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"],
                                                seed=seed + 1000 * (first_chain + c), family=w["family"],
-                                               n_outputs=w.get("K", 1))
+                                               n_outputs=w.get("K", 1), response=args.response)
                 sc = PySampler(stc, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
                 sc.set_likelihood([1.0] if w["family"] == "normal" else [])
                 out.append(sc)
@@ -258,7 +262,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(w, seed)
+        cpu = cpu_baseline(w, seed, response=args.response)
 
     if rank == 0:
         line = {
