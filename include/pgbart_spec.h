@@ -74,6 +74,8 @@
 #define PGB_FAMILY_BERNOULLI_LOGIT 2  /* y ~ Bern(expit(mu))                 */
 #define PGB_FAMILY_CATEGORICAL 3      /* y ~ Cat(softmax(mu[0..K-1]))        */
 #define PGB_FAMILY_NORMAL_MEANSCALE 4 /* y ~ N(mu[0], |mu[1]|), K = 2        */
+#define PGB_FAMILY_POISSON_LOG 5      /* y ~ Poisson(exp(mu))                */
+#define PGB_FAMILY_NEGBIN_LOG 6       /* y ~ NegBin(mean exp(mu), alpha)     params: alpha */
 
 /* RNG purposes (high half of counter word 3) */
 #define PGB_RNG_PROPOSE 1u  /* u0: prior coin, u1: split variable            */
@@ -511,12 +513,35 @@ PGB_HD double pgb_softplus(double t) {
 /* Per-row log-likelihood of the closed families with one linear predictor mu (K = 1).
  * y is the observed response (0/1 for the Bernoulli families).  Clamped to [-2047, 0] so that
  * n terms fit the fixed-point accumulator (scale cl). */
-PGB_HD double pgb_loglik1_t(int family, double y, double mu, const double* tn, const double* tp) {
-  const double smu = y > 0.5 ? mu : -mu;
-  double ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
+/* `param`: the family's scalar parameter (NEGBIN_LOG: alpha), 0 otherwise.
+ * The count families are written relative to the saturated model (minus half the deviance):
+ *   POISSON_LOG:  (y mu - e^mu) - (y log y - y)
+ *   NEGBIN_LOG:   (y mu - (alpha + y) log(alpha + e^mu)) - (y log y - (alpha + y) log(alpha + y))
+ * The subtracted terms depend on the data (and alpha) only, so they cancel in every particle
+ * weight; they make the value a quantity <= 0 that fits the fixed-point range like a log-pmf. */
+PGB_HD double pgb_loglik1p(int family, double y, double mu, double param, const double* tn, const double* tp) {
+  double ll;
+  if (family == PGB_FAMILY_POISSON_LOG || family == PGB_FAMILY_NEGBIN_LOG) {
+    const double yy = y > 0.0 ? y : 0.0;
+    const double em = pgb_exp(mu);
+    if (family == PGB_FAMILY_POISSON_LOG) {
+      const double sat = yy > 0.0 ? yy * pgb_log(yy) - yy : 0.0;
+      ll = (yy * mu - em) - sat;
+    } else {
+      const double ay = param + yy;
+      const double sat = yy > 0.0 ? yy * pgb_log(yy) - ay * pgb_log(ay) : -(param * pgb_log(param));
+      ll = (yy * mu - ay * pgb_log(param + em)) - sat;
+    }
+  } else {
+    const double smu = y > 0.5 ? mu : -mu;
+    ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
+  }
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 0.0) ll = 0.0;
   return ll;
+}
+PGB_HD double pgb_loglik1_t(int family, double y, double mu, const double* tn, const double* tp) {
+  return pgb_loglik1p(family, y, mu, 0.0, tn, tp);
 }
 PGB_HD double pgb_loglik1(int family, double y, double mu) {
   return pgb_loglik1_t(family, y, mu, pgb_ln_tn(), pgb_ln_tp());
@@ -553,10 +578,13 @@ PGB_HD double pgb_loglik_meanscale(double y, const double* mu) {
 }
 
 /* Per-row log-likelihood of every non-Normal(sigma) family at the K linear predictors mu. */
-PGB_HD double pgb_loglik(int family, int K, double y, const double* mu) {
+PGB_HD double pgb_loglikp(int family, int K, double y, const double* mu, double param) {
   if (family == PGB_FAMILY_CATEGORICAL) return pgb_loglik_cat(K, y, mu);
   if (family == PGB_FAMILY_NORMAL_MEANSCALE) return pgb_loglik_meanscale(y, mu);
-  return pgb_loglik1(family, y, mu[0]);
+  return pgb_loglik1p(family, y, mu[0], param, pgb_ln_tn(), pgb_ln_tp());
+}
+PGB_HD double pgb_loglik(int family, int K, double y, const double* mu) {
+  return pgb_loglikp(family, K, y, mu, 0.0);
 }
 
 /* ------------------------------------------------------------------ fixed point */

@@ -176,7 +176,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
-             s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
+             s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
+             s->family == PGB_FAMILY_NEGBIN_LOG) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -300,6 +301,9 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
   if (h->s.family == PGB_FAMILY_NORMAL) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
+    h->inv_sigma2 = params[0];
   } else if (n_params != 0) {
     return fail(PGB_E_INVALID, "this family has no parameters");
   }
@@ -309,7 +313,8 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
 /* ------------------------------------------------------------------ one tree update */
 /* per-row log-likelihood of the non-Normal families at linear predictor(s) mu[0..K-1] */
 static double o_loglik(const pgb_handle* h, double y, const double* mu) {
-  return pgb_loglik(h->s.family, h->s.n_outputs, y, mu);
+  /* inv_sigma2 doubles as "the family's scalar parameter" for the non-Normal families */
+  return pgb_loglikp(h->s.family, h->s.n_outputs, y, mu, h->inv_sigma2);
 }
 
 static void o_tree_begin(pgb_handle* h, int tree_id) {

@@ -6,14 +6,14 @@ Public names mirror what the reference imports from the external ``bartrs`` whee
 """
 
 from . import _abi
-from .pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NormalLikelihood,
-                     NormalMeanScaleLikelihood)
+from .pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
+                     NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
 from .importance import compute_variable_importance
 
 __version__ = "0.1.0"
 __all__ = [
-    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood",
+    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood",
     "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "_abi",
 ]

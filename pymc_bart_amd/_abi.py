@@ -44,6 +44,8 @@ FAMILIES = {
     "bernoulli_logit": FAMILY_BERNOULLI_LOGIT,
     "categorical": FAMILY_CATEGORICAL,
     "normal_meanscale": FAMILY_NORMAL_MEANSCALE,
+    "poisson_log": 5,
+    "negbin_log": 6,
 }
 
 #: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)

@@ -1714,8 +1714,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               iv[3] += pgb_quant(er * er, c2, &sat);
             } else {
               // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
-              iv[2] += pgb_quant(pgb_loglik1(S.family, yv, noi + S.init_leaf), S.sc.cl, &sat);
-              iv[3] += pgb_quant(pgb_loglik1(S.family, yv, st), S.sc.cl, &sat);
+              const double lp = S.ctrl[par ^ 1].inv_sigma2;  // the family's scalar parameter
+              iv[2] += pgb_quant(pgb_loglik1p(S.family, yv, noi + S.init_leaf, lp, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              iv[3] += pgb_quant(pgb_loglik1p(S.family, yv, st, lp, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
             }
           }
         }
@@ -2426,7 +2427,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           const uint32_t nl = (nid >> (8 * e)) & 255u;
           const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
           const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
-          const long long q = pgb_quant(pgb_loglik1_t(S.family, yv[e], mu, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
+          const long long q = pgb_quant(pgb_loglik1p(S.family, yv[e], mu, cn.inv_sigma2, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
           v0 += side == 0 ? q : 0;
           v1 += side == 1 ? q : 0;
           v2 += side == 2 ? q : 0;
@@ -2698,7 +2699,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
-             s->family == PGB_FAMILY_BERNOULLI_LOGIT) {
+             s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
+             s->family == PGB_FAMILY_NEGBIN_LOG) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -2985,6 +2987,10 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
   if (h->s.family == PGB_FAMILY_NORMAL) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {  // the slot doubles as "the family's parameter"
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
+    h->inv_sigma2 = params[0];
     h->sigma_dirty = 1;
   } else if (n_params != 0) {
     return fail(PGB_E_INVALID, "this family has no parameters");

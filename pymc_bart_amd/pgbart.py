@@ -85,6 +85,34 @@ class BernoulliLikelihood:
         return []
 
 
+class PoissonLikelihood:
+    """``y ~ Poisson(exp(BART))`` -- the count model of the PyMC-BART documentation (BART is built on
+    ``Y = log(counts)``; pass the counts as ``observed=`` to the step method)."""
+
+    family = "poisson_log"
+
+    def params(self, point=None):
+        return []
+
+
+class NegativeBinomialLikelihood:
+    """``y ~ NegativeBinomial(mu = exp(BART), alpha)``; ``alpha`` is read from the point by name or
+    fixed."""
+
+    family = "negbin_log"
+
+    def __init__(self, alpha=1.0):
+        self.alpha = alpha
+
+    def params(self, point=None):
+        a = self.alpha
+        if isinstance(a, str):
+            if point is None or a not in point:
+                raise KeyError(f"point has no value for {a!r}")
+            a = point[a]
+        return [float(np.asarray(a))]
+
+
 class CategoricalLikelihood:
     """``y ~ Categorical(softmax(BART[0..K-1]))`` -- K-vector leaves sharing one tree structure
     (reference ``tests/test_bart.py:140-164``: ``shape=(3, 9)``; cfg5 of BASELINE.json)."""

