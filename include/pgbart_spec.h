@@ -76,6 +76,8 @@
 #define PGB_FAMILY_NORMAL_MEANSCALE 4 /* y ~ N(mu[0], |mu[1]|), K = 2        */
 #define PGB_FAMILY_POISSON_LOG 5      /* y ~ Poisson(exp(mu))                */
 #define PGB_FAMILY_NEGBIN_LOG 6       /* y ~ NegBin(mean exp(mu), alpha)     params: alpha */
+#define PGB_FAMILY_ASYMLAPLACE 7      /* y ~ AsymmetricLaplace(b, q, mu): quantile regression   params: b, q */
+#define PGB_FAMILY_STUDENT_T 8        /* y ~ StudentT(nu, mu, sigma)         params: sigma, nu */
 
 /* RNG purposes (high half of counter word 3) */
 #define PGB_RNG_PROPOSE 1u  /* u0: prior coin, u1: split variable            */
@@ -519,7 +521,11 @@ PGB_HD double pgb_softplus(double t) {
  *   NEGBIN_LOG:   (y mu - (alpha + y) log(alpha + e^mu)) - (y log y - (alpha + y) log(alpha + y))
  * The subtracted terms depend on the data (and alpha) only, so they cancel in every particle
  * weight; they make the value a quantity <= 0 that fits the fixed-point range like a log-pmf. */
-PGB_HD double pgb_loglik1p(int family, double y, double mu, double param, const double* tn, const double* tp) {
+/*   ASYMLAPLACE(b, q):  -rho_q((y - mu) / b),  rho_q(u) = u (q - [u < 0])   (the check loss)
+ *   STUDENT_T(sigma, nu): -((nu + 1) / 2) log(1 + ((y - mu) / sigma)^2 / nu)
+ * (both without their mu-free normalising terms, hence <= 0). */
+PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double param2, const double* tn,
+                           const double* tp) {
   double ll;
   if (family == PGB_FAMILY_POISSON_LOG || family == PGB_FAMILY_NEGBIN_LOG) {
     const double yy = y > 0.0 ? y : 0.0;
@@ -532,6 +538,12 @@ PGB_HD double pgb_loglik1p(int family, double y, double mu, double param, const 
       const double sat = yy > 0.0 ? yy * pgb_log(yy) - ay * pgb_log(ay) : -(param * pgb_log(param));
       ll = (yy * mu - ay * pgb_log(param + em)) - sat;
     }
+  } else if (family == PGB_FAMILY_ASYMLAPLACE) {
+    const double u = (y - mu) / param;
+    ll = -(u * (u < 0.0 ? param2 - 1.0 : param2));
+  } else if (family == PGB_FAMILY_STUDENT_T) {
+    const double u = (y - mu) / param;
+    ll = (-0.5 * (param2 + 1.0)) * pgb_log(1.0 + (u * u) / param2);
   } else {
     const double smu = y > 0.5 ? mu : -mu;
     ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
@@ -539,6 +551,9 @@ PGB_HD double pgb_loglik1p(int family, double y, double mu, double param, const 
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 0.0) ll = 0.0;
   return ll;
+}
+PGB_HD double pgb_loglik1p(int family, double y, double mu, double param, const double* tn, const double* tp) {
+  return pgb_loglik1q(family, y, mu, param, 1.0, tn, tp);
 }
 PGB_HD double pgb_loglik1_t(int family, double y, double mu, const double* tn, const double* tp) {
   return pgb_loglik1p(family, y, mu, 0.0, tn, tp);
@@ -578,10 +593,13 @@ PGB_HD double pgb_loglik_meanscale(double y, const double* mu) {
 }
 
 /* Per-row log-likelihood of every non-Normal(sigma) family at the K linear predictors mu. */
-PGB_HD double pgb_loglikp(int family, int K, double y, const double* mu, double param) {
+PGB_HD double pgb_loglikq(int family, int K, double y, const double* mu, double param, double param2) {
   if (family == PGB_FAMILY_CATEGORICAL) return pgb_loglik_cat(K, y, mu);
   if (family == PGB_FAMILY_NORMAL_MEANSCALE) return pgb_loglik_meanscale(y, mu);
-  return pgb_loglik1p(family, y, mu[0], param, pgb_ln_tn(), pgb_ln_tp());
+  return pgb_loglik1q(family, y, mu[0], param, param2, pgb_ln_tn(), pgb_ln_tp());
+}
+PGB_HD double pgb_loglikp(int family, int K, double y, const double* mu, double param) {
+  return pgb_loglikq(family, K, y, mu, param, 1.0);
 }
 PGB_HD double pgb_loglik(int family, int K, double y, const double* mu) {
   return pgb_loglikp(family, K, y, mu, 0.0);

@@ -106,6 +106,7 @@ struct pgb_handle {
   double leaf_sd;                       /* output 0 */
   double leaf_sdx[PGB_MAX_OUTPUTS - 1]; /* outputs 1..K-1 */
   double inv_sigma2;
+  double lik_param2; /* second scalar parameter of the two-parameter families */
   int64_t iter;
   int32_t lower;
   otree* trees;     /* m accepted trees */
@@ -177,7 +178,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
-             s->family == PGB_FAMILY_NEGBIN_LOG) {
+             s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
+             s->family == PGB_FAMILY_STUDENT_T) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -236,6 +238,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   h->leaf_sd = s->init_leaf_sd;
   for (int k = 1; k < K; ++k) h->leaf_sdx[k - 1] = s->init_leaf_sd;
   h->inv_sigma2 = 1.0;
+  h->lik_param2 = 1.0;
   *out = h;
   return PGB_OK;
 }
@@ -304,6 +307,16 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
   } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
     h->inv_sigma2 = params[0];
+  } else if (h->s.family == PGB_FAMILY_ASYMLAPLACE) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0) || !(params[1] < 1.0))
+      return fail(PGB_E_INVALID, "ASYMLAPLACE needs b > 0 and 0 < q < 1");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
+  } else if (h->s.family == PGB_FAMILY_STUDENT_T) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0))
+      return fail(PGB_E_INVALID, "STUDENT_T needs sigma > 0 and nu > 0");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
   } else if (n_params != 0) {
     return fail(PGB_E_INVALID, "this family has no parameters");
   }
@@ -314,7 +327,7 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
 /* per-row log-likelihood of the non-Normal families at linear predictor(s) mu[0..K-1] */
 static double o_loglik(const pgb_handle* h, double y, const double* mu) {
   /* inv_sigma2 doubles as "the family's scalar parameter" for the non-Normal families */
-  return pgb_loglikp(h->s.family, h->s.n_outputs, y, mu, h->inv_sigma2);
+  return pgb_loglikq(h->s.family, h->s.n_outputs, y, mu, h->inv_sigma2, h->lik_param2);
 }
 
 static void o_tree_begin(pgb_handle* h, int tree_id) {
@@ -928,7 +941,7 @@ typedef struct {
   int64_t payload_bytes;
   int64_t rs_count, iter;
   int32_t lower, n_last;
-  double leaf_sd, leaf_sdx[PGB_MAX_OUTPUTS - 1], inv_sigma2;
+  double leaf_sd, leaf_sdx[PGB_MAX_OUTPUTS - 1], inv_sigma2, lik_param2;
   pgb_counters ctr;
 } ockpt;
 
@@ -979,6 +992,7 @@ int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes) {
   hd.leaf_sd = h->leaf_sd;
   memcpy(hd.leaf_sdx, h->leaf_sdx, sizeof hd.leaf_sdx);
   hd.inv_sigma2 = h->inv_sigma2;
+  hd.lik_param2 = h->lik_param2;
   hd.ctr = h->ctr;
   memcpy(host_buf, &hd, sizeof hd);
   char* o = (char*)host_buf + sizeof hd;
@@ -1020,6 +1034,7 @@ int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
   h->leaf_sd = hd.leaf_sd;
   memcpy(h->leaf_sdx, hd.leaf_sdx, sizeof hd.leaf_sdx);
   h->inv_sigma2 = hd.inv_sigma2;
+  h->lik_param2 = hd.lik_param2;
   h->ctr = hd.ctr;
   return PGB_OK;
 }

@@ -6,14 +6,14 @@ Public names mirror what the reference imports from the external ``bartrs`` whee
 """
 
 from . import _abi
-from .pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
-                     NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood)
+from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
+                     NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood, StudentTLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
 from .importance import compute_variable_importance
 
 __version__ = "0.1.0"
 __all__ = [
-    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood",
+    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood",
     "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "_abi",
 ]

@@ -46,6 +46,8 @@ FAMILIES = {
     "normal_meanscale": FAMILY_NORMAL_MEANSCALE,
     "poisson_log": 5,
     "negbin_log": 6,
+    "asymmetric_laplace": 7,
+    "student_t": 8,
 }
 
 #: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)

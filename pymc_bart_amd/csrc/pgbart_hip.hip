@@ -157,6 +157,7 @@ struct Ctrl {
   long long iter, rs_count, pend_iter;
   double leaf_sd, inv_sigma2;  // (leaf_sd of outputs 1..K-1: Dev::lsdx -- no arrays in this record,
                                //  the compiler would demote a by-value copy with an indexed array to LDS)
+  double lik_param2;  // second scalar parameter of the two-parameter likelihood families
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
   long long steps_done;  // asteps completed since creation (mirrored to the host flag)
   long long slot_no;     // k_ctrl launches so far
@@ -478,13 +479,17 @@ __device__ __forceinline__ void build_lvx(const DNode* nd, int n_nodes, const do
 }
 
 // ------------------------------------------------------------------ k_begin
-__global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, int set_sigma) {
+__global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, double lik_param2,
+                        int set_sigma) {
   const Dev& S = *Sp;
   Ctrl* c = &S.ctrl[par];
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     c->tune = tune;
     c->steps_left = n_steps;
-    if (set_sigma) c->inv_sigma2 = inv_sigma2;
+    if (set_sigma) {
+      c->inv_sigma2 = inv_sigma2;
+      c->lik_param2 = lik_param2;
+    }
     int bs = tune ? S.batch_tune : S.batch_draw;
     int upper = c->lower + bs;
     if (upper > S.m) upper = S.m;
@@ -1714,9 +1719,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               iv[3] += pgb_quant(er * er, c2, &sat);
             } else {
               // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
-              const double lp = S.ctrl[par ^ 1].inv_sigma2;  // the family's scalar parameter
-              iv[2] += pgb_quant(pgb_loglik1p(S.family, yv, noi + S.init_leaf, lp, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
-              iv[3] += pgb_quant(pgb_loglik1p(S.family, yv, st, lp, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              const double lp = S.ctrl[par ^ 1].inv_sigma2, lp2 = S.ctrl[par ^ 1].lik_param2;  // family parameters
+              iv[2] += pgb_quant(pgb_loglik1q(S.family, yv, noi + S.init_leaf, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              iv[3] += pgb_quant(pgb_loglik1q(S.family, yv, st, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
             }
           }
         }
@@ -2427,7 +2432,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           const uint32_t nl = (nid >> (8 * e)) & 255u;
           const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
           const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
-          const long long q = pgb_quant(pgb_loglik1p(S.family, yv[e], mu, cn.inv_sigma2, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
+          const long long q = pgb_quant(pgb_loglik1q(S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
           v0 += side == 0 ? q : 0;
           v1 += side == 1 ? q : 0;
           v2 += side == 2 ? q : 0;
@@ -2658,6 +2663,7 @@ struct pgb_handle {
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int sigma_dirty;
   double inv_sigma2;
+  double lik_param2;
   int lower_host;      // mirror of the batch cursor
   int last_lower, last_n;
   double slots_per_step;  // running estimate
@@ -2700,7 +2706,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
-             s->family == PGB_FAMILY_NEGBIN_LOG) {
+             s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
+             s->family == PGB_FAMILY_STUDENT_T) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -2733,6 +2740,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->steps_target = 0;
   h->bundles = 0;
   h->inv_sigma2 = 1.0;
+  h->lik_param2 = 1.0;
   h->sigma_dirty = 1;
   h->slots_per_step = 0.0;
   memset(&h->ctr, 0, sizeof h->ctr);
@@ -2892,6 +2900,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   c0.phase = PH_IDLE;
   c0.leaf_sd = s->init_leaf_sd;
   c0.inv_sigma2 = 1.0;
+  c0.lik_param2 = 1.0;
   Ctrl cc2[2] = {c0, c0};
   HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
   hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((2 * K * d.n_pad + 255) / 256)), dim3(256), 0, sm, st,
@@ -2991,6 +3000,18 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
   } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {  // the slot doubles as "the family's parameter"
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
     h->inv_sigma2 = params[0];
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_ASYMLAPLACE) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0) || !(params[1] < 1.0))
+      return fail(PGB_E_INVALID, "ASYMLAPLACE needs b > 0 and 0 < q < 1");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_STUDENT_T) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0))
+      return fail(PGB_E_INVALID, "STUDENT_T needs sigma > 0 and nu > 0");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
     h->sigma_dirty = 1;
   } else if (n_params != 0) {
     return fail(PGB_E_INVALID, "this family has no parameters");
@@ -3122,7 +3143,7 @@ static int begin_steps(pgb_handle* h, int tune, int n_steps) {
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   int par = (int)(h->slot & 1);
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, h->d_dev, par, tune, n_steps,
-                     h->inv_sigma2, h->sigma_dirty);
+                     h->inv_sigma2, h->lik_param2, h->sigma_dirty);
   h->steps_target += n_steps;
   h->sigma_dirty = 0;
   // host mirror of the batch cursor ([U] PGBART.astep batching)
@@ -3365,7 +3386,7 @@ struct CkptHeader {
   // host mirrors at the idle point
   long long slot, steps_target, flag;
   int32_t st_cur, alpha_cur, lower_host, last_lower, last_n, sigma_dirty;
-  double inv_sigma2;
+  double inv_sigma2, lik_param2;
   pgb_counters ctr;
 };
 
@@ -3407,6 +3428,7 @@ extern "C" int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes)
   hd.last_n = h->last_n;
   hd.sigma_dirty = h->sigma_dirty;
   hd.inv_sigma2 = h->inv_sigma2;
+  hd.lik_param2 = h->lik_param2;
   hd.ctr = h->ctr;
   memcpy(host_buf, &hd, sizeof hd);
   char* o = (char*)host_buf + sizeof hd;
@@ -3450,6 +3472,7 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
   h->last_n = hd.last_n;
   h->sigma_dirty = hd.sigma_dirty;
   h->inv_sigma2 = hd.inv_sigma2;
+  h->lik_param2 = hd.lik_param2;
   h->ctr = hd.ctr;
   return PGB_OK;
 }

@@ -113,6 +113,39 @@ class NegativeBinomialLikelihood:
         return [float(np.asarray(a))]
 
 
+def _from_point(value, point):
+    if isinstance(value, str):
+        if point is None or value not in point:
+            raise KeyError(f"point has no value for {value!r}")
+        value = point[value]
+    return float(np.asarray(value))
+
+
+class AsymmetricLaplaceLikelihood:
+    """``y ~ AsymmetricLaplace(b, q, mu = BART)``: BART as the ``q``-quantile of y (the quantile
+    regression example of the PyMC-BART documentation).  ``b`` by name from the point or fixed."""
+
+    family = "asymmetric_laplace"
+
+    def __init__(self, q=0.5, b=1.0):
+        self.q, self.b = q, b
+
+    def params(self, point=None):
+        return [_from_point(self.b, point), _from_point(self.q, point)]
+
+
+class StudentTLikelihood:
+    """``y ~ StudentT(nu, mu = BART, sigma)`` -- outlier-robust regression."""
+
+    family = "student_t"
+
+    def __init__(self, nu=4.0, sigma=1.0):
+        self.nu, self.sigma = nu, sigma
+
+    def params(self, point=None):
+        return [_from_point(self.sigma, point), _from_point(self.nu, point)]
+
+
 class CategoricalLikelihood:
     """``y ~ Categorical(softmax(BART[0..K-1]))`` -- K-vector leaves sharing one tree structure
     (reference ``tests/test_bart.py:140-164``: ``shape=(3, 9)``; cfg5 of BASELINE.json)."""

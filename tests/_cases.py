@@ -109,6 +109,18 @@ def make_case(name: str):
             Y = rng.negative_binomial(2.0, 2.0 / (2.0 + rate)).astype(float)
             c.update(family="negbin_log", lik_params=[2.0])
         c.update(m=12, P=12, steps=30, bart_Y=np.log(Y + 0.5))
+    elif name in ("quantile_asymlaplace", "robust_student_t"):  # two-parameter per-row families
+        n, p = 3500, 4
+        X = rng.uniform(-2, 2, size=(n, p))
+        X[rng.random(n) < 0.1, 3] = np.nan
+        f = np.sin(2 * X[:, 0]) + 0.5 * X[:, 1]
+        if name == "quantile_asymlaplace":
+            Y = f + rng.normal(0, 0.2 + 0.3 * (X[:, 0] > 0), n)      # heteroscedastic: quantiles differ from the mean
+            c.update(family="asymmetric_laplace", lik_params=[0.25, 0.9])
+        else:
+            Y = f + 0.2 * rng.standard_t(3, n)                        # heavy tails
+            c.update(family="student_t", lik_params=[0.2, 3.0])
+        c.update(m=10, P=12, steps=30)
     elif name in ("linear_response", "mix_response"):  # reference tests parametrise response=["constant","linear"]
         n, p = 3000, 4
         X = rng.uniform(-2, 2, size=(n, p))
@@ -151,7 +163,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -221,7 +233,7 @@ def random_case(seed):
     every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta."""
     rng = np.random.default_rng(seed)
     fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale",
-                      "poisson_log", "negbin_log"])
+                      "poisson_log", "negbin_log", "asymmetric_laplace", "student_t"])
     n = int(rng.choice([3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 5000, 20000]))
     p = int(rng.integers(1, 9))
     m = int(rng.integers(1, 12))
@@ -246,6 +258,8 @@ def random_case(seed):
         Y = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
     elif fam in ("poisson_log", "negbin_log"):
         Y = rng.poisson(np.exp(np.clip(f, -3, 3))).astype(float)
+    elif fam in ("asymmetric_laplace", "student_t"):
+        Y = f + rng.standard_t(3, n) * 0.5
     elif fam == "categorical":
         K = int(rng.integers(2, 8)); Y = rng.integers(0, K, n).astype(float)
     else:
@@ -259,6 +273,10 @@ def random_case(seed):
         extra["bart_Y"] = np.log(Y + 0.5)
         if fam == "negbin_log":
             extra["lik_params"] = [float(rng.uniform(0.3, 5.0))]
+    if fam == "asymmetric_laplace":
+        extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.05, 0.95))]
+    if fam == "student_t":
+        extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(1.0, 30.0))]
     return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

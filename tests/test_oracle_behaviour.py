@@ -687,3 +687,35 @@ def test_count_likelihoods_poisson_and_negative_binomial(oracle):
         s.set_likelihood([])
     s.set_likelihood([3.0])
     assert nbinom.logpmf(2, 3.0, 0.5) < 0  # (scipy available: the family is checked end to end above)
+
+
+def test_quantile_and_robust_regression_families(oracle):
+    """AsymmetricLaplace(b, q) makes BART the q-quantile of y (the quantile-regression example of the
+    PyMC-BART documentation); StudentT(nu, sigma) is the outlier-robust regression."""
+    from pymc_bart_amd import AsymmetricLaplaceLikelihood, StudentTLikelihood
+
+    rng = np.random.default_rng(17)
+    X = rng.uniform(-2, 2, size=(1500, 2))
+    f = np.sin(2 * X[:, 0])
+    Y = f + rng.normal(0, 0.2 + 0.3 * (X[:, 0] > 0), 1500)
+    cover = {}
+    for q in (0.1, 0.9):
+        step = PGBART([BARTOp(X, Y, m=20)], num_particles=10, likelihood=AsymmetricLaplaceLikelihood(q=q, b="b"),
+                      random_seed=2, backend=oracle)
+        for it in range(150):
+            mu, _ = step.astep(None, {"b": 0.2})
+        cover[q] = float(np.mean(Y <= mu))
+        assert step.counters["saturations"] == 0
+    assert 0.03 < cover[0.1] < 0.2 and 0.8 < cover[0.9] < 0.97   # BART tracks the requested quantile
+    # heavy-tailed noise with gross outliers: the Student-t fit stays near f
+    Yo = f + 0.1 * rng.standard_t(2, 1500)
+    Yo[::50] += 25.0
+    step = PGBART([BARTOp(X, np.clip(Yo, -3, 3), m=20)], num_particles=10, observed=Yo,
+                  likelihood=StudentTLikelihood(nu=3.0, sigma="s"), random_seed=3, backend=oracle)
+    for it in range(150):
+        mu, _ = step.astep(None, {"s": 0.15})
+    assert np.sqrt(np.mean((mu - f) ** 2)) < 0.35
+    st = PyBartSettings.from_data(X, Y, m=2, num_particles=4, family="asymmetric_laplace")
+    s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    with pytest.raises(_abi.PGBError, match="0 < q < 1"):
+        s.set_likelihood([0.2, 1.5])
