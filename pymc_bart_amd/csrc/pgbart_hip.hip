@@ -2268,7 +2268,9 @@ struct LJob {
 };
 
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
-template <int KT>
+// FAM: the likelihood family when known at compile time (single-output kernels: the per-row
+// evaluation then contains one family's code only), -1: read S.family.
+template <int KT, int FAM>
 __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   constexpr bool MK = KT != 1;
@@ -2278,10 +2280,11 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   __shared__ int s_n[2];
   // log Phi tables in LDS (single-output Bernoulli path): a per-lane row through the vector L1
   // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
-  __shared__ double s_ln[KT == 1 ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
+  constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
+  __shared__ double s_ln[PROBIT ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
   const Cmd* cmd = &S.cmd[par];
   if (!(cmd->kind & CMD_PARTITION)) return;
-  if constexpr (KT == 1) {
+  if constexpr (PROBIT) {
     const double* gtn = pgb_ln_tn();
     const double* gtp = pgb_ln_tp();
     for (int i = threadIdx.x; i < PGB_LN_TN_ROWS * 9; i += BT) s_ln[i] = gtn[i];
@@ -2432,7 +2435,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           const uint32_t nl = (nid >> (8 * e)) & 255u;
           const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
           const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
-          const long long q = pgb_quant(pgb_loglik1q(S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, s_ln, s_ln + PGB_LN_TN_ROWS * 9), cl, &sat);
+          const long long q = pgb_quant(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, s_ln,
+                                                      s_ln + (PROBIT ? PGB_LN_TN_ROWS * 9 : 0)), cl, &sat);
           v0 += side == 0 ? q : 0;
           v1 += side == 1 ? q : 0;
           v2 += side == 2 ? q : 0;
@@ -3079,15 +3083,25 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef LAUNCH_ROWS
 #undef ROWS_PTRS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
-      if (d.K > 1)
+#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_>), grows, dim3(BT), 0, h->stream, h->d_dev, par)
+      if (d.K > 1) {
         switch (d.K) {
-          case 2: hipLaunchKernelGGL(k_loglik<2>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
-          case 3: hipLaunchKernelGGL(k_loglik<3>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
-          case 4: hipLaunchKernelGGL(k_loglik<4>, grows, dim3(BT), 0, h->stream, h->d_dev, par); break;
-          default: hipLaunchKernelGGL(k_loglik<0>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+          case 2: LAUNCH_LL(2, -1); break;
+          case 3: LAUNCH_LL(3, -1); break;
+          case 4: LAUNCH_LL(4, -1); break;
+          default: LAUNCH_LL(0, -1);
         }
-      else
-        hipLaunchKernelGGL(k_loglik<1>, grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else {
+        switch (d.family) {
+          case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;
+          case PGB_FAMILY_BERNOULLI_LOGIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_LOGIT); break;
+          case PGB_FAMILY_POISSON_LOG: LAUNCH_LL(1, PGB_FAMILY_POISSON_LOG); break;
+          case PGB_FAMILY_NEGBIN_LOG: LAUNCH_LL(1, PGB_FAMILY_NEGBIN_LOG); break;
+          case PGB_FAMILY_ASYMLAPLACE: LAUNCH_LL(1, PGB_FAMILY_ASYMLAPLACE); break;
+          default: LAUNCH_LL(1, PGB_FAMILY_STUDENT_T);
+        }
+      }
+#undef LAUNCH_LL
     }
     h->slot += 1;
   }
