@@ -21,8 +21,8 @@
 //   * All row reductions are integer (fixed point) => bit-reproducible, independent of
 //     launch geometry and atomics order, and identical to the CPU oracle.
 //   * Kernel instances are compiled per data set where the hot loop has no registers or
-//     instructions to spare: k_rows<SubsetSplit columns?, Normal family?>, k_rows_mk<K>,
-//     k_loglik<K>, k_ctrl<multi-output?>.
+//     instructions to spare: k_rows<SubsetSplit columns?, Normal family?, linear response?>,
+//     k_rows_mk<K>, k_loglik<K, family>, k_ctrl<multi-output?, linear response?>.
 //   * No MFMA: the path is gather / partition / reduce (HBM / L2 bound).
 //
 #include <hip/hip_runtime.h>
