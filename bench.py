@@ -208,6 +208,7 @@ def main():
         s.step_async(tune, args.steps)
         cp1 = s.sync()
         ms, launches = s.profile(False)
+        clk_ms, clk_launches = s.profile_clock()
         tu = cp1["tree_updates"] - cp0["tree_updates"]
         rt = cp1["rows_touched"] - cp0["rows_touched"]
         alg = workloads.bytes_per_tree_update(n, rt / max(tu, 1), K=w.get("K", 1)) * tu
@@ -224,10 +225,17 @@ def main():
             "bound": "hbm", "kernel": "k_rows", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
+            # the same launches by the device clock (first to last reading of any workgroup): the
+            # interval a rocprofv3 kernel trace reports for the dispatch
+            "avg_kernel_us_device_clock": clk_ms * 1e3 / max(clk_launches, 1),
+            "achieved_device_clock": (alg / (clk_ms * 1e-3) / 1e9) if clk_ms > 0 else None,
+            "frac_device_clock": (alg / (clk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if clk_ms > 0 else None,
             "algorithmic_bytes_per_launch": alg / max(launches, 1),
             "note": "achieved = algorithmic bytes (sum over tree updates of 48 n + 40 rows_touched, "
                     "SURVEY.md 8d) / total k_rows time from HIP events attached to each k_rows dispatch "
-                    "(hipExtLaunchKernelGGL start/stop on the sampler's stream); "
+                    "(hipExtLaunchKernelGGL start/stop on the sampler's stream; the pair still brackets ~1-1.5 us "
+                    "of packet handling per launch -- the *_device_clock fields time the same launches "
+                    "from inside the kernel and agree with the rocprofv3 kernel trace); "
                     "traffic = HBM bytes per k_rows launch from profiles/r01_pmc_traffic.json: well "
                     "BELOW the algorithmic bytes because the 39 particles share the X columns and "
                     "{sum_trees, r} through L2 / Infinity Cache at this size; the algorithmic figure is the "

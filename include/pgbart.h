@@ -154,6 +154,10 @@ int pgb_predict(const pgb_tree_arrays* trees_host, const int32_t* forest_tree_id
 /* Profiling aid for bench.py: when enabled, the backend brackets every launch of
  * its dominant kernel with events on its stream and accumulates their duration. */
 int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out);
+/* The same region seen by the device clock: per launch, last reading of any workgroup minus the
+ * first reading of any workgroup (the interval a kernel trace reports); valid after
+ * pgb_profile(h, 0, ...).  CPU backends report 0. */
+int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out);
 
 /* Checkpoint / resume of one chain (what pickling the reference's step method into a PyMC worker
  * process carries: reference SURVEY 8b "must be picklable"; tree hand-off bart.py:134-135).

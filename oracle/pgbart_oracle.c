@@ -932,6 +932,13 @@ int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* l
   return PGB_OK;
 }
 
+int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out) {
+  (void)h;
+  if (kernel_ms_out) *kernel_ms_out = 0.0;
+  if (launches_out) *launches_out = 0;
+  return PGB_OK;
+}
+
 /* ------------------------------------------------------------------ checkpoint / resume
  * (same ABI as the HIP backend; the image layout is this backend's own) */
 typedef struct {

@@ -67,6 +67,7 @@ SYMBOLS = (
     "pgb_get_split_weights",
     "pgb_predict",
     "pgb_profile",
+    "pgb_profile_clock",
     "pgb_checkpoint_size",
     "pgb_checkpoint_save",
     "pgb_checkpoint_load",
@@ -169,6 +170,7 @@ class PGBLibrary:
             C.c_int64, vp, vp, C.c_int32, vp, vp,
         ]
         lib.pgb_profile.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.pgb_profile_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.pgb_checkpoint_size.argtypes = [vp, C.POINTER(C.c_int64)]
         lib.pgb_checkpoint_save.argtypes = [vp, vp, C.c_int64]
         lib.pgb_checkpoint_load.argtypes = [vp, vp, C.c_int64]

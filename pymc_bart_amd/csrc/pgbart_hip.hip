@@ -113,6 +113,8 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
 #define ACC_STRIDE 2 /* distance between copies, in records of 64 B: one 128-B line each */
 #endif
 #define ACC_PER (ACC_SLOTS * ACC_STRIDE)
+#define PROF_RING 4096   /* row-pass launches a profiled region may span */
+#define PROF_BLOCKS 1024 /* = the largest row grid */
 // the same for the log-likelihood sums of k_loglik (32-byte records): 8 copies, 128 B apart
 #define LL_SLOTS 8
 #define LL_STRIDE 4
@@ -218,6 +220,8 @@ struct Dev {  // kernel argument block (by value)
   LinP* tlin;             // [m][MAXN]        accepted trees' leaves
   LinP* lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
   AccU* accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
+  // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
+  long long* prof_stamps;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
   long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
 };
@@ -1547,6 +1551,15 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   const Cmd* cmd = &cmds[par];
   const int kind = cmd->kind;
   TRR(12, 0);
+  // profiling: every workgroup leaves its first and last device-clock reading; the host takes
+  // min(start) .. max(end) per launch -- the interval rocprofv3 reports for the dispatch
+  long long* pstamp = nullptr;
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+    pstamp = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
+    pstamp[0] = wall_clock64();
+    pstamp[1] = pstamp[0];
+  }
+#define PROF_END() do { if (pstamp) pstamp[1] = wall_clock64(); } while (0)
   if (kind == CMD_NOOP) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
@@ -1607,7 +1620,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     __syncthreads();
     TRR(13, 0);
     const int nact = s_n[0];
-    if (nact == 0 && !do_init) return;
+    if (nact == 0 && !do_init) { PROF_END(); return; }
     const int target = do_init ? S.rows_target_init : S.rows_target;
     int G = (nact * S.nchunks + target - 1) / target;
     if (G < 1) G = 1;
@@ -1882,6 +1895,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         if (iv[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)iv[4]);
       }
     }
+    PROF_END();
     return;
   }
 
@@ -1926,6 +1940,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
     atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
   }
+  PROF_END();
+#undef PROF_END
 }
 
 // ------------------------------------------------------------------ k_rows_mk
@@ -2678,6 +2694,10 @@ struct pgb_handle {
   size_t ev_used;
   double prof_ms;
   long long prof_launches;
+  long long* prof_buf;    // device-clock stamps (allocated on first use)
+  long long prof_slot0;   // first slot of the profiled region (device-clock stamps)
+  double prof_clock_ms;   // sum over launches of max(end) - min(start), 100 MHz device clock
+  long long prof_clock_launches;
 };
 
 template <typename T>
@@ -2736,6 +2756,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->slot = 0;
   h->has_subset = 0;
   h->rows_grid = 1024;
+  h->prof_buf = nullptr;
+  h->prof_clock_ms = 0.0;
+  h->prof_clock_launches = 0;
+  h->prof_slot0 = 0;
   if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
   h->st_cur = 0;
   h->alpha_cur = 0;
@@ -3499,8 +3523,53 @@ extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out,
     h->prof_ms = 0.0;
     h->prof_launches = 0;
     h->ev_used = 0;
+    h->prof_clock_ms = 0.0;
+    h->prof_clock_launches = 0;
+    h->prof_slot0 = h->slot;
+    if (!h->prof_buf) {
+      int rc = dalloc(h, &h->prof_buf, (size_t)PROF_RING * PROF_BLOCKS * 2);
+      if (rc != PGB_OK) return rc;
+      h->alloc_persist.back() = 0;
+    }
+    h->d.prof_stamps = h->prof_buf;
+    HIPCHK(hipMemsetAsync(h->d.prof_stamps, 0, (size_t)PROF_RING * PROF_BLOCKS * 2 * sizeof(long long), h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (!enable && h->prof && h->d.prof_stamps) {  // harvest the device-clock stamps, stop stamping
+    const long long n_launch = h->slot - h->prof_slot0;
+    if (n_launch > 0 && n_launch <= PROF_RING) {
+      std::vector<long long> st((size_t)PROF_RING * PROF_BLOCKS * 2);
+      HIPCHK(hipMemcpy(st.data(), h->d.prof_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      for (long long sl = h->prof_slot0; sl < h->slot; ++sl) {
+        const long long* row = st.data() + (size_t)(sl % PROF_RING) * PROF_BLOCKS * 2;
+        long long lo = 0, hi = 0;
+        bool any = false;
+        for (int b = 0; b < PROF_BLOCKS; ++b) {
+          if (row[2 * b] == 0) continue;
+          if (!any || row[2 * b] < lo) lo = row[2 * b];
+          if (!any || row[2 * b + 1] > hi) hi = row[2 * b + 1];
+          any = true;
+        }
+        if (any) {
+          h->prof_clock_ms += (double)(hi - lo) * 1.0e-5;  // 100 MHz ticks -> ms
+          h->prof_clock_launches += 1;
+        }
+      }
+    }
+    h->d.prof_stamps = nullptr;
+    HIPCHK(hipMemcpy(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice));
   }
   h->prof = enable ? 1 : 0;
+  return PGB_OK;
+}
+
+// Device-clock view of the last profiled region: sum over row-pass launches of
+// max(last reading of a workgroup) - min(first reading), and the number of launches seen.
+extern "C" int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (kernel_ms_out) *kernel_ms_out = h->prof_clock_ms;
+  if (launches_out) *launches_out = h->prof_clock_launches;
   return PGB_OK;
 }
 

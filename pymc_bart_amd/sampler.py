@@ -281,3 +281,12 @@ class PySampler:
         nl = C.c_int64()
         lib.check(lib.lib.pgb_profile(self._h, int(enable), C.byref(ms), C.byref(nl)), "pgb_profile")
         return float(ms.value), int(nl.value)
+
+    def profile_clock(self) -> tuple[float, int]:
+        """Device-clock duration of the row-pass launches of the last profiled region (after
+        ``profile(False)``): (total ms, launches)."""
+        lib = self.backend.lib
+        ms = C.c_double()
+        nl = C.c_int64()
+        lib.check(lib.lib.pgb_profile_clock(self._h, C.byref(ms), C.byref(nl)), "pgb_profile_clock")
+        return float(ms.value), int(nl.value)
