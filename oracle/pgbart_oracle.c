@@ -89,6 +89,7 @@ struct pgb_handle {
   pgb_scales sc;
   double* X; /* column-major p x n */
   double* y;
+  double* off; /* per-row offset of the linear predictor (single-output per-row families) */
   int32_t* rules;
   int64_t* alpha_vec; /* p  integer split weights (pgb_alpha_init + counts * unit) */
   int64_t* cdf;       /* p  prefix sums the sampler currently uses */
@@ -199,6 +200,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   int p = s->p, m = s->m, P = s->num_particles, K = s->n_outputs;
   h->X = (double*)malloc(sizeof(double) * (size_t)n * p);
   h->y = (double*)malloc(sizeof(double) * n);
+  h->off = (double*)calloc((size_t)n, sizeof(double));
   h->rules = (int32_t*)calloc(p, sizeof(int32_t));
   h->alpha_vec = (int64_t*)malloc(sizeof(int64_t) * p);
   h->cdf = (int64_t*)malloc(sizeof(int64_t) * p);
@@ -245,7 +247,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
 
 int pgb_destroy(pgb_handle* h) {
   if (!h) return PGB_OK;
-  free(h->X); free(h->y); free(h->rules); free(h->alpha_vec); free(h->cdf); free(h->col_has_nan); free(h->col_ex);
+  free(h->X); free(h->y); free(h->off); free(h->rules); free(h->alpha_vec); free(h->cdf); free(h->col_has_nan); free(h->col_ex);
   free(h->st); free(h->r); free(h->oldv); free(h->rs_mean); free(h->rs_m2); free(h->trees);
   free(h->lid); free(h->part); free(h->part2); free(h->arena); free(h->vi); free(h->last_ids);
   free(h);
@@ -296,6 +298,15 @@ int pgb_set_response(pgb_handle* h, const double* y) {
   if (!h || !y) return fail(PGB_E_INVALID, "null argument");
   memcpy(h->y, y, sizeof(double) * h->s.n);
   h->have_y = 1;
+  return PGB_OK;
+}
+
+int pgb_set_offset(pgb_handle* h, const double* off) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
+    return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
+  if (off) memcpy(h->off, off, sizeof(double) * h->s.n);
+  else memset(h->off, 0, sizeof(double) * h->s.n);
   return PGB_OK;
 }
 
@@ -376,8 +387,8 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
     } else {
       /* non-Normal families: C = log-lik of a fresh stump, E0 = log-lik of the current tree */
       double mu_stump[PGB_MAX_OUTPUTS], mu_cur[PGB_MAX_OUTPUTS];
-      mu_stump[0] = noi + s->init_leaf;
-      mu_cur[0] = h->st[i];
+      mu_stump[0] = (noi + h->off[i]) + s->init_leaf;
+      mu_cur[0] = h->st[i] + h->off[i];
       for (int k = 1; k < K; ++k) {
         const double stk = h->st[(size_t)k * n + i];
         const double ok = lv[k][lid[i]];
@@ -438,6 +449,7 @@ static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, cons
     int32_t i = seg[k];
     double mu[PGB_MAX_OUTPUTS];
     for (int o = 0; o < K; ++o) mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + v[o];
+    if (K == 1) mu[0] = ((h->st[i] - h->oldv[i]) + h->off[i]) + v[0];
     acc += pgb_quant(o_loglik(h, h->y[i], mu), h->sc.cl, &sat);
   }
   h->ctr.saturations += sat;

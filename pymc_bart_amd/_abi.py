@@ -58,6 +58,7 @@ SYMBOLS = (
     "pgb_destroy",
     "pgb_set_data",
     "pgb_set_response",
+    "pgb_set_offset",
     "pgb_set_likelihood",
     "pgb_step",
     "pgb_step_async",
@@ -158,6 +159,7 @@ class PGBLibrary:
         lib.pgb_destroy.argtypes = [vp]
         lib.pgb_set_data.argtypes = [vp, vp, C.c_int64, vp, vp]
         lib.pgb_set_response.argtypes = [vp, vp]
+        lib.pgb_set_offset.argtypes = [vp, vp]
         lib.pgb_set_likelihood.argtypes = [vp, vp, C.c_int32]
         lib.pgb_step.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]

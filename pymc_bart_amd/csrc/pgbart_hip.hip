@@ -177,6 +177,7 @@ struct Dev {  // kernel argument block (by value)
   const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
   const double* XT;  // [p][n_pad]
   const double* y;   // [n_pad]
+  const double* off; // [n_pad] offset of the linear predictor (single-output per-row families; 0 by default)
   double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
   double2* pack;     // [n_pad] {sum_trees, y - noi}
   double* rs_mean;
@@ -213,7 +214,7 @@ struct Dev {  // kernel argument block (by value)
   double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
   double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
   // ---- linear response (Normal family, K = 1, continuous columns)
-  int32_t response, pad_resp;
+  int32_t response, has_off;  // has_off: an offset of the linear predictor is set (else the array is all 0)
   double lin_R, inv_R;
   const int32_t* col_ex;  // [p] exponent bound of every column
   LinP* plin;             // [2][MAXP][MAXN]  particle leaves
@@ -1733,8 +1734,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             } else {
               // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
               const double lp = S.ctrl[par ^ 1].inv_sigma2, lp2 = S.ctrl[par ^ 1].lik_param2;  // family parameters
-              iv[2] += pgb_quant(pgb_loglik1q(S.family, yv, noi + S.init_leaf, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
-              iv[3] += pgb_quant(pgb_loglik1q(S.family, yv, st, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
+              iv[2] += pgb_quant(pgb_loglik1q(S.family, yv, (noi + offv) + S.init_leaf, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              iv[3] += pgb_quant(pgb_loglik1q(S.family, yv, st + offv, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
             }
           }
         }
@@ -2394,6 +2396,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     for (int e = 0; e < RPT; ++e) {
       yv[e] = S.y[base + e];
       nv[e] = noi[base + e];
+      if constexpr (KT == 1)
+        if (S.has_off) nv[e] = nv[e] + S.off[base + e];  // (adding the default 0.0 would give the same bits)
       if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
     }
     if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
@@ -2808,6 +2812,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   transient(h);
   DA(y, d.n_pad);
   transient(h);
+  double* off;
+  DA(off, d.n_pad);
+  transient(h);
+  d.off = off;
   const int K = d.K, KX = d.K - 1;
   DA(st, (size_t)2 * K * d.n_pad);
   DA(pack, d.n_pad);
@@ -2886,6 +2894,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   }
   HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(off, 0, d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
   HC(hipMemsetAsync(rs_mean, 0, (size_t)K * d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(rs_m2, 0, (size_t)K * d.n_pad * sizeof(double), sm));
@@ -3016,6 +3025,22 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
   HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_y = 1;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
+    return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
+  if (offset_dev)
+    HIPCHK(hipMemcpyAsync((void*)h->d.off, offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  else
+    HIPCHK(hipMemsetAsync((void*)h->d.off, 0, h->d.n * sizeof(double), h->stream));
+  if (h->d.has_off != (offset_dev ? 1 : 0)) {
+    h->d.has_off = offset_dev ? 1 : 0;
+    HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
   return PGB_OK;
 }
 

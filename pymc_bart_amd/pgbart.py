@@ -302,14 +302,18 @@ class PGBART(_Base):
     def astep(self, _q=None, point=None, offset=None):
         """Re-sample the next batch of trees; returns ``(sum_trees, [stats])``.
 
-        ``offset``: contribution of the *other* additive terms of a Normal model at the current
-        point (e.g. a second BART variable, reference ``tests/test_bart.py:211-241``): this step
-        method then fits ``observed - offset``.
+        ``offset``: contribution of the *other* additive terms of the model at the current point
+        (a second BART variable, reference ``tests/test_bart.py:211-241``; a log-exposure of a count
+        model): a Normal model fits ``observed - offset``, the per-row families add it to the linear
+        predictor.
         """
         if offset is not None:
-            if self.likelihood.family != "normal":
-                raise NotImplementedError("offsets are implemented for the Normal family only")
-            self.sampler.set_response(self._y_obs - np.asarray(offset, np.float64))
+            if self.likelihood.family == "normal":      # additive Normal model: fit what is left
+                self.sampler.set_response(self._y_obs - np.asarray(offset, np.float64))
+            elif self.shape == (self.num_observations,):  # per-row families: offset of the predictor
+                self.sampler.set_offset(offset)
+            else:
+                raise NotImplementedError("offsets are not implemented for multi-output families")
         self.sampler.set_likelihood(self.likelihood.params(point))
         if not self.tune and self._baseline is None:
             # first draw: freeze the forest the per-draw batches are deltas of (utils.py:124-127)

@@ -188,6 +188,16 @@ class PySampler:
         self._y = mem.from_host(np.ascontiguousarray(y_obs, dtype=np.float64))
         lib.check(lib.lib.pgb_set_response(self._h, mem.ptr(self._y)), "pgb_set_response")
 
+    def set_offset(self, offset) -> None:
+        """Per-row offset of the linear predictor (single-output per-row families): what the other
+        additive terms of the model contribute at the current point; ``None`` resets it."""
+        lib, mem = self.backend.lib, self.backend.mem
+        if offset is None:
+            lib.check(lib.lib.pgb_set_offset(self._h, None), "pgb_set_offset")
+            return
+        self._off = mem.from_host(np.ascontiguousarray(offset, dtype=np.float64))
+        lib.check(lib.lib.pgb_set_offset(self._h, mem.ptr(self._off)), "pgb_set_offset")
+
     # -- likelihood parameters at the current point -------------------------------
     def set_likelihood(self, params) -> None:
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(params, np.float64)))

@@ -109,6 +109,13 @@ def make_case(name: str):
             Y = rng.negative_binomial(2.0, 2.0 / (2.0 + rate)).astype(float)
             c.update(family="negbin_log", lik_params=[2.0])
         c.update(m=12, P=12, steps=30, bart_Y=np.log(Y + 0.5))
+    elif name == "poisson_exposure":  # per-row offset of the linear predictor (log-exposure of a count model)
+        n, p = 3000, 4
+        X = rng.normal(size=(n, p))
+        expo = rng.uniform(0.2, 5.0, n)
+        lograte = 0.7 * X[:, 0] + 0.5
+        Y = rng.poisson(expo * np.exp(lograte)).astype(float)
+        c.update(family="poisson_log", m=10, P=12, steps=30, bart_Y=np.log((Y + 0.5) / expo), offset=np.log(expo))
     elif name in ("quantile_asymlaplace", "robust_student_t"):  # two-parameter per-row families
         n, p = 3500, 4
         X = rng.uniform(-2, 2, size=(n, p))
@@ -163,7 +170,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -179,6 +186,8 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
     prior = np.ones(p) if c["prior"] is None else c["prior"]
     s = PySampler(st, X, Y, rules, prior, backend=backend)
+    if c.get("offset") is not None:
+        s.set_offset(c["offset"])
     sig_rng = np.random.default_rng(99)
     sums, vis, trees = [], [], []
     half = c["steps"] // 2
@@ -187,6 +196,8 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
             blob = s.checkpoint()
             del s
             s = PySampler(st, X, Y, rules, prior, backend=backend)
+            if c.get("offset") is not None:
+                s.set_offset(c["offset"])
             s.restore(blob)
         sig = float(0.5 + sig_rng.random())  # sigma moves like a Gibbs/NUTS neighbour
         s.set_likelihood([sig] if family == "normal" else c.get("lik_params", []))

@@ -719,3 +719,27 @@ def test_quantile_and_robust_regression_families(oracle):
     s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
     with pytest.raises(_abi.PGBError, match="0 < q < 1"):
         s.set_likelihood([0.2, 1.5])
+
+
+def test_offset_of_the_linear_predictor_for_count_models(oracle):
+    """A log-exposure (or any other additive term of the model) enters the per-row families as an
+    offset of the linear predictor: BART then fits the rate, not rate x exposure."""
+    from pymc_bart_amd import PoissonLikelihood
+
+    rng = np.random.default_rng(23)
+    X = rng.normal(size=(1500, 2))
+    expo = rng.uniform(0.2, 6.0, 1500)
+    lograte = 0.8 * X[:, 0] + 0.3
+    counts = rng.poisson(expo * np.exp(lograte)).astype(float)
+    op = BARTOp(X, np.log((counts + 0.5) / expo), m=20)
+    step = PGBART([op], num_particles=10, likelihood=PoissonLikelihood(), observed=counts, random_seed=6,
+                  backend=oracle)
+    for it in range(150):
+        mu, _ = step.astep(None, {}, offset=np.log(expo))
+    assert np.sqrt(np.mean((mu - lograte) ** 2)) < 0.3
+    assert abs(float(np.mean(mu - lograte))) < 0.1            # no exposure left in the fit
+    # the Normal family has no predictor offset in the ABI (the caller subtracts from the response)
+    st = PyBartSettings.from_data(X, lograte, m=2, num_particles=4)
+    s = PySampler(st, X, lograte, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    with pytest.raises(_abi.PGBError, match="per-row families"):
+        s.set_offset(np.zeros(1500))
