@@ -78,6 +78,7 @@
 #define PGB_FAMILY_NEGBIN_LOG 6       /* y ~ NegBin(mean exp(mu), alpha)     params: alpha */
 #define PGB_FAMILY_ASYMLAPLACE 7      /* y ~ AsymmetricLaplace(b, q, mu): quantile regression   params: b, q */
 #define PGB_FAMILY_STUDENT_T 8        /* y ~ StudentT(nu, mu, sigma)         params: sigma, nu */
+#define PGB_FAMILY_GAMMA_LOG 9        /* y ~ Gamma(alpha, mean exp(mu)), y > 0   params: alpha */
 
 /* RNG purposes (high half of counter word 3) */
 #define PGB_RNG_PROPOSE 1u  /* u0: prior coin, u1: split variable            */
@@ -523,6 +524,7 @@ PGB_HD double pgb_softplus(double t) {
  * weight; they make the value a quantity <= 0 that fits the fixed-point range like a log-pmf. */
 /*   ASYMLAPLACE(b, q):  -rho_q((y - mu) / b),  rho_q(u) = u (q - [u < 0])   (the check loss)
  *   STUDENT_T(sigma, nu): -((nu + 1) / 2) log(1 + ((y - mu) / sigma)^2 / nu)
+ *   GAMMA_LOG(alpha):    -alpha (y e^-mu + mu - 1 - log y)   (relative to the saturated model)
  * (both without their mu-free normalising terms, hence <= 0). */
 PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double param2, const double* tn,
                            const double* tp) {
@@ -538,6 +540,10 @@ PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double
       const double sat = yy > 0.0 ? yy * pgb_log(yy) - ay * pgb_log(ay) : -(param * pgb_log(param));
       ll = (yy * mu - ay * pgb_log(param + em)) - sat;
     }
+  } else if (family == PGB_FAMILY_GAMMA_LOG) {
+    /* -alpha (y e^-mu + mu) minus its maximum over mu, -alpha (1 + log y) */
+    const double yy = y > 1.0e-300 ? y : 1.0e-300;
+    ll = -param * (((yy * pgb_exp(-mu) + mu) - 1.0) - pgb_log(yy));
   } else if (family == PGB_FAMILY_ASYMLAPLACE) {
     const double u = (y - mu) / param;
     ll = -(u * (u < 0.0 ? param2 - 1.0 : param2));

@@ -180,7 +180,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
              s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
-             s->family == PGB_FAMILY_STUDENT_T) {
+             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -315,8 +315,8 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
   if (h->s.family == PGB_FAMILY_NORMAL) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
-  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {
-    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
+  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG || h->s.family == PGB_FAMILY_GAMMA_LOG) {
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG / GAMMA_LOG need alpha > 0");
     h->inv_sigma2 = params[0];
   } else if (h->s.family == PGB_FAMILY_ASYMLAPLACE) {
     if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0) || !(params[1] < 1.0))

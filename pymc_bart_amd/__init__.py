@@ -6,7 +6,7 @@ Public names mirror what the reference imports from the external ``bartrs`` whee
 """
 
 from . import _abi
-from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
+from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikelihood, GammaLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
                      NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood, StudentTLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
@@ -14,6 +14,6 @@ from .importance import compute_variable_importance
 
 __version__ = "0.1.0"
 __all__ = [
-    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood",
+    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood", "GammaLikelihood",
     "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "_abi",
 ]

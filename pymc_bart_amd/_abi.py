@@ -48,6 +48,7 @@ FAMILIES = {
     "negbin_log": 6,
     "asymmetric_laplace": 7,
     "student_t": 8,
+    "gamma_log": 9,
 }
 
 #: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)

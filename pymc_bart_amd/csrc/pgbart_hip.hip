@@ -2735,7 +2735,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
              s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
-             s->family == PGB_FAMILY_STUDENT_T) {
+             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
@@ -3050,8 +3050,9 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
     h->sigma_dirty = 1;
-  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG) {  // the slot doubles as "the family's parameter"
-    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG needs alpha > 0");
+  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG || h->s.family == PGB_FAMILY_GAMMA_LOG) {
+    // the slot doubles as "the family's parameter"
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG / GAMMA_LOG need alpha > 0");
     h->inv_sigma2 = params[0];
     h->sigma_dirty = 1;
   } else if (h->s.family == PGB_FAMILY_ASYMLAPLACE) {
@@ -3147,6 +3148,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
           case PGB_FAMILY_POISSON_LOG: LAUNCH_LL(1, PGB_FAMILY_POISSON_LOG); break;
           case PGB_FAMILY_NEGBIN_LOG: LAUNCH_LL(1, PGB_FAMILY_NEGBIN_LOG); break;
           case PGB_FAMILY_ASYMLAPLACE: LAUNCH_LL(1, PGB_FAMILY_ASYMLAPLACE); break;
+          case PGB_FAMILY_GAMMA_LOG: LAUNCH_LL(1, PGB_FAMILY_GAMMA_LOG); break;
           default: LAUNCH_LL(1, PGB_FAMILY_STUDENT_T);
         }
       }

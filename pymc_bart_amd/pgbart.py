@@ -134,6 +134,18 @@ class AsymmetricLaplaceLikelihood:
         return [_from_point(self.b, point), _from_point(self.q, point)]
 
 
+class GammaLikelihood:
+    """``y ~ Gamma(alpha, mean = exp(BART))`` for positive responses (BART built on ``log(y)``)."""
+
+    family = "gamma_log"
+
+    def __init__(self, alpha=1.0):
+        self.alpha = alpha
+
+    def params(self, point=None):
+        return [_from_point(self.alpha, point)]
+
+
 class StudentTLikelihood:
     """``y ~ StudentT(nu, mu = BART, sigma)`` -- outlier-robust regression."""
 

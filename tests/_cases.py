@@ -109,6 +109,12 @@ def make_case(name: str):
             Y = rng.negative_binomial(2.0, 2.0 / (2.0 + rate)).astype(float)
             c.update(family="negbin_log", lik_params=[2.0])
         c.update(m=12, P=12, steps=30, bart_Y=np.log(Y + 0.5))
+    elif name == "gamma_positive":  # positive continuous response, log link
+        n, p = 3000, 4
+        X = rng.normal(size=(n, p))
+        mean = np.exp(0.6 * X[:, 0] - 0.4 * (X[:, 1] > 0) + 0.5)
+        Y = rng.gamma(3.0, mean / 3.0)
+        c.update(family="gamma_log", lik_params=[3.0], m=10, P=12, steps=30, bart_Y=np.log(Y))
     elif name == "poisson_exposure":  # per-row offset of the linear predictor (log-exposure of a count model)
         n, p = 3000, 4
         X = rng.normal(size=(n, p))
@@ -170,7 +176,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -244,7 +250,7 @@ def random_case(seed):
     every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta."""
     rng = np.random.default_rng(seed)
     fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale",
-                      "poisson_log", "negbin_log", "asymmetric_laplace", "student_t"])
+                      "poisson_log", "negbin_log", "asymmetric_laplace", "student_t", "gamma_log"])
     n = int(rng.choice([3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 5000, 20000]))
     p = int(rng.integers(1, 9))
     m = int(rng.integers(1, 12))
@@ -271,6 +277,8 @@ def random_case(seed):
         Y = rng.poisson(np.exp(np.clip(f, -3, 3))).astype(float)
     elif fam in ("asymmetric_laplace", "student_t"):
         Y = f + rng.standard_t(3, n) * 0.5
+    elif fam == "gamma_log":
+        Y = rng.gamma(2.0, np.exp(np.clip(f, -3, 3)) / 2.0) + 1e-6
     elif fam == "categorical":
         K = int(rng.integers(2, 8)); Y = rng.integers(0, K, n).astype(float)
     else:
@@ -284,6 +292,9 @@ def random_case(seed):
         extra["bart_Y"] = np.log(Y + 0.5)
         if fam == "negbin_log":
             extra["lik_params"] = [float(rng.uniform(0.3, 5.0))]
+    if fam == "gamma_log":
+        extra["bart_Y"] = np.log(Y)
+        extra["lik_params"] = [float(rng.uniform(0.5, 5.0))]
     if fam == "asymmetric_laplace":
         extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.05, 0.95))]
     if fam == "student_t":
