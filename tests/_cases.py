@@ -299,6 +299,8 @@ def random_case(seed):
         extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.05, 0.95))]
     if fam == "student_t":
         extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(1.0, 30.0))]
+    if fam not in ("normal", "categorical", "normal_meanscale") and rng.random() < 0.3:
+        extra["offset"] = rng.normal(0, 0.3, n)  # another additive term of the linear predictor
     return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))
