@@ -227,7 +227,7 @@ def main():
             "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
             # the same launches by the device clock (first to last reading of any workgroup): the
             # interval a rocprofv3 kernel trace reports for the dispatch
-            "avg_kernel_us_device_clock": clk_ms * 1e3 / max(clk_launches, 1),
+            "avg_kernel_us_device_clock": (clk_ms * 1e3 / clk_launches) if clk_launches else None,
             "achieved_device_clock": (alg / (clk_ms * 1e-3) / 1e9) if clk_ms > 0 else None,
             "frac_device_clock": (alg / (clk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if clk_ms > 0 else None,
             "algorithmic_bytes_per_launch": alg / max(launches, 1),
