@@ -189,8 +189,8 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
-    if (s->family != PGB_FAMILY_NORMAL)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for the Normal family only");
+    if (s->n_outputs != 1)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for single-output families only");
   }
   pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
   if (!h) return fail(PGB_E_NOMEM, "calloc");
@@ -440,7 +440,8 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
 
 /* non-Normal families: fixed-point log-likelihood of `cnt` rows predicting the K-vector `v` from
  * this tree ([U] update_weight restricted to the rows whose prediction changed). */
-static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v) {
+static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v, double slope,
+                                double xbar, int svar) {
   unsigned sat = 0;
   int64_t acc = 0;
   const int K = h->s.n_outputs;
@@ -449,11 +450,18 @@ static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, cons
     int32_t i = seg[k];
     double mu[PGB_MAX_OUTPUTS];
     for (int o = 0; o < K; ++o) mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + v[o];
-    if (K == 1) mu[0] = ((h->st[i] - h->oldv[i]) + h->off[i]) + v[0];
+    if (K == 1) {
+      double vi = v[0];
+      if (svar >= 0) vi = pgb_leaf_pred(vi, slope, xbar, h->X[(size_t)svar * n + i]);
+      mu[0] = ((h->st[i] - h->oldv[i]) + h->off[i]) + vi;
+    }
     acc += pgb_quant(o_loglik(h, h->y[i], mu), h->sc.cl, &sat);
   }
   h->ctr.saturations += sat;
   return acc;
+}
+static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v) {
+  return o_seg_loglik_lin(h, seg, cnt, v, 0.0, 0.0, -1);
 }
 
 /* [U] ParticleTree.sample_tree + grow_tree for particle q in round `round`. */
@@ -644,8 +652,8 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
       va[o] = a->valx[o - 1];
       vb[o] = b->valx[o - 1];
     }
-    a->ll = o_seg_loglik(h, sl, cL, va);
-    b->ll = o_seg_loglik(h, sr, cR, vb);
+    a->ll = o_seg_loglik_lin(h, sl, cL, va, a->slope, a->xbar, a->svar);
+    b->ll = o_seg_loglik_lin(h, sr, cR, vb, b->slope, b->xbar, b->svar);
     if (sn) T->ll_orph += o_seg_loglik(h, sn, cN, zero_v);
     T->ll_tot = ((T->ll_tot - nd.ll) + a->ll) + b->ll;
     free(sn);

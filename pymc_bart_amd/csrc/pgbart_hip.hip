@@ -659,6 +659,55 @@ __device__ __forceinline__ int sample_var_weights(const long long* A, int p, dou
   return p - 1;
 }
 
+// linear response: the two children's linear parts from the sums the row pass left (shared by
+// k_ctrl and, for the per-row families, k_loglik: the very same arithmetic in both places)
+struct LinKids {
+  double slopeL, xbarL, slopeR, xbarR;
+  int svarL, svarR;
+  pgb_linfit fL, fR;
+  long long urL, urR;  // sum q(u r) of the children (the Normal family's SSE needs them)
+};
+__device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __restrict__ copies, int var, int cL, int cR,
+                                                long long aL, long long aR, uint32_t it, uint32_t round, uint32_t q) {
+  LinKids k;
+  k.slopeL = k.xbarL = k.slopeR = k.xbarR = 0.0;
+  k.svarL = k.svarR = -1;
+  k.fL = pgb_linfit{0.0, 0.0, 0.0};
+  k.fR = pgb_linfit{0.0, 0.0, 0.0};
+  long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+  for (int c = 0; c < ACC_SLOTS; ++c) {
+    const AccU t = copies[c * ACC_STRIDE];
+    for (int i2 = 0; i2 < 4; ++i2) { ul[i2] += t.uL[i2]; ur[i2] += t.uR[i2]; }
+  }
+  k.urL = ul[3];
+  k.urR = ur[3];
+  bool linL = true, linR = true;
+  if (S.response == PGB_RESPONSE_MIX) {  // [U] "mix": a fair coin per child
+    const pgb_u2 um = pgb_draw2(S.seed, it, round, q, PGB_RNG_MIX, 0);
+    linL = um.u0 < 0.5;
+    linR = um.u1 < 0.5;
+  }
+  const int ex = S.col_ex[var];
+  const double uscale = pgb_pow2(-ex), xs = pgb_pow2(ex);
+  if (linL) {
+    k.fL = pgb_lin_fit(cL, ul[0], ul[1], ul[2], aL, S.sc.inv_c1, S.inv_R, S.mdouble);
+    if (k.fL.slope_u != 0.0) {
+      k.svarL = var;
+      k.slopeL = k.fL.slope_u * uscale;
+      k.xbarL = k.fL.ubar * xs;
+    }
+  }
+  if (linR) {
+    k.fR = pgb_lin_fit(cR, ur[0], ur[1], ur[2], aR, S.sc.inv_c1, S.inv_R, S.mdouble);
+    if (k.fR.slope_u != 0.0) {
+      k.svarR = var;
+      k.slopeR = k.fR.slope_u * uscale;
+      k.xbarR = k.fR.ubar * xs;
+    }
+  }
+  return k;
+}
+
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
@@ -877,37 +926,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
             f.svarL = f.svarR = -1;
             f.slopeL = f.xbarL = f.slopeR = f.xbarR = 0.0;
-            if constexpr (LIN) {  // [U] fast_linear_fit on the split variable; "mix": a fair coin per child
-              long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
-              for (int k = 0; k < ACC_SLOTS; ++k) {
-                const AccU t = S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER + k * ACC_STRIDE];
-                for (int i2 = 0; i2 < 4; ++i2) { ul[i2] += t.uL[i2]; ur[i2] += t.uR[i2]; }
-              }
-              bool linL = true, linR = true;
-              if (S.response == PGB_RESPONSE_MIX) {
-                const pgb_u2 um = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q, PGB_RNG_MIX, 0);
-                linL = um.u0 < 0.5;
-                linR = um.u1 < 0.5;
-              }
-              const int ex = S.col_ex[j.var];
-              const double uscale = pgb_pow2(-ex), xs = pgb_pow2(ex);
-              if (linL) {
-                const pgb_linfit lf = pgb_lin_fit(cL, ul[0], ul[1], ul[2], f.aL, S.sc.inv_c1, S.inv_R, S.mdouble);
-                if (lf.slope_u != 0.0) {
-                  f.svarL = j.var;
-                  f.slopeL = lf.slope_u * uscale;
-                  f.xbarL = lf.ubar * xs;
-                  f.sseL = pgb_lin_sse(f.sseL, lf, ul[3], f.bL, S.sc.inv_c1);
-                }
-              }
-              if (linR) {
-                const pgb_linfit lf = pgb_lin_fit(cR, ur[0], ur[1], ur[2], f.aR, S.sc.inv_c1, S.inv_R, S.mdouble);
-                if (lf.slope_u != 0.0) {
-                  f.svarR = j.var;
-                  f.slopeR = lf.slope_u * uscale;
-                  f.xbarR = lf.ubar * xs;
-                  f.sseR = pgb_lin_sse(f.sseR, lf, ur[3], f.bR, S.sc.inv_c1);
-                }
+            if constexpr (LIN) {  // [U] fast_linear_fit on the split variable
+              const LinKids lk = lin_children(S, &S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER], j.var, cL, cR,
+                                              f.aL, f.aR, it, (uint32_t)(r - 1), (uint32_t)q);
+              f.svarL = lk.svarL; f.slopeL = lk.slopeL; f.xbarL = lk.xbarL;
+              f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
+              if (normal) {  // the weight of a linear leaf: SSE in closed form
+                if (lk.svarL >= 0) f.sseL = pgb_lin_sse(f.sseL, lk.fL, lk.urL, f.bL, S.sc.inv_c1);
+                if (lk.svarR >= 0) f.sseR = pgb_lin_sse(f.sseR, lk.fR, lk.urR, f.bR, S.sc.inv_c1);
               }
             }
             f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
@@ -2283,12 +2309,16 @@ struct LJob {
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
   double vLx[KXMAX], vRx[KXMAX];  // K-vector leaves: outputs 1..K-1
+  // linear response (single-output per-row families): the children's linear parts
+  double slopeL, xbarL, slopeR, xbarR;
+  int32_t svarL, svarR;
 };
 
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
 // FAM: the likelihood family when known at compile time (single-output kernels: the per-row
 // evaluation then contains one family's code only), -1: read S.family.
-template <int KT, int FAM>
+// LIN: linear response (single-output families): the children predict value + slope (x - xbar).
+template <int KT, int FAM, bool LIN>
 __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   constexpr bool MK = KT != 1;
@@ -2356,6 +2386,16 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       lj.vR = cv.vR;
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
+      lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
+      lj.svarL = lj.svarR = -1;
+      if constexpr (LIN) {
+        if (cv.ok == 1) {
+          const LinKids lk = lin_children(S, &S.accu[((size_t)par * MAXP + tid) * ACC_PER], j.var, cv.cL, cv.cR,
+                                          cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)tid);
+          lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
+          lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
+        }
+      }
       if constexpr (MK)
       for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
         const int KX = (KT > 0 ? KT : S.K) - 1;
@@ -2454,9 +2494,18 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           // (separate calls per side would run one after the other on a divergent wave)
           const uint32_t nl = (nid >> (8 * e)) & 255u;
           const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
-          const double mu = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);  // dropped: predicts 0
-          const long long q = pgb_quant(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, s_ln,
-                                                      s_ln + (PROBIT ? PGB_LN_TN_ROWS * 9 : 0)), cl, &sat);
+          double vleaf = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;  // dropped: predicts 0
+          if constexpr (LIN) {
+            const int sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
+            if (sv >= 0) {
+              const double xv = S.XT[lj.xoff + base + e];
+              vleaf = pgb_leaf_pred(vleaf, side == 0 ? lj.slopeL : lj.slopeR, side == 0 ? lj.xbarL : lj.xbarR, xv);
+            }
+          }
+          const double mu = nv[e] + vleaf;
+          const long long q = pgb_quant(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2,
+                                                      PROBIT ? s_ln : pgb_ln_tn(),
+                                                      PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl, &sat);
           v0 += side == 0 ? q : 0;
           v1 += side == 1 ? q : 0;
           v2 += side == 2 ? q : 0;
@@ -2744,8 +2793,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
-    if (s->family != PGB_FAMILY_NORMAL)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for the Normal family only");
+    if (s->n_outputs != 1)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for single-output families only");
   }
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -3121,7 +3170,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (d.response != PGB_RESPONSE_CONSTANT) {
-        LAUNCH_ROWS((k_rows<false, true, true>), ROWS_PTRS);
+        if (nrm) LAUNCH_ROWS((k_rows<false, true, true>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<false, false, true>), ROWS_PTRS);
       } else if (h->has_subset) {
         if (nrm) LAUNCH_ROWS((k_rows<true, true, false>), ROWS_PTRS);
         else LAUNCH_ROWS((k_rows<true, false, false>), ROWS_PTRS);
@@ -3133,7 +3183,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef LAUNCH_ROWS
 #undef ROWS_PTRS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
-#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_>), grows, dim3(BT), 0, h->stream, h->d_dev, par)
+#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par)
       if (d.K > 1) {
         switch (d.K) {
           case 2: LAUNCH_LL(2, -1); break;
@@ -3141,6 +3191,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
           case 4: LAUNCH_LL(4, -1); break;
           default: LAUNCH_LL(0, -1);
         }
+      } else if (d.response != PGB_RESPONSE_CONSTANT) {  // linear leaves: one instance, family read at run time
+        hipLaunchKernelGGL((k_loglik<1, -1, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
       } else {
         switch (d.family) {
           case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;

@@ -109,6 +109,19 @@ def make_case(name: str):
             Y = rng.negative_binomial(2.0, 2.0 / (2.0 + rate)).astype(float)
             c.update(family="negbin_log", lik_params=[2.0])
         c.update(m=12, P=12, steps=30, bart_Y=np.log(Y + 0.5))
+    elif name in ("linear_poisson", "mix_probit"):  # linear leaves with per-row families
+        n, p = 3000, 3
+        X = rng.uniform(-2, 2, size=(n, p))
+        X[rng.random(n) < 0.1, 2] = np.nan
+        f = np.where(X[:, 0] < 0, 1.0 * X[:, 0] + 0.5, -0.8 * X[:, 0] + 0.5)
+        if name == "linear_poisson":
+            Y = rng.poisson(np.exp(f)).astype(float)
+            c.update(family="poisson_log", response="linear", bart_Y=np.log(Y + 0.5))
+        else:
+            from scipy.special import ndtr
+            Y = (rng.random(n) < ndtr(f)).astype(float)
+            c.update(family="bernoulli_probit", response="mix")
+        c.update(m=8, P=12, steps=30)
     elif name == "gamma_positive":  # positive continuous response, log link
         n, p = 3000, 4
         X = rng.normal(size=(n, p))
@@ -176,7 +189,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -285,7 +298,7 @@ def random_case(seed):
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
     response = "constant"
-    if fam == "normal" and not rules.any():  # linear / mix need the Normal family and continuous columns
+    if K == 1 and not rules.any():  # linear / mix need scalar leaves and continuous columns
         response = str(rng.choice(["constant", "linear", "mix"]))
     extra = {}
     if fam in ("poisson_log", "negbin_log"):

@@ -632,13 +632,22 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
     np.testing.assert_allclose(ps.sample_posterior(X, list(range(10)))[:, 0, :], res["mu"], rtol=0, atol=1e-9)
     assert res["vi_counts"].sum(axis=0)[0] > res["vi_counts"].sum(axis=0)[1]
-    # not every combination exists: categorical rules and non-Normal families are rejected
+    # not every combination exists: categorical rules are rejected
     with pytest.raises(_abi.PGBError, match="ContinuousSplit"):
         PGBART([BARTOp(X, Y, m=2, response="linear", split_rules=["OneHotSplit", "ContinuousSplit"])], backend=oracle)
-    st = PyBartSettings.from_data(X, (Y > 0).astype(float), m=2, num_particles=4, family="bernoulli_probit",
+    # multi-output families have no linear leaves yet (the reference's test_shape[linear] case)
+    st = PyBartSettings.from_data(X, Y, m=2, num_particles=4, family="normal_meanscale", n_outputs=2,
                                   response="linear")
-    with pytest.raises(_abi.PGBError, match="Normal family"):
-        PySampler(st, X, (Y > 0).astype(float), np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    with pytest.raises(_abi.PGBError, match="single-output"):
+        PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    # every single-output family takes them
+    st = PyBartSettings.from_data(X, (Y > 0).astype(float), m=4, num_particles=6, family="bernoulli_probit",
+                                  response="linear")
+    s = PySampler(st, X, (Y > 0).astype(float), np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    s.set_likelihood([])
+    for _ in range(30):
+        s.step(True)
+    assert (s.export_trees(1).svar >= 0).any()
 
 
 def test_count_likelihoods_poisson_and_negative_binomial(oracle):
