@@ -752,3 +752,24 @@ def test_offset_of_the_linear_predictor_for_count_models(oracle):
     s = PySampler(st, X, lograte, np.zeros(2, np.int32), np.ones(2), backend=oracle)
     with pytest.raises(_abi.PGBError, match="per-row families"):
         s.set_offset(np.zeros(1500))
+
+
+def test_out_of_sample_fit_is_competitive_with_gradient_boosting(oracle):
+    """A reference-free quality pin: on Friedman's function (BASELINE.json configs[0] shape) the
+    posterior-mean prediction on held-out rows is at least as good as a tuned-by-default gradient
+    boosting regressor, up to 15 %."""
+    from sklearn.ensemble import GradientBoostingRegressor
+
+    rng = np.random.default_rng(3415)
+    X = rng.uniform(0, 1, (700, 5))
+    f = 10 * np.sin(np.pi * X[:, 0] * X[:, 1]) + 20 * (X[:, 2] - 0.5) ** 2 + 10 * X[:, 3] + 5 * X[:, 4]
+    Y = f + rng.normal(0, 1, 700)
+    tr, te = slice(0, 500), slice(500, 700)
+    op = BARTOp(X[tr], Y[tr], m=50)
+    sample_chain(op, tune=300, draws=200, random_seed=1, backend=oracle)
+    pred = _sample_posterior(_get_posterior_sampler(op, backend=oracle), X[te], np.random.default_rng(0), size=150)
+    bart_rmse = float(np.sqrt(np.mean((pred.mean(axis=0)[:, 0] - f[te]) ** 2)))
+    gbm = GradientBoostingRegressor(random_state=0).fit(X[tr], Y[tr])
+    gbm_rmse = float(np.sqrt(np.mean((gbm.predict(X[te]) - f[te]) ** 2)))
+    assert bart_rmse < 1.15 * gbm_rmse, (bart_rmse, gbm_rmse)
+    assert bart_rmse < 1.6   # in absolute terms: noise sd is 1, f has sd ~4.9
