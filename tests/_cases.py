@@ -228,7 +228,7 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
             parts = [ta.tree_id, ta.node_off, ta.var, ta.left, ta.right, ta.count, ta.split.view(np.int64),
                      ta.value.ravel().view(np.int64)]
             if c.get("response", "constant") != "constant":  # linear leaves are part of the fingerprint
-                parts += [ta.slope.view(np.int64), ta.xbar.view(np.int64), ta.svar]
+                parts += [ta.slope.ravel().view(np.int64), ta.xbar.view(np.int64), ta.svar]
             trees.append(np.concatenate(parts))
     forest = s.export_trees(1)
     ctr = s.counters.as_dict()
