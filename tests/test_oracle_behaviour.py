@@ -316,7 +316,9 @@ def test_categorical_model_recovers_classes(oracle, split_rule):
         np.testing.assert_allclose(pred[0], lo, atol=1e-9)
 
 
-def test_shape_two_outputs_mean_and_scale(oracle):
+@pytest.mark.filterwarnings("ignore:response=")
+@pytest.mark.parametrize("response", ["constant", "linear"], ids=["constant", "linear-response"])
+def test_shape_two_outputs_mean_and_scale(oracle, response):
     # reference tests/test_bart.py:107-123: w = BART(shape=(2, 250)); y ~ Normal(w[0], |w[1]|):
     # astep returns (2, n); the scale output must pick up heteroscedasticity
     from pymc_bart_amd.pgbart import NormalMeanScaleLikelihood
@@ -325,7 +327,7 @@ def test_shape_two_outputs_mean_and_scale(oracle):
     X = rng.normal(0, 1, size=(250, 3))
     sd = np.where(X[:, 0] > 0, 2.0, 0.3)
     Y = X[:, 1] + sd * rng.normal(0, 1, size=250)
-    op = BARTOp(X, Y, m=10)
+    op = BARTOp(X, Y, m=10, response=response)
     step = PGBART([op], num_particles=10, likelihood=NormalMeanScaleLikelihood(), random_seed=3415,
                   backend=oracle)
     assert step.shape == (2, 250)
