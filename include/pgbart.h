@@ -89,7 +89,7 @@ typedef struct {
   double* value;      /* [total_nodes * n_outputs]                              */
   /* linear response (NULL = not wanted): a leaf predicts value + slope * (x[svar] - xbar);
    * svar = -1 (slope 0) for constant leaves                                              */
-  double* slope;      /* [total_nodes]                                          */
+  double* slope;      /* [total_nodes * n_outputs]                              */
   double* xbar;       /* [total_nodes]                                          */
   int32_t* svar;      /* [total_nodes]                                          */
 } pgb_tree_arrays;

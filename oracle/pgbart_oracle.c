@@ -73,6 +73,7 @@ typedef struct {
   int64_t q_stx[PGB_MAX_OUTPUTS - 1];  /* sum of sum_trees over the node rows, outputs 1..K-1 */
   int64_t ll;  /* non-Normal families: fixed-point log-likelihood of the node's rows */
   double slope, xbar; /* linear response: the leaf predicts value + slope (x[svar] - xbar) */
+  double slopex[PGB_MAX_OUTPUTS - 1]; /* ... slopes of outputs 1..K-1 (svar / xbar are shared) */
   int32_t svar;       /* ... svar = -1: constant leaf                                       */
   int64_t seg; /* arena offset of the sorted row list (oracle only) */
 } onode;
@@ -189,8 +190,6 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
-    if (s->n_outputs != 1)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for single-output families only");
   }
   pgb_handle* h = (pgb_handle*)calloc(1, sizeof *h);
   if (!h) return fail(PGB_E_NOMEM, "calloc");
@@ -357,7 +356,7 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
     }
   const uint8_t* lid = h->lid + (size_t)tree_id * n;
   /* linear response: label -> (slope, xbar, column) of the tree being replaced */
-  static __thread double lb[256], lx[256];
+  static __thread double lb[256], lx[256], lbx[PGB_MAX_OUTPUTS - 1][256];
   static __thread int lj[256];
   for (int k = 0; k < 256; ++k) { lb[k] = 0.0; lx[k] = 0.0; lj[k] = -1; }
   if (s->response != PGB_RESPONSE_CONSTANT)
@@ -366,6 +365,7 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
         lb[T->nd[k].label] = T->nd[k].slope;
         lx[T->nd[k].label] = T->nd[k].xbar;
         lj[T->nd[k].label] = T->nd[k].svar;
+        for (int o = 1; o < K; ++o) lbx[o - 1][T->nd[k].label] = T->nd[k].svar >= 0 ? T->nd[k].slopex[o - 1] : 0.0;
       }
   unsigned sat = 0;
   int64_t A = 0, B = 0, C = 0, E0 = 0;
@@ -391,7 +391,9 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
       mu_cur[0] = h->st[i] + h->off[i];
       for (int k = 1; k < K; ++k) {
         const double stk = h->st[(size_t)k * n + i];
-        const double ok = lv[k][lid[i]];
+        double ok = lv[k][lid[i]];
+        if (lj[lid[i]] >= 0)
+          ok = pgb_leaf_pred(ok, lbx[k - 1][lid[i]], lx[lid[i]], h->X[(size_t)lj[lid[i]] * n + i]);
         const double noik = stk - ok;
         h->oldv[(size_t)k * n + i] = ok;
         Ax[k - 1] += pgb_quant(stk, h->sc.c1, &sat);
@@ -441,7 +443,7 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
 /* non-Normal families: fixed-point log-likelihood of `cnt` rows predicting the K-vector `v` from
  * this tree ([U] update_weight restricted to the rows whose prediction changed). */
 static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v, double slope,
-                                double xbar, int svar) {
+                                const double* slopex, double xbar, int svar) {
   unsigned sat = 0;
   int64_t acc = 0;
   const int K = h->s.n_outputs;
@@ -449,7 +451,11 @@ static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, 
   for (int64_t k = 0; k < cnt; ++k) {
     int32_t i = seg[k];
     double mu[PGB_MAX_OUTPUTS];
-    for (int o = 0; o < K; ++o) mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + v[o];
+    for (int o = 0; o < K; ++o) {
+      double vo = v[o];
+      if (svar >= 0) vo = pgb_leaf_pred(vo, o ? slopex[o - 1] : slope, xbar, h->X[(size_t)svar * n + i]);
+      mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + vo;
+    }
     if (K == 1) {
       double vi = v[0];
       if (svar >= 0) vi = pgb_leaf_pred(vi, slope, xbar, h->X[(size_t)svar * n + i]);
@@ -461,7 +467,7 @@ static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, 
   return acc;
 }
 static int64_t o_seg_loglik(pgb_handle* h, const int32_t* seg, int64_t cnt, const double* v) {
-  return o_seg_loglik_lin(h, seg, cnt, v, 0.0, 0.0, -1);
+  return o_seg_loglik_lin(h, seg, cnt, v, 0.0, NULL, 0.0, -1);
 }
 
 /* [U] ParticleTree.sample_tree + grow_tree for particle q in round `round`. */
@@ -513,6 +519,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   const int lin = s->response != PGB_RESPONSE_CONSTANT;
   const double uscale = pgb_pow2(-h->col_ex[j]);
   int64_t uL[4] = {0, 0, 0, 0}, uR[4] = {0, 0, 0, 0}; /* q_u, q_uu, q_us, q_ur */
+  int64_t uLx[PGB_MAX_OUTPUTS - 1] = {0}, uRx[PGB_MAX_OUTPUTS - 1] = {0}; /* q_us of outputs 1..K-1 */
   for (int64_t k = 0; k < nd.cnt; ++k) {
     int32_t i = seg[k];
     double x = xc[i];
@@ -533,6 +540,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
         uL[1] += pgb_quant((uu * uu) * h->lin_R, h->sc.c1, NULL);
         uL[2] += pgb_quant(uu * h->st[i], h->sc.c1, NULL);
         uL[3] += pgb_quant(uu * h->r[i], h->sc.c1, NULL);
+        for (int o = 1; o < K; ++o) uLx[o - 1] += pgb_quant(uu * h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
       }
     } else {
       sr[cR++] = i;
@@ -542,6 +550,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
         uR[1] += pgb_quant((uu * uu) * h->lin_R, h->sc.c1, NULL);
         uR[2] += pgb_quant(uu * h->st[i], h->sc.c1, NULL);
         uR[3] += pgb_quant(uu * h->r[i], h->sc.c1, NULL);
+        for (int o = 1; o < K; ++o) uRx[o - 1] += pgb_quant(uu * h->st[(size_t)o * s->n + i], h->sc.c1, NULL);
       }
     }
   }
@@ -624,7 +633,15 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     const double xs = pgb_pow2(h->col_ex[j]);
     if (linL) {
       pgb_linfit f = pgb_lin_fit(cL, uL[0], uL[1], uL[2], aL, h->sc.inv_c1, h->inv_R, (double)s->m);
-      if (f.slope_u != 0.0) {
+      /* K-vector leaves: one slope per output on the shared regressor; the leaf is linear
+         when any of them is non-zero */
+      int any = f.slope_u != 0.0;
+      for (int o = 1; o < K; ++o) {
+        pgb_linfit fk = pgb_lin_fit(cL, uL[0], uL[1], uLx[o - 1], a->q_stx[o - 1], h->sc.inv_c1, h->inv_R, (double)s->m);
+        a->slopex[o - 1] = fk.slope_u * uscale;
+        any |= fk.slope_u != 0.0;
+      }
+      if (any) {
         a->svar = j;
         a->slope = f.slope_u * uscale; /* per unit of x */
         a->xbar = f.ubar * xs;
@@ -633,7 +650,13 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
     }
     if (linR) {
       pgb_linfit f = pgb_lin_fit(cR, uR[0], uR[1], uR[2], aR, h->sc.inv_c1, h->inv_R, (double)s->m);
-      if (f.slope_u != 0.0) {
+      int any = f.slope_u != 0.0;
+      for (int o = 1; o < K; ++o) {
+        pgb_linfit fk = pgb_lin_fit(cR, uR[0], uR[1], uRx[o - 1], b->q_stx[o - 1], h->sc.inv_c1, h->inv_R, (double)s->m);
+        b->slopex[o - 1] = fk.slope_u * uscale;
+        any |= fk.slope_u != 0.0;
+      }
+      if (any) {
         b->svar = j;
         b->slope = f.slope_u * uscale;
         b->xbar = f.ubar * xs;
@@ -652,8 +675,8 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
       va[o] = a->valx[o - 1];
       vb[o] = b->valx[o - 1];
     }
-    a->ll = o_seg_loglik_lin(h, sl, cL, va, a->slope, a->xbar, a->svar);
-    b->ll = o_seg_loglik_lin(h, sr, cR, vb, b->slope, b->xbar, b->svar);
+    a->ll = o_seg_loglik_lin(h, sl, cL, va, a->slope, a->slopex, a->xbar, a->svar);
+    b->ll = o_seg_loglik_lin(h, sr, cR, vb, b->slope, b->slopex, b->xbar, b->svar);
     if (sn) T->ll_orph += o_seg_loglik(h, sn, cN, zero_v);
     T->ll_tot = ((T->ll_tot - nd.ll) + a->ll) + b->ll;
     free(sn);
@@ -731,14 +754,17 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
     double* ov = h->oldv + (size_t)o * n;
     double* rmean = h->rs_mean + (size_t)o * n;
     double* rm2 = h->rs_m2 + (size_t)o * n;
-    if (o > 0) { /* label -> value table of output o */
+    if (o > 0) { /* label -> value (and slope) table of output o */
       for (int k = 0; k < 256; ++k) lv[k] = 0.0;
       for (int k = 0; k < T->n_nodes; ++k)
-        if (T->nd[k].var < 0) lv[T->nd[k].label] = T->nd[k].valx[o - 1];
+        if (T->nd[k].var < 0) {
+          lv[T->nd[k].label] = T->nd[k].valx[o - 1];
+          if (T->nd[k].svar >= 0) lb[T->nd[k].label] = T->nd[k].slopex[o - 1];
+        }
     }
     for (int64_t i = 0; i < n; ++i) {
       double nv = lv[lid[i]];
-      if (o == 0 && lj[lid[i]] >= 0) nv = pgb_leaf_pred(nv, lb[lid[i]], lx[lid[i]], h->X[(size_t)lj[lid[i]] * n + i]);
+      if (lj[lid[i]] >= 0) nv = pgb_leaf_pred(nv, lb[lid[i]], lx[lid[i]], h->X[(size_t)lj[lid[i]] * n + i]);
       double noi = st[i] - ov[i];
       st[i] = noi + nv;
       if (tune) { /* [U] RunningSd.update (Welford) */
@@ -852,7 +878,8 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
       out->value[(size_t)(off + k) * K] = z->var < 0 ? z->value : 0.0;
       if (out->slope && out->xbar && out->svar) {
         const int islin = z->var < 0 && h->s.response != PGB_RESPONSE_CONSTANT && z->svar >= 0;
-        out->slope[off + k] = islin ? z->slope : 0.0;
+        out->slope[(size_t)(off + k) * K] = islin ? z->slope : 0.0;
+        for (int o = 1; o < K; ++o) out->slope[(size_t)(off + k) * K + o] = islin ? z->slopex[o - 1] : 0.0;
         out->xbar[off + k] = islin ? z->xbar : 0.0;
         out->svar[off + k] = islin ? z->svar : -1;
       }
@@ -892,14 +919,13 @@ static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const doubl
   for (;;) {
     int g = base + k;
     if (T->var[g] < 0) {
-      double v0 = T->value[(size_t)g * K];
-      if (T->svar && T->svar[g] >= 0) { /* linear leaf; a missing / excluded regressor: the mean */
-        const int js = T->svar[g];
-        const double xs = x[js];
-        if (!excl[js] && xs == xs) v0 = pgb_leaf_pred(v0, T->slope[g], T->xbar[g], xs);
+      int js = -1; /* linear leaf; a missing / excluded regressor: the mean */
+      if (T->svar && T->svar[g] >= 0 && !excl[T->svar[g]] && x[T->svar[g]] == x[T->svar[g]]) js = T->svar[g];
+      for (int o = 0; o < K; ++o) {
+        double vo = T->value[(size_t)g * K + o];
+        if (js >= 0) vo = pgb_leaf_pred(vo, T->slope[(size_t)g * K + o], T->xbar[g], x[js]);
+        acc[o] += w * vo;
       }
-      acc[0] += w * v0;
-      for (int o = 1; o < K; ++o) acc[o] += w * T->value[(size_t)g * K + o];
       return;
     }
     int j = T->var[g];

@@ -221,6 +221,12 @@ struct Dev {  // kernel argument block (by value)
   LinP* tlin;             // [m][MAXN]        accepted trees' leaves
   LinP* lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
   AccU* accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
+  // ... K-vector leaves: one slope per output on the shared regressor; output 0 lives in LinP,
+  // outputs 1..K-1 in arrays laid out like pvx / tvx / lvx / accx
+  double* psx;            // [2][MAXP][MAXN][KX]  particle leaf slopes
+  double* tsx;            // [m][MAXN][KX]        accepted trees' leaf slopes
+  double* lsx;            // [2][2][256][KX]      label -> slope tables: [par][0 new | 1 next]
+  long long* accux;       // [2][MAXP][AX_SLOTS][AX_REC]  row-pass sums of u st_k: left [k], right [KX + k]
   // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
   long long* prof_stamps;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
@@ -559,11 +565,13 @@ __device__ __forceinline__ long long root_A_x(const Dev& S, int acc_par, int k) 
 struct ChildX {
   double vL, vR;
   long long aL, aR;
+  double sL, sR;  // linear response: slopes on the shared regressor (0 for a constant leaf)
 };
 __device__ __forceinline__ ChildX child_values_x(const Dev& S, int ok, int cL, int cR, long long aLk,
                                                  long long aNk, long long pq, double pv, uint32_t it,
                                                  uint32_t round, uint32_t particle, int k, double lsd) {
   ChildX c;
+  c.sL = c.sR = 0.0;
   c.aL = aLk;
   c.aR = pq - aLk - aNk;
   if (ok == 1) {
@@ -666,6 +674,10 @@ struct LinKids {
   int svarL, svarR;
   pgb_linfit fL, fR;
   long long urL, urR;  // sum q(u r) of the children (the Normal family's SSE needs them)
+  // what the slopes of further outputs need (K-vector leaves, lin_children_x)
+  long long u0L, u1L, u0R, u1R;
+  bool linL, linR;
+  double uscale, xs;
 };
 __device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __restrict__ copies, int var, int cL, int cR,
                                                 long long aL, long long aR, uint32_t it, uint32_t round, uint32_t q) {
@@ -681,6 +693,7 @@ __device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __rest
   }
   k.urL = ul[3];
   k.urR = ur[3];
+  k.u0L = ul[0]; k.u1L = ul[1]; k.u0R = ur[0]; k.u1R = ur[1];
   bool linL = true, linR = true;
   if (S.response == PGB_RESPONSE_MIX) {  // [U] "mix": a fair coin per child
     const pgb_u2 um = pgb_draw2(S.seed, it, round, q, PGB_RNG_MIX, 0);
@@ -689,6 +702,8 @@ __device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __rest
   }
   const int ex = S.col_ex[var];
   const double uscale = pgb_pow2(-ex), xs = pgb_pow2(ex);
+  k.linL = linL; k.linR = linR;
+  k.uscale = uscale; k.xs = xs;
   if (linL) {
     k.fL = pgb_lin_fit(cL, ul[0], ul[1], ul[2], aL, S.sc.inv_c1, S.inv_R, S.mdouble);
     if (k.fL.slope_u != 0.0) {
@@ -706,6 +721,29 @@ __device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __rest
     }
   }
   return k;
+}
+// K-vector leaves: the slopes of extension output kx of both children (sums of u st_k from accux,
+// the sums of u / u^2 are shared with output 0); a leaf is linear when ANY output has a slope.
+__device__ __forceinline__ void lin_children_x(const Dev& S, LinKids& lk, ChildX& cx, int var, int cL, int cR,
+                                               long long usL, long long usR) {
+  if (lk.linL) {
+    const pgb_linfit f = pgb_lin_fit(cL, lk.u0L, lk.u1L, usL, cx.aL, S.sc.inv_c1, S.inv_R, S.mdouble);
+    cx.sL = f.slope_u * lk.uscale;
+    if (f.slope_u != 0.0 && lk.svarL < 0) {
+      lk.svarL = var;
+      lk.slopeL = lk.fL.slope_u * lk.uscale;
+      lk.xbarL = lk.fL.ubar * lk.xs;
+    }
+  }
+  if (lk.linR) {
+    const pgb_linfit f = pgb_lin_fit(cR, lk.u0R, lk.u1R, usR, cx.aR, S.sc.inv_c1, S.inv_R, S.mdouble);
+    cx.sR = f.slope_u * lk.uscale;
+    if (f.slope_u != 0.0 && lk.svarR < 0) {
+      lk.svarR = var;
+      lk.slopeR = lk.fR.slope_u * lk.uscale;
+      lk.xbarR = lk.fR.ubar * lk.xs;
+    }
+  }
 }
 
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
@@ -762,6 +800,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   const int KX = MK ? S.K - 1 : 0;
   if constexpr (MK) {
     if (tid < AX_PER) S.accx[((size_t)par * MAXP + p) * AX_PER + tid] = 0;
+    if constexpr (LIN)
+      if (tid < AX_PER) S.accux[((size_t)par * MAXP + p) * AX_PER + tid] = 0;
     if (b == 0)
       for (int i = tid; i < IA_SLOTS * 2 * KX; i += BT) S.iax[(size_t)par * IA_SLOTS * 2 * KX + i] = 0;
   }
@@ -842,6 +882,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       AccL al = {0, 0, 0, 0};
       DNode popn;  // the node this particle pops next if it is an old node (children: from Fin)
       memset(&popn, 0, sizeof popn);
+      LinKids lk;  // linear response: kept for the extension outputs below
+      lk.svarL = lk.svarR = -1;
+      lk.linL = lk.linR = false;
       if (isp) {
         j = JP[q];
         a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
@@ -927,8 +970,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             f.svarL = f.svarR = -1;
             f.slopeL = f.xbarL = f.slopeR = f.xbarR = 0.0;
             if constexpr (LIN) {  // [U] fast_linear_fit on the split variable
-              const LinKids lk = lin_children(S, &S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER], j.var, cL, cR,
-                                              f.aL, f.aR, it, (uint32_t)(r - 1), (uint32_t)q);
+              lk = lin_children(S, &S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER], j.var, cL, cR,
+                                f.aL, f.aR, it, (uint32_t)(r - 1), (uint32_t)q);
               f.svarL = lk.svarL; f.slopeL = lk.slopeL; f.xbarL = lk.xbarL;
               f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
               if (normal) {  // the weight of a linear leaf: SSE in closed form
@@ -951,7 +994,16 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, load_accx(S.accx, par ^ 1, q, k),
                                           load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
                                           (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
+            if constexpr (LIN)
+              if (f.ok == 1)
+                lin_children_x(S, lk, s_finx[q][k], j.var, f.cL, f.cR, load_accx(S.accux, par ^ 1, q, k),
+                               load_accx(S.accux, par ^ 1, q, KX + k));
           }
+          if constexpr (LIN)
+            if (j.active && f.ok == 1) {  // a further output may have made the leaf linear
+              f.svarL = lk.svarL; f.slopeL = lk.slopeL; f.xbarL = lk.xbarL;
+              f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
+            }
         }
         s_pop[q] = popn;
         pending = f.next_pop < f.n_nodes;
@@ -1032,12 +1084,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           if (f.ok == -1 && i == f.node) qv = s_finx[anc][k].aL;
           S.pvx[dn + e] = v;
           S.pqx[dn + e] = qv;
+          if constexpr (LIN) S.psx[dn + e] = S.psx[so + e];
         }
         if (f.ok == 1)
           for (int e = tid; e < 2 * KX; e += BT) {
             const int ch = e / KX, k = e % KX;
             S.pvx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].vR : s_finx[anc][k].vL;
             S.pqx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].aR : s_finx[anc][k].aL;
+            if constexpr (LIN) S.psx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].sR : s_finx[anc][k].sL;
           }
       }
       if (f.ok == 1 && tid >= BT - 2) {
@@ -1120,6 +1174,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         const size_t pn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX, tn = (size_t)tree_old * MAXN * KX;
         for (int e = tid; e < nn * KX; e += BT) S.tvx[tn + e] = S.pvx[pn + e];
         build_lvx(me->nd, nn, S.pvx + pn, KX, S.lvx + ((size_t)par * 2 + 0) * 256 * KX);
+        if constexpr (LIN) {
+          for (int e = tid; e < nn * KX; e += BT) S.tsx[tn + e] = S.psx[pn + e];
+          build_lvx(me->nd, nn, S.psx + pn, KX, S.lsx + ((size_t)par * 2 + 0) * 256 * KX);
+        }
       }
     }
     if (b == 0) {
@@ -1138,6 +1196,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         if (has_init && tree_new != tree_old)
           build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
                     S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+        if constexpr (LIN) {
+          if (sel == 0)
+            build_lvx(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tsx + (size_t)tree_old * MAXN * KX, KX,
+                      S.lsx + ((size_t)par * 2 + 0) * 256 * KX);
+          if (has_init && tree_new != tree_old)
+            build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tsx + (size_t)tree_new * MAXN * KX, KX,
+                      S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
+        }
       }
       if (sel == 0) {  // the old tree is kept: nobody writes S.trees[tree_old] in this slot
         if (tid == 0) {
@@ -1194,6 +1260,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           build_lvx(snd, nn, sel == 0 ? S.tvx + (size_t)tree_old * MAXN * KX
                                       : S.pvx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
                     KX, S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+        if constexpr (MK && LIN)
+          build_lvx(snd, nn, sel == 0 ? S.tsx + (size_t)tree_old * MAXN * KX
+                                      : S.psx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
+                    KX, S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
       }
     }
     if (b == 0 && tid == 0) {
@@ -1244,6 +1314,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     if constexpr (MK)
       build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
                 S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+    if constexpr (MK && LIN)
+      build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tsx + (size_t)tree_new * MAXN * KX, KX,
+                S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
   }
 
   // =================================================================== propose
@@ -1276,6 +1349,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       for (int k = 0; k < KX; ++k) {
         S.pvx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = S.init_leaf;
         S.pqx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = 0;  // patched by the next slot
+        if constexpr (LIN) S.psx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = 0.0;
       }
     }
     __syncthreads();
@@ -1982,7 +2056,9 @@ __device__ __forceinline__ double loglik_any(const Dev& S, double y, const doubl
 
 // KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay
 // in registers), 0: any K <= PGB_MAX_OUTPUTS.
-template <int KT>
+// LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory
+// (lvl for output 0 and the shared parts, lsx for the slopes of outputs 1..K-1)
+template <int KT, bool LIN>
 __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
@@ -2020,6 +2096,17 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
   double* st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * K * S.n_pad;
   const double c1 = S.sc.c1;
   const long long n = S.n, n_pad = S.n_pad;
+  // linear part of the prediction of output k for a row with label `id`: table t = 0 new | 1 next
+  auto lin_pred = [&](double v, int t, uint32_t id, int k, long long row) -> double {
+    if constexpr (LIN) {
+      const LinP lp = S.lvl[((size_t)par * 2 + t) * 256 + id];
+      if (lp.svar >= 0) {
+        const double sl = k == 0 ? lp.slope : S.lsx[(((size_t)par * 2 + t) * 256 + id) * KX + (k - 1)];
+        v = pgb_leaf_pred(v, sl, lp.xbar, S.XT[(size_t)lp.svar * n_pad + row]);
+      }
+    }
+    return v;
+  };
 
   if (do_part) {
     const Job* jobs = S.jobs + (size_t)par * MAXP;
@@ -2091,7 +2178,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
           for (int k = 0; k < K; ++k) {
             double st = st_in[(size_t)k * n_pad + row];
             if (do_final) {
-              const double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u][k];
+              const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][k], 0, (ids_sel >> (8 * e)) & 255u, k, row);
               st = st + nv;
               if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
                 const size_t ri = (size_t)k * n_pad + row;
@@ -2105,7 +2192,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
                 iv[2 + K + k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
               }
             }
-            const double o = s_lv[1][(ids_next >> (8 * e)) & 255u][k];
+            const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][k], 1, (ids_next >> (8 * e)) & 255u, k, row);
             const double noi = st - o;
             stv[e][k] = st;
             mu_stump[k] = noi + S.init_leaf;
@@ -2192,6 +2279,38 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
             vals[1 + K + k] = aN;
           }
         }
+        if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit): u, u^2 and
+          // u st_k per output; one wave total each, added by lane 63 (a rare path: no LDS staging)
+          const double uscale = pgb_pow2(-S.col_ex[rj.xoff / n_pad]);
+          long long su[2][2 + KB];
+#pragma unroll
+          for (int i = 0; i < 2 + KB; ++i) su[0][i] = su[1][i] = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (side[e] == 1 || side[e] == 2) {
+              const int sd = side[e] - 1;
+              const double uu = x[e] * uscale;
+              su[sd][0] += pgb_quant(uu * S.lin_R, c1, nullptr);
+              su[sd][1] += pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
+#pragma unroll
+              for (int k = 0; k < KB; ++k)
+                if (k < K) su[sd][2 + k] += pgb_quant(uu * stv[e][k], c1, nullptr);
+            }
+          }
+          AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+          long long* aux = S.accux + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
+#pragma unroll
+          for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int i = 0; i < 2 + KB; ++i) {
+              if (i >= 2 + K) continue;
+              const long long tot = wave_sum_dpp(su[sd][i]);
+              if (lane == 63 && tot != 0) {
+                long long* dst = i < 3 ? (sd ? &au->uR[i] : &au->uL[i]) : &aux[(sd ? KX : 0) + (i - 3)];
+                atomicAdd((unsigned long long*)dst, (unsigned long long)tot);
+              }
+            }
+        }
         const int nv = rj.check_nan ? NV : 1 + K;
 #pragma unroll
         for (int c4 = 0; c4 < (1 + 2 * KB + 3) / 4; ++c4) {
@@ -2266,7 +2385,7 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
     }
     for (int k = 0; k < K; ++k) {
       const size_t ri = (size_t)k * n_pad + row;
-      const double nv = s_lv[0][id_sel][k];
+      const double nv = lin_pred(s_lv[0][id_sel][k], 0, id_sel, k, row);
       const double st = st_in[ri] + nv;
       if (cmd->tune) {
         const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
@@ -2312,6 +2431,7 @@ struct LJob {
   // linear response (single-output per-row families): the children's linear parts
   double slopeL, xbarL, slopeR, xbarR;
   int32_t svarL, svarR;
+  double sLx[KXMAX], sRx[KXMAX];  // ... slopes of outputs 1..K-1 (K-vector leaves)
 };
 
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
@@ -2388,10 +2508,13 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
       lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
       lj.svarL = lj.svarR = -1;
+      LinKids lk;
+      lk.svarL = lk.svarR = -1;
+      lk.linL = lk.linR = false;
       if constexpr (LIN) {
         if (cv.ok == 1) {
-          const LinKids lk = lin_children(S, &S.accu[((size_t)par * MAXP + tid) * ACC_PER], j.var, cv.cL, cv.cR,
-                                          cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)tid);
+          lk = lin_children(S, &S.accu[((size_t)par * MAXP + tid) * ACC_PER], j.var, cv.cL, cv.cR,
+                            cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)tid);
           lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
@@ -2401,12 +2524,24 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         const int KX = (KT > 0 ? KT : S.K) - 1;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
         const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
-        const ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
-                                         load_accx(S.accx, par, tid, KX + kx), pq, pv,
-                                         it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
+        ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
+                                   load_accx(S.accx, par, tid, KX + kx), pq, pv,
+                                   it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
+        if constexpr (LIN) {
+          if (cv.ok == 1)
+            lin_children_x(S, lk, cx, j.var, cv.cL, cv.cR, load_accx(S.accux, par, tid, kx),
+                           load_accx(S.accux, par, tid, KX + kx));
+          lj.sLx[kx] = cx.sL;
+          lj.sRx[kx] = cx.sR;
+        }
       }
+      if constexpr (MK && LIN)
+        if (cv.ok == 1) {  // a further output may have made the leaf linear
+          lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
+          lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
+        }
       s_job[k] = lj;
     }
     if (tid == 0) s_n[0] = __popcll(m);
@@ -2452,11 +2587,26 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
             const uint32_t nl = (nid >> (8 * e)) & 255u;
             const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
             double mu[KB];
-            mu[0] = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);
+            double v0k = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;
+            int sv = -1;
+            double xv = 0.0, xb = 0.0;
+            if constexpr (LIN) {
+              sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
+              if (sv >= 0) {
+                xv = S.XT[lj.xoff + base + e];
+                xb = side == 0 ? lj.xbarL : lj.xbarR;
+                v0k = pgb_leaf_pred(v0k, side == 0 ? lj.slopeL : lj.slopeR, xb, xv);
+              }
+            }
+            mu[0] = nv[e] + v0k;
 #pragma unroll
             for (int k = 1; k < KB; ++k)
-              if (k < K) mu[k] = noi[(size_t)k * S.n_pad + base + e] +
-                      (side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0);
+              if (k < K) {
+                double vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
+                if constexpr (LIN)
+                  if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
+                mu[k] = noi[(size_t)k * S.n_pad + base + e] + vk;
+              }
             const long long q = pgb_quant(pgb_loglik(S.family, K, yv[e], mu), cl, &sat);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
@@ -2667,16 +2817,16 @@ __global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* fore
         const int g = base + k;
         const int j = T.var[g];
         if (j < 0) {
-          double v0 = T.value[(size_t)g * K];
-          if (T.svar != nullptr) {  // linear leaf; a missing / excluded regressor: the mean
-            const int js = T.svar[g];
-            if (js >= 0) {
-              const double xs = x[js];
-              if (!excl[js] && xs == xs) v0 = pgb_leaf_pred(v0, T.slope[g], T.xbar[g], xs);
-            }
+          int js = -1;  // linear leaf; a missing / excluded regressor: the mean
+          if (T.svar != nullptr) {
+            js = T.svar[g];
+            if (js >= 0 && (excl[js] || x[js] != x[js])) js = -1;
           }
-          acc[0] += w * v0;
-          for (int o = 1; o < K; ++o) acc[o] += w * T.value[(size_t)g * K + o];
+          for (int o = 0; o < K; ++o) {
+            double vo = T.value[(size_t)g * K + o];
+            if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)g * K + o], T.xbar[g], x[js]);
+            acc[o] += w * vo;
+          }
           break;
         }
         const double xv = x[j];
@@ -2793,8 +2943,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
-    if (s->n_outputs != 1)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix is implemented for single-output families only");
   }
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -2910,6 +3058,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.tlin, (size_t)d.m * MAXN);
     DA(d.lvl, (size_t)2 * 2 * 256);
     DA(d.accu, (size_t)2 * MAXP * ACC_PER);
+    if (KX > 0) {
+      DA(d.psx, (size_t)2 * MAXP * MAXN * KX);
+      DA(d.tsx, (size_t)d.m * MAXN * KX);
+      DA(d.lsx, (size_t)2 * 2 * 256 * KX);
+      DA(d.accux, (size_t)2 * MAXP * AX_PER);
+    }
   }
 #undef DA
   d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
@@ -2980,6 +3134,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, sm, d.tlin, n2);
     hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, sm, d.lvl, n3);
     HC(hipMemsetAsync(d.accu, 0, (size_t)2 * MAXP * ACC_PER * sizeof(AccU), sm));
+    if (KX > 0) {
+      HC(hipMemsetAsync(d.psx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.tsx, 0, (size_t)d.m * MAXN * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.lsx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.accux, 0, (size_t)2 * MAXP * AX_PER * sizeof(long long), sm));
+    }
   }
   Ctrl c0;
   memset(&c0, 0, sizeof c0);
@@ -3130,7 +3290,10 @@ static int enqueue_slots(pgb_handle* h, int count) {
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-    if (d.K > 1)
+    const bool lin = d.response != PGB_RESPONSE_CONSTANT;
+    if (d.K > 1 && lin)
+      hipLaunchKernelGGL((k_ctrl<true, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+    else if (d.K > 1)
       hipLaunchKernelGGL((k_ctrl<true, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
     else
       if (d.response != PGB_RESPONSE_CONSTANT)
@@ -3159,14 +3322,16 @@ static int enqueue_slots(pgb_handle* h, int count) {
     else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, ##__VA_ARGS__);    \
   } while (0)
 #define ROWS_PTRS (const Cmd*)d.cmd, (const Job*)d.jobs
-    if (d.K == 2) {
-      LAUNCH_ROWS(k_rows_mk<2>);
+    if (d.K > 1 && lin) {  // linear leaves: one instance for any K
+      LAUNCH_ROWS((k_rows_mk<0, true>));
+    } else if (d.K == 2) {
+      LAUNCH_ROWS((k_rows_mk<2, false>));
     } else if (d.K == 3) {
-      LAUNCH_ROWS(k_rows_mk<3>);
+      LAUNCH_ROWS((k_rows_mk<3, false>));
     } else if (d.K == 4) {
-      LAUNCH_ROWS(k_rows_mk<4>);
+      LAUNCH_ROWS((k_rows_mk<4, false>));
     } else if (d.K > 1) {
-      LAUNCH_ROWS(k_rows_mk<0>);
+      LAUNCH_ROWS((k_rows_mk<0, false>));
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (d.response != PGB_RESPONSE_CONSTANT) {
@@ -3184,7 +3349,9 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef ROWS_PTRS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
 #define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par)
-      if (d.K > 1) {
+      if (d.K > 1 && lin) {
+        hipLaunchKernelGGL((k_loglik<0, -1, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else if (d.K > 1) {
         switch (d.K) {
           case 2: LAUNCH_LL(2, -1); break;
           case 3: LAUNCH_LL(3, -1); break;
@@ -3345,10 +3512,16 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
   }
   if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
   std::vector<LinP> hl;
+  std::vector<double> hsx;  // slopes of outputs 1..K-1
   const bool want_lin = out->slope && out->xbar && out->svar;
   if (want_lin && d.response != PGB_RESPONSE_CONSTANT && nt > 0) {
     hl.resize((size_t)nt * MAXN);
     HIPCHK(hipMemcpy(hl.data(), d.tlin + (size_t)first * MAXN, hl.size() * sizeof(LinP), hipMemcpyDeviceToHost));
+    if (KX > 0) {
+      hsx.resize((size_t)nt * MAXN * KX);
+      HIPCHK(hipMemcpy(hsx.data(), d.tsx + (size_t)first * MAXN * KX, hsx.size() * sizeof(double),
+                       hipMemcpyDeviceToHost));
+    }
   }
   int off = 0;
   for (int t = 0; t < nt; ++t) {
@@ -3365,7 +3538,9 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
       out->value[(size_t)(off + k) * K] = z.var < 0 ? z.value : 0.0;
       if (want_lin) {
         const bool islin = z.var < 0 && !hl.empty() && hl[(size_t)t * MAXN + k].svar >= 0;
-        out->slope[off + k] = islin ? hl[(size_t)t * MAXN + k].slope : 0.0;
+        out->slope[(size_t)(off + k) * K] = islin ? hl[(size_t)t * MAXN + k].slope : 0.0;
+        for (int o = 1; o < K; ++o)
+          out->slope[(size_t)(off + k) * K + o] = islin ? hsx[((size_t)t * MAXN + k) * KX + o - 1] : 0.0;
         out->xbar[off + k] = islin ? hl[(size_t)t * MAXN + k].xbar : 0.0;
         out->svar[off + k] = islin ? (int32_t)hl[(size_t)t * MAXN + k].svar : -1;
       }
@@ -3446,7 +3621,7 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   const bool lin = trees->slope && trees->xbar && trees->svar;
   // ... then, for linear leaves, slope / xbar (8-byte) and svar (int32) after the exclusion flags
   const size_t off_lin = ((off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p + 7) / 8) * 8;
-  size_t bytes = lin ? off_lin + (size_t)N * 20 : off8 + (size_t)N * 16 + (size_t)N * K * 8 + p;
+  size_t bytes = lin ? off_lin + (size_t)N * K * 8 + (size_t)N * 12 : off8 + (size_t)N * 16 + (size_t)N * K * 8 + p;
   std::vector<uint8_t> hb(bytes);
   int32_t* hi = (int32_t*)hb.data();
   size_t o = 0;
@@ -3462,9 +3637,9 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   memcpy(h8 + (size_t)N * 16, trees->value, (size_t)N * K * 8);
   memcpy(h8 + (size_t)N * 16 + (size_t)N * K * 8, excl.data(), p);
   if (lin) {
-    memcpy(hb.data() + off_lin, trees->slope, (size_t)N * 8);
-    memcpy(hb.data() + off_lin + (size_t)N * 8, trees->xbar, (size_t)N * 8);
-    memcpy(hb.data() + off_lin + (size_t)N * 16, trees->svar, (size_t)N * 4);
+    memcpy(hb.data() + off_lin, trees->slope, (size_t)N * K * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * K * 8, trees->xbar, (size_t)N * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * K * 8 + (size_t)N * 8, trees->svar, (size_t)N * 4);
   }
   uint8_t* db = nullptr;
   HIPCHK(hipMalloc((void**)&db, bytes));
@@ -3480,8 +3655,8 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   T.count = (const long long*)(db + off8 + (size_t)N * 8);
   T.value = (const double*)(db + off8 + (size_t)N * 16);
   T.slope = lin ? (const double*)(db + off_lin) : nullptr;
-  T.xbar = lin ? (const double*)(db + off_lin + (size_t)N * 8) : nullptr;
-  T.svar = lin ? (const int32_t*)(db + off_lin + (size_t)N * 16) : nullptr;
+  T.xbar = lin ? (const double*)(db + off_lin + (size_t)N * K * 8) : nullptr;
+  T.svar = lin ? (const int32_t*)(db + off_lin + (size_t)N * K * 8 + (size_t)N * 8) : nullptr;
   const uint8_t* dexcl = db + off8 + (size_t)N * 16 + (size_t)N * K * 8;
   dim3 grid((unsigned)((n_rows + BT - 1) / BT), (unsigned)n_forests);
   hipLaunchKernelGGL(k_predict, grid, dim3(BT), 0, sm, T, di + o_f, n_forests, m, K, X_dev,

@@ -33,14 +33,15 @@ class TreeArrays:
     count: np.ndarray     # int64 [nodes]
     value: np.ndarray     # float64 [nodes, n_outputs]
     # linear response: a leaf predicts value + slope * (x[svar] - xbar); svar = -1: constant leaf
-    slope: np.ndarray = None  # float64 [nodes]
+    slope: np.ndarray = None  # float64 [nodes, n_outputs]
     xbar: np.ndarray = None   # float64 [nodes]
     svar: np.ndarray = None   # int32 [nodes]
 
     def __post_init__(self):
         nn = int(np.asarray(self.var).shape[0])
         if self.slope is None:
-            self.slope = np.zeros(nn, np.float64)
+            self.slope = np.zeros((nn, self.n_outputs), np.float64)
+        self.slope = np.ascontiguousarray(self.slope, np.float64).reshape(nn, self.n_outputs)
         if self.xbar is None:
             self.xbar = np.zeros(nn, np.float64)
         if self.svar is None:
@@ -66,7 +67,7 @@ class TreeArrays:
             right=np.zeros(total_nodes, np.int32),
             count=np.zeros(total_nodes, np.int64),
             value=np.zeros((total_nodes, n_outputs), np.float64),
-            slope=np.zeros(total_nodes, np.float64),
+            slope=np.zeros((total_nodes, n_outputs), np.float64),
             xbar=np.zeros(total_nodes, np.float64),
             svar=np.full(total_nodes, -1, np.int32),
         )
@@ -113,7 +114,7 @@ class TreeArrays:
             right=np.concatenate([p.right for p in parts]).astype(np.int32),
             count=np.concatenate([p.count for p in parts]).astype(np.int64),
             value=np.concatenate([p.value for p in parts], axis=0),
-            slope=np.concatenate([p.slope for p in parts]).astype(np.float64),
+            slope=np.concatenate([p.slope for p in parts], axis=0).astype(np.float64),
             xbar=np.concatenate([p.xbar for p in parts]).astype(np.float64),
             svar=np.concatenate([p.svar for p in parts]).astype(np.int32),
         )
@@ -164,7 +165,7 @@ def load_history(path):
                 left=arrs["left"][a:b].astype(np.int32), right=arrs["right"][a:b].astype(np.int32),
                 count=arrs["count"][a:b].astype(np.int64),
                 value=arrs["value"][a:b].reshape(b - a, K).astype(np.float64),
-                slope=arrs["slope"][a:b].astype(np.float64), xbar=arrs["xbar"][a:b].astype(np.float64),
+                slope=arrs["slope"].reshape(-1, K)[a:b].astype(np.float64), xbar=arrs["xbar"][a:b].astype(np.float64),
                 svar=arrs["svar"][a:b].astype(np.int32),
             ))
             t0 += nt
@@ -209,7 +210,7 @@ def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rule
         leaf = np.array(trees.value[g], dtype=np.float64)
         js = int(trees.svar[g])
         if js >= 0 and not excl[js] and not np.isnan(x[js]):  # linear leaf (a missing regressor: the mean)
-            leaf[0] = leaf[0] + trees.slope[g] * (x[js] - trees.xbar[g])
+            leaf = leaf + trees.slope[g] * (x[js] - trees.xbar[g])
         acc += w * leaf
 
     for d in range(forest_idx.shape[0]):

@@ -160,6 +160,19 @@ def make_case(name: str):
         X = rng.normal(0, 1, size=(n, p))
         Y = rng.normal(0, 1, size=n) * (0.5 + (X[:, 0] > 0)) + X[:, 1]
         c.update(m=2, P=10, steps=60, family="normal_meanscale", K=2)
+    elif name == "meanscale_k2_linear":  # reference tests/test_bart.py:107-123 with response="linear"
+        n, p = 250, 3
+        X = rng.normal(0, 1, size=(n, p))
+        Y = rng.normal(0, 1, size=n) * (0.5 + (X[:, 0] > 0)) + X[:, 1]
+        c.update(m=2, P=10, steps=60, family="normal_meanscale", K=2, response="linear")
+    elif name == "categorical_k3_mix":  # K-vector leaves with a slope per output, "mix", missing values
+        n, p, K = 3000, 4, 3
+        X = rng.uniform(-2, 2, size=(n, p))
+        X[rng.random(n) < 0.1, 1] = np.nan
+        F = np.stack([1.2 * X[:, 0], -1.2 * X[:, 0], 0.5 * np.nan_to_num(X[:, 1])])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=8, P=12, steps=24, family="categorical", K=K, response="mix")
     elif name == "onehot_fail_nan":  # failed one-hot splits that shed NaN rows (Normal family)
         n, p = 2500, 3
         X = rng.normal(size=(n, p))
@@ -189,7 +202,8 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit"]
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
+         "meanscale_k2_linear", "categorical_k3_mix"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -228,7 +242,7 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
             parts = [ta.tree_id, ta.node_off, ta.var, ta.left, ta.right, ta.count, ta.split.view(np.int64),
                      ta.value.ravel().view(np.int64)]
             if c.get("response", "constant") != "constant":  # linear leaves are part of the fingerprint
-                parts += [ta.slope.view(np.int64), ta.xbar.view(np.int64), ta.svar]
+                parts += [ta.slope.ravel().view(np.int64), ta.xbar.view(np.int64), ta.svar]
             trees.append(np.concatenate(parts))
     forest = s.export_trees(1)
     ctr = s.counters.as_dict()
@@ -298,7 +312,7 @@ def random_case(seed):
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
     response = "constant"
-    if K == 1 and not rules.any():  # linear / mix need scalar leaves and continuous columns
+    if not rules.any():  # linear / mix need continuous columns
         response = str(rng.choice(["constant", "linear", "mix"]))
     extra = {}
     if fam in ("poisson_log", "negbin_log"):

@@ -316,7 +316,9 @@ def test_categorical_model_recovers_classes(oracle, split_rule):
         np.testing.assert_allclose(pred[0], lo, atol=1e-9)
 
 
-def test_shape_two_outputs_mean_and_scale(oracle):
+@pytest.mark.filterwarnings("ignore:response=")
+@pytest.mark.parametrize("response", ["constant", "linear"], ids=["constant", "linear-response"])
+def test_shape_two_outputs_mean_and_scale(oracle, response):
     # reference tests/test_bart.py:107-123: w = BART(shape=(2, 250)); y ~ Normal(w[0], |w[1]|):
     # astep returns (2, n); the scale output must pick up heteroscedasticity
     from pymc_bart_amd.pgbart import NormalMeanScaleLikelihood
@@ -325,7 +327,7 @@ def test_shape_two_outputs_mean_and_scale(oracle):
     X = rng.normal(0, 1, size=(250, 3))
     sd = np.where(X[:, 0] > 0, 2.0, 0.3)
     Y = X[:, 1] + sd * rng.normal(0, 1, size=250)
-    op = BARTOp(X, Y, m=10)
+    op = BARTOp(X, Y, m=10, response=response)
     step = PGBART([op], num_particles=10, likelihood=NormalMeanScaleLikelihood(), random_seed=3415,
                   backend=oracle)
     assert step.shape == (2, 250)
@@ -635,11 +637,25 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     # not every combination exists: categorical rules are rejected
     with pytest.raises(_abi.PGBError, match="ContinuousSplit"):
         PGBART([BARTOp(X, Y, m=2, response="linear", split_rules=["OneHotSplit", "ContinuousSplit"])], backend=oracle)
-    # multi-output families have no linear leaves yet (the reference's test_shape[linear] case)
-    st = PyBartSettings.from_data(X, Y, m=2, num_particles=4, family="normal_meanscale", n_outputs=2,
+    # K-vector leaves carry one slope per output on the shared regressor (the reference's
+    # test_shape[linear-response] case: shape=(2, n) observed through Normal(w[0], |w[1]|))
+    st = PyBartSettings.from_data(X, Y, m=6, num_particles=8, family="normal_meanscale", n_outputs=2,
                                   response="linear")
-    with pytest.raises(_abi.PGBError, match="single-output"):
-        PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    s2 = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    s2.set_likelihood([])
+    for _ in range(40):
+        w, _ = s2.step(True)
+    assert w.shape == (2, 200) and np.isfinite(w).all()
+    forest = s2.export_trees(1)
+    assert forest.slope.shape == (forest.total_nodes, 2)
+    lin_leaves = forest.svar >= 0
+    assert lin_leaves.any() and (forest.slope[lin_leaves, 0] != 0).any() and (forest.slope[lin_leaves, 1] != 0).any()
+    assert np.all(forest.slope[~lin_leaves] == 0.0)
+    pred = predict_numpy(forest, np.arange(6)[None, :], X, np.zeros(2, np.int32))[0]
+    np.testing.assert_allclose(pred, w, rtol=0, atol=1e-9)          # sum_trees == sum of per-tree predictions
+    ps2 = PosteriorSampler(forest, np.arange(6, dtype=np.int32)[None, :], 6, 2, np.zeros(2, np.int32), backend=oracle)
+    np.testing.assert_allclose(ps2.sample_posterior(X, [0])[0], pred, atol=1e-12)
+    assert s2.counters.saturations == 0
     # every single-output family takes them
     st = PyBartSettings.from_data(X, (Y > 0).astype(float), m=4, num_particles=6, family="bernoulli_probit",
                                   response="linear")

@@ -346,3 +346,41 @@ def test_linear_leaves_predict_the_same_on_gpu_and_host(hip, oracle):
     assert any((ta.svar >= 0).any() for ta in [base] + batches)
     for a, b in zip([base] + batches, [res["oracle"][2][0]] + res["oracle"][2][1]):
         assert np.array_equal(a.slope, b.slope) and np.array_equal(a.xbar, b.xbar) and np.array_equal(a.svar, b.svar)
+
+
+def test_k_vector_linear_leaves_on_gpu(hip, oracle):
+    """The reference's test_shape[linear-response] model at a larger size: K = 2 leaves with one slope
+    per output on the shared regressor.  Chain, exported slopes and the prediction kernel (excluded
+    and missing regressors included) agree with the oracle / the host restatement."""
+    rng = np.random.default_rng(21)
+    n, m = 6000, 10
+    X = rng.uniform(-2, 2, size=(n, 3))
+    X[rng.random(n) < 0.05, 1] = np.nan
+    Y = np.where(X[:, 0] < 0, 1.5 * X[:, 0], -X[:, 0]) + rng.normal(0, 1, n) * (0.3 + 0.3 * (X[:, 2] > 0))
+    rules = np.zeros(3, np.int32)
+    out = {}
+    for name, be in (("hip", hip), ("oracle", oracle)):
+        st = PyBartSettings.from_data(X, Y, m=m, num_particles=12, family="normal_meanscale", n_outputs=2,
+                                      response="linear", seed=9)
+        s = PySampler(st, X, Y, rules, np.ones(3), backend=be)
+        s.set_likelihood([])
+        for it in range(30):
+            w, _ = s.step(it < 20)
+        forest = s.export_trees(1)
+        ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 2, rules, backend=be)
+        Xn = X[:400].copy()
+        Xn[::4, 0] = np.nan
+        out[name] = (w, forest, ps.sample_posterior(X[:400], [0]), ps.sample_posterior(Xn, [0], excluded=[2]))
+        assert s.counters.saturations == 0
+    (wh, fh, ph, pxh), (wo, fo, po, pxo) = out["hip"], out["oracle"]
+    assert np.array_equal(wh, wo)
+    for f in ("var", "split", "left", "right", "count", "value", "slope", "xbar", "svar"):
+        assert np.array_equal(getattr(fh, f), getattr(fo, f)), f
+    lin = fh.svar >= 0
+    assert fh.slope.shape == (fh.total_nodes, 2) and (fh.slope[lin, 0] != 0).any() and (fh.slope[lin, 1] != 0).any()
+    np.testing.assert_allclose(ph, po, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(pxh, pxo, rtol=0, atol=1e-12)
+    full = ~np.isnan(X[:400]).any(axis=1)  # (training rows with a missing split value leave their tree)
+    np.testing.assert_allclose(ph[0][:, full], wh[:, :400][:, full], rtol=0, atol=1e-9)  # sum_trees == predictions
+    host = predict_numpy(fh, np.arange(m)[None, :], Xn[:60], rules, excluded=[2])
+    np.testing.assert_allclose(pxh[0][:, :60], host[0], rtol=0, atol=1e-12)
