@@ -171,6 +171,7 @@ struct Dev {  // kernel argument block (by value)
   int32_t batch_tune, batch_draw;
   int32_t family, K;  // K = n_outputs; KX = K - 1 extension outputs live in the *x arrays below
   int32_t rows_target, rows_target_init;  // work items the row passes aim for (tuning knobs)
+  int32_t ll_target, ll_pad;              // ... and the log-likelihood pass
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
@@ -2423,15 +2424,17 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
 // leaf values are known (child_values, the same routine k_ctrl uses one launch later); this pass
 // evaluates the per-row log-likelihood of the rows of the leaf that was split -- left / right /
 // dropped by a missing value -- and reduces it in fixed point.  Same work items as PARTITION.
-struct LJob {
+// (a template: the single-output kernels keep 64 of these in LDS and carry none of the arrays)
+template <bool MK, bool LIN>
+struct LJobT {
   long long src, xoff;
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
-  double vLx[KXMAX], vRx[KXMAX];  // K-vector leaves: outputs 1..K-1
-  // linear response (single-output per-row families): the children's linear parts
+  double vLx[MK ? KXMAX : 1], vRx[MK ? KXMAX : 1];  // K-vector leaves: outputs 1..K-1
+  // linear response: the children's linear parts
   double slopeL, xbarL, slopeR, xbarR;
   int32_t svarL, svarR;
-  double sLx[KXMAX], sRx[KXMAX];  // ... slopes of outputs 1..K-1 (K-vector leaves)
+  double sLx[MK && LIN ? KXMAX : 1], sRx[MK && LIN ? KXMAX : 1];  // ... slopes of outputs 1..K-1
 };
 
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
@@ -2443,6 +2446,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   const Dev& S = *Sp;
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
+  typedef LJobT<MK, LIN> LJob;
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
@@ -2450,6 +2454,10 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
   constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
   __shared__ double s_ln[PROBIT ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
+  // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
+  // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
+  // SLOWER at cfg4, 184 k / 171 k vs 223 k particle-steps/s: with a quarter of the lanes active the
+  // rare branches of the evaluation are skipped wave-wide, with every lane active they never are.)
   const Cmd* cmd = &S.cmd[par];
   if (!(cmd->kind & CMD_PARTITION)) return;
   if constexpr (PROBIT) {
@@ -2549,7 +2557,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
   __syncthreads();
   const int nact = s_n[0];
   if (nact == 0) return;
-  int G = (nact * S.nchunks + S.rows_target - 1) / S.rows_target;
+  int G = (nact * S.nchunks + S.ll_target - 1) / S.ll_target;
   if (G < 1) G = 1;
   const int ngroups = (nact + G - 1) / G;
   const int nitems = S.nchunks * ngroups;
@@ -2612,12 +2620,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           }
         }
         const int slot = (g - g0) * 3;
-        v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2);
-        if (lane == 63) {
-          s_red[(slot + 0) * 4 + w] = v0;
-          s_red[(slot + 1) * 4 + w] = v1;
-          s_red[(slot + 2) * 4 + w] = v2;
-        }
+        const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+        if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
       }
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
@@ -2632,10 +2636,17 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       continue;
     }
     const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+    // the label words of the next particle are requested before this one is evaluated
+    uint32_t ids_n = s_job[g0].src < 0 ? root_ids : *(const uint32_t*)(S.lid + s_job[g0].src + base);
+    uint32_t nid_n = *(const uint32_t*)(newl + (size_t)s_job[g0].p * S.n_pad + base);
     for (int g = g0; g < g1; ++g) {
       const LJob& lj = s_job[g];
-      const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
-      const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
+      const uint32_t ids = ids_n, nid = nid_n;
+      if (g + 1 < g1) {
+        const LJob& ln = s_job[g + 1];
+        ids_n = ln.src < 0 ? root_ids : *(const uint32_t*)(S.lid + ln.src + base);
+        nid_n = *(const uint32_t*)(newl + (size_t)ln.p * S.n_pad + base);
+      }
       long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
@@ -2662,12 +2673,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         }
       }
       const int slot = (g - g0) * 3;
-      v0 = wave_sum_dpp(v0); v1 = wave_sum_dpp(v1); v2 = wave_sum_dpp(v2);
-      if (lane == 63) {
-        s_red[(slot + 0) * 4 + w] = v0;
-        s_red[(slot + 1) * 4 + w] = v1;
-        s_red[(slot + 2) * 4 + w] = v2;
-      }
+      const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+      if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
     }
     __syncthreads();
     for (int t = tid; t < (g1 - g0) * 3; t += BT) {
@@ -2884,6 +2891,7 @@ struct pgb_handle {
   int have_data, have_y;
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
+  int ll_grid;     // ... of the log-likelihood pass
   int sigma_dirty;
   double inv_sigma2;
   double lik_param2;
@@ -2962,6 +2970,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->prof_clock_launches = 0;
   h->prof_slot0 = 0;
   if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
+  h->ll_grid = h->rows_grid;
+  if (const char* e = getenv("PGB_LL_GRID")) h->ll_grid = atoi(e) > 0 ? atoi(e) : h->ll_grid;
   h->st_cur = 0;
   h->alpha_cur = 0;
   h->d_dev = nullptr;
@@ -2989,6 +2999,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.rows_target = ROWS_TARGET_ITEMS;
   d.rows_target_init = ROWS_TARGET_ITEMS_INIT;
   if (const char* e = getenv("PGB_ROWS_TARGET")) d.rows_target = atoi(e) > 0 ? atoi(e) : d.rows_target;
+  d.ll_target = d.rows_target;
+  d.ll_pad = 0;
+  if (const char* e = getenv("PGB_LL_TARGET")) d.ll_target = atoi(e) > 0 ? atoi(e) : d.ll_target;
   if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
@@ -3288,6 +3301,9 @@ static int enqueue_slots(pgb_handle* h, int count) {
   if (want < d.n_pad / BT) want = d.n_pad / BT;
   if (want > h->rows_grid) want = h->rows_grid;
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
+  long long wantl = (long long)d.nchunks * (d.P - 1);
+  if (wantl > h->ll_grid) wantl = h->ll_grid;
+  dim3 gll((unsigned)wantl);
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
     const bool lin = d.response != PGB_RESPONSE_CONSTANT;
@@ -3348,9 +3364,9 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef LAUNCH_ROWS
 #undef ROWS_PTRS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
-#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), grows, dim3(BT), 0, h->stream, h->d_dev, par)
+#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), gll, dim3(BT), 0, h->stream, h->d_dev, par)
       if (d.K > 1 && lin) {
-        hipLaunchKernelGGL((k_loglik<0, -1, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        hipLaunchKernelGGL((k_loglik<0, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
       } else if (d.K > 1) {
         switch (d.K) {
           case 2: LAUNCH_LL(2, -1); break;
@@ -3359,7 +3375,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
           default: LAUNCH_LL(0, -1);
         }
       } else if (d.response != PGB_RESPONSE_CONSTANT) {  // linear leaves: one instance, family read at run time
-        hipLaunchKernelGGL((k_loglik<1, -1, true>), grows, dim3(BT), 0, h->stream, h->d_dev, par);
+        hipLaunchKernelGGL((k_loglik<1, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
       } else {
         switch (d.family) {
           case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;

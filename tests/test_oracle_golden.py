@@ -17,7 +17,7 @@ def test_oracle_reproduces_golden_fingerprint(oracle, name):
 
 
 @pytest.mark.parametrize("name", ["nan_onehot_prior", "ragged_1025", "categorical_k4_cfg5_small",
-                                  "logit_nan_onehot", "mix_response"])
+                                  "logit_nan_onehot", "mix_response", "meanscale_k2_linear"])
 def test_checkpoint_resume_does_not_change_the_chain(oracle, name):
     """pgb_checkpoint_save -> destroy -> create -> pgb_checkpoint_load, in tuning and in the draws:
     the resumed chain reproduces the uninterrupted chain's committed fingerprint."""

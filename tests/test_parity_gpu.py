@@ -236,7 +236,8 @@ def test_concurrent_chains_on_one_gpu_equal_the_chains_run_alone(hip):
 
 
 @pytest.mark.parametrize("name", ["nan_onehot_prior", "ragged_1025", "max_particles",
-                                  "categorical_k4_cfg5_small", "probit_cfg4_small", "linear_response"])
+                                  "categorical_k4_cfg5_small", "probit_cfg4_small", "linear_response",
+                                  "categorical_k3_mix"])
 def test_checkpoint_resume_does_not_change_the_chain_gpu(hip, name):
     """A chain resumed from pgb_checkpoint_load on a fresh handle reproduces the committed
     fingerprint of the uninterrupted chain (cuts in tuning, at the boundary and in the draws)."""
