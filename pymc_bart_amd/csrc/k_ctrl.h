@@ -1,0 +1,1024 @@
+// k_ctrl.h -- part of pgbart_hip.hip (not a standalone header): k_ctrl: the control kernel (finish a round, weights, resampling, next proposal).
+// ------------------------------------------------------------------ k_ctrl
+struct Fin {  // result of finishing the pending split of an old particle (kept in LDS)
+  int ok;     // 1: children created, 0: no pending split, -1: failed one-hot split
+  int cL, cR;
+  int nn_old, n_nodes, n_leaves, next_pop;
+  int loc_gen, loc_slot;
+  int node, var, new_label, ccL, ccR;
+  uint8_t depth, label;
+  long long aL, aR, bL, bR, c2L, c2R;
+  long long llL, llR, ll_tot, ll_orph;  // Bernoulli families
+  double split, vL, vR, sseL, sseR, sse_tot, sse_orph;
+  // linear response: the children's linear parts (svar < 0: constant leaf)
+  double slopeL, xbarL, slopeR, xbarR;
+  int svarL, svarR;
+};
+
+// [U] normalize + inverse-CDF pick on ONE wave, one particle per lane: lanes [first, first+cnt)
+// hold log-weights.  Cumulative weights are the fixed-order wave scan the numeric contract
+// defines (pgb_scan64 / pgb_weights_scan / pgb_pick in include/pgbart_spec.h).
+__device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u) {
+  const int lane = threadIdx.x & 63;
+  const bool act = lane >= first && lane < first + cnt;
+  const double mx = wave_max_d(act ? lw : -1.0e308);
+  double W = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
+#define PGB_SCAN_STEP(ctrl, rm)                                                       \
+  {                                                                                   \
+    const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(W), ctrl, rm, 0xf, 0); \
+    const int th = __builtin_amdgcn_update_dpp(0, __double2hiint(W), ctrl, rm, 0xf, 0); \
+    W = W + __hiloint2double(th, tl);                                                 \
+  }
+  PGB_SCAN_STEP(0x111, 0xf)  // row_shr:1
+  PGB_SCAN_STEP(0x112, 0xf)  // row_shr:2
+  PGB_SCAN_STEP(0x114, 0xf)  // row_shr:4
+  PGB_SCAN_STEP(0x118, 0xf)  // row_shr:8
+  PGB_SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+  PGB_SCAN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef PGB_SCAN_STEP
+  const int last = first + cnt - 1;
+  const double thr = u * readlane_d(W, last);
+  const bool hit = act && (lane < last) && !(thr > W);
+  const unsigned long long m = __ballot(hit);
+  return m ? (int)__ffsll((long long)m) - 1 : last;
+}
+
+// [U] SampleSplittingVariable.rvs on one wave, from stored prefix sums (pgb_sample_var)
+__device__ __forceinline__ int sample_var_prefix(const long long* Sarr, int p, double u) {
+  const int lane = threadIdx.x & 63;
+  const double thr = u * (double)Sarr[p - 1];
+  for (int base = 0; base < p; base += 64) {
+    const int j = base + lane;
+    const bool hit = j < p && thr <= (double)Sarr[j];
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + (int)__ffsll((long long)m) - 1;
+  }
+  return p - 1;
+}
+
+// The same draw from the integer split weights themselves (sampler being rebuilt by this slot):
+// exact prefix sums, 64 variables per step with a running carry.
+__device__ __forceinline__ int sample_var_weights(const long long* A, int p, double u) {
+  const int lane = threadIdx.x & 63;
+  long long part = 0;
+  for (int j = lane; j < p; j += 64) part += A[j];
+  part = wave_sum_dpp(part);
+  const long long tot = ((long long)__builtin_amdgcn_readlane((int)(part >> 32), 63) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)part, 63);
+  const double thr = u * (double)tot;
+  long long carry = 0;
+  for (int base = 0; base < p; base += 64) {
+    const int j = base + lane;
+    long long run = wave_sum_dpp(j < p ? A[j] : 0) + carry;  // inclusive prefix through variable j
+    const bool hit = j < p && thr <= (double)run;
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + (int)__ffsll((long long)m) - 1;
+    carry = ((long long)__builtin_amdgcn_readlane((int)(run >> 32), 63) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)run, 63);
+  }
+  return p - 1;
+}
+
+// linear response: the two children's linear parts from the sums the row pass left (shared by
+// k_ctrl and, for the per-row families, k_loglik: the very same arithmetic in both places)
+struct LinKids {
+  double slopeL, xbarL, slopeR, xbarR;
+  int svarL, svarR;
+  pgb_linfit fL, fR;
+  long long urL, urR;  // sum q(u r) of the children (the Normal family's SSE needs them)
+  // what the slopes of further outputs need (K-vector leaves, lin_children_x)
+  long long u0L, u1L, u0R, u1R;
+  bool linL, linR;
+  double uscale, xs;
+};
+__device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __restrict__ copies, int var, int cL, int cR,
+                                                long long aL, long long aR, uint32_t it, uint32_t round, uint32_t q) {
+  LinKids k;
+  k.slopeL = k.xbarL = k.slopeR = k.xbarR = 0.0;
+  k.svarL = k.svarR = -1;
+  k.fL = pgb_linfit{0.0, 0.0, 0.0};
+  k.fR = pgb_linfit{0.0, 0.0, 0.0};
+  long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+  for (int c = 0; c < ACC_SLOTS; ++c) {
+    const AccU t = copies[c * ACC_STRIDE];
+    for (int i2 = 0; i2 < 4; ++i2) { ul[i2] += t.uL[i2]; ur[i2] += t.uR[i2]; }
+  }
+  k.urL = ul[3];
+  k.urR = ur[3];
+  k.u0L = ul[0]; k.u1L = ul[1]; k.u0R = ur[0]; k.u1R = ur[1];
+  bool linL = true, linR = true;
+  if (S.response == PGB_RESPONSE_MIX) {  // [U] "mix": a fair coin per child
+    const pgb_u2 um = pgb_draw2(S.seed, it, round, q, PGB_RNG_MIX, 0);
+    linL = um.u0 < 0.5;
+    linR = um.u1 < 0.5;
+  }
+  const int ex = S.col_ex[var];
+  const double uscale = pgb_pow2(-ex), xs = pgb_pow2(ex);
+  k.linL = linL; k.linR = linR;
+  k.uscale = uscale; k.xs = xs;
+  if (linL) {
+    k.fL = pgb_lin_fit(cL, ul[0], ul[1], ul[2], aL, S.sc.inv_c1, S.inv_R, S.mdouble);
+    if (k.fL.slope_u != 0.0) {
+      k.svarL = var;
+      k.slopeL = k.fL.slope_u * uscale;
+      k.xbarL = k.fL.ubar * xs;
+    }
+  }
+  if (linR) {
+    k.fR = pgb_lin_fit(cR, ur[0], ur[1], ur[2], aR, S.sc.inv_c1, S.inv_R, S.mdouble);
+    if (k.fR.slope_u != 0.0) {
+      k.svarR = var;
+      k.slopeR = k.fR.slope_u * uscale;
+      k.xbarR = k.fR.ubar * xs;
+    }
+  }
+  return k;
+}
+// K-vector leaves: the slopes of extension output kx of both children (sums of u st_k from accux,
+// the sums of u / u^2 are shared with output 0); a leaf is linear when ANY output has a slope.
+__device__ __forceinline__ void lin_children_x(const Dev& S, LinKids& lk, ChildX& cx, int var, int cL, int cR,
+                                               long long usL, long long usR) {
+  if (lk.linL) {
+    const pgb_linfit f = pgb_lin_fit(cL, lk.u0L, lk.u1L, usL, cx.aL, S.sc.inv_c1, S.inv_R, S.mdouble);
+    cx.sL = f.slope_u * lk.uscale;
+    if (f.slope_u != 0.0 && lk.svarL < 0) {
+      lk.svarL = var;
+      lk.slopeL = lk.fL.slope_u * lk.uscale;
+      lk.xbarL = lk.fL.ubar * lk.xs;
+    }
+  }
+  if (lk.linR) {
+    const pgb_linfit f = pgb_lin_fit(cR, lk.u0R, lk.u1R, usR, cx.aR, S.sc.inv_c1, S.inv_R, S.mdouble);
+    cx.sR = f.slope_u * lk.uscale;
+    if (f.slope_u != 0.0 && lk.svarR < 0) {
+      lk.svarR = var;
+      lk.slopeR = lk.fR.slope_u * lk.uscale;
+      lk.xbarR = lk.fR.ubar * lk.xs;
+    }
+  }
+}
+
+// MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
+template <bool MK, bool LIN>
+__global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
+void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias) {
+  // ctrls / ias repeat S.ctrl / S.initacc as kernel arguments (see k_rows)
+  const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
+  __shared__ Fin s_fin[MAXP];
+  __shared__ int s_i[16];
+  __shared__ double s_d[4];
+  __shared__ double s_pre[2][PGB_SELECT_TRIES + 2];  // [set][0: coin, 1+t: row draw of try t]
+  __shared__ double s_pre1[2][PGB_SELECT_TRIES + 2]; // second uniform of the same draws (subset masks)
+  __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
+  __shared__ double s_prior[PGB_MAX_DEPTH];           // P(leaf | depth): read once by the idle wave 3
+  __shared__ DNode s_pop[MAXP];                       // node each OLD particle would pop next (prefetched)
+
+  TR(0);
+  if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
+  const Ctrl c = load_uniform(&ctrls[par]);
+  Ctrl* co = &ctrls[par ^ 1];
+  const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
+  const int P = S.P, Lc = P - 1;
+  Cmd* cmd = &S.cmd[par];
+  InitAcc ia;  // statistics of the previous FINAL/INIT row pass (integer sums over IA_SLOTS lines)
+  {
+    const InitAcc* src = ias + (size_t)(par ^ 1) * IA_SLOTS;
+    ia = load_uniform(&src[0]);
+#pragma unroll
+    for (int k = 1; k < IA_SLOTS; ++k) {
+      const InitAcc t = load_uniform(&src[k]);
+      ia.A += t.A; ia.B += t.B; ia.C += t.C; ia.E0 += t.E0; ia.QSTD += t.QSTD;
+    }
+  }
+
+  // pending leaf_sd from the FINAL pass of the previous slot ([U] RunningSd -> leaf_sd)
+  double leaf_sd = c.leaf_sd;
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
+
+  if (b == 0 && tid == 0 && c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
+  if (tid < ACC_SLOTS) {
+    Acc z;
+    memset(&z, 0, sizeof z);
+    S.acc[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = z;
+    if constexpr (LIN) {
+      AccU zu;
+      memset(&zu, 0, sizeof zu);
+      S.accu[((size_t)par * MAXP + p) * ACC_PER + tid * ACC_STRIDE] = zu;
+    }
+  }
+  if (tid < LL_SLOTS && S.family != PGB_FAMILY_NORMAL)
+    S.accl[((size_t)par * MAXP + p) * LL_PER + tid * LL_STRIDE] = AccL{0, 0, 0, 0};
+  if (b == 0 && tid < IA_SLOTS) S.initacc[(size_t)par * IA_SLOTS + tid] = InitAcc{0, 0, 0, 0, 0, 0, 0, 0};
+  const int KX = MK ? S.K - 1 : 0;
+  if constexpr (MK) {
+    if (tid < AX_PER) S.accx[((size_t)par * MAXP + p) * AX_PER + tid] = 0;
+    if constexpr (LIN)
+      if (tid < AX_PER) S.accux[((size_t)par * MAXP + p) * AX_PER + tid] = 0;
+    if (b == 0)
+      for (int i = tid; i < IA_SLOTS * 2 * KX; i += BT) S.iax[(size_t)par * IA_SLOTS * 2 * KX + i] = 0;
+  }
+
+  if (c.phase == PH_IDLE) {
+    if (b == 0 && tid == 0) {
+      Ctrl o = c;
+      o.slot_no = c.slot_no + 1;
+      o.leaf_sd = leaf_sd;
+      if constexpr (MK)
+        for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
+      o.pend_leafsd = 0;
+      *co = o;
+      cmd->kind = CMD_NOOP;
+    }
+    return;
+  }
+
+  const bool begin = c.phase == PH_BEGIN;  // first tree of a step: nothing to finish
+  const bool normal = S.family == PGB_FAMILY_NORMAL;
+  TR(1);
+  const int r = c.round;  // >= 1 in PH_ROUND: round 0 is proposed by the slot that starts the tree
+  const uint32_t it = (uint32_t)c.iter;
+  const DPart* OT = S.parts + (size_t)par * MAXP;
+  DPart* NT = S.parts + (size_t)(par ^ 1) * MAXP;
+  const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs (+ particle headers) of the previous slot
+  Job* JN = S.jobs + (size_t)par * MAXP;
+  DPart* me = &NT[p];
+  const long long* cdfS = S.cdfS + (size_t)c.cdf_cur * S.p;
+  const long long* alpha = S.alpha + (size_t)c.alpha_cur * S.p;
+  // the sampler of the NEXT tree is rebuilt from the weights when this tree ends while tuning
+  const bool rebuild = !begin && c.tune && c.iter > S.m;
+
+  // Waves 1 and 2 make the draws of the two proposals this slot may need while wave 0 finishes the
+  // previous round; they depend only on (iter, round, particle).
+  //   set 0: round r of the current tree            (iter,     r, p)
+  //   set 1: round 0 of the next tree to be updated (iter + 1, 0, p)
+  if (tid >= 64 && tid < 192) {
+    const int set = (tid >> 6) - 1, l = tid & 63;
+    const pgb_u2 u = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p,
+                               l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
+    if (l <= PGB_SELECT_TRIES) {
+      s_pre[set][l] = u.u0;
+      s_pre1[set][l] = u.u1;
+    }
+    const double u1 = readlane_d(u.u1, 0);
+    const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
+    if (l == 0) s_i[8 + set] = jj;
+    TRX(9 + set, blockIdx.x == 1 && l == 0);
+  }
+
+  int anc = p;  // ancestor (old particle index) of new particle p
+  bool stop = false;
+  int sel = 0;
+  double sse0 = c.sse0;
+
+  if (!begin) {
+    // [U] init_particles: the root statistics of this tree arrive with the INIT pass that ran
+    // together with round 0; they are patched in here (round 1)
+    const bool r1 = r == 1;
+    const double root_sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
+    // weight of the reference particle p0: its SSE (Normal) or its log-likelihood (Bernoulli)
+    if (r1) sse0 = (double)ia.E0 * (normal ? S.sc.inv_c2 : S.sc.inv_cl);
+    // -------- wave 0: finish round r-1 for every old particle (lane q <-> old particle q),
+    //          then decide stop / ancestor / final choice
+    if (tid < 64) {
+      const int q = tid;
+      const bool isp = q >= 1 && q < P;
+      // this lane's record is built directly in LDS (a register copy with a final struct store
+      // defeats scalar replacement and ends up in scratch); slot 0 is unused in this phase
+      Fin& f = s_fin[isp ? q : 0];
+      double lw = 0.0;
+      bool pending = false;
+      // RNG + Box-Muller do not depend on memory: they run while the loads below are in flight
+      Job j;
+      Acc a;
+      JobL jl = {0, 0, 0, 0};
+      AccL al = {0, 0, 0, 0};
+      DNode popn;  // the node this particle pops next if it is an old node (children: from Fin)
+      memset(&popn, 0, sizeof popn);
+      LinKids lk;  // linear response: kept for the extension outputs below
+      lk.svarL = lk.svarR = -1;
+      lk.linL = lk.linR = false;
+      if (isp) {
+        j = JP[q];
+        a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
+        // requested as soon as the job header is here; consumed at the end of this phase
+        if (j.h_next_pop < j.h_n_nodes) popn = OT[q].nd[j.h_next_pop];
+        if (!normal) {
+          jl = S.jobl[(par ^ 1) * MAXP + q];
+          al = AccL{0, 0, 0, 0};
+          for (int k = 0; k < LL_SLOTS; ++k) {
+            const AccL t = S.accl[((size_t)(par ^ 1) * MAXP + q) * LL_PER + k * LL_STRIDE];
+            al.llL += t.llL; al.llR += t.llR; al.llN += t.llN;
+          }
+        }
+      }
+      // one Philox evaluation per lane: lane 0 draws the resampling offset, lane q the leaf noise
+      double z0, z1, u_res;
+      {
+        const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q,
+                                    q == 0 ? PGB_RNG_RESAMPLE : PGB_RNG_LEAF, 0);
+        u_res = readlane_d(ul.u0, 0);
+        pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+      }
+      if (isp) {
+        if (r1) {  // round-0 jobs were written before the root statistics existed
+          j.p_q_st = ia.A;
+          j.p_q_r = ia.B;
+          j.p_q_r2 = ia.C;
+          j.p_sse = root_sse;
+          j.h_sse_tot = root_sse;
+          j.h_sse_orph = 0.0;
+          jl.p_ll = ia.C;  // non-Normal families: C carries the stump's log-likelihood
+          jl.h_ll_tot = ia.C;
+          jl.h_ll_orph = 0;
+        }
+        f.ok = 0;
+        f.nn_old = j.h_n_nodes;
+        f.n_nodes = j.h_n_nodes;
+        f.n_leaves = j.h_n_leaves;
+        f.next_pop = j.h_next_pop;
+        f.sse_tot = j.h_sse_tot;
+        f.sse_orph = j.h_sse_orph;
+        // labels: wherever they were, unless the previous row pass rewrote them (split / refresh)
+        f.loc_gen = j.src_gen;
+        f.loc_slot = j.src_slot;
+        if (j.copy) {
+          f.loc_gen = c.lid_gen;
+          f.loc_slot = q;
+        }
+        f.ll_tot = jl.h_ll_tot;
+        f.ll_orph = jl.h_ll_orph;
+        if (j.active) {
+          const ChildVals cv = child_values(S, j.rule, j.cnt, j.p_q_st, j.p_value, a.cnts, a.aL, a.aN, z0, z1, leaf_sd);
+          const int cL = cv.cL, cR = cv.cR;
+          f.loc_gen = c.lid_gen;  // the row pass wrote this particle's labels here
+          f.loc_slot = q;
+          f.ok = cv.ok;
+          f.node = j.node;
+          f.cL = cL;
+          f.aL = a.aL; f.bL = a.bL; f.c2L = a.c2L;
+          f.ccL = j.ccL;
+          f.sse_orph = j.h_sse_orph + (double)a.c2N * S.sc.inv_c2;
+          f.ll_orph = jl.h_ll_orph + al.llN;
+          f.llL = al.llL;
+          if (cv.ok == -1) {
+            // [U] a one-hot split needs two distinct values: the grow fails and the node stays a
+            // leaf.  No row was relabelled except rows with a missing split value, which the pass
+            // dropped; the leaf sheds them (identity when there are none).
+            f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, j.p_value, S.sc.inv_c1, S.sc.inv_c2);
+            f.sse_tot = (j.h_sse_tot - j.p_sse) + f.sseL;
+            f.ll_tot = (jl.h_ll_tot - jl.p_ll) + al.llL;
+          } else {
+            f.cR = cR;
+            f.var = j.var; f.split = j.v; f.new_label = j.new_label;
+            f.ccR = j.ccR;
+            f.depth = (uint8_t)j.p_depth; f.label = (uint8_t)j.label;
+            f.aR = cv.aR;
+            f.bR = j.p_q_r - a.bL - a.bN;
+            f.c2R = j.p_q_r2 - a.c2L - a.c2N;
+            f.vL = cv.vL;
+            f.vR = cv.vR;
+            f.sseL = pgb_leaf_sse(cL, f.bL, f.c2L, f.vL, S.sc.inv_c1, S.sc.inv_c2);
+            f.sseR = pgb_leaf_sse(cR, f.bR, f.c2R, f.vR, S.sc.inv_c1, S.sc.inv_c2);
+            f.svarL = f.svarR = -1;
+            f.slopeL = f.xbarL = f.slopeR = f.xbarR = 0.0;
+            if constexpr (LIN) {  // [U] fast_linear_fit on the split variable
+              lk = lin_children(S, &S.accu[((size_t)(par ^ 1) * MAXP + q) * ACC_PER], j.var, cL, cR,
+                                f.aL, f.aR, it, (uint32_t)(r - 1), (uint32_t)q);
+              f.svarL = lk.svarL; f.slopeL = lk.slopeL; f.xbarL = lk.xbarL;
+              f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
+              if (normal) {  // the weight of a linear leaf: SSE in closed form
+                if (lk.svarL >= 0) f.sseL = pgb_lin_sse(f.sseL, lk.fL, lk.urL, f.bL, S.sc.inv_c1);
+                if (lk.svarR >= 0) f.sseR = pgb_lin_sse(f.sseR, lk.fR, lk.urR, f.bR, S.sc.inv_c1);
+              }
+            }
+            f.sse_tot = ((j.h_sse_tot - j.p_sse) + f.sseL) + f.sseR;
+            f.llR = al.llR;
+            f.ll_tot = ((jl.h_ll_tot - jl.p_ll) + al.llL) + al.llR;
+            f.n_nodes = j.h_n_nodes + 2;
+            f.n_leaves = j.h_n_leaves + 1;
+          }
+        }
+        if constexpr (MK) {
+          if (j.active)
+          for (int k = 0; k < KX; ++k) {
+            const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, load_accx(S.accx, par ^ 1, q, k),
+                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
+                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
+            if constexpr (LIN)
+              if (f.ok == 1)
+                lin_children_x(S, lk, s_finx[q][k], j.var, f.cL, f.cR, load_accx(S.accux, par ^ 1, q, k),
+                               load_accx(S.accux, par ^ 1, q, KX + k));
+          }
+          if constexpr (LIN)
+            if (j.active && f.ok == 1) {  // a further output may have made the leaf linear
+              f.svarL = lk.svarL; f.slopeL = lk.slopeL; f.xbarL = lk.xbarL;
+              f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
+            }
+        }
+        s_pop[q] = popn;
+        pending = f.next_pop < f.n_nodes;
+        lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
+                    : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
+      }
+      TR(2);
+      stop = __ballot(pending) == 0ull;
+      int pick;
+      if (!stop) {
+        // [U] systematic resampling of particles 1..P-1: ancestor of new particle p
+        const double ui = (u_res + (double)(p - 1)) / (double)Lc;
+        pick = wave_pick(lw, 1, Lc, ui);
+      } else {
+        // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
+        if (q == 0) lw = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
+        const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
+        pick = wave_pick(lw, 0, P, u_fin.u0);
+      }
+      if (tid == 0) {
+        s_i[0] = stop ? 1 : 0;
+        s_i[1] = pick;
+      }
+    }
+    __syncthreads();
+    stop = s_i[0] != 0;
+    if (stop) {
+      sel = s_i[1];
+      anc = p;  // no resampling in the final slot: particle p finishes itself
+    } else {
+      anc = s_i[1];
+    }
+    TR(3);
+    // -------- new particle p := old particle anc with its pending split applied (all threads)
+    {
+      const DPart* A = &OT[anc];
+      const Fin& f = s_fin[anc];
+      const int nn = f.nn_old;
+      for (int i = tid; i < nn; i += BT) {
+        DNode z = A->nd[i];
+        if (r1 && i == 0) {  // root statistics (see above)
+          z.q_st = ia.A;
+          z.q_r = normal ? ia.B : ia.C;  // Bernoulli families keep the node's log-likelihood here
+          z.q_r2 = ia.C;
+          z.sse = root_sse;
+        }
+        if (f.ok == 1 && i == f.node) {
+          z.var = f.var;
+          z.split = f.split;
+          z.left = (uint8_t)nn;
+          z.right = (uint8_t)(nn + 1);
+        } else if (f.ok == -1 && i == f.node) {
+          z.cnt = f.cL;
+          z.q_st = f.aL;
+          z.q_r = normal ? f.bL : f.llL;
+          z.q_r2 = f.c2L;
+          z.sse = f.sseL;
+          z.cc_row = f.ccL;
+        }
+        me->nd[i] = z;
+      }
+      if constexpr (LIN) {  // linear parts of the leaves
+        const LinP* la = S.plin + ((size_t)par * MAXP + anc) * MAXN;
+        LinP* lm = S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN;
+        for (int i = tid; i < nn; i += BT) lm[i] = la[i];
+        if (f.ok == 1 && tid < 2) {
+          lm[nn + tid] = tid == 0 ? LinP{f.slopeL, f.xbarL, (long long)f.svarL}
+                                  : LinP{f.slopeR, f.xbarR, (long long)f.svarR};
+        }
+      }
+      if constexpr (MK) {  // extension outputs of the node table
+        const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX, dn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX;
+        for (int e = tid; e < nn * KX; e += BT) {
+          const int i = e / KX, k = e % KX;
+          double v = S.pvx[so + e];
+          long long qv = S.pqx[so + e];
+          if (r1 && i == 0) qv = root_A_x(S, par ^ 1, k);
+          if (f.ok == -1 && i == f.node) qv = s_finx[anc][k].aL;
+          S.pvx[dn + e] = v;
+          S.pqx[dn + e] = qv;
+          if constexpr (LIN) S.psx[dn + e] = S.psx[so + e];
+        }
+        if (f.ok == 1)
+          for (int e = tid; e < 2 * KX; e += BT) {
+            const int ch = e / KX, k = e % KX;
+            S.pvx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].vR : s_finx[anc][k].vL;
+            S.pqx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].aR : s_finx[anc][k].aL;
+            if constexpr (LIN) S.psx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].sR : s_finx[anc][k].sL;
+          }
+      }
+      if (f.ok == 1 && tid >= BT - 2) {
+        const bool isL = tid == BT - 2;
+        DNode z;
+        memset(&z, 0, sizeof z);
+        z.var = -1;
+        z.depth = f.depth + 1;
+        z.label = isL ? f.label : (uint8_t)f.new_label;
+        z.cnt = isL ? f.cL : f.cR;
+        z.q_st = isL ? f.aL : f.aR;
+        z.q_r = normal ? (isL ? f.bL : f.bR) : (isL ? f.llL : f.llR);
+        z.q_r2 = isL ? f.c2L : f.c2R;
+        z.value = isL ? f.vL : f.vR;
+        z.sse = isL ? f.sseL : f.sseR;
+        z.cc_row = isL ? f.ccL : f.ccR;
+        me->nd[nn + (isL ? 0 : 1)] = z;
+      }
+    }
+  } else {
+    __syncthreads();  // waves 1/2 have published their draws
+  }
+  TR(4);
+
+  // =================================================================== end of a tree
+  // bookkeeping of the accepted tree; then (if another tree follows) fall through and propose
+  // its round 0 in this very slot
+  bool fresh = begin;       // propose round 0 of a new tree (fresh stump) instead of round r
+  int tree_new = c.lower + c.k;  // PH_BEGIN: the tree to start
+  bool has_init = begin;
+  int lower_next = c.lower, k_next = c.k, batch_next = c.batch_n;
+  bool more = true;
+  if (stop) {
+    const Fin& F = s_fin[p];
+    __syncthreads();  // the node copy above is complete (this workgroup reads it back below)
+    const int tree_old = c.lower + c.k;
+    more = (c.k + 1 < c.batch_n);
+    const bool next_step = (!more && c.steps_left > 1);
+    k_next = c.k + 1;
+    if (!more) {
+      int upper = c.lower + c.batch_n;
+      lower_next = upper < S.m ? upper : 0;
+      k_next = 0;
+      int bs = c.tune ? S.batch_tune : S.batch_draw;
+      int up2 = lower_next + bs;
+      if (up2 > S.m) up2 = S.m;
+      batch_next = up2 - lower_next;
+    }
+    tree_new = lower_next + k_next;
+    has_init = more || next_step;
+    fresh = has_init;
+
+    if (tid == 0) {  // particle header (kept for inspection / export)
+      me->n_nodes = F.n_nodes;
+      me->n_leaves = F.n_leaves;
+      me->next_pop = F.next_pop;
+      me->loc_gen = F.loc_gen;
+      me->loc_slot = F.loc_slot;
+      me->sse_tot = F.sse_tot;
+      me->sse_orph = F.sse_orph;
+    }
+    if (sel >= 1 && p == sel) {
+      // accepted a grown particle: store it as the tree and publish its label->value table
+      DTree* T = &S.trees[tree_old];
+      const int nn = F.n_nodes;
+      for (int i = tid; i < nn; i += BT) T->nd[i] = me->nd[i];
+      if (tid == 0) {
+        T->n_nodes = nn;
+        T->n_leaves = F.n_leaves;
+        cmd->sel_gen = F.loc_gen;
+        cmd->sel_slot = F.loc_slot;  // may be -1 (untouched root labels)
+      }
+      build_lv(me->nd, nn, cmd->lv_new);
+      if constexpr (LIN) {
+        const LinP* lm = S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN;
+        for (int i = tid; i < nn; i += BT) S.tlin[(size_t)tree_old * MAXN + i] = lm[i];
+        build_lvl(me->nd, nn, lm, S.lvl + ((size_t)par * 2 + 0) * 256);
+      }
+      if constexpr (MK) {  // extension outputs: store with the tree, publish label->value tables
+        const size_t pn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX, tn = (size_t)tree_old * MAXN * KX;
+        for (int e = tid; e < nn * KX; e += BT) S.tvx[tn + e] = S.pvx[pn + e];
+        build_lvx(me->nd, nn, S.pvx + pn, KX, S.lvx + ((size_t)par * 2 + 0) * 256 * KX);
+        if constexpr (LIN) {
+          for (int e = tid; e < nn * KX; e += BT) S.tsx[tn + e] = S.psx[pn + e];
+          build_lvx(me->nd, nn, S.psx + pn, KX, S.lsx + ((size_t)par * 2 + 0) * 256 * KX);
+        }
+      }
+    }
+    if (b == 0) {
+      if constexpr (LIN) {
+        if (sel == 0)
+          build_lvl(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tlin + (size_t)tree_old * MAXN,
+                    S.lvl + ((size_t)par * 2 + 0) * 256);
+        if (has_init && tree_new != tree_old)
+          build_lvl(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tlin + (size_t)tree_new * MAXN,
+                    S.lvl + ((size_t)par * 2 + 1) * 256);
+      }
+      if constexpr (MK) {
+        if (sel == 0)
+          build_lvx(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tvx + (size_t)tree_old * MAXN * KX, KX,
+                    S.lvx + ((size_t)par * 2 + 0) * 256 * KX);
+        if (has_init && tree_new != tree_old)
+          build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
+                    S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+        if constexpr (LIN) {
+          if (sel == 0)
+            build_lvx(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, S.tsx + (size_t)tree_old * MAXN * KX, KX,
+                      S.lsx + ((size_t)par * 2 + 0) * 256 * KX);
+          if (has_init && tree_new != tree_old)
+            build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tsx + (size_t)tree_new * MAXN * KX, KX,
+                      S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
+        }
+      }
+      if (sel == 0) {  // the old tree is kept: nobody writes S.trees[tree_old] in this slot
+        if (tid == 0) {
+          cmd->sel_slot = -2;
+          cmd->sel_gen = 0;
+        }
+        build_lv(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, cmd->lv_new);
+      }
+      // label table of the next tree to update (a different tree unless m == 1)
+      if (has_init && tree_new != tree_old)
+        build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+    }
+    // Bookkeeping that needs the accepted tree's split variables is done by the workgroup
+    // that owns a complete copy of that tree.
+    const bool owner = (sel == 0) ? (b == 0) : (p == sel);
+    if (owner) {
+      const DNode* snd = sel == 0 ? S.trees[tree_old].nd : me->nd;
+      const int nn = sel == 0 ? S.trees[tree_old].n_nodes : F.n_nodes;
+      if (c.tune) {
+        // [U] the sampler is rebuilt from the weights BEFORE this tree's counts are added; weights
+        // and prefix sums are double-buffered (other workgroups read the current ones in this slot)
+        long long* alpha_o = S.alpha + (size_t)(c.alpha_cur ^ 1) * S.p;
+        if (rebuild) {
+          long long* cdf_o = S.cdfS + (size_t)(c.cdf_cur ^ 1) * S.p;
+          if (tid < 64) {
+            long long carry = 0;
+            for (int base = 0; base < S.p; base += 64) {
+              const int j = base + tid;
+              const long long run = wave_sum_dpp(j < S.p ? alpha[j] : 0) + carry;
+              if (j < S.p) cdf_o[j] = run;
+              carry = ((long long)__builtin_amdgcn_readlane((int)(run >> 32), 63) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)run, 63);
+            }
+          }
+        }
+        for (int j = tid; j < S.p; j += BT) alpha_o[j] = alpha[j];
+        __syncthreads();
+        if (tid == 0)
+          for (int i = 0; i < nn; ++i)
+            if (snd[i].var >= 0) alpha_o[snd[i].var] += S.alpha_unit;
+      } else {
+        if (tid == 0)
+          for (int i = 0; i < nn; ++i)
+            if (snd[i].var >= 0) S.vi[snd[i].var] += 1;
+      }
+      if (tree_new == tree_old && has_init) {  // m == 1 corner: next update is this very tree
+        __syncthreads();
+        build_lv(snd, nn, cmd->lv_next);
+        if constexpr (LIN)
+          build_lvl(snd, nn, sel == 0 ? S.tlin + (size_t)tree_old * MAXN
+                                      : S.plin + ((size_t)(par ^ 1) * MAXP + p) * MAXN,
+                    S.lvl + ((size_t)par * 2 + 1) * 256);
+        if constexpr (MK)
+          build_lvx(snd, nn, sel == 0 ? S.tvx + (size_t)tree_old * MAXN * KX
+                                      : S.pvx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
+                    KX, S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+        if constexpr (MK && LIN)
+          build_lvx(snd, nn, sel == 0 ? S.tsx + (size_t)tree_old * MAXN * KX
+                                      : S.psx + ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX,
+                    KX, S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
+      }
+    }
+    if (b == 0 && tid == 0) {
+      cmd->tree_old = tree_old;
+      cmd->tune = c.tune;
+      cmd->rs_count = c.rs_count + (c.tune ? 1 : 0);
+      atomicAdd(&S.counters[1], 1ull);
+      atomicAdd(&S.counters[3], 1ull);
+    }
+    if (!has_init) {  // last tree of the last requested step
+      if (b == 0 && tid == 0) {
+        cmd->kind = CMD_FINAL;
+        cmd->st_cur = c.st_cur;
+        Ctrl o = c;
+        o.slot_no = c.slot_no + 1;
+        o.leaf_sd = leaf_sd;
+        if constexpr (MK)
+          for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
+        o.rs_count = c.rs_count + (c.tune ? 1 : 0);
+        o.pend_leafsd = c.tune ? 1 : 0;
+        o.pend_iter = c.iter;
+        o.round = 0;
+        o.k = k_next;
+        o.lower = lower_next;
+        o.batch_n = batch_next;
+        o.phase = PH_IDLE;
+        o.steps_left = 0;
+        o.steps_done = c.steps_done + 1;
+        if (c.tune) o.alpha_cur = c.alpha_cur ^ 1;
+        if (rebuild) o.cdf_cur = c.cdf_cur ^ 1;
+        *co = o;
+        // progress word the host polls (the row pass of this slot is still to run)
+        __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (tid == 0) {
+        Job z;
+        memset(&z, 0, sizeof z);
+        JN[p] = z;
+      }
+      return;
+    }
+  } else if (begin && b == 0) {
+    build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+    if constexpr (LIN)
+      build_lvl(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tlin + (size_t)tree_new * MAXN,
+                S.lvl + ((size_t)par * 2 + 1) * 256);
+    if constexpr (MK)
+      build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tvx + (size_t)tree_new * MAXN * KX, KX,
+                S.lvx + ((size_t)par * 2 + 1) * 256 * KX);
+    if constexpr (MK && LIN)
+      build_lvx(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, S.tsx + (size_t)tree_new * MAXN * KX, KX,
+                S.lsx + ((size_t)par * 2 + 1) * 256 * KX);
+  }
+
+  // =================================================================== propose
+  // [U] ParticleTree.sample_tree / grow_tree for new particle p: round r of the current tree, or
+  // round 0 of the tree this slot starts (fresh stump, [U] init_particles)
+  const int set = fresh ? 1 : 0;
+  const int rr = fresh ? 0 : r;  // round of the proposal
+  if (fresh) {
+    __syncthreads();  // every reader of s_fin[] of the finished tree is done
+    if (tid == 0) {  // slot 0 of s_fin is never a particle: it holds the fresh stump
+      Fin f0;
+      memset(&f0, 0, sizeof f0);
+      f0.nn_old = 1;
+      f0.n_nodes = 1;
+      f0.n_leaves = 1;
+      f0.next_pop = 0;
+      f0.loc_gen = 0;
+      f0.loc_slot = -1;
+      s_fin[0] = f0;
+      // root node; its statistics are patched in by the next slot
+      DNode z;
+      memset(&z, 0, sizeof z);
+      z.var = -1;
+      z.cc_row = -1;
+      z.cnt = (int32_t)S.n;
+      z.value = S.init_leaf;
+      me->nd[0] = z;
+      if constexpr (LIN) S.plin[((size_t)(par ^ 1) * MAXP + p) * MAXN] = LinP{0.0, 0.0, -1};
+      if constexpr (MK)
+      for (int k = 0; k < KX; ++k) {
+        S.pvx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = S.init_leaf;
+        S.pqx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = 0;  // patched by the next slot
+        if constexpr (LIN) S.psx[((size_t)(par ^ 1) * MAXP + p) * MAXN * KX + k] = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  const Fin& F = s_fin[fresh ? 0 : anc];
+  Job job;
+  memset(&job, 0, sizeof job);
+  job.src_gen = F.loc_gen;
+  job.src_slot = F.loc_slot;
+  job.h_n_nodes = F.n_nodes;
+  job.h_n_leaves = F.n_leaves;
+  job.h_next_pop = F.next_pop;
+  job.h_sse_tot = F.sse_tot;
+  job.h_sse_orph = F.sse_orph;
+  bool attempt = false;
+  int node = -1;
+  DNode nd;
+  memset(&nd, 0, sizeof nd);
+  if (tid == 0) {
+    const int np = F.next_pop;
+    if (np < F.n_nodes) {
+      atomicAdd(&S.counters[0], 1ull);
+      node = np;
+      // the popped node: the root of a fresh stump, an old node of the ancestor, or one of the
+      // children just created
+      if (fresh) {
+        nd.var = -1;
+        nd.cc_row = -1;
+        nd.cnt = (int32_t)S.n;
+        nd.value = S.init_leaf;
+      } else if (np < F.nn_old) {
+        nd = s_pop[anc];
+        if (r == 1 && np == 0) nd.q_st = ia.A, nd.q_r = normal ? ia.B : ia.C, nd.q_r2 = ia.C,
+            nd.sse = pgb_leaf_sse(S.n, ia.B, ia.C, S.init_leaf, S.sc.inv_c1, S.sc.inv_c2);
+      } else {
+        const bool isL = np == F.nn_old;
+        nd.var = -1;
+        nd.depth = F.depth + 1;
+        nd.label = isL ? F.label : (uint8_t)F.new_label;
+        nd.cnt = isL ? F.cL : F.cR;
+        nd.q_st = isL ? F.aL : F.aR;
+        nd.q_r = normal ? (isL ? F.bL : F.bR) : (isL ? F.llL : F.llR);
+        nd.q_r2 = isL ? F.c2L : F.c2R;
+        nd.sse = isL ? F.sseL : F.sseR;
+        nd.value = isL ? F.vL : F.vR;
+        nd.cc_row = isL ? F.ccL : F.ccR;
+      }
+      double pl = nd.depth < PGB_MAX_DEPTH ? s_prior[nd.depth] : 1.0;
+      attempt = (pl < s_pre[set][0]) && (F.n_nodes + 2 <= MAXN) && (nd.cnt >= 2);
+      s_i[5] = nd.cnt;
+      s_i[6] = nd.cc_row;
+      s_i[7] = nd.label;
+    }
+    s_i[3] = attempt ? 1 : 0;
+    s_i[4] = node;
+  }
+  __syncthreads();
+  attempt = s_i[3] != 0;
+  node = s_i[4];
+  job.h_next_pop = F.next_pop + (node >= 0 ? 1 : 0);
+  TR(5);
+  if (attempt) {
+    const int ncnt = s_i[5], ncc = s_i[6], nlabel = s_i[7];
+    // Everything below runs on wave 0 only (no workgroup barriers): the k-th row (ascending) of
+    // the leaf, k = floor(u * cnt)   ([U] get_split_value)
+    if (tid < 64) {
+      const int j = s_i[8 + set];
+      const double* xc = S.XT + (size_t)j * S.n_pad;
+      const bool subset_rule = S.rules[j] == PGB_RULE_SUBSET;
+      const uint8_t* lid =
+          job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
+      const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
+      int found = 0;
+      double v = 0.0;
+      TR(6);
+      // per-lane partial sums of the node's per-chunk row counts (independent of the retry)
+      const int per = (S.nchunks + 63) / 64;
+      const int c0 = lane_id() * per;
+      int c1 = c0 + per;
+      if (c1 > S.nchunks) c1 = S.nchunks;
+      int part = 0, pre = 0;
+      if (lid != nullptr) {
+        for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
+        pre = wave_incl_scan(part) - part;
+      }
+      for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
+        long long k = (long long)(s_pre[set][1 + tr] * (double)ncnt);
+        if (k > ncnt - 1) k = ncnt - 1;
+        long long row;
+        if (lid == nullptr) {
+          row = k;  // untouched root: every row belongs to it
+        } else {
+          // (1) which chunk holds the k-th row
+          const bool own = (long long)pre <= k && k < (long long)pre + part;
+          int cstar = 0, kk = 0;
+          if (own) {
+            kk = (int)(k - pre);
+            cstar = c0;
+            while (kk >= ccr[cstar]) {
+              kk -= ccr[cstar];
+              ++cstar;
+            }
+          }
+          const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
+          cstar = __builtin_amdgcn_readlane(cstar, ol);
+          kk = __builtin_amdgcn_readlane(kk, ol);
+          // (2) which row inside the chunk: 16 label bytes per lane
+          const uint4 ids = *(const uint4*)(lid + (size_t)cstar * CH + lane_id() * 16);
+          const uint32_t wds[4] = {ids.x, ids.y, ids.z, ids.w};
+          int mcnt = 0;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mcnt += (((wds[wd] >> (8 * e)) & 255u) == (uint32_t)nlabel);
+          const int pre2 = wave_incl_scan(mcnt) - mcnt;
+          const bool own2 = pre2 <= kk && kk < pre2 + mcnt;
+          int off = 0;
+          if (own2) {
+            int rem = kk - pre2;
+            for (int bb = 0; bb < 16; ++bb) {
+              if (((wds[bb >> 2] >> (8 * (bb & 3))) & 255u) == (uint32_t)nlabel) {
+                if (rem == 0) {
+                  off = bb;
+                  break;
+                }
+                --rem;
+              }
+            }
+          }
+          const int ol2 = (int)__ffsll((long long)__ballot(own2)) - 1;
+          off = __builtin_amdgcn_readlane(off, ol2);
+          row = (long long)cstar * CH + ol2 * 16 + off;
+        }
+        const double x = xc[row];
+        found = (x == x) ? 1 : 0;
+        v = x;
+        if (found && subset_rule) v = pgb_subset_value(s_pre1[set][1 + tr], x);
+      }
+      if (tid == 0) {
+        s_i[0] = found;
+        s_d[0] = v;
+      }
+    }
+    __syncthreads();
+    if (s_i[0]) {
+      const int j = s_i[8 + set];
+      job.active = 1;
+      job.node = node;
+      job.label = nlabel;
+      job.new_label = F.n_leaves;
+      job.var = j;
+      job.rule = S.rules[j];
+      job.check_nan = S.col_nan[j];
+      job.ccL = ((rr * MAXP + p) * 2);
+      job.ccR = job.ccL + 1;
+      job.cnt = ncnt;
+      job.v = s_d[0];
+    }
+  }
+  TR(7);
+  // Labels are only rewritten when a particle splits.  A particle that idles keeps pointing at
+  // its old generation; it is copied forward only when that generation is the next to be reused.
+  {
+    const int dst = (c.lid_gen + 1) % NGEN;
+    job.copy = (!job.active && job.src_slot >= 0 && job.src_gen == (dst + 1) % NGEN) ? 1 : 0;
+  }
+  if (tid == 0) {
+    if (job.active) {  // parent statistics travel with the job (the next slot needs nothing else)
+      job.p_q_st = nd.q_st;
+      job.p_q_r = nd.q_r;
+      job.p_q_r2 = nd.q_r2;
+      job.p_sse = nd.sse;
+      job.p_value = nd.value;
+      job.p_depth = nd.depth;
+      atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
+      if constexpr (MK)
+      for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
+        long long pq;
+        double pv;
+        if (fresh) {
+          pq = 0;  // root sums are not known yet: patched by the next slot
+          pv = S.init_leaf;
+        } else if (node < F.nn_old) {
+          const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX + (size_t)node * KX + k;
+          pq = (r == 1 && node == 0) ? root_A_x(S, par ^ 1, k) : S.pqx[so];
+          pv = S.pvx[so];
+          if (F.ok == -1 && node == F.node) pq = s_finx[anc][k].aL;
+        } else {
+          const bool isL = node == F.nn_old;
+          pq = isL ? s_finx[anc][k].aL : s_finx[anc][k].aR;
+          pv = isL ? s_finx[anc][k].vL : s_finx[anc][k].vR;
+        }
+        S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
+        S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
+      }
+    }
+    JN[p] = job;
+    if (!normal)  // the node's log-likelihood lives in q_r for these families
+      S.jobl[par * MAXP + p] = JobL{job.active ? nd.q_r : 0, F.ll_tot, F.ll_orph, 0};
+    me->n_nodes = F.n_nodes;
+    me->n_leaves = F.n_leaves;
+    me->next_pop = job.h_next_pop;
+    me->loc_gen = F.loc_gen;
+    me->loc_slot = F.loc_slot;
+    me->sse_tot = F.sse_tot;
+    me->sse_orph = F.sse_orph;
+  }
+#ifdef PGB_TRACE
+  if (b == 1 && tid == 0) {
+    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 15] = r;
+    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 14] = attempt;
+    TR(8);
+  }
+#endif
+  if (b == 0 && tid == 0) {
+    cmd->dst_gen = (c.lid_gen + 1) % NGEN;
+    cmd->st_cur = c.st_cur;
+    Ctrl o = c;
+    o.slot_no = c.slot_no + 1;
+    o.leaf_sd = leaf_sd;
+    if constexpr (MK)
+      for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
+    o.pend_leafsd = 0;
+    o.lid_gen = (c.lid_gen + 1) % NGEN;
+    o.sse0 = sse0;
+    o.phase = PH_ROUND;
+    if (!fresh) {
+      cmd->kind = CMD_PARTITION;
+      o.round = r + 1;
+      atomicAdd(&S.counters[3], 1ull);  // round r-1 is complete
+    } else {
+      // this slot starts a tree: FINAL of the previous one (if any) + INIT + round 0 in one row pass
+      cmd->kind = (stop ? CMD_FINAL : 0) | CMD_INIT | CMD_PARTITION;
+      cmd->tree_new = tree_new;
+      o.round = 1;
+      o.iter = c.iter + 1;
+      o.st_cur = c.st_cur ^ 1;  // INIT writes sum_trees_noi into the other buffer
+      if (stop) {
+        o.rs_count = c.rs_count + (c.tune ? 1 : 0);
+        o.pend_leafsd = c.tune ? 1 : 0;
+        o.pend_iter = c.iter;
+        o.k = k_next;
+        o.lower = lower_next;
+        o.batch_n = batch_next;
+        if (!more) {
+          o.steps_left = c.steps_left - 1;
+          o.steps_done = c.steps_done + 1;
+        }
+        if (c.tune) o.alpha_cur = c.alpha_cur ^ 1;
+        if (rebuild) o.cdf_cur = c.cdf_cur ^ 1;
+      }
+    }
+    *co = o;
+    if (fresh && stop && !more)  // a step completed (its FINAL runs in this slot's row pass)
+      __hip_atomic_store(S.host_flag, (unsigned long long)o.steps_done, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    TRX(11, true);
+  }
+}
+

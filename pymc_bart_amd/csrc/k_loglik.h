@@ -1,0 +1,272 @@
+// k_loglik.h -- part of pgbart_hip.hip (not a standalone header): k_loglik: per-row log-likelihood of the rows a round re-labelled (non-Normal families).
+// ------------------------------------------------------------------ k_loglik
+// Bernoulli families only ([U] update_weight): after the PARTITION pass of a slot, the children's
+// leaf values are known (child_values, the same routine k_ctrl uses one launch later); this pass
+// evaluates the per-row log-likelihood of the rows of the leaf that was split -- left / right /
+// dropped by a missing value -- and reduces it in fixed point.  Same work items as PARTITION.
+// (a template: the single-output kernels keep 64 of these in LDS and carry none of the arrays)
+template <bool MK, bool LIN>
+struct LJobT {
+  long long src, xoff;
+  double v, vL, vR;
+  int32_t p, rule, label, check_nan, ok, new_label;
+  double vLx[MK ? KXMAX : 1], vRx[MK ? KXMAX : 1];  // K-vector leaves: outputs 1..K-1
+  // linear response: the children's linear parts
+  double slopeL, xbarL, slopeR, xbarR;
+  int32_t svarL, svarR;
+  double sLx[MK && LIN ? KXMAX : 1], sRx[MK && LIN ? KXMAX : 1];  // ... slopes of outputs 1..K-1
+};
+
+// KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
+// FAM: the likelihood family when known at compile time (single-output kernels: the per-row
+// evaluation then contains one family's code only), -1: read S.family.
+// LIN: linear response (single-output families): the children predict value + slope (x - xbar).
+template <int KT, int FAM, bool LIN>
+__global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
+  constexpr bool MK = KT != 1;
+  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
+  typedef LJobT<MK, LIN> LJob;
+  __shared__ long long s_red[MAXP * 3 * 4];
+  __shared__ LJob s_job[MAXP];
+  __shared__ int s_n[2];
+  // log Phi tables in LDS (single-output Bernoulli path): a per-lane row through the vector L1
+  // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
+  constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
+  __shared__ double s_ln[PROBIT ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
+  // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
+  // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
+  // SLOWER at cfg4, 184 k / 171 k vs 223 k particle-steps/s: with a quarter of the lanes active the
+  // rare branches of the evaluation are skipped wave-wide, with every lane active they never are.)
+  const Cmd* cmd = &S.cmd[par];
+  if (!(cmd->kind & CMD_PARTITION)) return;
+  if constexpr (PROBIT) {
+    const double* gtn = pgb_ln_tn();
+    const double* gtp = pgb_ln_tp();
+    for (int i = threadIdx.x; i < PGB_LN_TN_ROWS * 9; i += BT) s_ln[i] = gtn[i];
+    for (int i = threadIdx.x; i < PGB_LN_TP_ROWS * 9; i += BT) s_ln[PGB_LN_TN_ROWS * 9 + i] = gtp[i];
+    // (the barrier after the job list below also publishes the tables)
+  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const Ctrl cn = S.ctrl[par ^ 1];  // the state this slot's k_ctrl produced
+  const int round = cn.round - 1;   // round of the proposals of this slot
+  const uint32_t it = (uint32_t)cn.iter;
+  // leaf_sd / root statistics in force for this round (k_ctrl of the NEXT slot resolves them the
+  // same way): a FINAL or INIT part of this slot's row pass may just have produced them
+  double leaf_sd = cn.leaf_sd;
+  long long rootA = 0;
+  {
+    const InitAcc* src = S.initacc + (size_t)par * IA_SLOTS;
+    long long qstd = 0;
+    for (int k = 0; k < IA_SLOTS; ++k) {
+      qstd += src[k].QSTD;
+      rootA += src[k].A;
+    }
+    if (cn.pend_leafsd && cn.pend_iter > 2) leaf_sd = ((double)qstd * S.sc.inv_c1) / (double)S.n;
+  }
+  const Job* jobs = S.jobs + (size_t)par * MAXP;
+  if (tid < 64) {
+    Job j;
+    j.active = 0;
+    if (tid >= 1 && tid < S.P) j = jobs[tid];
+    const bool has = j.active != 0;
+    const unsigned long long m = __ballot(has);
+    // one Philox evaluation per lane: the leaf noise of particle `tid` in this round
+    double z0, z1;
+    {
+      const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)round, (uint32_t)tid, PGB_RNG_LEAF, 0);
+      pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+    }
+    if (has) {
+      const int k = __popcll(m & ((1ull << tid) - 1ull));
+      const Acc a = load_acc(&S.acc[((size_t)par * MAXP + tid) * ACC_PER]);
+      const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
+                                        a.aL, a.aN, z0, z1, leaf_sd);
+      LJob lj;
+      lj.p = tid;
+      lj.rule = j.rule;
+      lj.label = j.label;
+      lj.new_label = j.new_label;
+      lj.check_nan = j.check_nan;
+      lj.ok = cv.ok;
+      lj.v = j.v;
+      lj.vL = cv.vL;
+      lj.vR = cv.vR;
+      lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+      lj.xoff = (long long)((size_t)j.var * S.n_pad);
+      lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
+      lj.svarL = lj.svarR = -1;
+      LinKids lk;
+      lk.svarL = lk.svarR = -1;
+      lk.linL = lk.linR = false;
+      if constexpr (LIN) {
+        if (cv.ok == 1) {
+          lk = lin_children(S, &S.accu[((size_t)par * MAXP + tid) * ACC_PER], j.var, cv.cL, cv.cR,
+                            cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)tid);
+          lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
+          lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
+        }
+      }
+      if constexpr (MK)
+      for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
+        const int KX = (KT > 0 ? KT : S.K) - 1;
+        const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
+        const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
+        ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
+                                   load_accx(S.accx, par, tid, KX + kx), pq, pv,
+                                   it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
+        lj.vLx[kx] = cx.vL;
+        lj.vRx[kx] = cx.vR;
+        if constexpr (LIN) {
+          if (cv.ok == 1)
+            lin_children_x(S, lk, cx, j.var, cv.cL, cv.cR, load_accx(S.accux, par, tid, kx),
+                           load_accx(S.accux, par, tid, KX + kx));
+          lj.sLx[kx] = cx.sL;
+          lj.sRx[kx] = cx.sR;
+        }
+      }
+      if constexpr (MK && LIN)
+        if (cv.ok == 1) {  // a further output may have made the leaf linear
+          lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
+          lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
+        }
+      s_job[k] = lj;
+    }
+    if (tid == 0) s_n[0] = __popcll(m);
+  }
+  __syncthreads();
+  const int nact = s_n[0];
+  if (nact == 0) return;
+  int G = (nact * S.nchunks + S.ll_target - 1) / S.ll_target;
+  if (G < 1) G = 1;
+  const int ngroups = (nact + G - 1) / G;
+  const int nitems = S.nchunks * ngroups;
+  const int K = KT > 0 ? KT : S.K;
+  const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * K * S.n_pad;
+  const double cl = S.sc.cl;
+  // The row pass of this slot has already sorted the rows of every split leaf: left rows kept the
+  // leaf's label, right rows carry the new one, dropped rows the orphan label.  Reading those
+  // bytes back (1 B per row) replaces a second read of the split column (8 B per row).
+  const uint8_t* __restrict__ const newl = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+  const long long n = S.n;
+  unsigned sat = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int chunk = item % S.nchunks, grp = item / S.nchunks;
+    const long long base = (long long)chunk * CH + tid * RPT;
+    double yv[RPT], nv[RPT];
+    uint32_t root_ids = 0;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+      yv[e] = S.y[base + e];
+      nv[e] = noi[base + e];
+      if constexpr (KT == 1)
+        if (S.has_off) nv[e] = nv[e] + S.off[base + e];  // (adding the default 0.0 would give the same bits)
+      if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+    }
+    if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      for (int g = g0; g < g1; ++g) {
+        const LJob& lj = s_job[g];
+        const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
+        const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
+        long long v0 = 0, v1 = 0, v2 = 0;
+        for (int e = 0; e < RPT; ++e) {
+          if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+            const uint32_t nl = (nid >> (8 * e)) & 255u;
+            const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
+            double mu[KB];
+            double v0k = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;
+            int sv = -1;
+            double xv = 0.0, xb = 0.0;
+            if constexpr (LIN) {
+              sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
+              if (sv >= 0) {
+                xv = S.XT[lj.xoff + base + e];
+                xb = side == 0 ? lj.xbarL : lj.xbarR;
+                v0k = pgb_leaf_pred(v0k, side == 0 ? lj.slopeL : lj.slopeR, xb, xv);
+              }
+            }
+            mu[0] = nv[e] + v0k;
+#pragma unroll
+            for (int k = 1; k < KB; ++k)
+              if (k < K) {
+                double vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
+                if constexpr (LIN)
+                  if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
+                mu[k] = noi[(size_t)k * S.n_pad + base + e] + vk;
+              }
+            const long long q = pgb_quant(pgb_loglik(S.family, K, yv[e], mu), cl, &sat);
+            if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
+          }
+        }
+        const int slot = (g - g0) * 3;
+        const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+        if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+      }
+      __syncthreads();
+      for (int t = tid; t < (g1 - g0) * 3; t += BT) {
+        const int gi = t / 3, i = t % 3;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        if (s != 0) {
+          AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
+          atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+    // the label words of the next particle are requested before this one is evaluated
+    uint32_t ids_n = s_job[g0].src < 0 ? root_ids : *(const uint32_t*)(S.lid + s_job[g0].src + base);
+    uint32_t nid_n = *(const uint32_t*)(newl + (size_t)s_job[g0].p * S.n_pad + base);
+    for (int g = g0; g < g1; ++g) {
+      const LJob& lj = s_job[g];
+      const uint32_t ids = ids_n, nid = nid_n;
+      if (g + 1 < g1) {
+        const LJob& ln = s_job[g + 1];
+        ids_n = ln.src < 0 ? root_ids : *(const uint32_t*)(S.lid + ln.src + base);
+        nid_n = *(const uint32_t*)(newl + (size_t)ln.p * S.n_pad + base);
+      }
+      long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) {
+        if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+          // ONE evaluation per row: the side only selects the leaf value and the accumulator
+          // (separate calls per side would run one after the other on a divergent wave)
+          const uint32_t nl = (nid >> (8 * e)) & 255u;
+          const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
+          double vleaf = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;  // dropped: predicts 0
+          if constexpr (LIN) {
+            const int sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
+            if (sv >= 0) {
+              const double xv = S.XT[lj.xoff + base + e];
+              vleaf = pgb_leaf_pred(vleaf, side == 0 ? lj.slopeL : lj.slopeR, side == 0 ? lj.xbarL : lj.xbarR, xv);
+            }
+          }
+          const double mu = nv[e] + vleaf;
+          const long long q = pgb_quant(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2,
+                                                      PROBIT ? s_ln : pgb_ln_tn(),
+                                                      PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl, &sat);
+          v0 += side == 0 ? q : 0;
+          v1 += side == 1 ? q : 0;
+          v2 += side == 2 ? q : 0;
+        }
+      }
+      const int slot = (g - g0) * 3;
+      const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+      if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+    }
+    __syncthreads();
+    for (int t = tid; t < (g1 - g0) * 3; t += BT) {
+      const int gi = t / 3, i = t % 3;
+      const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+      if (s != 0) {
+        AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
+        atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
+      }
+    }
+    __syncthreads();
+  }
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+}
+

@@ -1,0 +1,437 @@
+// k_rows.h -- part of pgbart_hip.hip (not a standalone header): k_rows: the single-output row pass (PARTITION / INIT / FINAL).
+// ------------------------------------------------------------------ k_rows
+// Persistent grid (<= 1024 workgroups): work items are looped over, because on MI355X the
+// dispatch of a workgroup costs ~3-4 ns and a (chunk x particle) grid of thousands of
+// workgroups was dispatch-bound, not bandwidth-bound (profiles/r01_*).
+//
+// PARTITION item = (1024-row chunk, group of G particles with work).  The workgroup loads and
+// quantises {sum_trees, r} of its rows ONCE and then, for each particle of the group, relabels
+// the rows of the leaf being split and reduces the left child's statistics.  Particles without
+// work in this round are not touched at all: their labels stay where they are (NGEN generations).
+// FINAL/INIT item = 256 rows.
+
+// Work items a row pass aims for (measured on cfg2: 640 for plain rounds, 768 for the fused
+// FINAL+INIT+round-0 pass whose INIT part is repeated by every particle group).
+#define ROWS_TARGET_ITEMS 640
+#define ROWS_TARGET_ITEMS_INIT 768
+
+struct RJob {  // the fields of a Job the row pass needs, cached in LDS
+  long long src;   // byte offset of the source labels in S.lid, -1: implicit root labels
+  long long xoff;  // element offset of the split column in S.XT
+  double v;
+  double uscale;  // linear response: 2^-ex of the split column
+  int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
+};
+
+// LIN: linear response (Normal family only): leaves predict value + slope (x[svar] - xbar); the
+// partition additionally reduces the sums pgb_lin_fit needs for both children.
+template <bool SUB, bool NORMAL, bool LIN>
+__global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
+                                                              const Cmd* __restrict__ cmds,
+                                                              const Job* __restrict__ jobs_all) {
+  // cmds / jobs_all repeat S.cmd / S.jobs as kernel arguments: their first loads then do not wait
+  // for the load of the argument block S itself (one dependent memory round trip less)
+  const Dev& S = *Sp;
+  constexpr int NRED = LIN ? 15 : 7;  // values reduced per particle
+  __shared__ long long s_red[MAXP * NRED * 4];
+  __shared__ double s_lv[2][256];
+  __shared__ LinP s_ll[LIN ? 2 : 1][LIN ? 256 : 1];  // label -> linear part: [0 new | 1 next]
+  __shared__ RJob s_job[MAXP];
+  __shared__ int s_n[2];
+  const Cmd* cmd = &cmds[par];
+  const int kind = cmd->kind;
+  TRR(12, 0);
+  // profiling: every workgroup leaves its first and last device-clock reading; the host takes
+  // min(start) .. max(end) per launch -- the interval rocprofv3 reports for the dispatch
+  long long* pstamp = nullptr;
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+    pstamp = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
+    pstamp[0] = wall_clock64();
+    pstamp[1] = pstamp[0];
+  }
+#define PROF_END() do { if (pstamp) pstamp[1] = wall_clock64(); } while (0)
+  if (kind == CMD_NOOP) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
+  const bool do_part = (kind & CMD_PARTITION) != 0;
+  constexpr bool normal = NORMAL;  // compiled per family class: the Normal instance carries no log-likelihood code
+
+  if (do_final || do_init) {
+    for (int i = tid; i < 256; i += BT) {
+      s_lv[0][i] = cmd->lv_new[i];
+      s_lv[1][i] = cmd->lv_next[i];
+      if constexpr (LIN) {
+        s_ll[0][i] = S.lvl[((size_t)par * 2 + 0) * 256 + i];
+        s_ll[1][i] = S.lvl[((size_t)par * 2 + 1) * 256 + i];
+      }
+    }
+  }
+  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
+  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
+  const uint8_t* sel_lid =
+      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
+  const double cntf = (double)cmd->rs_count;
+  // sum_trees buffers: an INIT reads st_in and writes sum_trees_noi to st_out (other workgroups of
+  // the same chunk still read st_in); a lone FINAL updates st_in in place
+  double* const st_in = S.st + (size_t)cmd->st_cur * S.n_pad;
+  double* const st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad;
+
+  if (do_part) {
+    const Job* jobs = jobs_all + (size_t)par * MAXP;
+    // list of particles with work in this pass (split or forced label refresh); their job
+    // fields are cached in LDS once per workgroup
+    if (tid < 64) {
+      Job j;
+      j.active = 0;
+      j.copy = 0;
+      if (tid >= 1 && tid < S.P) j = jobs[tid];  // one round trip: the whole job
+      const bool has = (j.active | j.copy) != 0;
+      const unsigned long long m = __ballot(has);
+      if (has) {
+        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        RJob rj;
+        rj.p = tid;
+        rj.active = j.active;
+        rj.check_nan = j.check_nan;
+        rj.rule = j.rule;
+        rj.label = j.label;
+        rj.new_label = j.new_label;
+        rj.ccL = j.ccL;
+        rj.ccR = j.ccR;
+        rj.v = j.v;
+        rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+        rj.xoff = (long long)((size_t)j.var * S.n_pad);
+        rj.uscale = 1.0;
+        if constexpr (LIN) rj.uscale = j.active ? pgb_pow2(-S.col_ex[j.var]) : 1.0;
+        s_job[k] = rj;
+      }
+      if (tid == 0) s_n[0] = __popcll(m);
+    }
+    __syncthreads();
+    TRR(13, 0);
+    const int nact = s_n[0];
+    if (nact == 0 && !do_init) { PROF_END(); return; }
+    const int target = do_init ? S.rows_target_init : S.rows_target;
+    int G = (nact * S.nchunks + target - 1) / target;
+    if (G < 1) G = 1;
+    int ngroups = (nact + G - 1) / G;
+    if (ngroups < 1) ngroups = 1;  // an INIT must run even if no particle splits
+    const int nitems = S.nchunks * ngroups;
+    uint8_t* __restrict__ const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+    const uint8_t* __restrict__ const lid0 = S.lid;
+    const double* __restrict__ const XT = S.XT;
+    const double c1 = S.sc.c1, c2 = S.sc.c2;
+    const long long n = S.n, n_pad = S.n_pad;
+    long long iv[5] = {0, 0, 0, 0, 0};  // INIT/FINAL statistics: A, B, C, E0, QSTD
+    unsigned sat = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      const int chunk = item % S.nchunks, grp = item / S.nchunks;
+      const long long base = (long long)chunk * CH + tid * RPT;
+      // rows of this thread: {sum_trees, r} quantised once, reused for every particle of the group
+      long long qa[RPT], qb[RPT], qc[RPT];
+      double strow[RPT], rrow[RPT];  // linear response: the unquantised {sum_trees, r} of the rows
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) strow[e] = rrow[e] = 0.0;
+      if (do_init) {
+        // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
+        // residuals (INIT) on the fly; the first group of each chunk also writes them back
+        const bool writer = grp == 0;
+        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_sel = 0;
+        if (do_final) {
+          if (cmd->sel_slot == -2) {
+            ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
+          } else {
+            if (sel_lid) {
+              ids_sel = *(const uint32_t*)(sel_lid + base);
+            } else {  // untouched root: label 0 (pad rows: orphan)
+#pragma unroll
+              for (int e = 0; e < RPT; ++e)
+                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+            }
+            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+          }
+          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+        }
+        // every input of the thread's four rows is requested BEFORE the first result is stored:
+        // the stores below may alias the loads as far as the compiler knows, so loads left inside
+        // the loop would be issued one row (one memory round trip) at a time
+        double st4[RPT], y4[RPT], mean4[RPT], m24[RPT];
+        {
+          const double2* __restrict__ sp = (const double2*)(st_in + base);
+          const double2* __restrict__ yp = (const double2*)(S.y + base);
+          const double2 s01 = sp[0], s23 = sp[1], y01 = yp[0], y23 = yp[1];
+          st4[0] = s01.x; st4[1] = s01.y; st4[2] = s23.x; st4[3] = s23.y;
+          y4[0] = y01.x; y4[1] = y01.y; y4[2] = y23.x; y4[3] = y23.y;
+          const bool upd = do_final && cmd->tune && writer;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
+            m24[e] = upd ? S.rs_m2[base + e] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          const long long row = base + e;
+          qa[e] = qb[e] = qc[e] = 0;
+          if (row >= n) continue;
+          double st = st4[e];  // sum_trees at a step boundary, sum_trees_noi inside an update
+          if (do_final) {
+            // [U] sum_trees = sum_trees_noi + new_tree.predict()
+            double nv = s_lv[0][(ids_sel >> (8 * e)) & 255u];
+            if constexpr (LIN) {
+              const LinP lp = s_ll[0][(ids_sel >> (8 * e)) & 255u];
+              if (lp.svar >= 0) nv = pgb_leaf_pred(nv, lp.slope, lp.xbar, XT[(size_t)lp.svar * n_pad + row]);
+            }
+            st = st + nv;
+            if (cmd->tune && writer) {  // [U] RunningSd.update (Welford)
+              const double mean0 = mean4[e], m20 = m24[e];
+              const double delta = nv - mean0;
+              const double mean = mean0 + delta / cntf;
+              const double delta2 = nv - mean;
+              const double m2 = m20 + delta * delta2;
+              S.rs_mean[row] = mean;
+              S.rs_m2[row] = m2;
+              iv[4] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+            }
+          }
+          // [U] sum_trees_noi = sum_trees - old_tree.predict()
+          double o = s_lv[1][(ids_next >> (8 * e)) & 255u];
+          if constexpr (LIN) {
+            const LinP lp = s_ll[1][(ids_next >> (8 * e)) & 255u];
+            if (lp.svar >= 0) o = pgb_leaf_pred(o, lp.slope, lp.xbar, XT[(size_t)lp.svar * n_pad + row]);
+          }
+          const double noi = st - o;
+          const double yv = y4[e];
+          const double r = normal ? yv - noi : 0.0;  // Bernoulli families: no residual algebra
+          unsigned sat1 = 0;
+          qa[e] = pgb_quant(st, c1, &sat1);
+          qb[e] = pgb_quant(r, c1, &sat1);
+          qc[e] = pgb_quant(r * r, c2, &sat1);
+          strow[e] = st;
+          rrow[e] = r;
+          if (writer) {  // saturation is counted where the values are produced, once
+            S.pack[row] = make_double2(st, r);
+            st_out[row] = noi;
+            sat += sat1;
+            iv[0] += qa[e];
+            iv[1] += qb[e];
+            if (normal) {
+              iv[2] += qc[e];
+              const double er = r - o;
+              iv[3] += pgb_quant(er * er, c2, &sat);
+            } else {
+              // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
+              const double lp = S.ctrl[par ^ 1].inv_sigma2, lp2 = S.ctrl[par ^ 1].lik_param2;  // family parameters
+              const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
+              iv[2] += pgb_quant(pgb_loglik1q(S.family, yv, (noi + offv) + S.init_leaf, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+              iv[3] += pgb_quant(pgb_loglik1q(S.family, yv, st + offv, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          const double2 sr = S.pack[base + e];
+          strow[e] = sr.x;
+          rrow[e] = sr.y;
+          qa[e] = pgb_quant(sr.x, c1, nullptr);
+          qb[e] = pgb_quant(sr.y, c1, nullptr);
+          qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
+        }
+      }
+      TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
+      uint32_t root_ids = 0;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+        if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      // software pipeline over the particles of the group: the labels and split-column values of
+      // particle g + 1 are requested before particle g is relabelled and reduced
+      uint32_t nx_ids = root_ids;
+      double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
+      if (g0 < g1) {
+        const RJob& rn = s_job[g0];
+        if (rn.src >= 0) nx_ids = *(const uint32_t*)(lid0 + rn.src + base);
+        if (rn.active) {
+          const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+          nx0 = xn[0];
+          nx1 = xn[1];
+        }
+      }
+      for (int g = g0; g < g1; ++g) {
+        const RJob& rj = s_job[g];
+        const uint32_t ids = nx_ids;
+        const double2 t0 = nx0, t1 = nx1;
+        if (g + 1 < g1) {
+          const RJob& rn = s_job[g + 1];
+          nx_ids = rn.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rn.src + base);
+          if (rn.active) {
+            const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+            nx0 = xn[0];
+            nx1 = xn[1];
+          }
+        }
+        uint32_t out = ids;
+        uint8_t* __restrict__ const dp = dst0 + (size_t)rj.p * n_pad + base;
+        if (!rj.active) {  // forced refresh only
+          *(uint32_t*)dp = out;
+          continue;
+        }
+        const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        const int slot = (g - g0) * NRED;
+        if (!rj.check_nan) {  // common case: the split column has no missing values
+          long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+              if (go_left_t<SUB>(rj.rule, x[e], rj.v)) {
+                v0 += 1;
+                v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
+              } else {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+                v0 += 1ll << 20;
+              }
+            }
+          }
+          *(uint32_t*)dp = out;
+          const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
+          if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
+        } else {
+          long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+              const double xv = x[e];
+              if (xv != xv) {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+                v[0] += 1ll << 40;
+                v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
+              } else if (go_left_t<SUB>(rj.rule, xv, rj.v)) {
+                v[0] += 1;
+                v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
+              } else {
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+                v[0] += 1ll << 20;
+              }
+            }
+          }
+          *(uint32_t*)dp = out;
+          const long long ta = wave_sum4(v[0], v[1], v[2], v[3]);
+          const long long tb = wave_sum4(v[4], v[5], v[6], 0);
+          if (lane < 4) s_red[(slot + lane) * 4 + w] = ta;
+          else if (lane < 7) s_red[(slot + lane) * 4 + w] = tb;  // lane 4..6: value (lane & 3) of the second set
+        }
+        if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit)
+          long long ul[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            const double xv = x[e];
+            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label && xv == xv) {
+              const double uu = xv * rj.uscale;
+              const long long q0 = pgb_quant(uu * S.lin_R, c1, nullptr);
+              const long long q1 = pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
+              const long long q2 = pgb_quant(uu * strow[e], c1, nullptr);
+              const long long q3 = pgb_quant(uu * rrow[e], c1, nullptr);
+              const bool gl = go_left_t<SUB>(rj.rule, xv, rj.v);
+              ul[0] += gl ? q0 : 0; ul[1] += gl ? q1 : 0; ul[2] += gl ? q2 : 0; ul[3] += gl ? q3 : 0;
+              ur[0] += gl ? 0 : q0; ur[1] += gl ? 0 : q1; ur[2] += gl ? 0 : q2; ur[3] += gl ? 0 : q3;
+            }
+          }
+          const long long tl = wave_sum4(ul[0], ul[1], ul[2], ul[3]);
+          const long long tr = wave_sum4(ur[0], ur[1], ur[2], ur[3]);
+          if (lane < 4) {
+            s_red[(slot + 7 + lane) * 4 + w] = tl;
+            s_red[(slot + 11 + lane) * 4 + w] = tr;
+          }
+        }
+      }
+      __syncthreads();
+      // one thread per (particle of the group, statistic): combine the 4 waves, publish
+      for (int t = tid; t < (g1 - g0) * NRED; t += BT) {
+        const int gi = t / NRED, i = t % NRED;
+        const RJob& rj = s_job[g0 + gi];
+        if (!rj.active || (i >= 4 && i < 7 && !rj.check_nan)) continue;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        if constexpr (LIN) {
+          if (i >= 7) {
+            AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+            if (s != 0) atomicAdd((unsigned long long*)(i < 11 ? &au->uL[i - 7] : &au->uR[i - 11]), (unsigned long long)s);
+            continue;
+          }
+        }
+        Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+        if (i == 0) {
+          const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
+          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+          if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+        } else if (s != 0) {
+          long long* dst = i == 1 ? &a->aL : i == 2 ? &a->bL : i == 3 ? &a->c2L : i == 4 ? &a->aN : i == 5 ? &a->bN : &a->c2N;
+          atomicAdd((unsigned long long*)dst, (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+    }
+    TRR(15, 0);  // item loop done
+    if (do_init) {  // statistics of the INIT (+FINAL) part, accumulated by the writer groups only
+      block_sum<5>(iv, s_red);
+      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (iv[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)iv[0]);
+        if (iv[1]) atomicAdd((unsigned long long*)&a->B, (unsigned long long)iv[1]);
+        if (iv[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)iv[2]);
+        if (iv[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)iv[3]);
+        if (iv[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)iv[4]);
+      }
+    }
+    PROF_END();
+    return;
+  }
+
+  // ---------------- lone FINAL (last tree of the last requested step): 256 rows per item
+  __syncthreads();
+  long long v[5] = {0, 0, 0, 0, 0};
+  unsigned sat = 0;
+  const int nitems = (int)(S.n_pad / BT);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long long row = (long long)item * BT + tid;
+    if (row >= S.n) continue;
+    double st = st_in[row];
+    uint32_t id_sel;
+    if (cmd->sel_slot == -2) {
+      id_sel = tl_old[row];  // old tree kept
+    } else {
+      id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;  // untouched root: label 0
+      tl_old[row] = (uint8_t)id_sel;
+    }
+    // [U] sum_trees = sum_trees_noi + new_tree.predict()
+    double nv = s_lv[0][id_sel];
+    if constexpr (LIN) {
+      const LinP lp = s_ll[0][id_sel];
+      if (lp.svar >= 0) nv = pgb_leaf_pred(nv, lp.slope, lp.xbar, S.XT[(size_t)lp.svar * S.n_pad + row]);
+    }
+    st = st + nv;
+    if (cmd->tune) {  // [U] RunningSd.update (Welford)
+      const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+      const double delta = nv - mean0;
+      const double mean = mean0 + delta / cntf;
+      const double delta2 = nv - mean;
+      const double m2 = m20 + delta * delta2;
+      S.rs_mean[row] = mean;
+      S.rs_m2[row] = m2;
+      v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
+    }
+    st_out[row] = st;
+  }
+  block_sum<5>(v, s_red);
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+  if (tid == 0 && cmd->tune && v[4]) {
+    InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+    atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v[4]);
+  }
+  PROF_END();
+#undef PROF_END
+}
+

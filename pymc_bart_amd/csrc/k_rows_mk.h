@@ -1,0 +1,373 @@
+// k_rows_mk.h -- part of pgbart_hip.hip (not a standalone header): k_rows_mk: the row pass for K-vector leaves.
+// ------------------------------------------------------------------ k_rows_mk
+// K-vector leaves (K > 1, Categorical-softmax): the same slot logic as k_rows with sum_trees, leaf
+// values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
+// the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
+__device__ __forceinline__ double loglik_any(const Dev& S, double y, const double* mu) {
+  return pgb_loglik(S.family, S.K, y, mu);
+}
+
+// KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay
+// in registers), 0: any K <= PGB_MAX_OUTPUTS.
+// LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory
+// (lvl for output 0 and the shared parts, lsx for the slopes of outputs 1..K-1)
+template <int KT, bool LIN>
+__global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+  const Dev& S = *Sp;
+  const int K = KT > 0 ? KT : S.K, KX = K - 1;
+  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops
+  __shared__ long long s_red[MAXP * (1 + 2 * KB) * 4];
+  __shared__ double s_lv[2][256][KB];
+  __shared__ RJob s_job[MAXP];
+  __shared__ int s_n[2];
+  const Cmd* cmd = &S.cmd[par];
+  const int kind = cmd->kind;
+  if (kind == CMD_NOOP) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
+  const bool do_part = (kind & CMD_PARTITION) != 0;
+  const int NV = 1 + 2 * K;  // per particle: counts, aL[K], aN[K]
+
+  if (do_final || do_init) {
+    const double* lx = S.lvx + (size_t)par * 2 * 256 * KX;
+    for (int i = tid; i < 256; i += BT) {
+      s_lv[0][i][0] = cmd->lv_new[i];
+      s_lv[1][i][0] = cmd->lv_next[i];
+      for (int k = 0; k < KX; ++k) {
+        s_lv[0][i][k + 1] = lx[(size_t)i * KX + k];
+        s_lv[1][i][k + 1] = lx[(size_t)256 * KX + (size_t)i * KX + k];
+      }
+    }
+  }
+  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
+  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
+  const uint8_t* sel_lid =
+      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
+  const double cntf = (double)cmd->rs_count;
+  // sum_trees buffers [2][K][n_pad]
+  const double* st_in = S.st + (size_t)cmd->st_cur * K * S.n_pad;
+  double* st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * K * S.n_pad;
+  const double c1 = S.sc.c1;
+  const long long n = S.n, n_pad = S.n_pad;
+  // linear part of the prediction of output k for a row with label `id`: table t = 0 new | 1 next
+  auto lin_pred = [&](double v, int t, uint32_t id, int k, long long row) -> double {
+    if constexpr (LIN) {
+      const LinP lp = S.lvl[((size_t)par * 2 + t) * 256 + id];
+      if (lp.svar >= 0) {
+        const double sl = k == 0 ? lp.slope : S.lsx[(((size_t)par * 2 + t) * 256 + id) * KX + (k - 1)];
+        v = pgb_leaf_pred(v, sl, lp.xbar, S.XT[(size_t)lp.svar * n_pad + row]);
+      }
+    }
+    return v;
+  };
+
+  if (do_part) {
+    const Job* jobs = S.jobs + (size_t)par * MAXP;
+    if (tid < 64) {
+      Job j;
+      j.active = 0;
+      j.copy = 0;
+      if (tid >= 1 && tid < S.P) j = jobs[tid];
+      const bool has = (j.active | j.copy) != 0;
+      const unsigned long long m = __ballot(has);
+      if (has) {
+        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        RJob rj;
+        rj.p = tid;
+        rj.active = j.active;
+        rj.check_nan = j.check_nan;
+        rj.rule = j.rule;
+        rj.label = j.label;
+        rj.new_label = j.new_label;
+        rj.ccL = j.ccL;
+        rj.ccR = j.ccR;
+        rj.v = j.v;
+        rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+        rj.xoff = (long long)((size_t)j.var * S.n_pad);
+        s_job[k] = rj;
+      }
+      if (tid == 0) s_n[0] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = s_n[0];
+    if (nact == 0 && !do_init) return;
+    const int target = do_init ? S.rows_target_init : S.rows_target;
+    int G = (nact * S.nchunks + target - 1) / target;
+    if (G < 1) G = 1;
+    int ngroups = (nact + G - 1) / G;
+    if (ngroups < 1) ngroups = 1;
+    const int nitems = S.nchunks * ngroups;
+    uint8_t* const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+    long long iv[2 + 2 * PGB_MAX_OUTPUTS];  // C, E0, A[K], QSTD[K]
+    for (int i = 0; i < 2 + 2 * K; ++i) iv[i] = 0;
+    unsigned sat = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      const int chunk = item % S.nchunks, grp = item / S.nchunks;
+      const long long base = (long long)chunk * CH + tid * RPT;
+      double stv[RPT][KB];  // sum_trees of this thread's rows, per output
+      if (do_init) {
+        const bool writer = grp == 0;
+        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_sel = 0;
+        if (do_final) {
+          if (cmd->sel_slot == -2) {
+            ids_sel = *(const uint32_t*)(tl_old + base);
+          } else {
+            if (sel_lid) {
+              ids_sel = *(const uint32_t*)(sel_lid + base);
+            } else {
+              for (int e = 0; e < RPT; ++e)
+                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+            }
+            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+          }
+          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+        }
+        for (int e = 0; e < RPT; ++e) {
+          const long long row = base + e;
+          for (int k = 0; k < K; ++k) stv[e][k] = 0.0;
+          if (row >= n) continue;
+          double mu_stump[KB], mu_cur[KB];
+          for (int k = 0; k < K; ++k) {
+            double st = st_in[(size_t)k * n_pad + row];
+            if (do_final) {
+              const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][k], 0, (ids_sel >> (8 * e)) & 255u, k, row);
+              st = st + nv;
+              if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
+                const size_t ri = (size_t)k * n_pad + row;
+                const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+                const double delta = nv - mean0;
+                const double mean = mean0 + delta / cntf;
+                const double delta2 = nv - mean;
+                const double m2 = m20 + delta * delta2;
+                S.rs_mean[ri] = mean;
+                S.rs_m2[ri] = m2;
+                iv[2 + K + k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+              }
+            }
+            const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][k], 1, (ids_next >> (8 * e)) & 255u, k, row);
+            const double noi = st - o;
+            stv[e][k] = st;
+            mu_stump[k] = noi + S.init_leaf;
+            mu_cur[k] = st;
+            if (writer) {
+              if (k == 0) S.pack[row] = make_double2(st, 0.0);
+              else S.packx[(size_t)(k - 1) * n_pad + row] = st;
+              st_out[(size_t)k * n_pad + row] = noi;
+              iv[2 + k] += pgb_quant(st, c1, &sat);
+            }
+          }
+          if (writer) {
+            const double yv = S.y[row];
+            iv[0] += pgb_quant(pgb_loglik(S.family, K, yv, mu_stump), S.sc.cl, &sat);  // C: fresh stump
+            iv[1] += pgb_quant(pgb_loglik(S.family, K, yv, mu_cur), S.sc.cl, &sat);    // E0: current tree
+          }
+        }
+      } else {
+        for (int e = 0; e < RPT; ++e) {
+          stv[e][0] = S.pack[base + e].x;
+          for (int k = 1; k < K; ++k) stv[e][k] = S.packx[(size_t)(k - 1) * n_pad + base + e];
+        }
+      }
+      uint32_t root_ids = 0;
+      for (int e = 0; e < RPT; ++e)
+        if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+      long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
+#pragma unroll
+      for (int e = 0; e < RPT; ++e)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) qst[e][k] = k < K ? pgb_quant(stv[e][k], c1, nullptr) : 0;
+      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      for (int g = g0; g < g1; ++g) {
+        const RJob& rj = s_job[g];
+        const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + rj.src + base);
+        uint32_t out = ids;
+        uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
+        if (!rj.active) {
+          *(uint32_t*)dp = out;
+          continue;
+        }
+        const double2* xp = (const double2*)(S.XT + rj.xoff + base);
+        const double2 t0 = xp[0], t1 = xp[1];
+        const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
+        long long cnts = 0;
+        for (int e = 0; e < RPT; ++e) {
+          side[e] = 0;
+          if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+            const double xv = x[e];
+            if (xv != xv) {
+              side[e] = 3;
+              out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+              cnts += 1ll << 40;
+            } else if (go_left(rj.rule, xv, rj.v)) {
+              side[e] = 1;
+              cnts += 1;
+            } else {
+              side[e] = 2;
+              out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+              cnts += 1ll << 20;
+            }
+          }
+        }
+        *(uint32_t*)dp = out;
+        const int slot = (g - g0) * NV;
+        // values of this particle: [0] counts, [1 + k] aL[k], [1 + K + k] aN[k]; reduced four at a
+        // time (wave_sum4); a column without missing values has no aN part
+        long long vals[1 + 2 * KB + 3];
+#pragma unroll
+        for (int i = 0; i < 1 + 2 * KB + 3; ++i) vals[i] = 0;
+        vals[0] = cnts;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          if (k < K) {
+            long long aL = 0, aN = 0;
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              const long long q = qst[e][k];
+              aL += side[e] == 1 ? q : 0;
+              aN += side[e] == 3 ? q : 0;
+            }
+            vals[1 + k] = aL;
+            vals[1 + K + k] = aN;
+          }
+        }
+        if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit): u, u^2 and
+          // u st_k per output; one wave total each, added by lane 63 (a rare path: no LDS staging)
+          const double uscale = pgb_pow2(-S.col_ex[rj.xoff / n_pad]);
+          long long su[2][2 + KB];
+#pragma unroll
+          for (int i = 0; i < 2 + KB; ++i) su[0][i] = su[1][i] = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (side[e] == 1 || side[e] == 2) {
+              const int sd = side[e] - 1;
+              const double uu = x[e] * uscale;
+              su[sd][0] += pgb_quant(uu * S.lin_R, c1, nullptr);
+              su[sd][1] += pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
+#pragma unroll
+              for (int k = 0; k < KB; ++k)
+                if (k < K) su[sd][2 + k] += pgb_quant(uu * stv[e][k], c1, nullptr);
+            }
+          }
+          AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+          long long* aux = S.accux + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
+#pragma unroll
+          for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int i = 0; i < 2 + KB; ++i) {
+              if (i >= 2 + K) continue;
+              const long long tot = wave_sum_dpp(su[sd][i]);
+              if (lane == 63 && tot != 0) {
+                long long* dst = i < 3 ? (sd ? &au->uR[i] : &au->uL[i]) : &aux[(sd ? KX : 0) + (i - 3)];
+                atomicAdd((unsigned long long*)dst, (unsigned long long)tot);
+              }
+            }
+        }
+        const int nv = rj.check_nan ? NV : 1 + K;
+#pragma unroll
+        for (int c4 = 0; c4 < (1 + 2 * KB + 3) / 4; ++c4) {
+          if (c4 * 4 < nv) {
+            const long long tot = wave_sum4(vals[c4 * 4], vals[c4 * 4 + 1], vals[c4 * 4 + 2], vals[c4 * 4 + 3]);
+            if (lane < 4 && c4 * 4 + lane < nv) s_red[(slot + c4 * 4 + lane) * 4 + w] = tot;
+          }
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < (g1 - g0) * NV; t += BT) {
+        const int gi = t / NV, i = t % NV;
+        const RJob& rj = s_job[g0 + gi];
+        if (!rj.active || (i > K && !rj.check_nan)) continue;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+        long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
+        if (i == 0) {
+          const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
+          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+          if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+        } else if (s != 0) {
+          const int k = (i - 1) % K;
+          const bool isN = (i - 1) >= K;
+          long long* dst = k == 0 ? (isN ? &a->aN : &a->aL) : &ax[(isN ? KX : 0) + k - 1];
+          atomicAdd((unsigned long long*)dst, (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+    }
+    if (do_init) {
+      // C, E0, A[0] (+QSTD[0]) -> InitAcc; A[k>0], QSTD[k>0] -> iax
+      long long v5[5] = {iv[2], 0, iv[0], iv[1], iv[2 + K]};
+      block_sum<5>(v5, s_red);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (v5[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v5[0]);
+        if (v5[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)v5[2]);
+        if (v5[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v5[3]);
+        if (v5[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v5[4]);
+      }
+      for (int k = 1; k < K; ++k) {
+        long long v2[2] = {iv[2 + k], iv[2 + K + k]};
+        block_sum<2>(v2, s_red);
+        if (tid == 0) {
+          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+          if (v2[0]) atomicAdd((unsigned long long*)&ix[k - 1], (unsigned long long)v2[0]);
+          if (v2[1]) atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v2[1]);
+        }
+      }
+      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+    }
+    return;
+  }
+
+  // ---------------- lone FINAL
+  __syncthreads();
+  long long qs[PGB_MAX_OUTPUTS];
+  for (int k = 0; k < K; ++k) qs[k] = 0;
+  unsigned sat = 0;
+  const int nitems = (int)(S.n_pad / BT);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long long row = (long long)item * BT + tid;
+    if (row >= S.n) continue;
+    uint32_t id_sel;
+    if (cmd->sel_slot == -2) {
+      id_sel = tl_old[row];
+    } else {
+      id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;
+      tl_old[row] = (uint8_t)id_sel;
+    }
+    for (int k = 0; k < K; ++k) {
+      const size_t ri = (size_t)k * n_pad + row;
+      const double nv = lin_pred(s_lv[0][id_sel][k], 0, id_sel, k, row);
+      const double st = st_in[ri] + nv;
+      if (cmd->tune) {
+        const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+        const double delta = nv - mean0;
+        const double mean = mean0 + delta / cntf;
+        const double delta2 = nv - mean;
+        const double m2 = m20 + delta * delta2;
+        S.rs_mean[ri] = mean;
+        S.rs_m2[ri] = m2;
+        qs[k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+      }
+      st_out[ri] = st;
+    }
+  }
+  if (cmd->tune) {
+    for (int k = 0; k < K; ++k) {
+      long long v1[1] = {qs[k]};
+      block_sum<1>(v1, s_red);
+      if (tid == 0 && v1[0]) {
+        if (k == 0) {
+          InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+          atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v1[0]);
+        } else {
+          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+          atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v1[0]);
+        }
+      }
+    }
+  }
+  if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+}
+

@@ -1,0 +1,228 @@
+// pgb_dev_types.h -- part of pgbart_hip.hip (not a standalone header): device-side records of the slot state machine (nodes, jobs, statistics, the Dev argument block).
+// ------------------------------------------------------------------ device structs
+struct DNode {  // 64 bytes
+  double split, value, sse;
+  long long q_st, q_r, q_r2;
+  int32_t cnt;
+  int32_t var;     // -1 leaf
+  int32_t cc_row;  // chunk-count row of this node (-1: root => all rows)
+  uint8_t left, right, depth, label;
+};
+
+struct DTree {  // an accepted tree
+  int32_t n_nodes, n_leaves;
+  int32_t pad[2];
+  DNode nd[MAXN];
+};
+
+struct DPart {  // a particle
+  int32_t n_nodes, n_leaves, next_pop;
+  int32_t loc_gen, loc_slot;  // where its leaf labels live (slot -1: implicit root labels)
+  int32_t pad;
+  double sse_tot, sse_orph;
+  DNode nd[MAXN];
+};
+
+struct Job {  // one particle's work for a PARTITION row pass + what the next k_ctrl needs (128 B)
+  int32_t active;
+  int32_t copy;  // no split, but the labels must be copied forward (their generation is next to be reused)
+  int32_t src_gen, src_slot;
+  int32_t node, label, new_label;
+  int32_t var, rule, check_nan;
+  int32_t ccL, ccR;
+  int32_t cnt;
+  double v;
+  // statistics of the node being split (the parent of the children the pass creates)
+  long long p_q_st, p_q_r, p_q_r2;
+  double p_sse, p_value;
+  // particle header after this round's pop (so that the next k_ctrl needs one load per particle)
+  double h_sse_tot, h_sse_orph;
+  int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
+  int32_t pad_;
+};
+// (No unions / arrays in records that are copied by value in kernels: they defeat scalar
+//  replacement and the copies get demoted to LDS or scratch.)
+
+struct JobL {  // non-Normal families: fixed-point log-likelihoods that travel with a Job
+  long long p_ll, h_ll_tot, h_ll_orph, pad;
+};
+struct AccL {  // non-Normal families (k_loglik): log-likelihood of the left / right children and of
+  long long llL, llR, llN, pad;  // the rows dropped by a missing split value
+};
+
+struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right = parent - both)
+  unsigned long long cnts;  // cntL | cntN << 32
+  long long aL, bL, c2L, aN, bN, c2N;
+  long long pad;
+};
+
+#define IA_SLOTS 8 /* the row pass spreads its atomics over this many cache lines */
+// Per-particle split statistics: every work item of a particle adds to the particle's record, and
+// atomics on ONE cache line serialise (~12 ns each: 98 chunks x 4 values = 4.7 us at cfg2).  The
+// record is therefore kept ACC_SLOTS times (item -> slot by chunk); readers sum the copies.
+#ifndef ACC_SLOTS
+#define ACC_SLOTS 4 /* measured at cfg2: 1 -> 1.52 M, 4 -> 1.62 M, 8 -> 1.58 M, 16 -> 1.51 M particle-steps/s */
+#endif
+#ifndef ACC_STRIDE
+#define ACC_STRIDE 2 /* distance between copies, in records of 64 B: one 128-B line each */
+#endif
+#define ACC_PER (ACC_SLOTS * ACC_STRIDE)
+#define PROF_RING 4096   /* row-pass launches a profiled region may span */
+#define PROF_BLOCKS 1024 /* = the largest row grid */
+// the same for the log-likelihood sums of k_loglik (32-byte records): 8 copies, 128 B apart
+#define LL_SLOTS 8
+#define LL_STRIDE 4
+#define LL_PER (LL_SLOTS * LL_STRIDE)
+// ... and for the extension-output sums of the multi-output row pass: 4 copies of 16 longs (128 B)
+#define AX_SLOTS 4
+#define AX_REC 16
+#define AX_PER (AX_SLOTS * AX_REC)
+struct InitAcc {   // one 64-byte line
+  long long A, B, C, E0, QSTD;
+  long long pad0, pad1, pad2;
+};
+
+enum { CMD_NOOP = 0, CMD_PARTITION = 1, CMD_INIT = 2, CMD_FINAL = 4 /* FINAL|INIT = 6 */ };
+enum { PH_IDLE = 0, PH_BEGIN = 1, PH_ROUND = 2 };
+
+// linear response: what a leaf adds to its constant value: slope * (x[svar] - xbar); svar < 0: nothing
+struct LinP {
+  double slope, xbar;
+  long long svar;
+};
+// linear response: sums of u = x 2^-ex over the left / right child of a split (see pgb_lin_fit):
+// q_u, q_uu, q_us, q_ur each
+struct AccU {
+  long long uL[4], uR[4];
+};
+
+struct Cmd {
+  int32_t kind;
+  int32_t tree_old, tree_new;
+  int32_t sel_gen, sel_slot;  // sel_slot == -2: the old tree was kept
+  int32_t tune, dst_gen, st_cur;
+  long long rs_count;
+  double lv_new[256], lv_next[256];
+};
+
+struct Ctrl {
+  int32_t phase, k, batch_n, lower;
+  int32_t tune, round, lid_gen, steps_left;
+  int32_t pend_leafsd, st_cur;  // st_cur: which sum_trees buffer is current
+  int32_t alpha_cur, cdf_cur;   // current buffers of the split weights / their prefix sums
+  long long iter, rs_count, pend_iter;
+  double leaf_sd, inv_sigma2;  // (leaf_sd of outputs 1..K-1: Dev::lsdx -- no arrays in this record,
+                               //  the compiler would demote a by-value copy with an indexed array to LDS)
+  double lik_param2;  // second scalar parameter of the two-parameter likelihood families
+  double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
+  long long steps_done;  // asteps completed since creation (mirrored to the host flag)
+  long long slot_no;     // k_ctrl launches so far
+};
+
+struct Dev {  // kernel argument block (by value)
+  long long n, n_pad;
+  int32_t p, m, P, nchunks;
+  int32_t batch_tune, batch_draw;
+  int32_t family, K;  // K = n_outputs; KX = K - 1 extension outputs live in the *x arrays below
+  int32_t rows_target, rows_target_init;  // work items the row passes aim for (tuning knobs)
+  int32_t ll_target, ll_pad;              // ... and the log-likelihood pass
+  unsigned long long seed;
+  double init_leaf, mdouble;
+  pgb_scales sc;
+  const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
+  const double* XT;  // [p][n_pad]
+  const double* y;   // [n_pad]
+  const double* off; // [n_pad] offset of the linear predictor (single-output per-row families; 0 by default)
+  double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
+  double2* pack;     // [n_pad] {sum_trees, y - noi}
+  double* rs_mean;
+  double* rs_m2;
+  uint8_t* tree_lid;  // [m][n_pad]
+  uint8_t* lid;       // [NGEN][MAXP][n_pad]
+  uint16_t* cc;       // [CC_ROUNDS*MAXP*2][nchunks]
+  DTree* trees;       // [m]
+  DPart* parts;       // [2][P]
+  Job* jobs;          // [2][P]
+  Acc* acc;           // [2][P][ACC_SLOTS]
+  AccL* accl;         // [2][P][LL_SLOTS]   (non-Normal families)
+  JobL* jobl;         // [2][P]   (non-Normal families)
+  InitAcc* initacc;   // [2][IA_SLOTS]
+  Cmd* cmd;           // [2]
+  Ctrl* ctrl;         // [2]
+  unsigned long long* counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
+  int32_t* vi;        // [p]
+  long long* alpha;   // [2][p] integer split weights (pgb_alpha_init + counts * alpha_unit)
+  long long* cdfS;    // [2][p] their prefix sums, as used by the sampler
+  long long alpha_unit;
+  double max_prior;
+  const int32_t* rules;
+  const int32_t* col_nan;
+  // ---- K-vector leaves (K > 1): output 0 uses the scalar fields, outputs 1..K-1 these arrays
+  double* packx;      // [KX][n_pad]            sum_trees of outputs 1.. (as of INIT, like pack.x)
+  double* pvx;        // [2][MAXP][MAXN][KX]    particle leaf values
+  long long* pqx;     // [2][MAXP][MAXN][KX]    particle node sums of sum_trees
+  double* tvx;        // [m][MAXN][KX]          accepted trees' leaf values
+  long long* accx;    // [2][MAXP][AX_SLOTS][AX_REC]  row-pass statistics: aL[k], aN[k] (copies, see AX_SLOTS)
+  long long* iax;     // [2][IA_SLOTS][2*KX]    INIT/FINAL statistics: A[k], QSTD[k]
+  double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
+  long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
+  double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
+  double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
+  // ---- linear response (Normal family, K = 1, continuous columns)
+  int32_t response, has_off;  // has_off: an offset of the linear predictor is set (else the array is all 0)
+  double lin_R, inv_R;
+  const int32_t* col_ex;  // [p] exponent bound of every column
+  LinP* plin;             // [2][MAXP][MAXN]  particle leaves
+  LinP* tlin;             // [m][MAXN]        accepted trees' leaves
+  LinP* lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
+  AccU* accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
+  // ... K-vector leaves: one slope per output on the shared regressor; output 0 lives in LinP,
+  // outputs 1..K-1 in arrays laid out like pvx / tvx / lvx / accx
+  double* psx;            // [2][MAXP][MAXN][KX]  particle leaf slopes
+  double* tsx;            // [m][MAXN][KX]        accepted trees' leaf slopes
+  double* lsx;            // [2][2][256][KX]      label -> slope tables: [par][0 new | 1 next]
+  long long* accux;       // [2][MAXP][AX_SLOTS][AX_REC]  row-pass sums of u st_k: left [k], right [KX + k]
+  // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
+  long long* prof_stamps;
+  unsigned long long* host_flag;  // pinned host word: number of completed asteps
+  long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
+};
+
+#ifdef PGB_TRACE
+#define TRACE_SLOTS 4096
+#define TR(i)                                                                              \
+  do {                                                                                     \
+    if (blockIdx.x == 1 && threadIdx.x == 0)                                               \
+      S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64();         \
+  } while (0)
+#define TRX(i, cond)                                                                       \
+  do {                                                                                     \
+    if (cond) S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+// stamps of the row pass (entries 12..15 of the slot's record), taken by one chosen workgroup
+#define TRR(i, blk)                                                                                  \
+  do {                                                                                               \
+    if (blockIdx.x == (blk) && threadIdx.x == 0)                                                     \
+      S.trace[(size_t)((S.ctrl[par ^ 1].slot_no - 1) % TRACE_SLOTS) * 16 + (i)] = wall_clock64();    \
+  } while (0)
+#else
+#define TR(i) ((void)0)
+#define TRX(i, cond) ((void)0)
+#define TRR(i, blk) ((void)0)
+#endif
+
+// A read of a wave-uniform, kernel-invariant record (written by an EARLIER launch) through the
+// constant address space: the compiler can then use scalar (SMEM) loads and keep the record in
+// SGPRs instead of issuing per-lane flat loads.
+#define PGB_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T out;
+  __builtin_memcpy(&out, (const PGB_CONST_AS void*)(unsigned long long)p, sizeof(T));
+  return out;
+#else
+  return *p;
+#endif
+}
+

@@ -1,0 +1,828 @@
+// pgb_host.h -- part of pgbart_hip.hip (not a standalone header): host side: handles, the C ABI of include/pgbart.h, slot enqueueing.
+// ------------------------------------------------------------------ host side
+static thread_local char g_err[512];
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return PGB_E_DEVICE;
+}
+#define HIPCHK(expr)                                     \
+  do {                                                   \
+    hipError_t e_ = (expr);                              \
+    if (e_ != hipSuccess) return fail_hip(e_, #expr);    \
+  } while (0)
+
+struct pgb_handle {
+  pgb_settings s;
+  Dev d;
+  Dev* d_dev;                          // device-resident copy passed to every kernel
+  volatile unsigned long long* flag;   // pinned host word written by k_ctrl (completed asteps)
+  long long steps_target;              // asteps requested so far
+  std::vector<hipEvent_t> bundle_ev;   // throttle: at most 3 bundles of slots in flight
+  long long bundles;
+  hipStream_t stream;
+  std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;     // per allocation: payload size ...
+  std::vector<char> alloc_persist;     // ... and whether a checkpoint carries it
+  long long slot;  // next slot index (parity = slot & 1)
+  int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
+  int have_data, have_y;
+  int has_subset;  // any SubsetSplit column: selects the row-pass instance
+  int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
+  int ll_grid;     // ... of the log-likelihood pass
+  int sigma_dirty;
+  double inv_sigma2;
+  double lik_param2;
+  int lower_host;      // mirror of the batch cursor
+  int last_lower, last_n;
+  double slots_per_step;  // running estimate
+  pgb_counters ctr;
+  // profiling of the dominant kernel (k_rows)
+  int prof;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  double prof_ms;
+  long long prof_launches;
+  long long* prof_buf;    // device-clock stamps (allocated on first use)
+  long long prof_slot0;   // first slot of the profiled region (device-clock stamps)
+  double prof_clock_ms;   // sum over launches of max(end) - min(start), 100 MHz device clock
+  long long prof_clock_launches;
+};
+
+template <typename T>
+static int dalloc(pgb_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+  h->allocs.push_back(q);
+  h->alloc_bytes.push_back(count * sizeof(T));
+  h->alloc_persist.push_back(1);
+  *p = (T*)q;
+  return PGB_OK;
+}
+// data, per-tree scratch and pointer tables are rebuilt by create/set_data: not part of a checkpoint
+static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
+
+extern "C" const char* pgb_last_error(void) { return g_err; }
+extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
+
+extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
+  if (!s || !out) return fail(PGB_E_INVALID, "null argument");
+  if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
+  if (s->n >= (1ll << 31) - CH) return fail(PGB_E_UNSUPPORTED, "n too large");
+  if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
+    return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
+  if (s->family == PGB_FAMILY_CATEGORICAL) {
+    if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
+      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+  } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
+    if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
+  } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
+             s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
+             s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
+             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG) {
+    if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
+  } else {
+    return fail(PGB_E_UNSUPPORTED, "unknown family");
+  }
+  if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  if (s->response != PGB_RESPONSE_CONSTANT) {
+    if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
+      return fail(PGB_E_UNSUPPORTED, "unknown response");
+  }
+  int ndev = 0;
+  hipError_t e0 = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev < 1) {
+    snprintf(g_err, sizeof g_err, "no HIP device visible (%s, count %d); this backend has no CPU fallback",
+             hipGetErrorString(e0), ndev);
+    return PGB_E_DEVICE;
+  }
+  pgb_handle* h = new pgb_handle();
+  h->s = *s;
+  h->stream = (hipStream_t)stream;
+  h->slot = 0;
+  h->has_subset = 0;
+  h->rows_grid = 1024;
+  h->prof_buf = nullptr;
+  h->prof_clock_ms = 0.0;
+  h->prof_clock_launches = 0;
+  h->prof_slot0 = 0;
+  if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
+  h->ll_grid = h->rows_grid;
+  if (const char* e = getenv("PGB_LL_GRID")) h->ll_grid = atoi(e) > 0 ? atoi(e) : h->ll_grid;
+  h->st_cur = 0;
+  h->alpha_cur = 0;
+  h->d_dev = nullptr;
+  h->flag = nullptr;
+  h->steps_target = 0;
+  h->bundles = 0;
+  h->inv_sigma2 = 1.0;
+  h->lik_param2 = 1.0;
+  h->sigma_dirty = 1;
+  h->slots_per_step = 0.0;
+  memset(&h->ctr, 0, sizeof h->ctr);
+  Dev& d = h->d;
+  memset(&d, 0, sizeof d);
+  d.n = s->n;
+  d.nchunks = (int)((s->n + CH - 1) / CH);
+  d.n_pad = (long long)d.nchunks * CH;
+  d.p = s->p;
+  d.m = s->m;
+  d.P = s->num_particles;
+  d.family = s->family;
+  d.K = s->n_outputs;
+  d.response = s->response;
+  d.lin_R = pgb_pow2(s->range_exp - 1);
+  d.inv_R = pgb_pow2(1 - s->range_exp);
+  d.rows_target = ROWS_TARGET_ITEMS;
+  d.rows_target_init = ROWS_TARGET_ITEMS_INIT;
+  if (const char* e = getenv("PGB_ROWS_TARGET")) d.rows_target = atoi(e) > 0 ? atoi(e) : d.rows_target;
+  d.ll_target = d.rows_target;
+  d.ll_pad = 0;
+  if (const char* e = getenv("PGB_LL_TARGET")) d.ll_target = atoi(e) > 0 ? atoi(e) : d.ll_target;
+  if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
+  d.batch_tune = s->batch_tune;
+  d.batch_draw = s->batch_draw;
+  d.seed = s->seed;
+  d.init_leaf = s->init_leaf;
+  d.mdouble = (double)s->m;
+  d.sc = pgb_make_scales(s->n, s->range_exp);
+  int rc;
+  double *XT, *y, *st, *rs_mean, *rs_m2, *prior_leaf;
+  long long *alpha, *cdfS;
+  double2* pack;
+  uint8_t *tree_lid, *lid;
+  uint16_t* cc;
+  int32_t *vi, *rules, *col_nan;
+#define DA(ptr, cnt) \
+  if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
+  DA(XT, (size_t)d.p * d.n_pad);
+  transient(h);
+  DA(y, d.n_pad);
+  transient(h);
+  double* off;
+  DA(off, d.n_pad);
+  transient(h);
+  d.off = off;
+  const int K = d.K, KX = d.K - 1;
+  DA(st, (size_t)2 * K * d.n_pad);
+  DA(pack, d.n_pad);
+  DA(rs_mean, (size_t)K * d.n_pad);
+  DA(rs_m2, (size_t)K * d.n_pad);
+  if (KX > 0) {  // K-vector leaves: extension outputs
+    DA(d.packx, (size_t)KX * d.n_pad);
+    DA(d.pvx, (size_t)2 * MAXP * MAXN * KX);
+    DA(d.pqx, (size_t)2 * MAXP * MAXN * KX);
+    DA(d.tvx, (size_t)d.m * MAXN * KX);
+    DA(d.accx, (size_t)2 * MAXP * AX_PER);
+    DA(d.iax, (size_t)2 * IA_SLOTS * 2 * KX);
+    DA(d.lvx, (size_t)2 * 2 * 256 * KX);
+    DA(d.jqx, (size_t)2 * MAXP * KX);
+    DA(d.jvx, (size_t)2 * MAXP * KX);
+    DA(d.lsdx, (size_t)2 * KXMAX);
+  }
+  DA(tree_lid, (size_t)d.m * d.n_pad);
+  DA(lid, (size_t)NGEN * MAXP * d.n_pad);
+  transient(h);  // particle labels live for one tree update only
+  DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
+  DA(d.trees, d.m);
+  DA(d.parts, 2 * MAXP);
+  DA(d.jobs, 2 * MAXP);
+  DA(d.acc, 2 * MAXP * ACC_PER);
+  DA(d.accl, 2 * MAXP * LL_PER);
+  DA(d.jobl, 2 * MAXP);
+  DA(d.initacc, 2 * IA_SLOTS);
+  DA(d.cmd, 2);
+  DA(d.ctrl, 2);
+  DA(d.counters, 8);
+  DA(vi, d.p);
+  DA(alpha, 2 * d.p);
+  DA(cdfS, 2 * d.p);
+  DA(prior_leaf, PGB_MAX_DEPTH);
+  DA(rules, d.p);
+  DA(col_nan, d.p);
+  int32_t* col_ex;
+  DA(col_ex, d.p);
+  d.col_ex = col_ex;
+  if (d.response != PGB_RESPONSE_CONSTANT) {
+    DA(d.plin, (size_t)2 * MAXP * MAXN);
+    DA(d.tlin, (size_t)d.m * MAXN);
+    DA(d.lvl, (size_t)2 * 2 * 256);
+    DA(d.accu, (size_t)2 * MAXP * ACC_PER);
+    if (KX > 0) {
+      DA(d.psx, (size_t)2 * MAXP * MAXN * KX);
+      DA(d.tsx, (size_t)d.m * MAXN * KX);
+      DA(d.lsx, (size_t)2 * 2 * 256 * KX);
+      DA(d.accux, (size_t)2 * MAXP * AX_PER);
+    }
+  }
+#undef DA
+  d.XT = XT; d.y = y; d.st = st; d.pack = pack; d.rs_mean = rs_mean; d.rs_m2 = rs_m2;
+  d.tree_lid = tree_lid; d.lid = lid; d.cc = cc; d.vi = vi; d.alpha = alpha; d.cdfS = cdfS;
+  d.rules = rules; d.col_nan = col_nan; d.prior_leaf = prior_leaf;
+  hipStream_t sm = h->stream;
+  hipError_t e;
+#define HC(expr) \
+  if ((e = (expr)) != hipSuccess) { int r_ = fail_hip(e, #expr); pgb_destroy(h); return r_; }
+  {
+    void* hp = nullptr;
+    HC(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    h->flag = (volatile unsigned long long*)hp;
+    *h->flag = 0;
+    void* dp = nullptr;
+    HC(hipHostGetDevicePointer(&dp, hp, 0));
+    d.host_flag = (unsigned long long*)dp;
+#ifdef PGB_TRACE
+    if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * 16)) != PGB_OK) { pgb_destroy(h); return rc; }
+    transient(h);
+    HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * 16 * sizeof(long long), sm));
+#endif
+    if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
+    transient(h);  // holds device pointers
+    HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
+    for (int i = 0; i < 4; ++i) {
+      hipEvent_t ev;
+      HC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      h->bundle_ev.push_back(ev);
+    }
+  }
+  HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
+  HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(off, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
+  HC(hipMemsetAsync(rs_mean, 0, (size_t)K * d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(rs_m2, 0, (size_t)K * d.n_pad * sizeof(double), sm));
+  if (KX > 0) {
+    HC(hipMemsetAsync(d.packx, 0, (size_t)KX * d.n_pad * sizeof(double), sm));
+    HC(hipMemsetAsync(d.pvx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(double), sm));
+    HC(hipMemsetAsync(d.pqx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.accx, 0, (size_t)2 * MAXP * AX_PER * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.iax, 0, (size_t)2 * IA_SLOTS * 2 * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.lvx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
+    HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
+    hipLaunchKernelGGL(k_fill_f64, dim3(1), dim3(256), 0, sm, d.lsdx, (long long)2 * KXMAX, s->init_leaf_sd);
+    // every accepted tree starts as a stump whose K-vector leaf is init_leaf
+    hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,
+                       d.tvx, (long long)d.m * MAXN * KX, s->init_leaf);
+  }
+  HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)NGEN * MAXP * d.n_pad, sm));
+  HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
+  HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
+  HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
+  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * LL_PER * sizeof(AccL), sm));
+  HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
+  HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
+  HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
+  HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
+  HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
+  HC(hipMemsetAsync(col_nan, 0, d.p * sizeof(int32_t), sm));
+  HC(hipMemsetAsync(col_ex, 0, d.p * sizeof(int32_t), sm));
+  if (d.response != PGB_RESPONSE_CONSTANT) {
+    const long long n1 = (long long)2 * MAXP * MAXN, n2 = (long long)d.m * MAXN, n3 = 2 * 2 * 256;
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, sm, d.plin, n1);
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, sm, d.tlin, n2);
+    hipLaunchKernelGGL(k_init_linp, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, sm, d.lvl, n3);
+    HC(hipMemsetAsync(d.accu, 0, (size_t)2 * MAXP * ACC_PER * sizeof(AccU), sm));
+    if (KX > 0) {
+      HC(hipMemsetAsync(d.psx, 0, (size_t)2 * MAXP * MAXN * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.tsx, 0, (size_t)d.m * MAXN * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.lsx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
+      HC(hipMemsetAsync(d.accux, 0, (size_t)2 * MAXP * AX_PER * sizeof(long long), sm));
+    }
+  }
+  Ctrl c0;
+  memset(&c0, 0, sizeof c0);
+  c0.phase = PH_IDLE;
+  c0.leaf_sd = s->init_leaf_sd;
+  c0.inv_sigma2 = 1.0;
+  c0.lik_param2 = 1.0;
+  Ctrl cc2[2] = {c0, c0};
+  HC(hipMemcpyAsync(d.ctrl, cc2, sizeof cc2, hipMemcpyHostToDevice, sm));
+  hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((2 * K * d.n_pad + 255) / 256)), dim3(256), 0, sm, st,
+                     2 * K * d.n_pad, s->init_sum);
+  hipLaunchKernelGGL(k_init_tree_lid, dim3((unsigned)((d.n_pad * d.m + 255) / 256)), dim3(256), 0, sm,
+                     tree_lid, d.n, d.n_pad, d.m);
+  hipLaunchKernelGGL(k_init_trees, dim3((d.m + 63) / 64), dim3(64), 0, sm, d.trees, d.m, d.n,
+                     s->init_leaf);
+  HC(hipGetLastError());
+  HC(hipStreamSynchronize(sm));
+#undef HC
+  *out = h;
+  return PGB_OK;
+}
+
+extern "C" int pgb_destroy(pgb_handle* h) {
+  if (!h) return PGB_OK;
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->bundle_ev) (void)hipEventDestroy(e);
+  if (h->flag) (void)hipHostFree((void*)h->flag);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
+                            const double* split_prior_host) {
+  if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
+  Dev& d = h->d;
+  if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
+  double mx = 0.0;
+  h->has_subset = 0;
+  for (int j = 0; j < d.p; ++j) {
+    if (rules_host[j] == PGB_RULE_SUBSET) h->has_subset = 1;
+    if (rules_host[j] != PGB_RULE_CONTINUOUS && rules_host[j] != PGB_RULE_ONEHOT &&
+        rules_host[j] != PGB_RULE_SUBSET)
+      return fail(PGB_E_UNSUPPORTED, "unknown split rule");
+    if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
+    if (split_prior_host[j] > mx) mx = split_prior_host[j];
+    if (d.response != PGB_RESPONSE_CONSTANT && rules_host[j] != PGB_RULE_CONTINUOUS)
+      return fail(PGB_E_UNSUPPORTED, "response linear/mix needs ContinuousSplit columns");
+  }
+  d.max_prior = mx;
+  d.alpha_unit = pgb_alpha_unit(mx);
+  hipStream_t sm = h->stream;
+  HIPCHK(hipMemcpyAsync((void*)d.rules, rules_host, d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
+  // the prior is staged in the (not yet used) running-sd buffer and quantised on the device
+  HIPCHK(hipMemcpyAsync(d.rs_mean, split_prior_host, (size_t)(d.p < d.n_pad ? d.p : 0) * sizeof(double),
+                        hipMemcpyHostToDevice, sm));
+  HIPCHK(hipMemsetAsync((void*)d.col_nan, 0, d.p * sizeof(int32_t), sm));
+  dim3 grid((unsigned)(d.n_pad / 32), (unsigned)((d.p + 31) / 32));
+  hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
+                     d.n_pad, d.p, (int32_t*)d.col_nan);
+  double* prior_stage = nullptr;
+  if (d.p >= d.n_pad) {  // more columns than padded rows: stage through a temporary
+    HIPCHK(hipMalloc((void**)&prior_stage, d.p * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(prior_stage, split_prior_host, d.p * sizeof(double), hipMemcpyHostToDevice, sm));
+  }
+  hipLaunchKernelGGL(k_init_alpha, dim3(1), dim3(64), 0, sm, prior_stage ? prior_stage : d.rs_mean, mx,
+                     d.alpha, d.cdfS, d.p);
+  if (d.response != PGB_RESPONSE_CONSTANT) {  // exponent bound of every column (u = x 2^-ex)
+    double* amax_dev = nullptr;
+    HIPCHK(hipMalloc((void**)&amax_dev, d.p * sizeof(double)));
+    hipLaunchKernelGGL(k_colmax, dim3((unsigned)d.p), dim3(BT), 0, sm, d.XT, d.n, d.n_pad, amax_dev);
+    std::vector<double> amax(d.p);
+    HIPCHK(hipMemcpyAsync(amax.data(), amax_dev, d.p * sizeof(double), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+    (void)hipFree(amax_dev);
+    std::vector<int32_t> ex(d.p);
+    for (int j = 0; j < d.p; ++j) ex[j] = pgb_col_exponent(amax[j]);
+    HIPCHK(hipMemcpyAsync((void*)d.col_ex, ex.data(), d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+  }
+  HIPCHK(hipMemsetAsync(d.rs_mean, 0, d.n_pad * sizeof(double), sm));
+  HIPCHK(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));  // alpha_unit, max_prior
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(sm));
+  if (prior_stage) (void)hipFree(prior_stage);
+  h->have_data = 1;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
+  if (!h || !y_dev) return fail(PGB_E_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_y = 1;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
+    return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
+  if (offset_dev)
+    HIPCHK(hipMemcpyAsync((void*)h->d.off, offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  else
+    HIPCHK(hipMemsetAsync((void*)h->d.off, 0, h->d.n * sizeof(double), h->stream));
+  if (h->d.has_off != (offset_dev ? 1 : 0)) {
+    h->d.has_off = offset_dev ? 1 : 0;
+    HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
+  if (!h || !params) return fail(PGB_E_INVALID, "null argument");
+  if (h->s.family == PGB_FAMILY_NORMAL) {
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
+    h->inv_sigma2 = 1.0 / (params[0] * params[0]);
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_NEGBIN_LOG || h->s.family == PGB_FAMILY_GAMMA_LOG) {
+    // the slot doubles as "the family's parameter"
+    if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NEGBIN_LOG / GAMMA_LOG need alpha > 0");
+    h->inv_sigma2 = params[0];
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_ASYMLAPLACE) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0) || !(params[1] < 1.0))
+      return fail(PGB_E_INVALID, "ASYMLAPLACE needs b > 0 and 0 < q < 1");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
+    h->sigma_dirty = 1;
+  } else if (h->s.family == PGB_FAMILY_STUDENT_T) {
+    if (n_params != 2 || !(params[0] > 0.0) || !(params[1] > 0.0))
+      return fail(PGB_E_INVALID, "STUDENT_T needs sigma > 0 and nu > 0");
+    h->inv_sigma2 = params[0];
+    h->lik_param2 = params[1];
+    h->sigma_dirty = 1;
+  } else if (n_params != 0) {
+    return fail(PGB_E_INVALID, "this family has no parameters");
+  }
+  return PGB_OK;
+}
+
+static int enqueue_slots(pgb_handle* h, int count) {
+  Dev& d = h->d;
+  long long want = (long long)d.nchunks * (d.P - 1);
+  if (want < d.n_pad / BT) want = d.n_pad / BT;
+  if (want > h->rows_grid) want = h->rows_grid;
+  dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
+  long long wantl = (long long)d.nchunks * (d.P - 1);
+  if (wantl > h->ll_grid) wantl = h->ll_grid;
+  dim3 gll((unsigned)wantl);
+  for (int i = 0; i < count; ++i) {
+    int par = (int)(h->slot & 1);
+    const bool lin = d.response != PGB_RESPONSE_CONSTANT;
+    if (d.K > 1 && lin)
+      hipLaunchKernelGGL((k_ctrl<true, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+    else if (d.K > 1)
+      hipLaunchKernelGGL((k_ctrl<true, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+    else
+      if (d.response != PGB_RESPONSE_CONSTANT)
+        hipLaunchKernelGGL((k_ctrl<false, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+      else
+        hipLaunchKernelGGL((k_ctrl<false, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+      if (h->ev_used + 2 > h->ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+          return fail(PGB_E_DEVICE, "hipEventCreate");
+        h->ev.push_back(a);
+        h->ev.push_back(b);
+      }
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+    }
+    // Profiling: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. they
+    // carry the start / end timestamps of the kernel's own AQL packet -- the interval rocprofv3
+    // reports -- rather than bracketing the launch with two extra barrier packets.
+#define LAUNCH_ROWS(KERN, ...)                                                                    \
+  do {                                                                                            \
+    if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par, ##__VA_ARGS__); \
+    else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, ##__VA_ARGS__);    \
+  } while (0)
+#define ROWS_PTRS (const Cmd*)d.cmd, (const Job*)d.jobs
+    if (d.K > 1 && lin) {  // linear leaves: one instance for any K
+      LAUNCH_ROWS((k_rows_mk<0, true>));
+    } else if (d.K == 2) {
+      LAUNCH_ROWS((k_rows_mk<2, false>));
+    } else if (d.K == 3) {
+      LAUNCH_ROWS((k_rows_mk<3, false>));
+    } else if (d.K == 4) {
+      LAUNCH_ROWS((k_rows_mk<4, false>));
+    } else if (d.K > 1) {
+      LAUNCH_ROWS((k_rows_mk<0, false>));
+    } else {
+      const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
+      if (d.response != PGB_RESPONSE_CONSTANT) {
+        if (nrm) LAUNCH_ROWS((k_rows<false, true, true>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<false, false, true>), ROWS_PTRS);
+      } else if (h->has_subset) {
+        if (nrm) LAUNCH_ROWS((k_rows<true, true, false>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<true, false, false>), ROWS_PTRS);
+      } else {
+        if (nrm) LAUNCH_ROWS((k_rows<false, true, false>), ROWS_PTRS);
+        else LAUNCH_ROWS((k_rows<false, false, false>), ROWS_PTRS);
+      }
+    }
+#undef LAUNCH_ROWS
+#undef ROWS_PTRS
+    if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
+#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), gll, dim3(BT), 0, h->stream, h->d_dev, par)
+      if (d.K > 1 && lin) {
+        hipLaunchKernelGGL((k_loglik<0, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else if (d.K > 1) {
+        switch (d.K) {
+          case 2: LAUNCH_LL(2, -1); break;
+          case 3: LAUNCH_LL(3, -1); break;
+          case 4: LAUNCH_LL(4, -1); break;
+          default: LAUNCH_LL(0, -1);
+        }
+      } else if (d.response != PGB_RESPONSE_CONSTANT) {  // linear leaves: one instance, family read at run time
+        hipLaunchKernelGGL((k_loglik<1, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else {
+        switch (d.family) {
+          case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;
+          case PGB_FAMILY_BERNOULLI_LOGIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_LOGIT); break;
+          case PGB_FAMILY_POISSON_LOG: LAUNCH_LL(1, PGB_FAMILY_POISSON_LOG); break;
+          case PGB_FAMILY_NEGBIN_LOG: LAUNCH_LL(1, PGB_FAMILY_NEGBIN_LOG); break;
+          case PGB_FAMILY_ASYMLAPLACE: LAUNCH_LL(1, PGB_FAMILY_ASYMLAPLACE); break;
+          case PGB_FAMILY_GAMMA_LOG: LAUNCH_LL(1, PGB_FAMILY_GAMMA_LOG); break;
+          default: LAUNCH_LL(1, PGB_FAMILY_STUDENT_T);
+        }
+      }
+#undef LAUNCH_LL
+    }
+    h->slot += 1;
+  }
+  HIPCHK(hipGetLastError());
+  return PGB_OK;
+}
+
+static int harvest_profile(pgb_handle* h) {
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    h->prof_ms += ms;
+    h->prof_launches += 1;
+  }
+  h->ev_used = 0;
+  return PGB_OK;
+}
+
+// Enqueue bundles of slots until the device reports that all requested asteps are complete.
+// The device publishes its progress in a pinned host word (k_ctrl, final slot of a step); the
+// host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
+// are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
+#define BUNDLE 8
+static int run_until_idle(pgb_handle* h, int n_steps) {
+  Dev& d = h->d;
+  long long start = h->slot;
+  long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
+  int rc;
+  while (*h->flag < (unsigned long long)h->steps_target) {
+    hipEvent_t ev = h->bundle_ev[h->bundles & 3];
+    if (h->bundles >= 3) {
+      // wait for bundle (bundles - 3) before reusing its event: keeps <= 3 bundles queued
+      HIPCHK(hipEventSynchronize(h->bundle_ev[(h->bundles - 3) & 3]));
+      if (*h->flag >= (unsigned long long)h->steps_target) break;
+    }
+    if ((rc = enqueue_slots(h, BUNDLE)) != PGB_OK) return rc;
+    HIPCHK(hipEventRecord(ev, h->stream));
+    h->bundles += 1;
+    if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
+  Ctrl c;
+  HIPCHK(hipMemcpy(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost));
+  if (c.phase != PH_IDLE) return fail(PGB_E_STATE, "device not idle after the progress flag fired");
+  h->st_cur = c.st_cur;
+  h->alpha_cur = c.alpha_cur;
+  return PGB_OK;
+}
+
+static int begin_steps(pgb_handle* h, int tune, int n_steps) {
+  Dev& d = h->d;
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  int par = (int)(h->slot & 1);
+  hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, h->d_dev, par, tune, n_steps,
+                     h->inv_sigma2, h->lik_param2, h->sigma_dirty);
+  h->steps_target += n_steps;
+  h->sigma_dirty = 0;
+  // host mirror of the batch cursor ([U] PGBART.astep batching)
+  for (int i = 0; i < n_steps; ++i) {
+    int bs = tune ? d.batch_tune : d.batch_draw;
+    int upper = h->lower_host + bs;
+    if (upper > d.m) upper = d.m;
+    h->last_lower = h->lower_host;
+    h->last_n = upper - h->lower_host;
+    h->lower_host = upper < d.m ? upper : 0;
+  }
+  return PGB_OK;
+}
+
+static int fetch_counters(pgb_handle* h, pgb_counters* out) {
+  unsigned long long c[8];
+  HIPCHK(hipMemcpyAsync(c, h->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->ctr.particle_steps = (int64_t)c[0];
+  h->ctr.tree_updates = (int64_t)c[1];
+  h->ctr.rows_touched = (int64_t)c[2];
+  h->ctr.rounds = (int64_t)c[3];
+  h->ctr.saturations = (int64_t)c[4];
+  h->ctr.slots = (int64_t)c[5];
+  if (out) *out = h->ctr;
+  return PGB_OK;
+}
+
+extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi_counts_host_out,
+                        pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  int rc;
+  if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
+  if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
+  if (sum_trees_dev_out)  // [K][n] out of the padded [K][n_pad] buffer
+    HIPCHK(hipMemcpy2DAsync(sum_trees_dev_out, h->d.n * sizeof(double),
+                            h->d.st + (size_t)h->st_cur * h->d.K * h->d.n_pad, h->d.n_pad * sizeof(double),
+                            h->d.n * sizeof(double), (size_t)h->d.K, hipMemcpyDeviceToDevice, h->stream));
+  if (vi_counts_host_out)
+    HIPCHK(hipMemcpyAsync(vi_counts_host_out, h->d.vi, h->d.p * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          h->stream));
+  if ((rc = fetch_counters(h, counters_out)) != PGB_OK) return rc;
+  return PGB_OK;
+}
+
+extern "C" int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
+  if (!h || n_steps < 1) return fail(PGB_E_INVALID, "bad argument");
+  int rc;
+  if ((rc = begin_steps(h, tune, n_steps)) != PGB_OK) return rc;
+  return run_until_idle(h, n_steps);
+}
+
+extern "C" int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  return fetch_counters(h, counters_out);
+}
+
+extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  Dev& d = h->d;
+  int first = which == 0 ? h->last_lower : 0;
+  int nt = which == 0 ? h->last_n : d.m;
+  std::vector<DTree> host(nt);
+  if (nt > 0) {
+    HIPCHK(hipMemcpyAsync(host.data(), d.trees + first, sizeof(DTree) * nt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  int total = 0;
+  for (int t = 0; t < nt; ++t) total += host[t].n_nodes;
+  const int K = d.K, KX = d.K - 1;
+  if (!out->var) {
+    out->n_trees = nt;
+    out->n_outputs = K;
+    out->total_nodes = total;
+    return PGB_OK;
+  }
+  std::vector<double> hx;
+  if (KX > 0 && nt > 0) {
+    hx.resize((size_t)nt * MAXN * KX);
+    HIPCHK(hipMemcpy(hx.data(), d.tvx + (size_t)first * MAXN * KX, hx.size() * sizeof(double),
+                     hipMemcpyDeviceToHost));
+  }
+  if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
+  std::vector<LinP> hl;
+  std::vector<double> hsx;  // slopes of outputs 1..K-1
+  const bool want_lin = out->slope && out->xbar && out->svar;
+  if (want_lin && d.response != PGB_RESPONSE_CONSTANT && nt > 0) {
+    hl.resize((size_t)nt * MAXN);
+    HIPCHK(hipMemcpy(hl.data(), d.tlin + (size_t)first * MAXN, hl.size() * sizeof(LinP), hipMemcpyDeviceToHost));
+    if (KX > 0) {
+      hsx.resize((size_t)nt * MAXN * KX);
+      HIPCHK(hipMemcpy(hsx.data(), d.tsx + (size_t)first * MAXN * KX, hsx.size() * sizeof(double),
+                       hipMemcpyDeviceToHost));
+    }
+  }
+  int off = 0;
+  for (int t = 0; t < nt; ++t) {
+    const DTree& T = host[t];
+    out->tree_id[t] = first + t;
+    out->node_off[t] = off;
+    for (int k = 0; k < T.n_nodes; ++k) {
+      const DNode& z = T.nd[k];
+      out->var[off + k] = z.var;
+      out->split[off + k] = z.var >= 0 ? z.split : 0.0;
+      out->left[off + k] = z.var >= 0 ? (int32_t)z.left : -1;
+      out->right[off + k] = z.var >= 0 ? (int32_t)z.right : -1;
+      out->count[off + k] = z.cnt;
+      out->value[(size_t)(off + k) * K] = z.var < 0 ? z.value : 0.0;
+      if (want_lin) {
+        const bool islin = z.var < 0 && !hl.empty() && hl[(size_t)t * MAXN + k].svar >= 0;
+        out->slope[(size_t)(off + k) * K] = islin ? hl[(size_t)t * MAXN + k].slope : 0.0;
+        for (int o = 1; o < K; ++o)
+          out->slope[(size_t)(off + k) * K + o] = islin ? hsx[((size_t)t * MAXN + k) * KX + o - 1] : 0.0;
+        out->xbar[off + k] = islin ? hl[(size_t)t * MAXN + k].xbar : 0.0;
+        out->svar[off + k] = islin ? (int32_t)hl[(size_t)t * MAXN + k].svar : -1;
+      }
+      for (int o = 1; o < K; ++o)
+        out->value[(size_t)(off + k) * K + o] = z.var < 0 ? hx[((size_t)t * MAXN + k) * KX + o - 1] : 0.0;
+    }
+    off += T.n_nodes;
+  }
+  out->node_off[nt] = off;
+  return PGB_OK;
+}
+
+extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  Dev& d = h->d;
+  Ctrl c;
+  InitAcc ia[IA_SLOTS];
+  HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ia, &d.initacc[(size_t)((h->slot & 1) ^ 1) * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double leaf_sd = c.leaf_sd;
+  long long qstd = 0;
+  for (int k = 0; k < IA_SLOTS; ++k) qstd += ia[k].QSTD;
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = ((double)qstd * d.sc.inv_c1) / (double)d.n;
+  if (leaf_sd_out) {
+    leaf_sd_out[0] = leaf_sd;
+    const int KX = d.K - 1;
+    if (KX > 0) {
+      std::vector<long long> ix((size_t)IA_SLOTS * 2 * KX);
+      HIPCHK(hipMemcpy(ix.data(), d.iax + (size_t)((h->slot & 1) ^ 1) * IA_SLOTS * 2 * KX,
+                       ix.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double lsdx[2 * KXMAX];
+      HIPCHK(hipMemcpy(lsdx, d.lsdx, sizeof lsdx, hipMemcpyDeviceToHost));
+      for (int k = 0; k < KX; ++k) {
+        double v = lsdx[(h->slot & 1) * KXMAX + k];
+        if (c.pend_leafsd && c.pend_iter > 2) {
+          long long q = 0;
+          for (int sl = 0; sl < IA_SLOTS; ++sl) q += ix[(size_t)sl * 2 * KX + KX + k];
+          v = ((double)q * d.sc.inv_c1) / (double)d.n;
+        }
+        leaf_sd_out[k + 1] = v;
+      }
+    }
+  }
+  if (iter_out) *iter_out = c.iter;
+  if (lower_out) *lower_out = c.lower;
+  return PGB_OK;
+}
+
+extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
+  if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  std::vector<long long> a((size_t)h->d.p);
+  HIPCHK(hipMemcpyAsync(a.data(), h->d.alpha + (size_t)h->alpha_cur * h->d.p, h->d.p * sizeof(long long),
+                        hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // in units of the caller's prior: prior_j + number of tuning counts (up to 2^-24 rounding)
+  for (int j = 0; j < h->d.p; ++j) out[j] = (double)a[j] * (h->d.max_prior * pgb_pow2(-PGB_ALPHA_BITS));
+  return PGB_OK;
+}
+
+extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
+                           int32_t m, const double* X_dev, int64_t n_rows, int32_t p, int64_t ldx,
+                           const int32_t* rules_host, const int32_t* excluded_host, int32_t n_excluded,
+                           double* out_dev, void* stream) {
+  if (!trees || !forest_tree_idx || !X_dev || !out_dev || !rules_host)
+    return fail(PGB_E_INVALID, "null argument");
+  if (trees->n_outputs < 1 || trees->n_outputs > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "n_outputs");
+  if (n_forests < 1 || n_rows < 1) return PGB_OK;
+  hipStream_t sm = (hipStream_t)stream;
+  const int K = trees->n_outputs, N = trees->total_nodes, NT = trees->n_trees;
+  std::vector<uint8_t> excl((size_t)p, 0);
+  for (int e = 0; e < n_excluded; ++e)
+    if (excluded_host[e] >= 0 && excluded_host[e] < p) excl[excluded_host[e]] = 1;
+  // one upload buffer: [node_off | var | left | right | rules | fidx] int32, then 8-byte arrays
+  size_t n_i32 = (size_t)(NT + 1) + 3 * (size_t)N + p + (size_t)n_forests * m;
+  size_t off8 = ((n_i32 * 4 + 7) / 8) * 8;
+  const bool lin = trees->slope && trees->xbar && trees->svar;
+  // ... then, for linear leaves, slope / xbar (8-byte) and svar (int32) after the exclusion flags
+  const size_t off_lin = ((off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p + 7) / 8) * 8;
+  size_t bytes = lin ? off_lin + (size_t)N * K * 8 + (size_t)N * 12 : off8 + (size_t)N * 16 + (size_t)N * K * 8 + p;
+  std::vector<uint8_t> hb(bytes);
+  int32_t* hi = (int32_t*)hb.data();
+  size_t o = 0;
+  memcpy(hi + o, trees->node_off, (NT + 1) * 4); size_t o_off = o; o += NT + 1;
+  memcpy(hi + o, trees->var, N * 4); size_t o_var = o; o += N;
+  memcpy(hi + o, trees->left, N * 4); size_t o_l = o; o += N;
+  memcpy(hi + o, trees->right, N * 4); size_t o_r = o; o += N;
+  memcpy(hi + o, rules_host, p * 4); size_t o_rules = o; o += p;
+  memcpy(hi + o, forest_tree_idx, (size_t)n_forests * m * 4); size_t o_f = o; o += (size_t)n_forests * m;
+  uint8_t* h8 = hb.data() + off8;
+  memcpy(h8, trees->split, (size_t)N * 8);
+  memcpy(h8 + (size_t)N * 8, trees->count, (size_t)N * 8);
+  memcpy(h8 + (size_t)N * 16, trees->value, (size_t)N * K * 8);
+  memcpy(h8 + (size_t)N * 16 + (size_t)N * K * 8, excl.data(), p);
+  if (lin) {
+    memcpy(hb.data() + off_lin, trees->slope, (size_t)N * K * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * K * 8, trees->xbar, (size_t)N * 8);
+    memcpy(hb.data() + off_lin + (size_t)N * K * 8 + (size_t)N * 8, trees->svar, (size_t)N * 4);
+  }
+  uint8_t* db = nullptr;
+  HIPCHK(hipMalloc((void**)&db, bytes));
+  hipError_t e = hipMemcpyAsync(db, hb.data(), bytes, hipMemcpyHostToDevice, sm);
+  if (e != hipSuccess) { (void)hipFree(db); return fail_hip(e, "hipMemcpyAsync"); }
+  const int32_t* di = (const int32_t*)db;
+  PredTrees T;
+  T.node_off = di + o_off;
+  T.var = di + o_var;
+  T.left = di + o_l;
+  T.right = di + o_r;
+  T.split = (const double*)(db + off8);
+  T.count = (const long long*)(db + off8 + (size_t)N * 8);
+  T.value = (const double*)(db + off8 + (size_t)N * 16);
+  T.slope = lin ? (const double*)(db + off_lin) : nullptr;
+  T.xbar = lin ? (const double*)(db + off_lin + (size_t)N * K * 8) : nullptr;
+  T.svar = lin ? (const int32_t*)(db + off_lin + (size_t)N * K * 8 + (size_t)N * 8) : nullptr;
+  const uint8_t* dexcl = db + off8 + (size_t)N * 16 + (size_t)N * K * 8;
+  dim3 grid((unsigned)((n_rows + BT - 1) / BT), (unsigned)n_forests);
+  hipLaunchKernelGGL(k_predict, grid, dim3(BT), 0, sm, T, di + o_f, n_forests, m, K, X_dev,
+                     (long long)n_rows, p, (long long)ldx, di + o_rules, dexcl, out_dev);
+  e = hipGetLastError();
+  hipError_t e2 = hipStreamSynchronize(sm);
+  (void)hipFree(db);
+  if (e != hipSuccess) return fail_hip(e, "k_predict launch");
+  if (e2 != hipSuccess) return fail_hip(e2, "k_predict");
+  return PGB_OK;
+}
+
