@@ -385,3 +385,18 @@ def test_k_vector_linear_leaves_on_gpu(hip, oracle):
     np.testing.assert_allclose(ph[0][:, full], wh[:, :400][:, full], rtol=0, atol=1e-9)  # sum_trees == predictions
     host = predict_numpy(fh, np.arange(m)[None, :], Xn[:60], rules, excluded=[2])
     np.testing.assert_allclose(pxh[0][:, :60], host[0], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["nan_onehot_prior", "probit_cfg4_small", "categorical_k3_mix", "linear_response"])
+def test_results_do_not_depend_on_launch_geometry(hip, name, monkeypatch):
+    """All row reductions are integer sums, so the draws cannot depend on how the rows are cut into
+    work items or how many workgroups run them: odd grids and item targets (read at pgb_create)
+    reproduce the committed fingerprint."""
+    c = make_case(name)
+    for env in ({"PGB_ROWS_GRID": "7", "PGB_ROWS_TARGET": "3", "PGB_ROWS_TARGET_INIT": "5", "PGB_LL_GRID": "5",
+                 "PGB_LL_TARGET": "2"},
+                {"PGB_ROWS_GRID": "333", "PGB_ROWS_TARGET": "100000", "PGB_ROWS_TARGET_INIT": "1",
+                 "PGB_LL_GRID": "1000", "PGB_LL_TARGET": "99999"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert digest(run_case(c, hip)) == GOLD[name], env
