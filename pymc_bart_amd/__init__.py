@@ -10,10 +10,12 @@ from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikel
                      NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood, StudentTLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
-from .importance import compute_variable_importance
+from .importance import compute_variable_importance, get_variable_inclusion, vi_to_kulprit
+from .partial import individual_conditional_expectation, partial_dependence
 
 __version__ = "0.1.0"
 __all__ = [
     "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood", "GammaLikelihood",
-    "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "_abi",
+    "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "get_variable_inclusion", "vi_to_kulprit",
+    "partial_dependence", "individual_conditional_expectation", "_abi",
 ]

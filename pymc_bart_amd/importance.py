@@ -157,3 +157,31 @@ def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0,
         "preds": preds.squeeze(),
         "preds_all": full.squeeze(),
     }
+
+
+def get_variable_inclusion(vi, X, labels=None, to_kulprit: bool = False):
+    """Normalised variable inclusion, most used covariate first (reference ``utils.py:747-806``).
+
+    ``vi``: see :func:`inclusion_counts` -- for a model with several BART variables pass the stat
+    strings of the one in question (upstream selects it from the InferenceData by model / name).
+    Returns ``(shares, labels)``, or with ``to_kulprit=True`` the nested list of label prefixes
+    ``[[], [l0], [l0, l1], ...]`` that Kulprit's ``project`` takes as a path."""
+    p = int(np.shape(X)[1])
+    counts = inclusion_counts(vi, p).astype(np.float64)
+    order = np.argsort(counts / counts.sum())[::-1]
+    if hasattr(X, "columns") and hasattr(X, "to_numpy"):
+        names = [str(c) for c in np.asarray(X.columns)[order]]
+    elif labels is not None:
+        names = list(labels)  # as upstream: taken as given, i.e. already in the returned order
+    else:
+        names = [str(int(i)) for i in order]
+    if to_kulprit:
+        return [names[:k] for k in range(p + 1)]
+    return (counts / counts.sum())[order], names
+
+
+def vi_to_kulprit(vi_results: dict) -> list:
+    """Label prefixes of a :func:`compute_variable_importance` result, "+ " markers removed
+    (reference ``utils.py:1093-1108``): ``[[], [l0], [l0, l1], ...]`` without the full model."""
+    clean = [str(lab).strip("+ ") for lab in vi_results["labels"]]
+    return [clean[:k] for k in range(len(clean))]

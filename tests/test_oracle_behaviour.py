@@ -789,3 +789,63 @@ def test_out_of_sample_fit_is_competitive_with_gradient_boosting(oracle):
     gbm_rmse = float(np.sqrt(np.mean((gbm.predict(X[te]) - f[te]) ** 2)))
     assert bart_rmse < 1.15 * gbm_rmse, (bart_rmse, gbm_rmse)
     assert bart_rmse < 1.6   # in absolute terms: noise sd is 1, f has sd ~4.9
+
+
+def test_partial_dependence_ice_and_inclusion_helpers(oracle):
+    # the numbers behind the reference's plot_pdp / plot_ice (utils.py:168-487), its
+    # get_variable_inclusion (utils.py:747-806; use: tests/test_bart.py:205-208) and vi_to_kulprit
+    # (utils.py:1093-1108; use: tests/test_utils.py:84-86)
+    from pymc_bart_amd import (compute_variable_importance, get_variable_inclusion,
+                               individual_conditional_expectation, partial_dependence, vi_to_kulprit)
+    from pymc_bart_amd.partial import pdp_grid
+
+    rng = np.random.default_rng(8)
+    X = rng.uniform(-1, 1, size=(300, 3))
+    Y = 2.0 * X[:, 0] + (X[:, 2] > 0) + rng.normal(0, 0.1, 300)
+    op = BARTOp(X, Y, m=20)
+    res = sample_chain(op, tune=150, draws=60, random_seed=11, backend=oracle)
+
+    # grids: quantiles (default), linear, insample
+    assert pdp_grid(X).shape == (9, 3) and pdp_grid(X, "linear").shape == (10, 3)
+    np.testing.assert_allclose(pdp_grid(X, "linear", 5)[[0, -1]], [X.min(0), X.max(0)])
+    np.testing.assert_allclose(pdp_grid(X, "quantiles", [0.5])[0], np.median(X, axis=0))
+    assert pdp_grid(X, "insample") is not None and pdp_grid(X, "insample").shape == X.shape
+    with pytest.raises(ValueError):
+        pdp_grid(X, "nope")
+
+    pd_ = partial_dependence(op, X, xs_interval="linear", xs_values=9, samples=40, random_seed=3, backend=oracle)
+    assert set(pd_["pd"]) == {0, 1, 2} and pd_["pd"][0].shape == (40, 9, 1) and pd_["labels"][1] == "X_1"
+    m0, m1 = pd_["pd"][0].mean(axis=0)[:, 0], pd_["pd"][1].mean(axis=0)[:, 0]
+    slope = np.polyfit(pd_["x"][0], m0, 1)[0]
+    assert 1.5 < slope < 2.3                        # the linear effect of x0 is recovered ...
+    assert np.ptp(m1) < 0.25 * np.ptp(m0)           # ... x1 has none
+    step = pd_["pd"][2].mean(axis=0)[:, 0]
+    assert 0.7 < step[-1] - step[0] < 1.3           # the unit jump along x2
+    assert abs(pd_["reference"] - Y.mean()) < 0.3
+    # same generator, same call pattern -> same numbers; var_idx restricts the sweep
+    again = partial_dependence(op, X, var_idx=[0], xs_interval="linear", xs_values=9, samples=40, random_seed=3,
+                               backend=oracle)
+    assert np.array_equal(again["pd"][0], pd_["pd"][0]) and set(again["pd"]) == {0}
+    doubled = partial_dependence(op, X, var_idx=[0], xs_interval="linear", xs_values=9, samples=40, random_seed=3,
+                                 func=lambda a: 2 * a, backend=oracle)
+    assert np.array_equal(doubled["pd"][0], 2 * pd_["pd"][0])
+
+    ice = individual_conditional_expectation(op, X, var_idx=[0, 1], instances=6, samples=15, random_seed=4,
+                                             backend=oracle)
+    assert ice["ice"][0].shape == (6, 300, 1) and len(ice["instances"]) == 6
+    assert np.all(ice["ice"][0][:, 0, 0] == 0.0)    # centred on the first row
+    order = np.argsort(ice["x"][0])
+    rise = ice["ice"][0][:, order[-20:], 0].mean() - ice["ice"][0][:, order[:20], 0].mean()
+    assert 2.5 < rise < 4.5                          # ~ 2 * (0.9 - (-0.9))
+    raw = individual_conditional_expectation(op, X, var_idx=[0], instances=6, samples=15, centered=False,
+                                             random_seed=4, backend=oracle)
+    np.testing.assert_allclose(raw["ice"][0] - raw["ice"][0][:, :1, :], ice["ice"][0], atol=1e-12)
+
+    share, labels = get_variable_inclusion(res["variable_inclusion"], X)
+    assert share.shape == (3,) and abs(share.sum() - 1) < 1e-12 and np.all(np.diff(share) <= 0)
+    assert labels[0] in ("0", "2") and labels[-1] == "1" and all(isinstance(s, str) for s in labels)
+    path = get_variable_inclusion(res["variable_inclusion"], X, to_kulprit=True)
+    assert path[0] == [] and path[-1] == labels and len(path) == 4
+    vi = compute_variable_importance(res["variable_inclusion"], op, X, samples=10, random_seed=1, backend=oracle)
+    terms = vi_to_kulprit(vi)
+    assert len(terms) == 3 and terms[0] == [] and all("+" not in t for ts in terms[1:] for t in ts)

@@ -400,3 +400,27 @@ def test_results_do_not_depend_on_launch_geometry(hip, name, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert digest(run_case(c, hip)) == GOLD[name], env
+
+
+def test_partial_dependence_sweep_on_gpu_matches_the_oracle(hip, oracle):
+    """The PDP / ICE sweeps (all-but-one covariate excluded, k_predict) give the oracle's numbers."""
+    from pymc_bart_amd import individual_conditional_expectation, partial_dependence
+
+    rng = np.random.default_rng(31)
+    X = rng.uniform(-1, 1, size=(2000, 4))
+    X[rng.random(2000) < 0.05, 3] = np.nan
+    Y = 2.0 * X[:, 0] - X[:, 1] ** 2 + rng.normal(0, 0.1, 2000)
+    got = {}
+    for name, be in (("hip", hip), ("oracle", oracle)):
+        op = BARTOp(X, Y, m=15)
+        sample_chain(op, tune=20, draws=10, num_particles=10, random_seed=6, sigma=0.2, backend=be)
+        Xc = np.nan_to_num(X)
+        pd_ = partial_dependence(op, Xc, xs_interval="linear", xs_values=12, samples=20, random_seed=2, backend=be)
+        ice = individual_conditional_expectation(op, Xc[:200], var_idx=[0, 1], instances=4, samples=8,
+                                                 random_seed=2, backend=be)
+        got[name] = (pd_, ice)
+    for j in range(4):
+        np.testing.assert_allclose(got["hip"][0]["pd"][j], got["oracle"][0]["pd"][j], rtol=0, atol=1e-12)
+    for j in (0, 1):
+        np.testing.assert_allclose(got["hip"][1]["ice"][j], got["oracle"][1]["ice"][j], rtol=0, atol=1e-12)
+    assert got["hip"][0]["reference"] == pytest.approx(got["oracle"][0]["reference"], abs=1e-12)
