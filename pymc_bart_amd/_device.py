@@ -35,6 +35,10 @@ class TorchHipMemory:
         t = self.torch.from_numpy(np.ascontiguousarray(arr))
         return t.to(self.device, non_blocking=False)
 
+    def is_resident(self, obj) -> bool:
+        """True for a float64 matrix that already lives in this GPU's HBM (a tensor from :meth:`from_host`)."""
+        return isinstance(obj, self.torch.Tensor) and obj.is_cuda and obj.dtype == self.torch.float64
+
     def empty(self, shape, dtype=np.float64):
         tdt = {np.float64: self.torch.float64, np.int32: self.torch.int32}[np.dtype(dtype).type]
         return self.torch.empty(shape, dtype=tdt, device=self.device)

@@ -92,78 +92,134 @@ __global__ void k_init_alpha(const double* prior, double max_prior, long long* a
 // out[d][k][row] = sum over the m trees of forest d of the leaf value reached by X[row,:]
 // (PosteriorSampler.sample_posterior, utils.py:66-69); excluded / NaN splits average both
 // subtrees by their training counts (CHANGELOG.md:410-411).  One thread per (row, forest).
+//
+// A traversal is a chain of dependent loads, so a node is ONE 32-byte record (packed on the host
+// per call: split variable, children as pool-wide indices, split rule and "excluded" folded into
+// flags, the split value and the training count) instead of a lookup in five arrays plus the rule
+// and exclusion tables: one memory round trip per level for the node and one for the row's value.
+struct PNode {
+  int32_t var;          // split variable, -1: leaf
+  int32_t left, right;  // pool-wide node indices
+  int32_t flags;        // bit 0: the split variable is excluded; bits 1..2: split rule
+  double split;
+  double cnt;           // training rows in the node (exact in a double)
+};
 struct PredTrees {
-  const int32_t* node_off;
-  const int32_t* var;
-  const double* split;
-  const int32_t* left;
-  const int32_t* right;
-  const long long* count;
-  const double* value;
-  // linear leaves (svar == nullptr: none)
-  const double* slope;
-  const double* xbar;
-  const int32_t* svar;
+  const PNode* node;      // [total_nodes]
+  const int32_t* root;    // [n_trees] pool-wide index of every tree's root
+  const double* value;    // [total_nodes][K]
+  // linear leaves (svar == nullptr: none); svar is -1 for constant leaves AND for excluded regressors
+  const double* slope;    // [total_nodes][K]
+  const double* xbar;     // [total_nodes]
+  const int32_t* svar;    // [total_nodes]
 };
 
-__global__ __launch_bounds__(BT) void k_predict(PredTrees T, const int32_t* forest_idx, int n_forests,
-                                                int m, int K, const double* __restrict__ X,
-                                                long long n_rows, int p, long long ldx,
-                                                const int32_t* rules, const uint8_t* excl,
-                                                double* out) {
-  const long long row = (long long)blockIdx.x * BT + threadIdx.x;
-  const int d = blockIdx.y;
+// The row's values: the threads of a wave own consecutive rows of a row-major matrix, so a read of
+// "my row, my split variable" touches 64 different cache lines per instruction -- that, not the node
+// chain, bounded the first version (44 G tree-traversals/s at cfg2).  LDSX: the wave first copies its
+// 64 rows (coalesced) into LDS, transposed [column][lane] with a pad of one; the traversal reads
+// from there.  One wave per workgroup; the workgroup loops over a share of the forests so that the
+// staged rows serve several.  (p <= PRED_LDS_MAXP: 64 KB of LDS; wider matrices use global reads.)
+#define PRED_BT 64
+#ifndef PRED_LDS_MAXP
+#define PRED_LDS_MAXP 126
+#endif
+// CONT: every column follows the ContinuousSplit rule (the usual case): one compare per level.
+template <bool LDSX, bool CONT>
+__global__ __launch_bounds__(PRED_BT) void k_predict(PredTrees T, const int32_t* __restrict__ forest_idx,
+                                                     int n_forests, int m, int K, int p,
+                                                     const double* __restrict__ X, long long n_rows,
+                                                     long long ldx, double* __restrict__ out) {
+  extern __shared__ double s_x[];  // LDSX: [p][65]
+  const int lane = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * PRED_BT;
+  const long long row = row0 + lane;
+  if constexpr (LDSX) {
+    const long long rows_here = n_rows - row0 < PRED_BT ? n_rows - row0 : PRED_BT;
+    if (ldx == p) {  // the block of rows is contiguous: fully coalesced copy
+      const double* __restrict__ src = X + row0 * ldx;
+      const int tot = (int)rows_here * p;
+      for (int i = lane; i < tot; i += PRED_BT) s_x[(i % p) * 65 + i / p] = src[i];
+    } else {
+      for (int r = 0; r < (int)rows_here; ++r)
+        for (int j = lane; j < p; j += PRED_BT) s_x[j * 65 + r] = X[(row0 + r) * ldx + j];
+    }
+    __syncthreads();
+  }
   if (row >= n_rows) return;
-  const double* x = X + row * ldx;
-  double acc[PGB_MAX_OUTPUTS];
-  for (int o = 0; o < K; ++o) acc[o] = 0.0;
+  const double* __restrict__ x = X + row * ldx;
+  auto xval = [&](int j) -> double {
+    if constexpr (LDSX) return s_x[j * 65 + lane];
+    else return x[j];
+  };
   int stk_node[PGB_MAX_DEPTH + 2];
   double stk_w[PGB_MAX_DEPTH + 2];
-  for (int t = 0; t < m; ++t) {
-    const int base = T.node_off[forest_idx[(size_t)d * m + t]];
-    int sp = 0;
-    stk_node[0] = 0;
-    stk_w[0] = 1.0;
-    sp = 1;
-    while (sp > 0) {
-      --sp;
-      int k = stk_node[sp];
-      double w = stk_w[sp];
+  for (int d = blockIdx.y; d < n_forests; d += gridDim.y) {
+    double acc[PGB_MAX_OUTPUTS];
+    for (int o = 0; o < K; ++o) acc[o] = 0.0;
+    // the root of the next tree is requested while this one is walked; the explicit stack (private
+    // memory) is touched only by walks that meet an excluded variable or a missing value
+    const int32_t* __restrict__ fi = forest_idx + (size_t)d * m;
+    int g_next = T.root[fi[0]];
+    for (int t = 0; t < m; ++t) {
+      int g = g_next;
+      if (t + 1 < m) g_next = T.root[fi[t + 1]];
+      double w = 1.0;
+      int sp = 0;
       for (;;) {
-        const int g = base + k;
-        const int j = T.var[g];
-        if (j < 0) {
+        // the record as two 16-byte words, requested together (a struct copy is split into per-field
+        // loads that the compiler sinks to their uses: three dependent round trips per level)
+        const uint4* __restrict__ np = (const uint4*)(T.node + g);
+        uint4 n0 = np[0], n1 = np[1];
+        // (an empty asm that "uses" all eight words: without it the loads are narrowed and sunk again)
+        asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));
+        PNode nd;
+        nd.var = (int32_t)n0.x; nd.left = (int32_t)n0.y; nd.right = (int32_t)n0.z; nd.flags = (int32_t)n0.w;
+        nd.split = __hiloint2double((int)n1.y, (int)n1.x);
+        bool done = false;  // this branch of the walk has ended
+        if (nd.var < 0) {
           int js = -1;  // linear leaf; a missing / excluded regressor: the mean
+          double xs = 0.0;
           if (T.svar != nullptr) {
             js = T.svar[g];
-            if (js >= 0 && (excl[js] || x[js] != x[js])) js = -1;
+            if (js >= 0) {
+              xs = xval(js);
+              if (xs != xs) js = -1;
+            }
           }
           for (int o = 0; o < K; ++o) {
             double vo = T.value[(size_t)g * K + o];
-            if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)g * K + o], T.xbar[g], x[js]);
+            if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)g * K + o], T.xbar[g], xs);
             acc[o] += w * vo;
           }
-          break;
+          done = true;
+        } else {
+          const double xv = xval(nd.var);
+          if ((nd.flags & 1) || xv != xv) {
+            const double cl = T.node[nd.left].cnt, cr = T.node[nd.right].cnt;
+            const double tot = cl + cr;
+            if (!(tot > 0.0)) {
+              done = true;
+            } else {  // depth-first, left first (same summation order as the oracle's recursion)
+              stk_node[sp] = nd.right;
+              stk_w[sp] = w * (cr / tot);
+              ++sp;
+              g = nd.left;
+              w = w * (cl / tot);
+            }
+          } else {
+            const bool gl = CONT ? xv <= nd.split : pgb_go_left(nd.flags >> 1, xv, nd.split) != 0;
+            g = gl ? nd.left : nd.right;
+          }
         }
-        const double xv = x[j];
-        if (excl[j] || xv != xv) {
-          const int l = T.left[g], r = T.right[g];
-          const double cl = (double)T.count[base + l], cr = (double)T.count[base + r];
-          const double tot = cl + cr;
-          if (!(tot > 0.0)) break;
-          // depth-first, left first (same summation order as the oracle's recursion)
-          stk_node[sp] = r;
-          stk_w[sp] = w * (cr / tot);
-          ++sp;
-          k = l;
-          w = w * (cl / tot);
-          continue;
+        if (done) {
+          if (sp == 0) break;
+          --sp;
+          g = stk_node[sp];
+          w = stk_w[sp];
         }
-        const bool gl = pgb_go_left(rules[j], xv, T.split[g]) != 0;
-        k = gl ? T.left[g] : T.right[g];
       }
     }
+    for (int o = 0; o < K; ++o) out[((size_t)d * K + o) * n_rows + row] = acc[o];
   }
-  for (int o = 0; o < K; ++o) out[((size_t)d * K + o) * n_rows + row] = acc[o];
 }
-

@@ -772,52 +772,77 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   std::vector<uint8_t> excl((size_t)p, 0);
   for (int e = 0; e < n_excluded; ++e)
     if (excluded_host[e] >= 0 && excluded_host[e] < p) excl[excluded_host[e]] = 1;
-  // one upload buffer: [node_off | var | left | right | rules | fidx] int32, then 8-byte arrays
-  size_t n_i32 = (size_t)(NT + 1) + 3 * (size_t)N + p + (size_t)n_forests * m;
-  size_t off8 = ((n_i32 * 4 + 7) / 8) * 8;
   const bool lin = trees->slope && trees->xbar && trees->svar;
-  // ... then, for linear leaves, slope / xbar (8-byte) and svar (int32) after the exclusion flags
-  const size_t off_lin = ((off8 + (size_t)N * 8 /*split*/ + (size_t)N * 8 /*count*/ + (size_t)N * K * 8 + p + 7) / 8) * 8;
-  size_t bytes = lin ? off_lin + (size_t)N * K * 8 + (size_t)N * 12 : off8 + (size_t)N * 16 + (size_t)N * K * 8 + p;
+  // one upload buffer: [PNode N | value N K | (slope N K | xbar N) | root NT | fidx | (svar N)]
+  const size_t o_val = (size_t)N * sizeof(PNode);
+  const size_t o_slope = o_val + (size_t)N * K * 8;
+  const size_t o_xbar = o_slope + (lin ? (size_t)N * K * 8 : 0);
+  const size_t o_root = o_xbar + (lin ? (size_t)N * 8 : 0);
+  const size_t o_f = o_root + (size_t)NT * 4;
+  const size_t o_svar = o_f + (size_t)n_forests * m * 4;
+  const size_t bytes = o_svar + (lin ? (size_t)N * 4 : 0);
   std::vector<uint8_t> hb(bytes);
-  int32_t* hi = (int32_t*)hb.data();
-  size_t o = 0;
-  memcpy(hi + o, trees->node_off, (NT + 1) * 4); size_t o_off = o; o += NT + 1;
-  memcpy(hi + o, trees->var, N * 4); size_t o_var = o; o += N;
-  memcpy(hi + o, trees->left, N * 4); size_t o_l = o; o += N;
-  memcpy(hi + o, trees->right, N * 4); size_t o_r = o; o += N;
-  memcpy(hi + o, rules_host, p * 4); size_t o_rules = o; o += p;
-  memcpy(hi + o, forest_tree_idx, (size_t)n_forests * m * 4); size_t o_f = o; o += (size_t)n_forests * m;
-  uint8_t* h8 = hb.data() + off8;
-  memcpy(h8, trees->split, (size_t)N * 8);
-  memcpy(h8 + (size_t)N * 8, trees->count, (size_t)N * 8);
-  memcpy(h8 + (size_t)N * 16, trees->value, (size_t)N * K * 8);
-  memcpy(h8 + (size_t)N * 16 + (size_t)N * K * 8, excl.data(), p);
-  if (lin) {
-    memcpy(hb.data() + off_lin, trees->slope, (size_t)N * K * 8);
-    memcpy(hb.data() + off_lin + (size_t)N * K * 8, trees->xbar, (size_t)N * 8);
-    memcpy(hb.data() + off_lin + (size_t)N * K * 8 + (size_t)N * 8, trees->svar, (size_t)N * 4);
+  PNode* hn = (PNode*)hb.data();
+  int32_t* hroot = (int32_t*)(hb.data() + o_root);
+  int32_t* hsvar = (int32_t*)(hb.data() + o_svar);
+  for (int t = 0; t < NT; ++t) {
+    const int base = trees->node_off[t], end = trees->node_off[t + 1];
+    hroot[t] = base;
+    for (int g = base; g < end; ++g) {
+      PNode z;
+      z.var = trees->var[g];
+      if (z.var >= p) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
+      z.left = z.var >= 0 ? base + trees->left[g] : -1;
+      z.right = z.var >= 0 ? base + trees->right[g] : -1;
+      z.flags = z.var >= 0 ? ((rules_host[z.var] << 1) | (excl[z.var] ? 1 : 0)) : 0;
+      z.split = trees->split[g];
+      z.cnt = (double)trees->count[g];
+      hn[g] = z;
+      if (lin) {
+        const int js = trees->svar[g];
+        hsvar[g] = (js >= 0 && js < p && !excl[js]) ? js : -1;
+      }
+    }
   }
+  memcpy(hb.data() + o_val, trees->value, (size_t)N * K * 8);
+  if (lin) {
+    memcpy(hb.data() + o_slope, trees->slope, (size_t)N * K * 8);
+    memcpy(hb.data() + o_xbar, trees->xbar, (size_t)N * 8);
+  }
+  memcpy(hb.data() + o_f, forest_tree_idx, (size_t)n_forests * m * 4);
   uint8_t* db = nullptr;
   HIPCHK(hipMalloc((void**)&db, bytes));
   hipError_t e = hipMemcpyAsync(db, hb.data(), bytes, hipMemcpyHostToDevice, sm);
   if (e != hipSuccess) { (void)hipFree(db); return fail_hip(e, "hipMemcpyAsync"); }
-  const int32_t* di = (const int32_t*)db;
   PredTrees T;
-  T.node_off = di + o_off;
-  T.var = di + o_var;
-  T.left = di + o_l;
-  T.right = di + o_r;
-  T.split = (const double*)(db + off8);
-  T.count = (const long long*)(db + off8 + (size_t)N * 8);
-  T.value = (const double*)(db + off8 + (size_t)N * 16);
-  T.slope = lin ? (const double*)(db + off_lin) : nullptr;
-  T.xbar = lin ? (const double*)(db + off_lin + (size_t)N * K * 8) : nullptr;
-  T.svar = lin ? (const int32_t*)(db + off_lin + (size_t)N * K * 8 + (size_t)N * 8) : nullptr;
-  const uint8_t* dexcl = db + off8 + (size_t)N * 16 + (size_t)N * K * 8;
-  dim3 grid((unsigned)((n_rows + BT - 1) / BT), (unsigned)n_forests);
-  hipLaunchKernelGGL(k_predict, grid, dim3(BT), 0, sm, T, di + o_f, n_forests, m, K, X_dev,
-                     (long long)n_rows, p, (long long)ldx, di + o_rules, dexcl, out_dev);
+  T.node = (const PNode*)db;
+  T.value = (const double*)(db + o_val);
+  T.slope = lin ? (const double*)(db + o_slope) : nullptr;
+  T.xbar = lin ? (const double*)(db + o_xbar) : nullptr;
+  T.root = (const int32_t*)(db + o_root);
+  T.svar = lin ? (const int32_t*)(db + o_svar) : nullptr;
+  // one wave per workgroup; enough workgroups to fill the chip, each looping over its share of forests
+  const long long gx = (n_rows + PRED_BT - 1) / PRED_BT;
+  long long want_wgs = p <= PRED_LDS_MAXP ? 16384 : 4096;  // measured at cfg2 (32 forests x 100k rows): 10.0 vs 11.7 ms
+  if (const char* ev = getenv("PGB_PRED_WGS")) want_wgs = atoll(ev) > 0 ? atoll(ev) : want_wgs;
+  long long gy = (want_wgs + gx - 1) / gx;
+  if (gy > n_forests) gy = n_forests;
+  if (gy < 1) gy = 1;
+  dim3 grid((unsigned)gx, (unsigned)gy);
+  bool cont = true;
+  for (int j = 0; j < p; ++j) cont = cont && rules_host[j] == PGB_RULE_CONTINUOUS;
+#define LAUNCH_PRED(L_, C_, LDS_)                                                                               \
+  hipLaunchKernelGGL((k_predict<L_, C_>), grid, dim3(PRED_BT), (LDS_), sm, T, (const int32_t*)(db + o_f), n_forests, \
+                     m, K, (int)p, X_dev, (long long)n_rows, (long long)ldx, out_dev)
+  const size_t lds = (size_t)p * 65 * sizeof(double);
+  if (p <= PRED_LDS_MAXP) {
+    if (cont) LAUNCH_PRED(true, true, lds);
+    else LAUNCH_PRED(true, false, lds);
+  } else {
+    if (cont) LAUNCH_PRED(false, true, 0);
+    else LAUNCH_PRED(false, false, 0);
+  }
+#undef LAUNCH_PRED
   e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(sm);
   (void)hipFree(db);

@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .utils import _decode_vi, _get_posterior_sampler, _sample_posterior
+from .utils import _decode_vi, _get_posterior_sampler, _resident_rows, _sample_posterior
 
 CI_PROB = 0.94  # ArviZ's default rcParams["stats.ci_prob"], used by the reference for the r2 interval
 
@@ -96,8 +96,10 @@ def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0,
     if method == "backward_VI" and not 1 <= fixed < p:
         raise ValueError("fixed must be greater than 0 and less than the number of variables")
 
+    rows = _resident_rows(sampler, X)  # O(p) .. O(p^2) sweeps over the same rows: uploaded once
+
     def predict(excluded):
-        return _sample_posterior(sampler, X=X, rng=rng, size=samples,
+        return _sample_posterior(sampler, X=rows, rng=rng, size=samples,
                                  excluded=None if excluded is None else list(excluded))
 
     full = predict(None)

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .utils import _get_posterior_sampler, _sample_posterior
+from .utils import _get_posterior_sampler, _resident_rows, _sample_posterior
 
 DEFAULT_QUANTILES = (0.05, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.95)  # upstream's default grid
 
@@ -67,11 +67,12 @@ def partial_dependence(bart, X, var_idx=None, xs_interval: str = "quantiles", xs
     sampler = _samplers(bart, backend)
     rng = np.random.default_rng(random_seed)
     grid = pdp_grid(Xm, xs_interval, xs_values)
+    rows = _resident_rows(sampler, grid)  # one upload for the sweep over the covariates
     out = {"x": {}, "pd": {}, "labels": {}, "reference": None}
     means = []
     for j in cols:
         others = [v for v in range(p) if v != j]
-        pd_j = _sample_posterior(sampler, X=grid, rng=rng, size=samples, excluded=others)
+        pd_j = _sample_posterior(sampler, X=rows, rng=rng, size=samples, excluded=others)
         if func is not None:
             pd_j = func(pd_j)
         out["x"][j] = grid[:, j]

@@ -273,12 +273,25 @@ class PosteriorSampler:
             self._backend = default_backend()
         return self._backend
 
-    def sample_posterior(self, X, draw_indices, excluded=None) -> np.ndarray:
+    def resident_rows(self, X):
+        """Upload ``X`` once; the returned handle is accepted by :meth:`sample_posterior` in place of the
+        matrix (backends without device memory hand the matrix back)."""
         be = self._get_backend()
         X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
         if X.ndim == 1:
             X = X[:, None]
-        n_rows, p = X.shape
+        return be.mem.from_host(X) if hasattr(be.mem, "is_resident") else X
+
+    def sample_posterior(self, X, draw_indices, excluded=None) -> np.ndarray:
+        be = self._get_backend()
+        # `X` may already be resident in HBM (``resident_rows``): sweeps that predict on the same rows
+        # again and again -- variable importance, partial dependence -- then upload them once
+        resident = getattr(be.mem, "is_resident", lambda a: False)(X)
+        if not resident:
+            X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+            if X.ndim == 1:
+                X = X[:, None]
+        n_rows, p = (int(v) for v in X.shape)
         rules = self.rules
         if rules.shape[0] < p:
             rules = np.concatenate([rules, np.zeros(p - rules.shape[0], np.int32)])
@@ -286,7 +299,7 @@ class PosteriorSampler:
         fidx = np.ascontiguousarray(self.forest_idx[idx], dtype=np.int32)
         excl = np.ascontiguousarray(np.asarray([] if excluded is None else excluded, dtype=np.int32))
         K = self._n_outputs
-        xd = be.mem.from_host(X)
+        xd = X if resident else be.mem.from_host(X)
         outd = be.mem.empty((fidx.shape[0] * K * n_rows,), np.float64)
         carr = self.pool.as_c()
         rc = be.lib.lib.pgb_predict(

@@ -63,12 +63,20 @@ def _sample_posterior(sampler, X, rng: np.random.Generator, size=None, excluded=
         lead = tuple(int(v) for v in size)
     n_pred = int(np.prod(lead, dtype=np.int64)) if lead else 1
     group = sampler if isinstance(sampler, list) else [sampler]
-    rows = np.ascontiguousarray(X, dtype=np.float64)
+    rows = X if not isinstance(X, (np.ndarray, list, tuple)) and hasattr(X, "data_ptr") \
+        else np.ascontiguousarray(X, dtype=np.float64)  # (a handle from _resident_rows passes through)
     picks = rng.integers(0, group[0].n_draws, size=n_pred).tolist()
     drop = None if excluded is None else [int(v) for v in excluded]
     blocks = [np.asarray(g.sample_posterior(rows, picks, drop)) for g in group]  # (n_pred, K_g, n_rows)
     stacked = blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=1)
     return np.moveaxis(stacked, 1, 2).reshape(lead + (stacked.shape[2], stacked.shape[1]))
+
+
+def _resident_rows(sampler, X):
+    """``X`` uploaded once for a sweep of predictions on the same rows (see
+    ``PosteriorSampler.resident_rows``); a list of samplers shares the handle of its first chain."""
+    first = sampler[0] if isinstance(sampler, list) else sampler
+    return first._chain_samplers[0].resident_rows(X)
 
 
 class _MultiChainSampler:
