@@ -104,9 +104,19 @@ struct PNode {
   double split;
   double cnt;           // training rows in the node (exact in a double)
 };
+// The same tree for the walk that needs no marginalisation (16 bytes, children tree-local): leaves
+// point at themselves with split = +inf, so a walk is exactly `depth` steps for every row -- no
+// leaf test, no divergence -- and ends on its leaf.
+struct FNode {
+  double split;
+  int32_t var;
+  uint8_t left, right;
+  uint16_t pad;
+};
 struct PredTrees {
   const PNode* node;      // [total_nodes]
-  const int32_t* root;    // [n_trees] pool-wide index of every tree's root
+  const FNode* fnode;     // [total_nodes]
+  const int2* root;       // [n_trees] {pool-wide index of the root, depth | 0x100 when the tree needs the general walk}
   const double* value;    // [total_nodes][K]
   // linear leaves (svar == nullptr: none); svar is -1 for constant leaves AND for excluded regressors
   const double* slope;    // [total_nodes][K]
@@ -152,6 +162,17 @@ __global__ __launch_bounds__(PRED_BT) void k_predict(PredTrees T, const int32_t*
     if constexpr (LDSX) return s_x[j * 65 + lane];
     else return x[j];
   };
+  // Rows without a missing value take the fixed-length walk through every tree that does not split
+  // on an excluded variable (decided per wave / per tree, so that the walk stays uniform).
+  bool clean = CONT;
+  if (CONT) {
+    bool nan = false;
+    for (int j = 0; j < p; ++j) {
+      const double v = xval(j);
+      nan = nan || v != v;
+    }
+    clean = __ballot(nan) == 0ull;
+  }
   int stk_node[PGB_MAX_DEPTH + 2];
   double stk_w[PGB_MAX_DEPTH + 2];
   for (int d = blockIdx.y; d < n_forests; d += gridDim.y) {
@@ -160,10 +181,30 @@ __global__ __launch_bounds__(PRED_BT) void k_predict(PredTrees T, const int32_t*
     // the root of the next tree is requested while this one is walked; the explicit stack (private
     // memory) is touched only by walks that meet an excluded variable or a missing value
     const int32_t* __restrict__ fi = forest_idx + (size_t)d * m;
-    int g_next = T.root[fi[0]];
+    int2 r_next = T.root[fi[0]];
     for (int t = 0; t < m; ++t) {
-      int g = g_next;
-      if (t + 1 < m) g_next = T.root[fi[t + 1]];
+      const int2 rt = r_next;
+      if (t + 1 < m) r_next = T.root[fi[t + 1]];
+      if (clean && !(rt.y & 0x100)) {
+        const uint4* __restrict__ fn = (const uint4*)(T.fnode + rt.x);
+        int gl = 0;
+        for (int l = 0; l < rt.y; ++l) {
+          uint4 q = fn[gl];
+          asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));  // one 16-byte load, not three sunk ones
+          const double xv = xval((int)q.z);
+          gl = xv <= __hiloint2double((int)q.y, (int)q.x) ? (int)(q.w & 255u) : (int)((q.w >> 8) & 255u);
+        }
+        const int gg = rt.x + gl;
+        int js = -1;
+        if (T.svar != nullptr) js = T.svar[gg];
+        for (int o = 0; o < K; ++o) {
+          double vo = T.value[(size_t)gg * K + o];
+          if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)gg * K + o], T.xbar[gg], xval(js));
+          acc[o] += vo;  // (the general walk adds 1.0 * vo: the same bits)
+        }
+        continue;
+      }
+      int g = rt.x;
       double w = 1.0;
       int sp = 0;
       for (;;) {

@@ -773,21 +773,40 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   for (int e = 0; e < n_excluded; ++e)
     if (excluded_host[e] >= 0 && excluded_host[e] < p) excl[excluded_host[e]] = 1;
   const bool lin = trees->slope && trees->xbar && trees->svar;
-  // one upload buffer: [PNode N | value N K | (slope N K | xbar N) | root NT | fidx | (svar N)]
-  const size_t o_val = (size_t)N * sizeof(PNode);
+  // one upload buffer: [PNode N | FNode N | value N K | (slope N K | xbar N) | root NT | fidx | (svar N)]
+  const size_t o_fn = (size_t)N * sizeof(PNode);
+  const size_t o_val = o_fn + (size_t)N * sizeof(FNode);
   const size_t o_slope = o_val + (size_t)N * K * 8;
   const size_t o_xbar = o_slope + (lin ? (size_t)N * K * 8 : 0);
   const size_t o_root = o_xbar + (lin ? (size_t)N * 8 : 0);
-  const size_t o_f = o_root + (size_t)NT * 4;
+  const size_t o_f = o_root + (size_t)NT * sizeof(int2);
   const size_t o_svar = o_f + (size_t)n_forests * m * 4;
   const size_t bytes = o_svar + (lin ? (size_t)N * 4 : 0);
   std::vector<uint8_t> hb(bytes);
   PNode* hn = (PNode*)hb.data();
-  int32_t* hroot = (int32_t*)(hb.data() + o_root);
+  FNode* hf = (FNode*)(hb.data() + o_fn);
+  int2* hroot = (int2*)(hb.data() + o_root);
+  std::vector<int> depth_of;
   int32_t* hsvar = (int32_t*)(hb.data() + o_svar);
   for (int t = 0; t < NT; ++t) {
     const int base = trees->node_off[t], end = trees->node_off[t + 1];
-    hroot[t] = base;
+    // depth of the tree and whether it can take the fixed-length walk (<= 255 nodes, children after
+    // their parent as both backends build them, no split on an excluded variable)
+    const int nn = end - base;
+    bool general = nn > 255 || nn < 1;
+    int depth = 0;
+    depth_of.assign((size_t)(nn > 0 ? nn : 1), 0);
+    for (int k = 0; k < nn && !general; ++k) {
+      const int g = base + k;
+      if (trees->var[g] < 0) continue;
+      const int l = trees->left[g], r = trees->right[g];
+      if (l <= k || r <= k || l >= nn || r >= nn) { general = true; break; }
+      if (trees->var[g] < p && excl[trees->var[g]]) general = true;
+      depth_of[l] = depth_of[r] = depth_of[k] + 1;
+      if (depth_of[k] + 1 > depth) depth = depth_of[k] + 1;
+    }
+    if (depth > 255) general = true;
+    hroot[t] = make_int2(base, general ? 0x100 : depth);
     for (int g = base; g < end; ++g) {
       PNode z;
       z.var = trees->var[g];
@@ -798,6 +817,14 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
       z.split = trees->split[g];
       z.cnt = (double)trees->count[g];
       hn[g] = z;
+      FNode f;
+      f.pad = 0;
+      if (z.var >= 0 && !general) {
+        f.split = z.split; f.var = z.var; f.left = (uint8_t)trees->left[g]; f.right = (uint8_t)trees->right[g];
+      } else {  // a leaf points at itself: x <= +inf for every value that is not NaN
+        f.split = __builtin_inf(); f.var = 0; f.left = f.right = (uint8_t)((g - base) & 255);
+      }
+      hf[g] = f;
       if (lin) {
         const int js = trees->svar[g];
         hsvar[g] = (js >= 0 && js < p && !excl[js]) ? js : -1;
@@ -819,7 +846,8 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   T.value = (const double*)(db + o_val);
   T.slope = lin ? (const double*)(db + o_slope) : nullptr;
   T.xbar = lin ? (const double*)(db + o_xbar) : nullptr;
-  T.root = (const int32_t*)(db + o_root);
+  T.fnode = (const FNode*)(db + o_fn);
+  T.root = (const int2*)(db + o_root);
   T.svar = lin ? (const int32_t*)(db + o_svar) : nullptr;
   // one wave per workgroup; enough workgroups to fill the chip, each looping over its share of forests
   const long long gx = (n_rows + PRED_BT - 1) / PRED_BT;

@@ -424,3 +424,33 @@ def test_partial_dependence_sweep_on_gpu_matches_the_oracle(hip, oracle):
     for j in (0, 1):
         np.testing.assert_allclose(got["hip"][1]["ice"][j], got["oracle"][1]["ice"][j], rtol=0, atol=1e-12)
     assert got["hip"][0]["reference"] == pytest.approx(got["oracle"][0]["reference"], abs=1e-12)
+
+
+def test_prediction_kernel_paths_agree_with_the_oracle(hip, oracle):
+    """k_predict has a fixed-length walk (rows without missing values, trees without excluded
+    variables) and a general walk, rows staged in LDS (p <= 126) or read from HBM (wider): every
+    combination gives the oracle's sums."""
+    rng = np.random.default_rng(17)
+    for p, rules_kind in ((5, "cont"), (150, "cont"), (6, "mixed")):
+        n = 1500
+        X = rng.normal(size=(n, p))
+        rules = np.zeros(p, np.int32)
+        if rules_kind == "mixed":
+            X[:, 1] = rng.integers(0, 4, n)
+            rules[1] = 1
+        Y = X[:, 0] - 2 * (X[:, p - 1] > 0) + rng.normal(0, 0.3, n)
+        st = PyBartSettings.from_data(X, Y, m=12, num_particles=8, seed=5)
+        out = {}
+        for name, be in (("hip", hip), ("oracle", oracle)):
+            s = PySampler(st, X, Y, rules, np.ones(p), backend=be)
+            s.set_likelihood([0.5])
+            for it in range(12):
+                s.step(it < 8)
+            forest = s.export_trees(1)
+            ps = PosteriorSampler(forest, np.arange(12, dtype=np.int32)[None, :], 12, 1, rules, backend=be)
+            Xn = X[:700].copy()
+            Xn[100:140:3, 0] = np.nan                      # some waves carry missing values, others do not
+            out[name] = (ps.sample_posterior(X, [0]), ps.sample_posterior(Xn, [0]),
+                         ps.sample_posterior(Xn, [0], excluded=[0]), ps.sample_posterior(X[:65], [0], excluded=[p - 1]))
+        for a, b in zip(out["hip"], out["oracle"]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
