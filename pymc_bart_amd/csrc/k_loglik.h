@@ -17,6 +17,48 @@ struct LJobT {
   double sLx[MK && LIN ? KXMAX : 1], sRx[MK && LIN ? KXMAX : 1];  // ... slopes of outputs 1..K-1
 };
 
+// Categorical-softmax with K known at compile time: pgb_loglik_cat's arithmetic with K - 1
+// exponentials instead of K.  The largest predictor contributes exp(0), which pgb_exp returns as
+// exactly 1.0, so the K - 1 other differences are gathered (selects), exponentiated, and put back
+// in output order for the same serial sum: the same bits.  Falls back to the spec routine when no
+// difference is exactly 0 (a NaN predictor).
+template <int KC>
+__device__ __forceinline__ double loglik_cat_fast(double y, const double* mu) {
+  double mx = mu[0];
+#pragma unroll
+  for (int k = 1; k < KC; ++k)
+    if (mu[k] > mx) mx = mu[k];
+  double dd[KC];
+  int imax = -1;
+#pragma unroll
+  for (int k = KC - 1; k >= 0; --k) {
+    dd[k] = mu[k] - mx;
+    if (dd[k] == 0.0) imax = k;  // the first maximum
+  }
+  if (imax < 0) return pgb_loglik_cat(KC, y, mu);
+  double ee[KC - 1];
+#pragma unroll
+  for (int j = 0; j < KC - 1; ++j) ee[j] = pgb_exp(j >= imax ? dd[j + 1] : dd[j]);
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    double ek = 1.0;
+    if (k != imax) ek = k > imax ? ee[k > 0 ? k - 1 : 0] : ee[k < KC - 1 ? k : 0];
+    sum += ek;
+  }
+  int c = (int)y;
+  if (c < 0) c = 0;
+  if (c > KC - 1) c = KC - 1;
+  double muc = mu[0];
+#pragma unroll
+  for (int k = 1; k < KC; ++k)
+    if (c == k) muc = mu[k];
+  double ll = (muc - mx) - pgb_log(sum);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 0.0) ll = 0.0;
+  return ll;
+}
+
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
 // FAM: the likelihood family when known at compile time (single-output kernels: the per-row
 // evaluation then contains one family's code only), -1: read S.family.
@@ -195,7 +237,13 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
                   if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
                 mu[k] = noi[(size_t)k * S.n_pad + base + e] + vk;
               }
-            const long long q = pgb_quant(pgb_loglik(S.family, K, yv[e], mu), cl, &sat);
+            double llv;
+            if constexpr (KT >= 2) {
+              llv = S.family == PGB_FAMILY_CATEGORICAL ? loglik_cat_fast<KT>(yv[e], mu) : pgb_loglik(S.family, K, yv[e], mu);
+            } else {
+              llv = pgb_loglik(S.family, K, yv[e], mu);
+            }
+            const long long q = pgb_quant(llv, cl, &sat);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
         }
