@@ -184,7 +184,9 @@ PGB_HD double pgb_exp(double x) {
   if (x > 700.0) x = 700.0;
   if (x < -700.0) x = -700.0;
   double kf = x * 1.4426950408889634074; /* 1/ln2 */
-  kf = (kf >= 0.0) ? (double)(int64_t)(kf + 0.5) : (double)(int64_t)(kf - 0.5);
+  /* |kf| <= 1010 after the clamp: 32-bit conversions give the same integers as 64-bit ones and are
+   * single instructions on the GPU (f64 <-> i64 is emulated there) */
+  kf = (kf >= 0.0) ? (double)(int32_t)(kf + 0.5) : (double)(int32_t)(kf - 0.5);
   double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
   double p = 1.6059043836821613e-10;      /* 1/13! */
   p = PGB_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
@@ -200,8 +202,8 @@ PGB_HD double pgb_exp(double x) {
   p = PGB_FMA(p, r, 0.5);
   p = PGB_FMA(p, r, 1.0);
   p = PGB_FMA(p, r, 1.0);
-  int64_t k = (int64_t)kf;
-  double scale = pgb_u2d((uint64_t)(k + 1023) << 52);
+  int32_t k = (int32_t)kf;
+  double scale = pgb_u2d((uint64_t)(uint32_t)(k + 1023) << 52);
   return p * scale;
 }
 
@@ -212,11 +214,11 @@ PGB_HD double pgb_log(double x) {
   if (!(x == x)) return x;
   if (!(x > 0.0)) return -1.0e300;
   uint64_t b = pgb_d2u(x);
-  int64_t e = (int64_t)((b >> 52) & 0x7FF) - 1023;
+  int32_t e = (int32_t)((b >> 52) & 0x7FF) - 1023; /* (32-bit: see pgb_exp) */
   if (e == -1023) { /* subnormal: rescale */
     x = x * 4503599627370496.0;
     b = pgb_d2u(x);
-    e = (int64_t)((b >> 52) & 0x7FF) - 1023 - 52;
+    e = (int32_t)((b >> 52) & 0x7FF) - 1023 - 52;
   }
   double m = pgb_u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
   if (m > 1.4142135623730951) {
