@@ -454,3 +454,19 @@ def test_prediction_kernel_paths_agree_with_the_oracle(hip, oracle):
                          ps.sample_posterior(Xn, [0], excluded=[0]), ps.sample_posterior(X[:65], [0], excluded=[p - 1]))
         for a, b in zip(out["hip"], out["oracle"]):
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+
+
+def test_prediction_rejects_a_matrix_narrower_than_the_trees(hip):
+    """A tree that splits on column j cannot be evaluated on a matrix with fewer than j + 1 columns:
+    the library says so instead of reading past the rows."""
+    from pymc_bart_amd import _abi
+
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(400, 4))
+    Y = 3.0 * X[:, 3] + rng.normal(0, 0.1, 400)
+    op = BARTOp(X, Y, m=5)
+    sample_chain(op, tune=10, draws=3, num_particles=8, random_seed=1, sigma=0.3, backend=hip)
+    s = _get_posterior_sampler(op, backend=hip)
+    assert _sample_posterior(s, X, np.random.default_rng(0), size=2).shape == (2, 400, 1)
+    with pytest.raises(_abi.PGBError, match="column"):
+        _sample_posterior(s, X[:, :2], np.random.default_rng(0), size=2)
