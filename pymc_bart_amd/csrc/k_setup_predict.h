@@ -131,6 +131,9 @@ struct PredTrees {
 // from there.  One wave per workgroup; the workgroup loops over a share of the forests so that the
 // staged rows serve several.  (p <= PRED_LDS_MAXP: 64 KB of LDS; wider matrices use global reads.)
 #define PRED_BT 64
+#ifndef PRED_WALKS
+#define PRED_WALKS 4 /* interleaved fixed-length walks per lane */
+#endif
 #ifndef PRED_LDS_MAXP
 #define PRED_LDS_MAXP 126
 #endif
@@ -178,13 +181,64 @@ __global__ __launch_bounds__(PRED_BT) void k_predict(PredTrees T, const int32_t*
   for (int d = blockIdx.y; d < n_forests; d += gridDim.y) {
     double acc[PGB_MAX_OUTPUTS];
     for (int o = 0; o < K; ++o) acc[o] = 0.0;
-    // the root of the next tree is requested while this one is walked; the explicit stack (private
-    // memory) is touched only by walks that meet an excluded variable or a missing value
+    // Trees are taken PRED_WALKS at a time when all of them qualify for the fixed-length walk: that
+    // many independent chains of (node, value) loads per lane; the roots of the next group are
+    // requested before the current group is walked.  Otherwise one tree at a time (the explicit
+    // stack -- private memory -- is touched only by walks that marginalise).
     const int32_t* __restrict__ fi = forest_idx + (size_t)d * m;
-    int2 r_next = T.root[fi[0]];
+    int2 rnx[PRED_WALKS];
+    bool have_nx = false;
     for (int t = 0; t < m; ++t) {
-      const int2 rt = r_next;
-      if (t + 1 < m) r_next = T.root[fi[t + 1]];
+      if (clean && t + PRED_WALKS <= m) {
+        int2 rw[PRED_WALKS];
+        int any_general = 0;
+#pragma unroll
+        for (int w = 0; w < PRED_WALKS; ++w) {
+          rw[w] = have_nx ? rnx[w] : T.root[fi[t + w]];
+          any_general |= rw[w].y & 0x100;
+        }
+        have_nx = false;
+        if (!any_general) {
+          if (t + 2 * PRED_WALKS <= m) {
+#pragma unroll
+            for (int w = 0; w < PRED_WALKS; ++w) rnx[w] = T.root[fi[t + PRED_WALKS + w]];
+            have_nx = true;
+          }
+          int steps = 0, gw[PRED_WALKS];
+#pragma unroll
+          for (int w = 0; w < PRED_WALKS; ++w) {
+            steps = rw[w].y > steps ? rw[w].y : steps;  // a finished walk idles on its leaf
+            gw[w] = 0;
+          }
+          for (int l = 0; l < steps; ++l) {
+            uint4 q[PRED_WALKS];
+#pragma unroll
+            for (int w = 0; w < PRED_WALKS; ++w) q[w] = ((const uint4*)(T.fnode + rw[w].x))[gw[w]];
+#pragma unroll
+            for (int w = 0; w < PRED_WALKS; ++w)
+              asm volatile("" : "+v"(q[w].x), "+v"(q[w].y), "+v"(q[w].z), "+v"(q[w].w));  // whole 16-byte loads
+#pragma unroll
+            for (int w = 0; w < PRED_WALKS; ++w) {
+              const double xv = xval((int)q[w].z);
+              gw[w] = xv <= __hiloint2double((int)q[w].y, (int)q[w].x) ? (int)(q[w].w & 255u) : (int)((q[w].w >> 8) & 255u);
+            }
+          }
+#pragma unroll
+          for (int w = 0; w < PRED_WALKS; ++w) {  // tree t first, then t + 1, ...: the order of the plain loop
+            const int hg = rw[w].x + gw[w];
+            int js = -1;
+            if (T.svar != nullptr) js = T.svar[hg];
+            for (int o = 0; o < K; ++o) {
+              double vo = T.value[(size_t)hg * K + o];
+              if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)hg * K + o], T.xbar[hg], xval(js));
+              acc[o] += vo;  // (the general walk adds 1.0 * vo: the same bits)
+            }
+          }
+          t += PRED_WALKS - 1;
+          continue;
+        }
+      }
+      const int2 rt = T.root[fi[t]];
       if (clean && !(rt.y & 0x100)) {
         const uint4* __restrict__ fn = (const uint4*)(T.fnode + rt.x);
         int gl = 0;
@@ -200,7 +254,7 @@ __global__ __launch_bounds__(PRED_BT) void k_predict(PredTrees T, const int32_t*
         for (int o = 0; o < K; ++o) {
           double vo = T.value[(size_t)gg * K + o];
           if (js >= 0) vo = pgb_leaf_pred(vo, T.slope[(size_t)gg * K + o], T.xbar[gg], xval(js));
-          acc[o] += vo;  // (the general walk adds 1.0 * vo: the same bits)
+          acc[o] += vo;
         }
         continue;
       }
