@@ -398,7 +398,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             f.n_leaves = j.h_n_leaves + 1;
           }
         }
-        if constexpr (MK) {
+        if constexpr (MK && LIN) {  // (constant leaves: waves 1..3 do this, see below)
           if (j.active)
           for (int k = 0; k < KX; ++k) {
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
@@ -438,6 +438,30 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       if (tid == 0) {
         s_i[0] = stop ? 1 : 0;
         s_i[1] = pick;
+      }
+    }
+    if constexpr (MK && !LIN) {
+      // K-vector leaves: the children's values of outputs 1..K-1 (a Philox draw, a Box-Muller pair and
+      // two leaf values each) are independent of everything wave 0 does above, so waves 1..3 compute
+      // them meanwhile -- output k on wave 1 + k % 3, old particle q on lane q -- instead of wave 0
+      // doing K - 1 of those chains one after the other.  Same routine, same inputs.
+      if (tid >= 64) {
+        const int wv = tid >> 6, q = tid & 63;
+        if (q >= 1 && q < P && JP[q].active) {
+          unsigned long long cnts = 0;
+#pragma unroll
+          for (int cpy = 0; cpy < ACC_SLOTS; ++cpy)
+            cnts += S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER + cpy * ACC_STRIDE].cnts;
+          const int cL = (int)(cnts & 0xFFFFFFFFull), cN = (int)(cnts >> 32), cR = JP[q].cnt - cL - cN;
+          const int ok = (JP[q].rule != PGB_RULE_CONTINUOUS && cR == 0) ? -1 : 1;  // as child_values decides
+          for (int k = wv - 1; k < KX; k += 3) {
+            const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            s_finx[q][k] = child_values_x(S, ok, cL, cR, load_accx(S.accx, par ^ 1, q, k),
+                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
+                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
+          }
+        }
       }
     }
     __syncthreads();
