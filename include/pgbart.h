@@ -67,6 +67,7 @@ typedef struct {
   int64_t rounds;         /* SMC rounds                                          */
   int64_t saturations;    /* fixed-point saturation events (should stay 0)       */
   int64_t slots;          /* backend-specific: kernel slots consumed             */
+  int64_t partitions;     /* executed split partitions (grow attempts that found a split value) */
 } pgb_counters;
 
 /* SoA tree storage: the counterpart of bartrs' TreeArrays (pymc_bart/pymc_bart.py:2).
@@ -131,8 +132,18 @@ int pgb_set_likelihood(pgb_handle* h, const double* params_host, int32_t n_param
 int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi_counts_host_out,
              pgb_counters* counters_out);
 
-/* Asynchronous variant for throughput runs: enqueue `n_steps` steps and return;
- * pgb_sync waits for them and fills the counters.                               */
+/* The same astep with HOST outputs -- what PGBART.astep hands back to PyMC's trace (SURVEY.md 8a
+ * a2: sum_trees (K,n) device->host per step): sum_trees_host_out receives K*n doubles (pinned
+ * memory makes the copy a single DMA; pageable memory works), vi / counters as in pgb_step.  The
+ * trees this step re-sampled are fetched in the same device->host transaction, so a following
+ * pgb_export_trees(h, 0, ...) is served from host memory without touching the device.           */
+int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host_out, int32_t* vi_counts_host_out,
+                  pgb_counters* counters_out);
+
+/* Asynchronous variant for throughput runs: pgb_step_async starts `n_steps` asteps and RETURNS
+ * while they run (a worker thread owned by the handle feeds the device state machine; CPU backends
+ * may run them before returning); pgb_sync waits for them, reports their error if any and fills
+ * the counters.  Every other call on the handle waits for a running job first.                 */
 int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps);
 int pgb_sync(pgb_handle* h, pgb_counters* counters_out);
 
@@ -164,6 +175,11 @@ int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* l
  * first reading of any workgroup (the interval a kernel trace reports); valid after
  * pgb_profile(h, 0, ...).  CPU backends report 0. */
 int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out);
+/* Per-kernel view of the last profiled region (valid after pgb_profile(h, 0, ...)): which = 0 the
+ * control kernel, 1 the row pass, 2 the per-row log-likelihood pass, 3 the fused slot kernel.
+ * Total event time, launches, and the workgroups of one launch.  CPU backends report 0.          */
+int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int64_t* launches_out,
+                       int32_t* workgroups_out);
 
 /* Checkpoint / resume of one chain (what pickling the reference's step method into a PyMC worker
  * process carries: reference SURVEY 8b "must be picklable"; tree hand-off bart.py:134-135).

@@ -501,6 +501,7 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   }
   if (!found) return;
   h->ctr.rows_touched += nd.cnt;
+  h->ctr.partitions += 1;
   int rule = h->rules[j];
   /* stable partition of the sorted segment; NaN rows fall in neither child [U] */
   int64_t offL = arena_alloc(h, nd.cnt);
@@ -834,6 +835,12 @@ int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_out, int32_t* vi_out
   return PGB_OK;
 }
 
+/* host outputs: on this backend "device" memory is host memory, so the two calls coincide */
+int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_out, int32_t* vi_out,
+                  pgb_counters* counters_out) {
+  return pgb_step(h, tune, sum_trees_out, vi_out, counters_out);
+}
+
 int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   for (int i = 0; i < n_steps; ++i) {
@@ -945,6 +952,25 @@ static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const doubl
   }
 }
 
+/* A malformed history (truncated file, mismatched m) must be an error, not an out-of-bounds walk:
+ * 1 = forest index outside the tree list, 2 = inconsistent node arrays, 3 = split column >= p. */
+static int pgb_validate_forest(const pgb_tree_arrays* T, const int32_t* fidx, int32_t n_forests, int32_t m,
+                               int32_t p) {
+  for (int64_t i = 0; i < (int64_t)n_forests * m; ++i)
+    if (fidx[i] < 0 || fidx[i] >= T->n_trees) return 1;
+  if (T->n_trees < 0 || T->total_nodes < 0) return 2;
+  for (int t = 0; t < T->n_trees; ++t) {
+    const int base = T->node_off[t], end = T->node_off[t + 1];
+    if (base < 0 || end <= base || end > T->total_nodes) return 2;
+    for (int g = base; g < end; ++g) {
+      if (T->var[g] < 0) continue;
+      if (T->var[g] >= p) return 3;
+      if (T->left[g] < 0 || T->right[g] < 0 || T->left[g] >= end - base || T->right[g] >= end - base) return 2;
+    }
+  }
+  return 0;
+}
+
 int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
                 int32_t m, const double* X, int64_t n_rows, int32_t p, int64_t ldx,
                 const int32_t* rules, const int32_t* excluded, int32_t n_excluded, double* out,
@@ -953,6 +979,12 @@ int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, in
   if (!trees || !forest_tree_idx || !X || !out || !rules)
     return fail(PGB_E_INVALID, "null argument");
   int K = trees->n_outputs;
+  {
+    int vrc = pgb_validate_forest(trees, forest_tree_idx, n_forests, m, p);
+    if (vrc == 1) return fail(PGB_E_INVALID, "forest_tree_idx entry outside [0, n_trees)");
+    if (vrc == 2) return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
+    if (vrc == 3) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
+  }
   uint8_t* excl = (uint8_t*)calloc(p, 1);
   for (int e = 0; e < n_excluded; ++e)
     if (excluded[e] >= 0 && excluded[e] < p) excl[excluded[e]] = 1;
@@ -982,6 +1014,16 @@ int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_ou
   (void)h;
   if (kernel_ms_out) *kernel_ms_out = 0.0;
   if (launches_out) *launches_out = 0;
+  return PGB_OK;
+}
+
+int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int64_t* launches_out,
+                       int32_t* workgroups_out) {
+  (void)h;
+  (void)which;
+  if (kernel_ms_out) *kernel_ms_out = 0.0;
+  if (launches_out) *launches_out = 0;
+  if (workgroups_out) *workgroups_out = 0;
   return PGB_OK;
 }
 

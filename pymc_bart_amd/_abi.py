@@ -62,6 +62,7 @@ SYMBOLS = (
     "pgb_set_offset",
     "pgb_set_likelihood",
     "pgb_step",
+    "pgb_step_host",
     "pgb_step_async",
     "pgb_sync",
     "pgb_export_trees",
@@ -70,6 +71,7 @@ SYMBOLS = (
     "pgb_predict",
     "pgb_profile",
     "pgb_profile_clock",
+    "pgb_profile_kernel",
     "pgb_checkpoint_size",
     "pgb_checkpoint_save",
     "pgb_checkpoint_load",
@@ -107,6 +109,7 @@ class Counters(C.Structure):
         ("rounds", C.c_int64),
         ("saturations", C.c_int64),
         ("slots", C.c_int64),
+        ("partitions", C.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -163,6 +166,7 @@ class PGBLibrary:
         lib.pgb_set_offset.argtypes = [vp, vp]
         lib.pgb_set_likelihood.argtypes = [vp, vp, C.c_int32]
         lib.pgb_step.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
+        lib.pgb_step_host.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]
         lib.pgb_sync.argtypes = [vp, C.POINTER(Counters)]
         lib.pgb_export_trees.argtypes = [vp, C.c_int32, C.POINTER(TreeArraysC)]
@@ -174,6 +178,8 @@ class PGBLibrary:
         ]
         lib.pgb_profile.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.pgb_profile_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.pgb_profile_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32)]
         lib.pgb_checkpoint_size.argtypes = [vp, C.POINTER(C.c_int64)]
         lib.pgb_checkpoint_save.argtypes = [vp, vp, C.c_int64]
         lib.pgb_checkpoint_load.argtypes = [vp, vp, C.c_int64]

@@ -43,6 +43,12 @@ class TorchHipMemory:
         tdt = {np.float64: self.torch.float64, np.int32: self.torch.int32}[np.dtype(dtype).type]
         return self.torch.empty(shape, dtype=tdt, device=self.device)
 
+    def host_result(self, n: int) -> np.ndarray:
+        """A float64 host array the GPU can DMA into directly: page-locked memory from torch's
+        caching host allocator (recycled once the array is dropped, so steady-state cost is a free-list
+        pop), handed out as a plain ndarray that owns a reference to its storage."""
+        return self.torch.empty((int(n),), dtype=self.torch.float64, pin_memory=True).numpy()
+
     @staticmethod
     def ptr(buf) -> int:
         return int(buf.data_ptr())

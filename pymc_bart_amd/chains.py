@@ -51,6 +51,7 @@ def sample_chain(op: BARTOp, tune: int, draws: int, num_particles: int = 10, ran
             vi_stats.append(stats[0]["variable_inclusion"])
     p = step.num_variates
     vi = np.array([_decode_vi(s, p) for s in vi_stats], dtype=np.int64).reshape(-1, p)
+    step.flush_history()
     return {
         "chain": chain,
         "mu": mu_draws,
@@ -114,7 +115,9 @@ def gather_chains(result: dict, dist=None, dst: int = 0):
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    dense = torch.from_numpy(np.concatenate([result["mu"], result["sigma"][:, None]], axis=1)).to(dev)
+    # keep_draws=False: only sigma travels densely
+    mu = result["mu"] if result["mu"] is not None else np.empty((result["sigma"].shape[0], 0))
+    dense = torch.from_numpy(np.concatenate([mu, result["sigma"][:, None]], axis=1)).to(dev)
     parts = [torch.empty_like(dense) for _ in range(world)]
     dist.all_gather(parts, dense)
     small = {k: result[k] for k in ("chain", "variable_inclusion", "vi_counts", "history", "counters")}
@@ -126,7 +129,7 @@ def gather_chains(result: dict, dist=None, dst: int = 0):
     for r in range(world):
         d = parts[r].cpu().numpy()
         item = dict(gathered[r])
-        item["mu"] = d[:, :-1]
+        item["mu"] = d[:, :-1] if result["mu"] is not None else None
         item["sigma"] = d[:, -1]
         out.append(item)
     return out

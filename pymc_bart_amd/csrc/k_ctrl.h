@@ -961,6 +961,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       job.p_value = nd.value;
       job.p_depth = nd.depth;
       atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
+      atomicAdd(&S.counters[6], 1ull);
       if constexpr (MK)
       for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
         long long pq;

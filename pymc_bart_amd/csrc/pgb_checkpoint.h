@@ -25,12 +25,14 @@ static long long ckpt_payload(const pgb_handle* h, long long* n_allocs) {
 
 extern "C" int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out) {
   if (!h || !bytes_out) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   *bytes_out = (int64_t)sizeof(CkptHeader) + ckpt_payload(h, nullptr);
   return PGB_OK;
 }
 
 extern "C" int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes) {
   if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   CkptHeader hd;
   memset(&hd, 0, sizeof hd);
@@ -64,6 +66,7 @@ extern "C" int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes)
 
 extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
   if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   if (bytes < (int64_t)sizeof(CkptHeader)) return fail(PGB_E_INVALID, "checkpoint truncated");
   CkptHeader hd;
@@ -101,12 +104,15 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
 
 extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
-  if (kernel_ms_out) *kernel_ms_out = h->prof_ms;
-  if (launches_out) *launches_out = h->prof_launches;
+  JOIN_ASYNC(h);
+  if (kernel_ms_out) *kernel_ms_out = h->prof_ms[PK_ROWS] + h->prof_ms[PK_SLOT];
+  if (launches_out) *launches_out = h->prof_launches[PK_ROWS] + h->prof_launches[PK_SLOT];
   if (enable && !h->prof) {
-    h->prof_ms = 0.0;
-    h->prof_launches = 0;
-    h->ev_used = 0;
+    for (int k = 0; k < PK_COUNT; ++k) {
+      h->prof_ms[k] = 0.0;
+      h->prof_launches[k] = 0;
+      h->ev_used[k] = 0;
+    }
     h->prof_clock_ms = 0.0;
     h->prof_clock_launches = 0;
     h->prof_slot0 = h->slot;
@@ -152,8 +158,20 @@ extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out,
 // max(last reading of a workgroup) - min(first reading), and the number of launches seen.
 extern "C" int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
   if (kernel_ms_out) *kernel_ms_out = h->prof_clock_ms;
   if (launches_out) *launches_out = h->prof_clock_launches;
+  return PGB_OK;
+}
+
+extern "C" int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int64_t* launches_out,
+                                  int32_t* workgroups_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
+  if (which < 0 || which >= PK_COUNT) return fail(PGB_E_INVALID, "unknown kernel");
+  if (kernel_ms_out) *kernel_ms_out = h->prof_ms[which];
+  if (launches_out) *launches_out = h->prof_launches[which];
+  if (workgroups_out) *workgroups_out = h->prof_wgs[which];
   return PGB_OK;
 }
 

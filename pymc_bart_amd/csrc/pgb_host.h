@@ -1,5 +1,6 @@
 // pgb_host.h -- part of pgbart_hip.hip (not a standalone header): host side: handles, the C ABI of include/pgbart.h, slot enqueueing.
 // ------------------------------------------------------------------ host side
+enum { PK_CTRL = 0, PK_ROWS = 1, PK_LL = 2, PK_SLOT = 3, PK_COUNT = 4 };
 static thread_local char g_err[512];
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
@@ -31,8 +32,10 @@ struct pgb_handle {
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
+  int fused;       // one launch per SMC round (k_slot) instead of {k_ctrl ; k_rows}
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int ll_grid;     // ... of the log-likelihood pass
+  int slot_grid;   // ... of the fused slot kernel: every workgroup runs the control phase, so never more than fit at once
   int sigma_dirty;
   double inv_sigma2;
   double lik_param2;
@@ -40,17 +43,49 @@ struct pgb_handle {
   int last_lower, last_n;
   double slots_per_step;  // running estimate
   pgb_counters ctr;
-  // profiling of the dominant kernel (k_rows)
+  // profiling: events attached to the dispatches of a region, per kernel (PK_*); the row pass is
+  // the dominant kernel pgb_profile reports
   int prof;
-  std::vector<hipEvent_t> ev;
-  size_t ev_used;
-  double prof_ms;
-  long long prof_launches;
+  std::vector<hipEvent_t> ev[PK_COUNT];
+  size_t ev_used[PK_COUNT];
+  double prof_ms[PK_COUNT];
+  long long prof_launches[PK_COUNT];
+  int prof_wgs[PK_COUNT];
+  // host-facing results of the last pgb_step_host (mapped pinned block written by k_export_step)
+  unsigned char* out_host;   // host address
+  unsigned char* out_dev;    // the same block as the device sees it
+  StepOutLayout out_layout;
+  double* st_dense;          // [K][n] staging of sum_trees in HBM
+  int out_valid;             // the block holds the trees of the last step (pgb_export_trees(0) reads it)
+  // pgb_step_async: a worker thread feeds the state machine while the caller goes on
+  int device;
+  std::thread worker;
+  int job_running, job_rc;
+  char job_err[512];
   long long* prof_buf;    // device-clock stamps (allocated on first use)
   long long prof_slot0;   // first slot of the profiled region (device-clock stamps)
   double prof_clock_ms;   // sum over launches of max(end) - min(start), 100 MHz device clock
   long long prof_clock_launches;
 };
+
+// A running pgb_step_async job owns the handle: every other entry point waits for it first.
+static int join_async(pgb_handle* h) {
+  if (h->worker.joinable()) h->worker.join();
+  if (h->job_running) {
+    h->job_running = 0;
+    if (h->job_rc != PGB_OK) {
+      const int rc = h->job_rc;
+      h->job_rc = PGB_OK;
+      return fail(rc, h->job_err);
+    }
+  }
+  return PGB_OK;
+}
+#define JOIN_ASYNC(h)                          \
+  do {                                         \
+    int rcj_ = join_async(h);                  \
+    if (rcj_ != PGB_OK) return rcj_;           \
+  } while (0)
 
 template <typename T>
 static int dalloc(pgb_handle* h, T** p, size_t count) {
@@ -107,11 +142,27 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->has_subset = 0;
   h->rows_grid = 1024;
   h->prof_buf = nullptr;
+  h->prof = 0;
+  for (int k = 0; k < PK_COUNT; ++k) {
+    h->ev_used[k] = 0;
+    h->prof_ms[k] = 0.0;
+    h->prof_launches[k] = 0;
+    h->prof_wgs[k] = 0;
+  }
+  h->out_host = h->out_dev = nullptr;
+  h->st_dense = nullptr;
+  h->out_valid = 0;
+  h->job_running = 0;
+  h->job_rc = PGB_OK;
+  h->device = 0;
+  (void)hipGetDevice(&h->device);
   h->prof_clock_ms = 0.0;
   h->prof_clock_launches = 0;
   h->prof_slot0 = 0;
   if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
   h->ll_grid = h->rows_grid;
+  h->slot_grid = 256;  // one workgroup of SLOT_TEAMS row teams per CU
+  if (const char* e = getenv("PGB_SLOT_GRID")) h->slot_grid = atoi(e) > 0 ? atoi(e) : h->slot_grid;
   if (const char* e = getenv("PGB_LL_GRID")) h->ll_grid = atoi(e) > 0 ? atoi(e) : h->ll_grid;
   h->st_cur = 0;
   h->alpha_cur = 0;
@@ -144,6 +195,17 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.ll_pad = 0;
   if (const char* e = getenv("PGB_LL_TARGET")) d.ll_target = atoi(e) > 0 ? atoi(e) : d.ll_target;
   if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
+  // One launch per SMC round where the round is latency-bound: Normal likelihood, one output, constant
+  // leaves, and few enough (particle, chunk) pairs that a work item holds <= GMAXF particles.
+  {
+    const bool can = s->family == PGB_FAMILY_NORMAL && s->n_outputs == 1 && s->response == PGB_RESPONSE_CONSTANT &&
+                     s->p <= CDF_LDS;
+    // measured on MI355X at cfg2 (profiles/r02_*): the fused schedule is SLOWER than the two-kernel slot
+    // (22.5 vs 16.7 us per round: every workgroup repeats the control phase on a busy memory system),
+    // so it is opt-in: PGB_FUSED=1
+    h->fused = 0;
+    if (const char* e = getenv("PGB_FUSED")) h->fused = can && atoi(e) != 0;
+  }
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
   d.seed = s->seed;
@@ -191,10 +253,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
-  DA(d.acc, 2 * MAXP * ACC_PER);
+  DA(d.acc, 3 * MAXP * ACC_PER);  // (the fused slot kernel keeps a ring of three)
   DA(d.accl, 2 * MAXP * LL_PER);
   DA(d.jobl, 2 * MAXP);
-  DA(d.initacc, 2 * IA_SLOTS);
+  DA(d.initacc, 3 * IA_SLOTS);
   DA(d.cmd, 2);
   DA(d.ctrl, 2);
   DA(d.counters, 8);
@@ -240,6 +302,20 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     transient(h);
     HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * 16 * sizeof(long long), sm));
 #endif
+    {  // host-facing results of pgb_step_host: mapped pinned block + dense sum_trees staging
+      int cap_trees = s->batch_tune > s->batch_draw ? s->batch_tune : s->batch_draw;
+      if (cap_trees > s->m) cap_trees = s->m;
+      h->out_layout = stepout_layout(d.p, cap_trees, d.K, d.response != PGB_RESPONSE_CONSTANT);
+      void* hp2 = nullptr;
+      HC(hipHostMalloc(&hp2, (size_t)h->out_layout.bytes, hipHostMallocMapped | hipHostMallocCoherent));
+      memset(hp2, 0, (size_t)h->out_layout.bytes);
+      h->out_host = (unsigned char*)hp2;
+      void* dp2 = nullptr;
+      HC(hipHostGetDevicePointer(&dp2, hp2, 0));
+      h->out_dev = (unsigned char*)dp2;
+      if ((rc = dalloc(h, &h->st_dense, (size_t)d.K * d.n)) != PGB_OK) { pgb_destroy(h); return rc; }
+      transient(h);
+    }
     if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
     transient(h);  // holds device pointers
     HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
@@ -273,10 +349,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
-  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.acc, 0, 3 * MAXP * ACC_PER * sizeof(Acc), sm));
   HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * LL_PER * sizeof(AccL), sm));
   HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
-  HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
+  HC(hipMemsetAsync(d.initacc, 0, 3 * IA_SLOTS * sizeof(InitAcc), sm));
   HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
   HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
   HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
@@ -318,9 +394,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
 
 extern "C" int pgb_destroy(pgb_handle* h) {
   if (!h) return PGB_OK;
-  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->worker.joinable()) h->worker.join();
+  for (int k = 0; k < PK_COUNT; ++k)
+    for (hipEvent_t e : h->ev[k]) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->bundle_ev) (void)hipEventDestroy(e);
   if (h->flag) (void)hipHostFree((void*)h->flag);
+  if (h->out_host) (void)hipHostFree((void*)h->out_host);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return PGB_OK;
@@ -329,6 +408,7 @@ extern "C" int pgb_destroy(pgb_handle* h) {
 extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
                             const double* split_prior_host) {
   if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   Dev& d = h->d;
   if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
   double mx = 0.0;
@@ -385,6 +465,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
 
 extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
   if (!h || !y_dev) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_y = 1;
@@ -393,6 +474,7 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
 
 extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
   if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
     return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
   if (offset_dev)
@@ -409,6 +491,7 @@ extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
 
 extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
   if (!h || !params) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   if (h->s.family == PGB_FAMILY_NORMAL) {
     if (n_params != 1 || !(params[0] > 0.0)) return fail(PGB_E_INVALID, "NORMAL needs sigma > 0");
     h->inv_sigma2 = 1.0 / (params[0] * params[0]);
@@ -436,6 +519,35 @@ extern "C" int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n
   return PGB_OK;
 }
 
+// Profiling: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. they carry
+// the start / end timestamps of the kernel's own AQL packet -- the interval rocprofv3 reports --
+// rather than bracketing the launch with two extra barrier packets.
+static int prof_events(pgb_handle* h, int k, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!h->prof) return PGB_OK;
+  if (h->ev_used[k] + 2 > h->ev[k].size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+      return fail(PGB_E_DEVICE, "hipEventCreate");
+    h->ev[k].push_back(a);
+    h->ev[k].push_back(b);
+  }
+  *e0 = h->ev[k][h->ev_used[k]];
+  *e1 = h->ev[k][h->ev_used[k] + 1];
+  h->ev_used[k] += 2;
+  return PGB_OK;
+}
+#define LAUNCH_KT(PK_, KERN, GRID_, THREADS_, ...)                                               \
+  do {                                                                                           \
+    hipEvent_t e0_, e1_;                                                                         \
+    int rc_ = prof_events(h, (PK_), &e0_, &e1_);                                                 \
+    if (rc_ != PGB_OK) return rc_;                                                               \
+    h->prof_wgs[(PK_)] = (int)(GRID_).x;                                                         \
+    if (h->prof) hipExtLaunchKernelGGL((KERN), (GRID_), dim3(THREADS_), 0, h->stream, e0_, e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERN), (GRID_), dim3(THREADS_), 0, h->stream, __VA_ARGS__);          \
+  } while (0)
+#define LAUNCH_K(PK_, KERN, GRID_, ...) LAUNCH_KT(PK_, KERN, GRID_, BT, __VA_ARGS__)
+
 static int enqueue_slots(pgb_handle* h, int count) {
   Dev& d = h->d;
   long long want = (long long)d.nchunks * (d.P - 1);
@@ -445,69 +557,55 @@ static int enqueue_slots(pgb_handle* h, int count) {
   long long wantl = (long long)d.nchunks * (d.P - 1);
   if (wantl > h->ll_grid) wantl = h->ll_grid;
   dim3 gll((unsigned)wantl);
+  const Dev* dd = (const Dev*)h->d_dev;
+  const bool lin = d.response != PGB_RESPONSE_CONSTANT;
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-    const bool lin = d.response != PGB_RESPONSE_CONSTANT;
-    if (d.K > 1 && lin)
-      hipLaunchKernelGGL((k_ctrl<true, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
-    else if (d.K > 1)
-      hipLaunchKernelGGL((k_ctrl<true, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
-    else
-      if (d.response != PGB_RESPONSE_CONSTANT)
-        hipLaunchKernelGGL((k_ctrl<false, true>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
-      else
-        hipLaunchKernelGGL((k_ctrl<false, false>), gctrl, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, d.ctrl, (const InitAcc*)d.initacc);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->prof) {
-      if (h->ev_used + 2 > h->ev.size()) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
-          return fail(PGB_E_DEVICE, "hipEventCreate");
-        h->ev.push_back(a);
-        h->ev.push_back(b);
-      }
-      e0 = h->ev[h->ev_used];
-      e1 = h->ev[h->ev_used + 1];
-      h->ev_used += 2;
+    if (h->fused) {
+      const int s3 = (int)(h->slot % 3);
+      long long wg = (want + SLOT_TEAMS - 1) / SLOT_TEAMS;  // `want` row items, SLOT_TEAMS per workgroup
+      if (wg > h->slot_grid) wg = h->slot_grid;
+      dim3 gslot((unsigned)wg);
+      if (h->has_subset) LAUNCH_KT(PK_SLOT, (k_slot<true>), gslot, SLOT_BT, dd, par, s3, d.ctrl);
+      else LAUNCH_KT(PK_SLOT, (k_slot<false>), gslot, SLOT_BT, dd, par, s3, d.ctrl);
+      h->slot += 1;
+      continue;
     }
-    // Profiling: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. they
-    // carry the start / end timestamps of the kernel's own AQL packet -- the interval rocprofv3
-    // reports -- rather than bracketing the launch with two extra barrier packets.
-#define LAUNCH_ROWS(KERN, ...)                                                                    \
-  do {                                                                                            \
-    if (h->prof) hipExtLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, e0, e1, 0, (const Dev*)h->d_dev, par, ##__VA_ARGS__); \
-    else hipLaunchKernelGGL((KERN), grows, dim3(BT), 0, h->stream, (const Dev*)h->d_dev, par, ##__VA_ARGS__);    \
-  } while (0)
-#define ROWS_PTRS (const Cmd*)d.cmd, (const Job*)d.jobs
+#define CTRL_ARGS dd, par, d.ctrl, (const InitAcc*)d.initacc
+    if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS);
+    else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS);
+    else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS);
+    else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), gctrl, CTRL_ARGS);
+#undef CTRL_ARGS
+#define ROWS_ARGS dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
-      LAUNCH_ROWS((k_rows_mk<0, true>));
+      LAUNCH_K(PK_ROWS, (k_rows_mk<0, true>), grows, dd, par);
     } else if (d.K == 2) {
-      LAUNCH_ROWS((k_rows_mk<2, false>));
+      LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par);
     } else if (d.K == 3) {
-      LAUNCH_ROWS((k_rows_mk<3, false>));
+      LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par);
     } else if (d.K == 4) {
-      LAUNCH_ROWS((k_rows_mk<4, false>));
+      LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
     } else if (d.K > 1) {
-      LAUNCH_ROWS((k_rows_mk<0, false>));
+      LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
-      if (d.response != PGB_RESPONSE_CONSTANT) {
-        if (nrm) LAUNCH_ROWS((k_rows<false, true, true>), ROWS_PTRS);
-        else LAUNCH_ROWS((k_rows<false, false, true>), ROWS_PTRS);
+      if (lin) {
+        if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, true>), grows, ROWS_ARGS);
+        else LAUNCH_K(PK_ROWS, (k_rows<false, false, true>), grows, ROWS_ARGS);
       } else if (h->has_subset) {
-        if (nrm) LAUNCH_ROWS((k_rows<true, true, false>), ROWS_PTRS);
-        else LAUNCH_ROWS((k_rows<true, false, false>), ROWS_PTRS);
+        if (nrm) LAUNCH_K(PK_ROWS, (k_rows<true, true, false>), grows, ROWS_ARGS);
+        else LAUNCH_K(PK_ROWS, (k_rows<true, false, false>), grows, ROWS_ARGS);
       } else {
-        if (nrm) LAUNCH_ROWS((k_rows<false, true, false>), ROWS_PTRS);
-        else LAUNCH_ROWS((k_rows<false, false, false>), ROWS_PTRS);
+        if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, false>), grows, ROWS_ARGS);
+        else LAUNCH_K(PK_ROWS, (k_rows<false, false, false>), grows, ROWS_ARGS);
       }
     }
-#undef LAUNCH_ROWS
-#undef ROWS_PTRS
+#undef ROWS_ARGS
     if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
-#define LAUNCH_LL(KT_, FAM_) hipLaunchKernelGGL((k_loglik<KT_, FAM_, false>), gll, dim3(BT), 0, h->stream, h->d_dev, par)
+#define LAUNCH_LL(KT_, FAM_) LAUNCH_K(PK_LL, (k_loglik<KT_, FAM_, false>), gll, dd, par)
       if (d.K > 1 && lin) {
-        hipLaunchKernelGGL((k_loglik<0, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
+        LAUNCH_K(PK_LL, (k_loglik<0, -1, true>), gll, dd, par);
       } else if (d.K > 1) {
         switch (d.K) {
           case 2: LAUNCH_LL(2, -1); break;
@@ -515,8 +613,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
           case 4: LAUNCH_LL(4, -1); break;
           default: LAUNCH_LL(0, -1);
         }
-      } else if (d.response != PGB_RESPONSE_CONSTANT) {  // linear leaves: one instance, family read at run time
-        hipLaunchKernelGGL((k_loglik<1, -1, true>), gll, dim3(BT), 0, h->stream, h->d_dev, par);
+      } else if (lin) {  // linear leaves: one instance, family read at run time
+        LAUNCH_K(PK_LL, (k_loglik<1, -1, true>), gll, dd, par);
       } else {
         switch (d.family) {
           case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;
@@ -537,13 +635,15 @@ static int enqueue_slots(pgb_handle* h, int count) {
 }
 
 static int harvest_profile(pgb_handle* h) {
-  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-    h->prof_ms += ms;
-    h->prof_launches += 1;
+  for (int k = 0; k < PK_COUNT; ++k) {
+    for (size_t i = 0; i + 1 < h->ev_used[k]; i += 2) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, h->ev[k][i], h->ev[k][i + 1]));
+      h->prof_ms[k] += ms;
+      h->prof_launches[k] += 1;
+    }
+    h->ev_used[k] = 0;
   }
-  h->ev_used = 0;
   return PGB_OK;
 }
 
@@ -552,7 +652,7 @@ static int harvest_profile(pgb_handle* h) {
 // host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
 // are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
 #define BUNDLE 8
-static int run_until_idle(pgb_handle* h, int n_steps) {
+static int feed_until_flag(pgb_handle* h, int n_steps) {
   Dev& d = h->d;
   long long start = h->slot;
   long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
@@ -569,6 +669,13 @@ static int run_until_idle(pgb_handle* h, int n_steps) {
     h->bundles += 1;
     if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
   }
+  return PGB_OK;
+}
+
+static int run_until_idle(pgb_handle* h, int n_steps) {
+  Dev& d = h->d;
+  int rc;
+  if ((rc = feed_until_flag(h, n_steps)) != PGB_OK) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
   Ctrl c;
@@ -583,6 +690,7 @@ static int begin_steps(pgb_handle* h, int tune, int n_steps) {
   Dev& d = h->d;
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   int par = (int)(h->slot & 1);
+  h->out_valid = 0;
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, h->d_dev, par, tune, n_steps,
                      h->inv_sigma2, h->lik_param2, h->sigma_dirty);
   h->steps_target += n_steps;
@@ -599,16 +707,21 @@ static int begin_steps(pgb_handle* h, int tune, int n_steps) {
   return PGB_OK;
 }
 
-static int fetch_counters(pgb_handle* h, pgb_counters* out) {
-  unsigned long long c[8];
-  HIPCHK(hipMemcpyAsync(c, h->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+static void counters_from(pgb_handle* h, const unsigned long long* c) {
   h->ctr.particle_steps = (int64_t)c[0];
   h->ctr.tree_updates = (int64_t)c[1];
   h->ctr.rows_touched = (int64_t)c[2];
   h->ctr.rounds = (int64_t)c[3];
   h->ctr.saturations = (int64_t)c[4];
   h->ctr.slots = (int64_t)c[5];
+  h->ctr.partitions = (int64_t)c[6];
+}
+
+static int fetch_counters(pgb_handle* h, pgb_counters* out) {
+  unsigned long long c[8];
+  HIPCHK(hipMemcpyAsync(c, h->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  counters_from(h, c);
   if (out) *out = h->ctr;
   return PGB_OK;
 }
@@ -616,6 +729,7 @@ static int fetch_counters(pgb_handle* h, pgb_counters* out) {
 extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi_counts_host_out,
                         pgb_counters* counters_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
   int rc;
   if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
   if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
@@ -630,21 +744,108 @@ extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, 
   return PGB_OK;
 }
 
+// PGBART.astep's return path in one device -> host transaction: the state machine runs to its idle
+// point, k_export_step writes the small results (trees of this step, vi, counters, control words)
+// into the mapped pinned block and densifies sum_trees, one DMA moves sum_trees to the caller,
+// ONE stream synchronisation ends the call.
+extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host_out,
+                             int32_t* vi_counts_host_out, pgb_counters* counters_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
+  Dev& d = h->d;
+  int rc;
+  if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
+  if ((rc = feed_until_flag(h, 1)) != PGB_OK) return rc;
+  const int nt = h->last_n;
+  if (nt > h->out_layout.cap_trees) return fail(PGB_E_STATE, "step batch exceeds the export block");
+  const long long dense_blocks = sum_trees_host_out ? ((long long)d.K * d.n + BT - 1) / BT : 0;
+  long long grid = dense_blocks < 512 ? dense_blocks : 512;
+  if (grid < nt) grid = nt;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_export_step, dim3((unsigned)grid), dim3(BT), 0, h->stream, (const Dev*)h->d_dev,
+                     (int)(h->slot & 1), h->last_lower, nt, h->out_dev, h->out_layout,
+                     sum_trees_host_out ? h->st_dense : nullptr);
+  if (sum_trees_host_out)
+    HIPCHK(hipMemcpyAsync(sum_trees_host_out, h->st_dense, (size_t)d.K * d.n * sizeof(double),
+                          hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
+  const StepOutHdr* H = (const StepOutHdr*)h->out_host;
+  if (H->phase != PH_IDLE) return fail(PGB_E_STATE, "device not idle after the progress flag fired");
+  h->st_cur = H->st_cur;
+  h->alpha_cur = H->alpha_cur;
+  counters_from(h, H->counters);
+  h->out_valid = 1;
+  if (vi_counts_host_out) memcpy(vi_counts_host_out, h->out_host + h->out_layout.vi, (size_t)d.p * sizeof(int32_t));
+  if (counters_out) *counters_out = h->ctr;
+  return PGB_OK;
+}
+
 extern "C" int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
   if (!h || n_steps < 1) return fail(PGB_E_INVALID, "bad argument");
-  int rc;
-  if ((rc = begin_steps(h, tune, n_steps)) != PGB_OK) return rc;
-  return run_until_idle(h, n_steps);
+  JOIN_ASYNC(h);
+  if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  h->job_running = 1;
+  h->job_rc = PGB_OK;
+  h->job_err[0] = 0;
+  h->worker = std::thread([h, tune, n_steps]() {
+    int rc = PGB_OK;
+    if (hipSetDevice(h->device) != hipSuccess) rc = fail(PGB_E_DEVICE, "hipSetDevice in the step worker");
+    if (rc == PGB_OK) rc = begin_steps(h, tune, n_steps);
+    if (rc == PGB_OK) rc = run_until_idle(h, n_steps);
+    h->job_rc = rc;
+    if (rc != PGB_OK) snprintf(h->job_err, sizeof h->job_err, "%s", g_err);  // this thread's message
+  });
+  return PGB_OK;
 }
 
 extern "C" int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
   return fetch_counters(h, counters_out);
+}
+
+// the trees of the last pgb_step_host, already in host memory (k_export_step)
+static int export_from_block(pgb_handle* h, pgb_tree_arrays* out) {
+  const StepOutHdr* H = (const StepOutHdr*)h->out_host;
+  const StepOutLayout& L = h->out_layout;
+  const int nt = H->n_trees, total = H->total_nodes, K = H->K;
+  if (!out->var) {
+    out->n_trees = nt;
+    out->n_outputs = K;
+    out->total_nodes = total;
+    return PGB_OK;
+  }
+  if (out->n_trees != nt || out->total_nodes != total) return fail(PGB_E_INVALID, "size mismatch");
+  const unsigned char* B = h->out_host;
+  for (int t = 0; t < nt; ++t) out->tree_id[t] = H->first + t;
+  memcpy(out->node_off, B + L.node_off, (size_t)(nt + 1) * 4);
+  memcpy(out->var, B + L.var, (size_t)total * 4);
+  memcpy(out->left, B + L.left, (size_t)total * 4);
+  memcpy(out->right, B + L.right, (size_t)total * 4);
+  memcpy(out->split, B + L.split, (size_t)total * 8);
+  memcpy(out->count, B + L.count, (size_t)total * 8);
+  memcpy(out->value, B + L.value, (size_t)total * 8 * K);
+  if (out->slope && out->xbar && out->svar) {
+    if (H->lin) {
+      memcpy(out->slope, B + L.slope, (size_t)total * 8 * K);
+      memcpy(out->xbar, B + L.xbar, (size_t)total * 8);
+      memcpy(out->svar, B + L.svar, (size_t)total * 4);
+    } else {
+      memset(out->slope, 0, (size_t)total * 8 * K);
+      memset(out->xbar, 0, (size_t)total * 8);
+      for (int g = 0; g < total; ++g) out->svar[g] = -1;
+    }
+  }
+  return PGB_OK;
 }
 
 extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   Dev& d = h->d;
+  if (which == 0 && h->out_valid) return export_from_block(h, out);
   int first = which == 0 ? h->last_lower : 0;
   int nt = which == 0 ? h->last_n : d.m;
   std::vector<DTree> host(nt);
@@ -712,12 +913,13 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
 
 extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
   Dev& d = h->d;
   Ctrl c;
   InitAcc ia[IA_SLOTS];
   HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(ia, &d.initacc[(size_t)((h->slot & 1) ^ 1) * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost,
-                        h->stream));
+  const size_t ia_read = h->fused ? (size_t)((h->slot + 2) % 3) : (size_t)((h->slot & 1) ^ 1);  // the last slot's sums
+  HIPCHK(hipMemcpyAsync(ia, &d.initacc[ia_read * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   double leaf_sd = c.leaf_sd;
   long long qstd = 0;
@@ -750,6 +952,7 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
 
 extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  JOIN_ASYNC(h);
   std::vector<long long> a((size_t)h->d.p);
   HIPCHK(hipMemcpyAsync(a.data(), h->d.alpha + (size_t)h->alpha_cur * h->d.p, h->d.p * sizeof(long long),
                         hipMemcpyDeviceToHost, h->stream));
@@ -767,6 +970,22 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
     return fail(PGB_E_INVALID, "null argument");
   if (trees->n_outputs < 1 || trees->n_outputs > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "n_outputs");
   if (n_forests < 1 || n_rows < 1) return PGB_OK;
+  // a malformed history (truncated file, mismatched m) is an error, not an out-of-bounds walk
+  if (trees->n_trees < 0 || trees->total_nodes < 0) return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
+  for (long long i = 0; i < (long long)n_forests * m; ++i)
+    if (forest_tree_idx[i] < 0 || forest_tree_idx[i] >= trees->n_trees)
+      return fail(PGB_E_INVALID, "forest_tree_idx entry outside [0, n_trees)");
+  for (int t = 0; t < trees->n_trees; ++t) {
+    const int base = trees->node_off[t], end = trees->node_off[t + 1];
+    if (base < 0 || end <= base || end > trees->total_nodes)
+      return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
+    for (int g = base; g < end; ++g) {
+      if (trees->var[g] < 0) continue;
+      if (trees->var[g] >= p) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
+      if (trees->left[g] < 0 || trees->right[g] < 0 || trees->left[g] >= end - base || trees->right[g] >= end - base)
+        return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
+    }
+  }
   hipStream_t sm = (hipStream_t)stream;
   const int K = trees->n_outputs, N = trees->total_nodes, NT = trees->n_trees;
   std::vector<uint8_t> excl((size_t)p, 0);

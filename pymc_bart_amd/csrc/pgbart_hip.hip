@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "pgbart.h"
@@ -52,8 +53,10 @@
 #include "pgb_leaf_values.h"
 #include "k_ctrl.h"
 #include "k_rows.h"
+#include "k_slot.h"
 #include "k_rows_mk.h"
 #include "k_loglik.h"
 #include "k_setup_predict.h"
+#include "k_export.h"
 #include "pgb_host.h"
 #include "pgb_checkpoint.h"

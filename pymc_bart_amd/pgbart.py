@@ -189,6 +189,11 @@ def _op_of(var):
     return owner.op if owner is not None and hasattr(owner, "op") else var
 
 
+# serialises the append + index pair of PGBART._publish (once per chain; chains run as threads of one
+# process in chains.sample_chains and share the op)
+_PUBLISH_LOCK = __import__("threading").Lock()
+
+
 def _eval(x):
     return x.eval() if hasattr(x, "eval") and not isinstance(x, np.ndarray) else x
 
@@ -215,7 +220,7 @@ class PGBART(_Base):
 
     def __init__(self, vars=None, num_particles=10, batch=(0.1, 0.1), model=None,  # noqa: A002
                  initial_point=None, compile_kwargs=None, *, likelihood=None, observed=None,
-                 random_seed=None, chain=0, backend=None):
+                 random_seed=None, chain=0, backend=None, range_exp=None):
         if vars is None or len(vars) != 1:
             raise ValueError("PGBART samples exactly one BART variable per step method")
         self._var = vars[0]
@@ -266,7 +271,7 @@ class PGBART(_Base):
         self.settings = PyBartSettings.from_data(
             X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
             family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
-            batch=batch, seed=seed, response=self.response,
+            batch=batch, seed=seed, response=self.response, y_obs=y_obs, range_exp=range_exp,
         )
         self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
         self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
@@ -277,6 +282,8 @@ class PGBART(_Base):
         self._baseline = None
         self._batches = []
         self._registered = False
+        self._published = 0      # batches already sent to the op's history list
+        self._offset = None      # last offset applied (re-applied after unpickling)
         self.shape = (self.num_observations,) if n_outputs == 1 else (n_outputs, self.num_observations)
         if _HAVE_PYMC and model is not None:  # pragma: no cover
             shared = {}
@@ -297,6 +304,8 @@ class PGBART(_Base):
         self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
                                  self._split_prior, backend=None)
         self.sampler.restore(blob)
+        if self._offset is not None:  # the image carries the chain, not the caller-owned response
+            self._apply_offset(self._offset)
 
     # -- PyMC step-method surface ---------------------------------------------------
     @staticmethod
@@ -320,12 +329,7 @@ class PGBART(_Base):
         predictor.
         """
         if offset is not None:
-            if self.likelihood.family == "normal":      # additive Normal model: fit what is left
-                self.sampler.set_response(self._y_obs - np.asarray(offset, np.float64))
-            elif self.shape == (self.num_observations,):  # per-row families: offset of the predictor
-                self.sampler.set_offset(offset)
-            else:
-                raise NotImplementedError("offsets are not implemented for multi-output families")
+            self._apply_offset(offset)
         self.sampler.set_likelihood(self.likelihood.params(point))
         if not self.tune and self._baseline is None:
             # first draw: freeze the forest the per-draw batches are deltas of (utils.py:124-127)
@@ -337,6 +341,16 @@ class PGBART(_Base):
         stats = {"variable_inclusion": _encode_vi(vi), "tune": self.tune}
         return sum_trees, [stats]
 
+    def _apply_offset(self, offset):
+        offset = np.asarray(offset, np.float64)
+        if self.likelihood.family == "normal":      # additive Normal model: fit what is left
+            self.sampler.set_response(self._y_obs - offset)
+        elif self.shape == (self.num_observations,):  # per-row families: offset of the predictor
+            self.sampler.set_offset(offset)
+        else:
+            raise NotImplementedError("offsets are not implemented for multi-output families")
+        self._offset = np.array(offset, copy=True)
+
     def step(self, point):
         """Duck-typed ``step``: writes the new ``sum_trees`` into ``point[<bart name>]``."""
         sum_trees, stats = self.astep(None, point)
@@ -345,17 +359,33 @@ class PGBART(_Base):
         return out, stats
 
     def _publish(self):
-        entry = (self._baseline, self._batches)
+        """Hand this chain's history to the op (reference ``bart.py:134-135`` -> ``utils.py:124-127``).
+
+        A plain list holds ``(baseline, batches)`` by reference: it is appended once (under the op's
+        lock: PyMC-style worker threads of several chains share the op) and grows with
+        ``self._batches``.  A ``multiprocessing.Manager().list()`` proxy pickles what it is given, so
+        re-assigning the whole history every draw would move O(draws^2) bytes: there the entry is
+        re-sent every ``_PROXY_EVERY`` draws and by :meth:`flush_history` (called by ``stop`` /
+        the end of sampling)."""
         trees = self.bart.all_trees
         if not self._registered:
-            trees.append(entry)
-            self._slot = len(trees) - 1
+            with _PUBLISH_LOCK:
+                trees.append((self._baseline, self._batches))
+                self._slot = len(trees) - 1
             self._registered = True
-        else:
-            try:
-                trees[self._slot] = entry  # Manager().list() proxies need re-assignment
-            except Exception:  # noqa: BLE001
-                pass
+            self._is_proxy = not isinstance(trees, list)
+            self._published = len(self._batches)
+            return
+        if self._is_proxy and len(self._batches) - self._published >= self._PROXY_EVERY:
+            self.flush_history()
+
+    _PROXY_EVERY = 64
+
+    def flush_history(self):
+        """Make the op's history entry current (needed for proxy lists only; a no-op otherwise)."""
+        if self._registered and getattr(self, "_is_proxy", False) and self._published < len(self._batches):
+            self.bart.all_trees[self._slot] = (self._baseline, self._batches)
+            self._published = len(self._batches)
 
     @property
     def counters(self) -> dict:

@@ -57,10 +57,15 @@ def prior_leaf_table(alpha: float, beta: float) -> np.ndarray:
     return tab
 
 
-def range_exponent(Y: np.ndarray) -> int:
-    """Fixed-point range: |sum_trees| and residuals stay below 2^e, with 8x headroom."""
-    a = float(np.max(np.abs(Y))) if Y.size else 1.0
-    a = max(a, 1e-30)
+def range_exponent(*arrays) -> int:
+    """Fixed-point range: |sum_trees| and residuals stay below 2^e, with 8x headroom over the
+    largest magnitude in ``arrays`` (the BART response ``Y`` and, when it differs, the observed
+    response the likelihood sees)."""
+    a = 1e-30
+    for arr in arrays:
+        arr = np.asarray(arr, np.float64)
+        if arr.size:
+            a = max(a, float(np.nanmax(np.abs(arr))))
     return int(math.ceil(math.log2(a))) + 3
 
 
@@ -105,15 +110,21 @@ class PyBartSettings:
 
     @classmethod
     def from_data(cls, X, Y, m=50, num_particles=10, n_outputs=1, family="normal", alpha=0.95,
-                  beta=2.0, batch=(0.1, 0.1), seed=0, response="constant") -> "PyBartSettings":
+                  beta=2.0, batch=(0.1, 0.1), seed=0, response="constant", y_obs=None,
+                  range_exp=None) -> "PyBartSettings":
+        """``y_obs``: the observed response when it is not ``Y`` itself (it enters the fixed-point
+        range); ``range_exp``: override the range, e.g. for additive models whose offsets move the
+        partial residuals far outside the data's own range."""
         Y = np.asarray(Y, np.float64)
         n, p = X.shape
         mean = float(Y.mean())
         is_binary = bool(np.all((Y == 0) | (Y == 1)))
         # [U] leaf_sd = 3/sqrt(m) for 0/1 responses, std(Y)/sqrt(m) otherwise
         leaf_sd = 3.0 / math.sqrt(m) if is_binary else float(Y.std()) / math.sqrt(m)
-        rexp = range_exponent(Y)
-        if family != "normal":
+        rexp = range_exponent(Y) if y_obs is None else range_exponent(Y, y_obs)
+        if range_exp is not None:
+            rexp = int(range_exp)
+        elif family != "normal":
             rexp = max(rexp, 10)  # latent link scale: |sum_trees| < 1024 (separable data drifts far)
         return cls(
             n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
@@ -123,10 +134,15 @@ class PyBartSettings:
         )
 
     def batch_sizes(self) -> tuple[int, int]:
-        # [U] batch = (max(1, int(m*0.1)), max(1, int(m*0.1))); ints are taken as counts
+        """Trees re-sampled per step while (tuning, drawing).  Upstream's rule for the fractions it
+        takes: ``max(1, int(m * b))`` -- so ``batch=(1.0, 1.0)`` means every tree, every step.  A
+        Python ``int`` (not a float) is taken as a tree count, an extension upstream does not have."""
         out = []
         for b in self.batch:
-            out.append(int(b) if b >= 1 else max(1, int(self.m * b)))
+            if isinstance(b, (int, np.integer)) and not isinstance(b, (bool, np.bool_)):
+                out.append(max(1, min(int(b), self.m)))
+            else:
+                out.append(max(1, min(self.m, int(self.m * float(b)))))
         return out[0], out[1]
 
     def as_c(self) -> _abi.Settings:
@@ -173,6 +189,8 @@ class PySampler:
         self._out = mem.empty((settings.n_outputs * settings.n,), np.float64)
         self._vi = np.zeros(settings.p, np.int32)
         self.counters = _abi.Counters()
+        self._sat_seen = 0   # saturation events already reported
+        self._steps = 0      # asteps issued (to name the one that overflowed)
 
     def __del__(self):
         try:
@@ -207,20 +225,30 @@ class PySampler:
 
     # -- one astep -----------------------------------------------------------------
     def step(self, tune: bool, fetch: bool = True):
+        """One astep.  ``fetch=True`` (what ``PGBART.astep`` does): ``sum_trees`` comes back as a host
+        array through ``pgb_step_host`` -- one device->host transaction that also carries the step's
+        trees, so the following ``export_trees(0)`` does not touch the device.  ``fetch=False``:
+        ``pgb_step`` leaves ``sum_trees`` in the device buffer :meth:`sum_trees_device` returns."""
         lib, mem = self.backend.lib, self.backend.mem
+        K, n = self.settings.n_outputs, self.settings.n
+        self._steps += 1
+        if fetch:
+            st = mem.host_result(K * n)
+            rc = lib.lib.pgb_step_host(self._h, int(bool(tune)), st.ctypes.data, self._vi.ctypes.data,
+                                       C.byref(self.counters))
+            lib.check(rc, "pgb_step_host")
+            self._check_saturation()
+            return (st.reshape(K, n) if K > 1 else st), self._vi.copy()
         rc = lib.lib.pgb_step(self._h, int(bool(tune)), mem.ptr(self._out), self._vi.ctypes.data,
                               C.byref(self.counters))
         lib.check(rc, "pgb_step")
         self._check_saturation()
-        st = None
-        if fetch:
-            st = mem.to_host(self._out)
-            K = self.settings.n_outputs
-            st = st.reshape(K, self.settings.n) if K > 1 else st.reshape(self.settings.n)
-        return st, self._vi.copy()
+        return None, self._vi.copy()
 
     def step_async(self, tune: bool, n_steps: int) -> None:
+        """Start ``n_steps`` asteps and return while they run; :meth:`sync` waits for them."""
         lib = self.backend.lib
+        self._steps += int(n_steps)
         lib.check(lib.lib.pgb_step_async(self._h, int(bool(tune)), int(n_steps)), "pgb_step_async")
 
     def sync(self) -> dict:
@@ -232,11 +260,14 @@ class PySampler:
     def _check_saturation(self) -> None:
         """Fixed-point sums are exact only inside the declared range (PyBartSettings.range_exp);
         a saturated term makes the draws invalid, so it is an error, not a statistic."""
-        if self.counters.saturations > 0:
+        new = int(self.counters.saturations) - self._sat_seen
+        if new > 0:
+            self._sat_seen = int(self.counters.saturations)  # later steps are judged on their own
             raise _abi.PGBError(
-                f"{self.counters.saturations} fixed-point saturation events: |sum_trees| or the "
-                f"residuals left the range 2^{self.settings.range_exp}; re-create the sampler with "
-                "a larger PyBartSettings.range_exp"
+                f"{new} fixed-point saturation events by astep {self._steps}: |sum_trees| or the "
+                f"residuals left the range 2^{self.settings.range_exp} (an offset / observed response far "
+                "outside the range the sampler was sized for?); this draw is invalid -- re-create the "
+                "sampler with a larger PyBartSettings.range_exp (PGBART(range_exp=...))"
             )
 
     def sum_trees_device(self):
@@ -291,6 +322,19 @@ class PySampler:
         nl = C.c_int64()
         lib.check(lib.lib.pgb_profile(self._h, int(enable), C.byref(ms), C.byref(nl)), "pgb_profile")
         return float(ms.value), int(nl.value)
+
+    def profile_kernels(self) -> dict:
+        """Per-kernel event time of the last profiled region (after ``profile(False)``):
+        ``{name: {"ms", "launches", "workgroups"}}`` for the kernels that ran."""
+        lib = self.backend.lib
+        out = {}
+        for which, name in enumerate(("k_ctrl", "k_rows", "k_loglik", "k_slot")):
+            ms, nl, wg = C.c_double(), C.c_int64(), C.c_int32()
+            lib.check(lib.lib.pgb_profile_kernel(self._h, which, C.byref(ms), C.byref(nl), C.byref(wg)),
+                      "pgb_profile_kernel")
+            if nl.value:
+                out[name] = {"ms": float(ms.value), "launches": int(nl.value), "workgroups": int(wg.value)}
+        return out
 
     def profile_clock(self) -> tuple[float, int]:
         """Device-clock duration of the row-pass launches of the last profiled region (after

@@ -32,6 +32,10 @@ class NumpyMemory:
         return np.zeros(shape, dtype=dtype)
 
     @staticmethod
+    def host_result(n):
+        return np.empty(int(n), np.float64)
+
+    @staticmethod
     def ptr(buf):
         return buf.ctypes.data
 
@@ -54,6 +58,21 @@ def build_oracle(force: bool = False) -> str:
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])
     return ORACLE_SO
+
+
+def build_oracle_native() -> tuple[str, str]:
+    """The oracle compiled for THIS host's cores (bench.py's cpu_baseline leg: the stated baseline must
+    not be a strawman).  -ffp-contract=off stays: the numeric contract forbids fusing, so the native
+    build produces the same bits.  Falls back to the portable build if the compiler refuses."""
+    src = os.path.join(ORACLE_DIR, "pgbart_oracle.c")
+    out = os.path.join(ORACLE_DIR, "libpgbart_oracle_native.so")
+    flags = "gcc -O3 -march=native -std=gnu11 -ffp-contract=off"
+    try:
+        subprocess.check_call(flags.split() + ["-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+                                               "-o", out, "-lm"], stderr=subprocess.DEVNULL)
+        return out, flags
+    except (subprocess.CalledProcessError, OSError):
+        return build_oracle(), "gcc -O2 -std=gnu11 -ffp-contract=off (portable build; -march=native failed)"
 
 
 _BACKEND = None

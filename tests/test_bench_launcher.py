@@ -1,0 +1,45 @@
+"""bench.py launches its own ranks.  No GPU here: the dry-run mode exercises the
+launcher, the gloo process group, the max-over-ranks / sum-over-ranks aggregation and the JSON
+line over a counter stub; a real multi-GPU request on a box without GPUs must fail loudly instead
+of printing a 1-GPU line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, timeout=240):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout,
+                          env=env, cwd=ROOT)
+
+
+def test_dry_run_two_ranks_over_gloo():
+    r = _run("--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1", "--burnin", "2", "--repeats", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reported_by_collective"] == 2
+    assert d["config"]["chains"] == 2 and d["scaling"] == "weak"
+    assert d["data"] == "dry-run" and d["value"] is None  # never mistaken for a measurement
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["repeats"] == 3
+    assert d["gather_ms"] >= 0 and d["steps"] == 4
+
+
+def test_multi_gpu_request_without_gpus_fails_loudly():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("GPUs present")
+    r = _run("--gpus", "2", "--steps", "2", "--warmup", "0")
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no JSON line at all

@@ -1,0 +1,154 @@
+"""Host-side rules of the step method that do not need a GPU (round-1 ADVICE items): batch sizes as
+upstream computes them, fixed-point range sizing and saturation reporting, history publication,
+malformed histories rejected by the predictor, offsets surviving a pickle round trip."""
+import pickle
+
+import numpy as np
+import pytest
+
+from pymc_bart_amd import _abi
+from pymc_bart_amd.pgbart import PGBART, BARTOp, NormalLikelihood
+from pymc_bart_amd.sampler import PyBartSettings, PySampler
+from pymc_bart_amd.trees import PosteriorSampler
+
+
+def _data(n=300, p=3, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, p))
+    return X, X[:, 0] - X[:, 1] + rng.normal(0, 0.2, n)
+
+
+def test_batch_fractions_follow_upstream_and_ints_are_counts():
+    """[U] batch = (max(1, int(m*b)), ...): batch=(1.0, 1.0) re-samples EVERY tree each step."""
+    X, Y = _data()
+    st = PyBartSettings.from_data(X, Y, m=20, batch=(1.0, 1.0))
+    assert st.batch_sizes() == (20, 20)
+    assert PyBartSettings.from_data(X, Y, m=20, batch=(0.1, 0.26)).batch_sizes() == (2, 5)
+    assert PyBartSettings.from_data(X, Y, m=5, batch=(0.1, 0.1)).batch_sizes() == (1, 1)
+    assert PyBartSettings.from_data(X, Y, m=20, batch=(3, 2)).batch_sizes() == (3, 2)   # Python ints: counts
+    assert PyBartSettings.from_data(X, Y, m=20, batch=(1, 1)).batch_sizes() == (1, 1)
+    assert PyBartSettings.from_data(X, Y, m=20, batch=(50, 1.0)).batch_sizes() == (20, 20)
+
+
+def test_all_trees_per_step_when_batch_is_one(oracle):
+    X, Y = _data()
+    st = PyBartSettings.from_data(X, Y, m=20, num_particles=5, batch=(1.0, 1.0), seed=1)
+    s = PySampler(st, X, Y, np.zeros(3, np.int32), np.ones(3), backend=oracle)
+    s.set_likelihood([1.0])
+    s.step(True)
+    assert s.counters.tree_updates == 20
+
+
+def test_range_covers_the_observed_response_and_saturation_is_reported_once(oracle):
+    X, Y = _data()
+    # the likelihood's response is far outside Y's own range: the range must follow it
+    st = PyBartSettings.from_data(X, Y, m=10, y_obs=Y + 500.0)
+    assert st.range_exp >= 12 and PyBartSettings.from_data(X, Y, m=10).range_exp < 8
+    assert PyBartSettings.from_data(X, Y, m=10, range_exp=20).range_exp == 20
+    # an offset that leaves the range: that step raises (and names itself), later steps do not
+    step = PGBART([BARTOp(X, Y, m=10)], num_particles=5, likelihood=NormalLikelihood(1.0), random_seed=3,
+                  backend=oracle)
+    step.astep(None)
+    with pytest.raises(_abi.PGBError, match="by astep 2"):
+        step.astep(None, offset=np.full(X.shape[0], 1.0e4))
+    step.astep(None, offset=np.zeros(X.shape[0]))      # the chain is usable again
+    step.astep(None)
+    wide = PGBART([BARTOp(X, Y, m=10)], num_particles=5, likelihood=NormalLikelihood(1.0), random_seed=3,
+                  backend=oracle, range_exp=18)
+    wide.astep(None, offset=np.full(X.shape[0], 1.0e4))  # sized for it: no error
+
+
+def test_history_is_published_once_and_grows_in_place(oracle):
+    X, Y = _data()
+    op = BARTOp(X, Y, m=6)
+    a = PGBART([op], num_particles=4, random_seed=1, chain=0, backend=oracle)
+    b = PGBART([op], num_particles=4, random_seed=1, chain=1, backend=oracle)
+    for s in (a, b):
+        s.stop_tuning()
+    for _ in range(5):
+        a.astep(None)
+        b.astep(None)
+    assert len(op.all_trees) == 2 and a._slot != b._slot
+    assert len(op.all_trees[a._slot][1]) == 5 and op.all_trees[a._slot][1] is a._batches
+
+
+def test_proxy_history_is_sent_in_strides_not_every_draw(oracle):
+    class Proxy:  # the part of multiprocessing.Manager().list() the step method uses
+        def __init__(self):
+            self.items, self.sets = [], 0
+
+        def append(self, x):
+            self.items.append(pickle.loads(pickle.dumps(x)))
+
+        def __len__(self):
+            return len(self.items)
+
+        def __setitem__(self, i, x):
+            self.sets += 1
+            self.items[i] = pickle.loads(pickle.dumps(x))
+
+        def __getitem__(self, i):
+            return self.items[i]
+
+    X, Y = _data(n=120)
+    op = BARTOp(X, Y, m=4, all_trees=Proxy())
+    s = PGBART([op], num_particles=4, random_seed=1, backend=oracle)
+    s._PROXY_EVERY = 8
+    s.stop_tuning()
+    for _ in range(20):
+        s.astep(None)
+    assert op.all_trees.sets == 2            # draws 9 and 17, not 19 re-sends
+    s.flush_history()
+    assert op.all_trees.sets == 3 and len(op.all_trees[0][1]) == 20
+
+
+def test_predictor_rejects_malformed_histories(oracle):
+    X, Y = _data()
+    step = PGBART([BARTOp(X, Y, m=5)], num_particles=5, random_seed=2, backend=oracle)
+    step.stop_tuning()
+    for _ in range(3):
+        step.astep(None)
+    ps = PosteriorSampler.from_history(step._batches, step._baseline, 5, 1, backend=oracle)
+    good = ps.sample_posterior(X[:4], [0, 1], [])
+    assert good.shape == (2, 1, 4)
+    # a forest index outside the tree list (mismatched m / truncated file)
+    with pytest.raises(_abi.PGBError, match="forest_tree_idx"):
+        bad = PosteriorSampler.from_history(step._batches, step._baseline, 5, 1, backend=oracle)
+        bad.forest_idx = bad.forest_idx.copy()
+        bad.forest_idx[0, 0] = 10_000
+        bad.sample_posterior(X[:4], [0], [])
+    with pytest.raises(_abi.PGBError, match="inconsistent"):
+        bad = PosteriorSampler.from_history(step._batches, step._baseline, 5, 1, backend=oracle)
+        k = int(np.argmax(bad.pool.var >= 0))
+        assert bad.pool.var[k] >= 0
+        bad.pool.left = bad.pool.left.copy()
+        bad.pool.left[k] = 300
+        bad.sample_posterior(X[:4], [0], [])
+
+
+def test_offset_survives_pickling(oracle, monkeypatch):
+    import pymc_bart_amd.sampler as sm
+
+    monkeypatch.setattr(sm, "_DEFAULT_BACKEND", oracle)   # unpickling builds on the default backend
+    X, Y = _data()
+    off = np.linspace(-1, 1, X.shape[0])
+    a = PGBART([BARTOp(X, Y + off, m=6)], num_particles=5, likelihood=NormalLikelihood(1.0), random_seed=9,
+               backend=oracle)
+    b = PGBART([BARTOp(X, Y + off, m=6)], num_particles=5, likelihood=NormalLikelihood(1.0), random_seed=9,
+               backend=oracle)
+    for s in (a, b):
+        s.astep(None, offset=off)
+    b2 = pickle.loads(pickle.dumps(b))
+    for _ in range(4):                       # the caller does NOT repeat the offset
+        ra, _ = a.astep(None)
+        rb, _ = b2.astep(None)
+        assert np.array_equal(ra, rb)
+
+
+def test_gather_without_dense_draws():
+    from pymc_bart_amd.chains import gather_chains
+
+    res = {"chain": 0, "mu": None, "sigma": np.ones(3), "variable_inclusion": [], "vi_counts": np.zeros((3, 2)),
+           "history": (None, []), "counters": {}, "step": object()}
+    out = gather_chains(res)
+    assert out[0]["mu"] is None and "step" not in out[0]

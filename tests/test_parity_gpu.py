@@ -67,6 +67,58 @@ def test_step_async_equals_stepwise(hip):
         assert ca[k] == cb[k]
 
 
+@pytest.mark.parametrize("name", ["nan_onehot_prior", "categorical_k4_cfg5_small", "mix_response"])
+def test_host_output_step_equals_the_device_output_step(hip, name):
+    """pgb_step_host (PGBART.astep's return path: mapped block + one DMA) against pgb_step (device
+    buffer + per-item copies): same sum_trees, same vi, same exported trees, same counters."""
+    c = make_case(name)
+    X, Y = c["X"], c["Y"]
+    p = X.shape[1]
+    fam = c.get("family", "normal")
+    st = PyBartSettings.from_data(X, c.get("bart_Y", Y), m=c["m"], num_particles=c["P"], seed=11, family=fam,
+                                  n_outputs=c.get("K", 1), response=c.get("response", "constant"))
+    rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
+    prior = np.ones(p) if c["prior"] is None else c["prior"]
+    a = PySampler(st, X, Y, rules, prior, backend=hip)
+    b = PySampler(st, X, Y, rules, prior, backend=hip)
+    K, n = st.n_outputs, st.n
+    for it in range(14):
+        for s in (a, b):
+            s.set_likelihood([0.7] if fam == "normal" else c.get("lik_params", []))
+        sa, va = a.step(it < 7)                    # host path
+        _, vb = b.step(it < 7, fetch=False)        # device path
+        sb = hip.mem.to_host(b.sum_trees_device())
+        sb = sb.reshape(K, n) if K > 1 else sb
+        assert np.array_equal(sa, sb) and np.array_equal(va, vb)
+        ta, tb = a.export_trees(0), b.export_trees(0)   # a: served from the mapped block; b: fetched
+        for f in ("tree_id", "node_off", "var", "left", "right", "count", "split", "value", "slope", "xbar", "svar"):
+            assert np.array_equal(getattr(ta, f), getattr(tb, f)), f
+        assert a.counters.as_dict() == b.counters.as_dict()
+
+
+def test_step_async_returns_before_the_work_is_done_and_errors_surface_in_sync(hip):
+    """pgb_step_async hands the steps to the handle's worker thread and returns; pgb_sync waits."""
+    import time
+
+    w = workloads.cfg2(seed=1, n=50_000, p=10, m=50, num_particles=20)
+    st = PyBartSettings.from_data(w["X"], w["Y"], m=50, num_particles=20, seed=3)
+    s = PySampler(st, w["X"], w["Y"], np.zeros(10, np.int32), np.ones(10), backend=hip)
+    s.set_likelihood([1.0])
+    s.step_async(False, 2)
+    s.sync()
+    t0 = time.perf_counter()
+    s.step_async(False, 200)
+    t_call = time.perf_counter() - t0
+    c = s.sync()
+    t_all = time.perf_counter() - t0
+    assert c["tree_updates"] == 202 * 5
+    assert t_call < 0.25 * t_all, (t_call, t_all)
+    # a call that needs the handle while a job runs waits for it (no interleaving)
+    s.step_async(False, 20)
+    st1, _ = s.step(False)
+    assert s.counters.tree_updates == 223 * 5 and st1.shape == (50_000,)
+
+
 def test_predict_kernel_matches_oracle_and_numpy(hip, oracle):
     rng = np.random.default_rng(5)
     X = rng.normal(size=(700, 4))
@@ -400,6 +452,32 @@ def test_results_do_not_depend_on_launch_geometry(hip, name, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert digest(run_case(c, hip)) == GOLD[name], env
+
+
+@pytest.mark.parametrize("name", ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
+                                  "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "subset_rule"])
+def test_fused_slot_kernel_and_two_kernel_slot_agree(hip, name, monkeypatch):
+    """k_slot (one launch per SMC round) and {k_ctrl ; k_rows} are two schedules of the same contract:
+    both reproduce the committed fingerprint, under the default geometry and under odd ones (tiny grids
+    make a workgroup loop over several groups, tiny targets force the 16-particle cap of a work item)."""
+    c = make_case(name)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PGB_FUSED", fused)
+        for env in ({}, {"PGB_ROWS_GRID": "7", "PGB_ROWS_TARGET": "3", "PGB_ROWS_TARGET_INIT": "5"},
+                    {"PGB_ROWS_GRID": "333", "PGB_ROWS_TARGET": "100000", "PGB_ROWS_TARGET_INIT": "1"}):
+            for k in ("PGB_ROWS_GRID", "PGB_ROWS_TARGET", "PGB_ROWS_TARGET_INIT"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            g = run_case(c, hip)
+            assert digest(g) == GOLD[name], (fused, env)
+            assert g["counters"]["saturations"] == 0
+            # ... and it really was the schedule asked for
+            s = g["sampler"]
+            s.profile(True)
+            s.step(False)
+            s.profile(False)
+            assert set(s.profile_kernels()) == ({"k_slot"} if fused == "1" else {"k_ctrl", "k_rows"})
 
 
 def test_partial_dependence_sweep_on_gpu_matches_the_oracle(hip, oracle):
