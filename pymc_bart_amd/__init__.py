@@ -13,6 +13,23 @@ from .trees import PosteriorSampler, TreeArrays
 from .importance import compute_variable_importance, get_variable_inclusion, vi_to_kulprit
 from .partial import individual_conditional_expectation, partial_dependence
 
+
+def _register_step_method():
+    """Import side effect the reference relies on (``pymc_bart/__init__.py:15-18``: ``import bartrs``
+    makes PGBART known to ``pm.sample``'s step assignment): BART variables get PGBART through
+    ``competence`` without an explicit ``step=`` (reference ``tests/test_bart.py:167-208``)."""
+    try:
+        import pymc as pm
+    except Exception:  # noqa: BLE001 - PyMC is optional
+        return False
+    methods = list(getattr(pm, "STEP_METHODS", ()))
+    if PGBART not in methods:
+        pm.STEP_METHODS = methods + [PGBART]
+    return True
+
+
+_register_step_method()
+
 __version__ = "0.1.0"
 __all__ = [
     "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood", "GammaLikelihood",

@@ -1,0 +1,167 @@
+"""What the step method needs from a PyMC model, and how it gets it.
+
+Upstream's PGBART evaluates the model's whole data log-likelihood through PyTensor for every particle
+(``SURVEY.md`` Appendix A: ``update_weight``).  A device kernel cannot call PyTensor, so this step
+method works with a closed family of likelihoods (``DESIGN.md`` deviation 9) and has to find out
+WHICH member a model uses, and -- every step -- the current value of its other parameters.
+
+It does so numerically rather than by pattern-matching graphs: ``probe(x)`` evaluates the parameters
+of the observed variable's distribution with the BART variable set to ``x`` and every other variable
+at its current (shared) value; a handful of probes decide the family and the link, and ONE probe per
+step (``x = 0``) yields the offset (everything added to the BART term: a second BART variable,
+reference ``tests/test_bart.py:211-241``; a log-exposure) and the scalar parameters (``sigma``, ...).
+
+``identify`` / ``Binding`` are plain NumPy and tested without PyMC.  ``bind_model`` builds ``probe``
+from a real model with PyTensor; PyMC is not installable on the build box, so that function follows the
+public PyMC API from memory (marked [P]) and fails with a clear ``NotImplementedError`` whenever the
+model is outside the closed family.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import expit, ndtr, ndtri
+
+from .pgbart import (BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood, NormalLikelihood,
+                     NormalMeanScaleLikelihood, PoissonLikelihood)
+
+_TOL = 1e-8
+
+
+class Binding:
+    """The likelihood of a model as the sampler sees it: a family object plus, per step, the scalar
+    parameters and the offset of the linear predictor, both read from ``probe`` at ``x = 0``."""
+
+    def __init__(self, likelihood, probe, shape, kind, has_offset):
+        self.likelihood = likelihood
+        self.probe = probe
+        self.shape = shape
+        self.kind = kind
+        self.has_offset = has_offset
+
+    def current(self):
+        """(params, offset) at the current values of the other variables."""
+        _, p = self.probe(np.zeros(self.shape))
+        k = self.kind
+        if k == "normal":
+            return [_scalar(p[1], "sigma")], (np.asarray(p[0], float) if self.has_offset else None)
+        if k == "bernoulli_probit":
+            return [], (ndtri(np.clip(p[0], 1e-300, 1 - 1e-16)) if self.has_offset else None)
+        if k == "bernoulli_logit":
+            pc = np.clip(p[0], 1e-300, 1 - 1e-16)
+            return [], (np.log(pc) - np.log1p(-pc) if self.has_offset else None)
+        if k == "poisson":
+            return [], (np.log(p[0]) if self.has_offset else None)
+        if k == "negbin":
+            return [_scalar(p[1], "alpha")], (np.log(p[0]) if self.has_offset else None)
+        return [], None  # categorical / mean-scale: no free parameters, no offsets
+
+
+def _scalar(a, what):
+    a = np.asarray(a, float)
+    if a.size > 1 and not np.allclose(a, a.flat[0], rtol=1e-12, atol=0):
+        raise NotImplementedError(f"{what} varies across observations: not in the closed likelihood family")
+    return float(a.flat[0])
+
+
+def _close(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return a.shape == b.shape and np.allclose(a, b, rtol=1e-7, atol=_TOL)
+
+
+def identify(probe, shape, seed=0) -> Binding:
+    """Decide the likelihood family from numeric probes.
+
+    ``probe(x) -> (dist_name, [parameter arrays])`` with ``x`` shaped like the BART variable (``(n,)`` or
+    ``(K, n)``).  Raises ``NotImplementedError`` (naming what it saw) outside the closed family."""
+    rng = np.random.default_rng(seed)
+    shape = tuple(shape)
+    x0, xr = np.zeros(shape), rng.normal(0.0, 0.7, size=shape)
+    name, p0 = probe(x0)
+    _, pr = probe(xr)
+    name = str(name).lower()
+    if name in ("normal", "normal_rv"):
+        if len(shape) == 1:
+            if not _close(np.asarray(pr[0]) - np.asarray(p0[0]), xr):
+                raise NotImplementedError("Normal likelihood whose mean is not (BART + other terms)")
+            if not _close(pr[1], p0[1]):
+                raise NotImplementedError("Normal likelihood whose sigma depends on the BART variable")
+            has_off = bool(np.any(np.asarray(p0[0]) != 0.0))
+            return Binding(NormalLikelihood(_scalar(p0[1], "sigma")), probe, shape, "normal", has_off)
+        if shape[0] == 2 and _close(pr[0], xr[0]) and _close(pr[1], np.abs(xr[1])):
+            return Binding(NormalMeanScaleLikelihood(), probe, shape, "meanscale", False)
+        raise NotImplementedError("multi-output Normal likelihood other than Normal(BART[0], |BART[1]|)")
+    if name in ("bernoulli", "bernoulli_rv"):
+        p_0, p_r = np.asarray(p0[0], float), np.asarray(pr[0], float)
+        o = ndtri(np.clip(p_0, 1e-300, 1 - 1e-16))
+        if _close(p_r, ndtr(xr + o)):
+            return Binding(BernoulliLikelihood("probit"), probe, shape, "bernoulli_probit", bool(np.any(np.abs(o) > 1e-12)))
+        o = np.log(p_0) - np.log1p(-p_0)
+        if _close(p_r, expit(xr + o)):
+            return Binding(BernoulliLikelihood("logit"), probe, shape, "bernoulli_logit", bool(np.any(np.abs(o) > 1e-12)))
+        raise NotImplementedError("Bernoulli likelihood whose link is neither probit nor logit")
+    if name in ("categorical", "categorical_rv"):
+        K = shape[0]
+        pm_ = np.asarray(pr[0], float)
+        if pm_.shape == (shape[1], K):  # (n, K): the reference model transposes (tests/test_bart.py:156)
+            pm_ = pm_.T
+        e = np.exp(xr - xr.max(axis=0))
+        if pm_.shape == shape and _close(pm_, e / e.sum(axis=0)):
+            return Binding(CategoricalLikelihood(K), probe, shape, "categorical", False)
+        raise NotImplementedError("Categorical likelihood whose probabilities are not softmax(BART)")
+    if name in ("poisson", "poisson_rv"):
+        if _close(np.log(pr[0]) - np.log(p0[0]), xr):
+            return Binding(PoissonLikelihood(), probe, shape, "poisson", bool(np.any(np.log(p0[0]) != 0.0)))
+        raise NotImplementedError("Poisson likelihood whose rate is not exp(BART + other terms)")
+    if name in ("negative_binomial", "negativebinomial", "nbinom", "negative_binomial_rv"):
+        if _close(np.log(pr[0]) - np.log(p0[0]), xr) and _close(pr[1], p0[1]):
+            return Binding(NegativeBinomialLikelihood(_scalar(p0[1], "alpha")), probe, shape, "negbin",
+                           bool(np.any(np.log(p0[0]) != 0.0)))
+        raise NotImplementedError("NegativeBinomial likelihood outside mu = exp(BART + other terms), alpha free")
+    raise NotImplementedError(
+        f"observed distribution {name!r} is not in this sampler's closed likelihood family (Normal, "
+        "Bernoulli probit/logit, Categorical softmax, Normal mean/scale, Poisson, NegativeBinomial); "
+        "pass likelihood= explicitly if it is one of them in disguise")
+
+
+def bind_model(vars, model=None, initial_point=None, compile_kwargs=None):  # noqa: A002  [P]
+    """Everything ``PGBART.__init__`` takes from a PyMC model: the BART value variable and its op, the
+    shared replacements ``ArrayStepShared`` keeps current, the observed response, and ``probe``.
+
+    [P] Written against PyMC >= 5 / PyTensor from memory of the public API (``modelcontext``,
+    ``make_shared_replacements``, ``join_nonshared_inputs``, ``model.replace_rvs_by_values``), the
+    calls upstream's PGBART made to compile its log-likelihood; not runnable on the build box."""
+    from pymc.model import modelcontext
+    from pymc.pytensorf import compile_pymc, inputvars, join_nonshared_inputs, make_shared_replacements
+    from pytensor.graph.traversal import ancestors
+
+    model = modelcontext(model)
+    if initial_point is None:
+        initial_point = model.initial_point()
+    if vars is None:
+        vars = model.value_vars  # noqa: A001
+    else:
+        vars = inputvars([model.rvs_to_values.get(v, v) for v in vars])  # noqa: A001
+    value_bart = vars[0]
+    bart_rv = model.values_to_rvs[value_bart]
+    shared = make_shared_replacements(initial_point, [value_bart], model)
+    users = [rv for rv in model.observed_RVs if bart_rv in set(ancestors([rv]))]
+    if len(users) != 1:
+        raise NotImplementedError(f"the BART variable must feed exactly one observed variable, found {len(users)}")
+    rv = users[0]
+    op = rv.owner.op
+    params = list(op.dist_params(rv.owner)) if hasattr(op, "dist_params") else list(rv.owner.inputs[2:])
+    outs = model.replace_rvs_by_values(params)
+    out_list, inarray0 = join_nonshared_inputs(initial_point, outs, [value_bart], shared)
+    fn = compile_pymc([inarray0], out_list, **(compile_kwargs or {}))
+    fn.trust_input = True
+    shape = tuple(np.shape(initial_point[value_bart.name]))
+    dist_name = getattr(op, "name", type(op).__name__)
+
+    def probe(x):
+        return dist_name, [np.asarray(o) for o in fn(np.asarray(x, dtype=inarray0.dtype).ravel())]
+
+    y_obs = np.asarray(model.rvs_to_values[rv].data if hasattr(model.rvs_to_values[rv], "data")
+                       else model.rvs_to_values[rv].eval(), dtype=np.float64)
+    return {"value_var": value_bart, "op": bart_rv.owner.op, "shared": shared, "observed": y_obs,
+            "binding": identify(probe, shape), "initial_point": initial_point}

@@ -56,6 +56,21 @@ class BARTOp:
         self.initval = float(self.Y.mean())
 
 
+def _from_point(value, point):
+    """A likelihood parameter: a number, a shared variable (``get_value()``: what ``ArrayStepShared.step``
+    keeps current under PyMC), a callable, or the name of an entry of ``point``."""
+    if isinstance(value, str):
+        if point is None or value not in point:
+            raise KeyError(f"point has no value for {value!r}; under PyMC bind the parameter to a shared "
+                           "variable (PGBART(..., shared={name: var})) or let PGBART derive it from the model")
+        value = point[value]
+    elif hasattr(value, "get_value"):
+        value = value.get_value()
+    elif callable(value):
+        value = value()
+    return float(np.asarray(value))
+
+
 class NormalLikelihood:
     """``y ~ Normal(mu = BART, sigma)``; ``sigma`` is read from the point by name or fixed."""
 
@@ -65,12 +80,7 @@ class NormalLikelihood:
         self.sigma = sigma
 
     def params(self, point=None):
-        s = self.sigma
-        if isinstance(s, str):
-            if point is None or s not in point:
-                raise KeyError(f"point has no value for {s!r}")
-            s = point[s]
-        return [float(np.asarray(s))]
+        return [_from_point(self.sigma, point)]
 
 
 class BernoulliLikelihood:
@@ -105,20 +115,7 @@ class NegativeBinomialLikelihood:
         self.alpha = alpha
 
     def params(self, point=None):
-        a = self.alpha
-        if isinstance(a, str):
-            if point is None or a not in point:
-                raise KeyError(f"point has no value for {a!r}")
-            a = point[a]
-        return [float(np.asarray(a))]
-
-
-def _from_point(value, point):
-    if isinstance(value, str):
-        if point is None or value not in point:
-            raise KeyError(f"point has no value for {value!r}")
-        value = point[value]
-    return float(np.asarray(value))
+        return [_from_point(self.alpha, point)]
 
 
 class AsymmetricLaplaceLikelihood:
@@ -194,6 +191,34 @@ def _op_of(var):
 _PUBLISH_LOCK = __import__("threading").Lock()
 
 
+def _pick_device():
+    """A step method unpickled in a worker process (PyMC runs chains as processes and is not told which
+    chain it carries) picks its GPU: LOCAL_RANK (torch.distributed launchers), PGBART_DEVICE, else the
+    worker's ordinal in its pool, modulo the visible devices.  No-op without a GPU."""
+    import os
+
+    try:
+        import torch
+
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            return None
+        if "LOCAL_RANK" in os.environ:
+            idx = int(os.environ["LOCAL_RANK"])
+        elif "PGBART_DEVICE" in os.environ:
+            idx = int(os.environ["PGBART_DEVICE"])
+        else:
+            import multiprocessing as mp
+
+            ident = getattr(mp.current_process(), "_identity", ())
+            idx = (ident[0] - 1) if ident else torch.cuda.current_device()
+        idx %= ndev
+        torch.cuda.set_device(idx)
+        return idx
+    except Exception:  # noqa: BLE001 - never fatal: the current device stays
+        return None
+
+
 def _eval(x):
     return x.eval() if hasattr(x, "eval") and not isinstance(x, np.ndarray) else x
 
@@ -219,12 +244,25 @@ class PGBART(_Base):
     stats_dtypes = [{"variable_inclusion": object, "tune": bool}]
 
     def __init__(self, vars=None, num_particles=10, batch=(0.1, 0.1), model=None,  # noqa: A002
-                 initial_point=None, compile_kwargs=None, *, likelihood=None, observed=None,
+                 initial_point=None, compile_kwargs=None, *, likelihood=None, observed=None, shared=None,
                  random_seed=None, chain=0, backend=None, range_exp=None):
-        if vars is None or len(vars) != 1:
-            raise ValueError("PGBART samples exactly one BART variable per step method")
+        self._binding = None
+        duck = vars is not None and len(vars) == 1 and getattr(vars[0], "owner", None) is None
+        if _HAVE_PYMC and not duck and likelihood is None:  # pragma: no cover - needs a real PyMC model
+            # reference call convention (tests/test_bart.py:231-235): PGBART([rv], num_particles=...) inside
+            # a model context; family, observed response and shared variables come from the model
+            from ._pymc_bridge import bind_model
+
+            bound = bind_model(vars, model, initial_point, compile_kwargs)
+            vars = [bound["value_var"]]  # noqa: A001
+            self._binding = bound["binding"]
+            likelihood, observed, shared = self._binding.likelihood, bound["observed"], bound["shared"]
+            op = bound["op"]
+        else:
+            if vars is None or len(vars) != 1:
+                raise ValueError("PGBART samples exactly one BART variable per step method")
+            op = _op_of(vars[0])
         self._var = vars[0]
-        op = _op_of(self._var)
         self.bart = op
         X = np.asarray(_eval(op.X), dtype=np.float64)
         Y = np.asarray(_eval(op.Y), dtype=np.float64)
@@ -285,9 +323,10 @@ class PGBART(_Base):
         self._published = 0      # batches already sent to the op's history list
         self._offset = None      # last offset applied (re-applied after unpickling)
         self.shape = (self.num_observations,) if n_outputs == 1 else (n_outputs, self.num_observations)
-        if _HAVE_PYMC and model is not None:  # pragma: no cover
-            shared = {}
-            super().__init__(vars, shared)
+        if _Base is not object:
+            # ArrayStepShared keeps `shared` current (step(point) copies the other variables' values into
+            # them before astep(q) runs): likelihood parameters bound to those variables are read there
+            super().__init__([self._var], dict(shared or {}))
 
     # -- pickling: PyMC sends the step method to its worker processes ----------
     def __getstate__(self):
@@ -301,6 +340,7 @@ class PGBART(_Base):
     def __setstate__(self, d):
         blob = d.pop("_checkpoint")
         self.__dict__.update(d)
+        _pick_device()
         self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
                                  self._split_prior, backend=None)
         self.sampler.restore(blob)
@@ -328,9 +368,15 @@ class PGBART(_Base):
         model): a Normal model fits ``observed - offset``, the per-row families add it to the linear
         predictor.
         """
+        if self._binding is not None:  # pragma: no cover - PyMC model: parameters and offset at the shared values
+            params, model_offset = self._binding.current()
+            if model_offset is not None:
+                offset = model_offset
+        else:
+            params = self.likelihood.params(point)
         if offset is not None:
             self._apply_offset(offset)
-        self.sampler.set_likelihood(self.likelihood.params(point))
+        self.sampler.set_likelihood(params)
         if not self.tune and self._baseline is None:
             # first draw: freeze the forest the per-draw batches are deltas of (utils.py:124-127)
             self._baseline = self.sampler.export_trees(1)
@@ -351,12 +397,14 @@ class PGBART(_Base):
             raise NotImplementedError("offsets are not implemented for multi-output families")
         self._offset = np.array(offset, copy=True)
 
-    def step(self, point):
-        """Duck-typed ``step``: writes the new ``sum_trees`` into ``point[<bart name>]``."""
-        sum_trees, stats = self.astep(None, point)
-        out = dict(point)
-        out[getattr(self.bart, "name", "mu")] = sum_trees
-        return out, stats
+    if _Base is object:  # without PyMC: the part of ArrayStepShared.step this class needs
+
+        def step(self, point):
+            """Duck-typed ``step``: writes the new ``sum_trees`` into ``point[<bart name>]``."""
+            sum_trees, stats = self.astep(None, point)
+            out = dict(point)
+            out[getattr(self.bart, "name", "mu")] = sum_trees
+            return out, stats
 
     def _publish(self):
         """Hand this chain's history to the op (reference ``bart.py:134-135`` -> ``utils.py:124-127``).

@@ -1,0 +1,271 @@
+"""PGBART against the PyMC step-method API -- with an in-test double of
+``pymc.step_methods`` because PyMC cannot be installed on the build box.
+
+The double reproduces what ``pm.sample`` does with a step method [P]:
+``ArrayStepShared.step(point)`` copies the OTHER variables' current values into shared variables, ravels
+the step's own variable into ``q``, calls ``astep(q)`` with that single argument and puts the result
+back into the point; ``pm.STEP_METHODS`` is the registry ``import pymc_bart`` extends
+(reference ``pymc_bart/__init__.py:15-18``); ``competence`` decides the assignment
+(reference ``tests/test_bart.py:167-208``); the manual form is ``PGBART([mu1], num_particles=5)`` handed to
+``pm.sample(step=[...])`` (``tests/test_bart.py:231-235``).
+"""
+import enum
+import importlib
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+
+
+class _Shared:
+    def __init__(self, value):
+        self.value = np.asarray(value, float)
+
+    def set_value(self, v, borrow=False):
+        self.value = np.asarray(v, float)
+
+    def get_value(self):
+        return self.value
+
+
+class _Competence(enum.IntEnum):
+    INCOMPATIBLE = 0
+    COMPATIBLE = 1
+    PREFERRED = 2
+    IDEAL = 3
+
+
+class _ArrayStepShared:
+    """[P] pymc.step_methods.arraystep.ArrayStepShared, reduced to what a single-variable step uses."""
+
+    def __init__(self, vars, shared, blocked=True, rng=None):  # noqa: A002
+        self.vars = vars
+        self.var_names = tuple(v.name for v in vars)
+        self.shared = dict(shared)
+        self.blocked = blocked
+
+    def step(self, point):
+        for name, shared_var in self.shared.items():
+            shared_var.set_value(point[name], borrow=True)
+        q = np.concatenate([np.ravel(point[n]) for n in self.var_names])
+        apoint, stats = self.astep(q)                       # ONE argument, as PyMC calls it
+        new_point = dict(point)
+        (name,) = self.var_names
+        new_point[name] = np.asarray(apoint).reshape(np.shape(point[name]))
+        return new_point, stats
+
+
+@pytest.fixture()
+def fake_pymc(monkeypatch, oracle):
+    pm = types.ModuleType("pymc")
+    pm.STEP_METHODS = ["NUTS", "Metropolis"]
+    sm = types.ModuleType("pymc.step_methods")
+    arr = types.ModuleType("pymc.step_methods.arraystep")
+    arr.ArrayStepShared = _ArrayStepShared
+    comp = types.ModuleType("pymc.step_methods.compound")
+    comp.Competence = _Competence
+    for name, mod in (("pymc", pm), ("pymc.step_methods", sm), ("pymc.step_methods.arraystep", arr),
+                      ("pymc.step_methods.compound", comp)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    import pymc_bart_amd
+    import pymc_bart_amd.pgbart as pgb
+    import pymc_bart_amd.sampler as smp
+
+    importlib.reload(pgb)
+    importlib.reload(pymc_bart_amd)
+    monkeypatch.setattr(smp, "_DEFAULT_BACKEND", oracle)
+    yield pm, pgb
+    for name in ("pymc", "pymc.step_methods", "pymc.step_methods.arraystep", "pymc.step_methods.compound"):
+        sys.modules.pop(name, None)
+    importlib.reload(pgb)
+    importlib.reload(pymc_bart_amd)
+
+
+def _two_term_data(seed=3415, n=30):
+    rng = np.random.default_rng(seed)
+    X1, X2 = rng.normal(size=(n, 3)), rng.normal(size=(n, 2))
+    Y1 = X1[:, 0] + rng.normal(0, 0.1, n)
+    Y2 = X2[:, 1] + rng.normal(0, 0.1, n)
+    return X1, X2, Y1, Y2, Y1 + Y2 + rng.normal(0, 0.1, n)
+
+
+def test_import_registers_the_step_method_and_competence_is_ideal(fake_pymc):
+    pm, pgb = fake_pymc
+    assert pgb.PGBART in pm.STEP_METHODS and pm.STEP_METHODS[:2] == ["NUTS", "Metropolis"]
+    assert issubclass(pgb.PGBART, _ArrayStepShared)
+    X1, _, Y1, _, _ = _two_term_data()
+    op = pgb.BARTOp(X1, Y1, m=3, name="mu1")
+    assert pgb.PGBART.competence(op, has_grad=False) is _Competence.IDEAL
+    assert pgb.PGBART.competence(object(), has_grad=True) is _Competence.INCOMPATIBLE
+    assert pgb.PGBART.name == "pgbart" and pgb.PGBART.generates_stats and not pgb.PGBART.default_blocked
+    assert pgb.PGBART.stats_dtypes_shapes == {"variable_inclusion": (object, []), "tune": (bool, [])}
+
+
+def test_manual_steps_for_two_bart_variables_run_through_step_point(fake_pymc, oracle):
+    """The reference's only direct use of the boundary (tests/test_bart.py:211-241): two BART terms in one
+    Normal likelihood, one PGBART each, sigma owned by another sampler.  Everything reaches the step
+    methods the way PyMC delivers it: through ``step(point)`` -> shared variables -> ``astep(q)``."""
+    _, pgb = fake_pymc
+    X1, X2, Y1, Y2, Y = _two_term_data()
+    sigma_sh = {1: _Shared(1.0), 2: _Shared(1.0)}
+    other_sh = {1: _Shared(np.zeros(30)), 2: _Shared(np.zeros(30))}
+    mu1, mu2 = pgb.BARTOp(X1, Y1, m=3, name="mu1"), pgb.BARTOp(X2, Y2, m=3, name="mu2")
+
+    def make(op, k, other_name):
+        # y ~ Normal(mu_k + mu_other, sigma): the other term is this step's offset, read from ITS shared copy
+        st = pgb.PGBART([op], num_particles=5, likelihood=pgb.NormalLikelihood(sigma_sh[k]), observed=Y,
+                        shared={"sigma": sigma_sh[k], other_name: other_sh[k]}, random_seed=3415, backend=oracle)
+        st.offset_from = other_sh[k]
+        return st
+
+    step1, step2 = make(mu1, 1, "mu2"), make(mu2, 2, "mu1")
+    for st in (step1, step2):  # additive model: the offset comes from the shared copy of the other term
+        orig = st.astep
+        st.astep = (lambda q, _o=orig, _s=st: _o(q, offset=_s.offset_from.get_value()))
+    point = {"mu1": np.full(30, Y1.mean()), "mu2": np.full(30, Y2.mean()), "sigma": 0.5}
+    rng = np.random.default_rng(1)
+    draws = {"mu1": [], "mu2": []}
+    for it in range(40):
+        if it == 20:
+            step1.stop_tuning()
+            step2.stop_tuning()
+        for st in (step1, step2):
+            point, stats = st.step(point)
+            assert set(stats[0]) == {"variable_inclusion", "tune"} and stats[0]["tune"] == (it < 20)
+        res = Y - point["mu1"] - point["mu2"]
+        point["sigma"] = float(np.sqrt((1.0 + 0.5 * res @ res) / rng.gamma(1.0 + 15.0)))
+        if it >= 20:
+            draws["mu1"].append(point["mu1"])
+            draws["mu2"].append(point["mu2"])
+    assert np.array(draws["mu1"]).shape == (20, 30) and np.array(draws["mu2"]).shape == (20, 30)
+    assert step1.sampler.settings.n == 30 and sigma_sh[1].get_value() == pytest.approx(point["sigma"], rel=0.5)
+    fit = np.mean(draws["mu1"], axis=0) + np.mean(draws["mu2"], axis=0)
+    assert np.corrcoef(fit, Y)[0, 1] > 0.8
+    assert len(mu1.all_trees) == 1 and len(mu2.all_trees) == 1      # separate histories per BART variable
+    assert len(mu1.all_trees[0][1]) == 20
+
+
+def test_sigma_arrives_through_the_shared_variable_not_through_a_point_argument(fake_pymc, oracle):
+    _, pgb = fake_pymc
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(200, 3))
+    Y = X[:, 0] + rng.normal(0, 0.3, 200)
+    sh = _Shared(1.0)
+
+    def run(sigmas):
+        st = pgb.PGBART([pgb.BARTOp(X, Y, m=5)], num_particles=6, batch=(1.0, 1.0), likelihood=pgb.NormalLikelihood(sh),
+                        shared={"sigma": sh}, random_seed=7, backend=oracle)
+        point = {"mu": np.full(200, Y.mean()), "sigma": 1.0}
+        outs = []
+        for s in sigmas:
+            point["sigma"] = s
+            point, _ = st.step(point)
+            outs.append(point["mu"].copy())
+        return np.array(outs)
+
+    a = run([1.0, 0.05, 0.2, 3.0])
+    b = run([1.0, 0.05, 0.2, 3.0])
+    c = run([1.0, 50.0, 0.2, 3.0])
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[0], c[0]) and not np.array_equal(a[1], c[1])   # the second step saw another sigma
+    with pytest.raises(KeyError, match="shared"):                          # a name needs a point; PyMC passes none
+        pgb.PGBART([pgb.BARTOp(X, Y, m=5)], num_particles=6, likelihood=pgb.NormalLikelihood("sigma"),
+                   random_seed=7, backend=oracle).astep(np.zeros(200))
+
+
+def test_pickled_step_method_keeps_the_pymc_surface(fake_pymc, oracle):
+    _, pgb = fake_pymc
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(100, 2))
+    Y = X[:, 1] + rng.normal(0, 0.2, 100)
+    sh = _Shared(0.5)
+    st = pgb.PGBART([pgb.BARTOp(X, Y, m=4)], num_particles=5, likelihood=pgb.NormalLikelihood(0.5),
+                    shared={"sigma": sh}, random_seed=5, backend=oracle)
+    point = {"mu": np.full(100, Y.mean()), "sigma": 0.5}
+    point, _ = st.step(point)
+    twin = pickle.loads(pickle.dumps(st))
+    a, _ = st.step(point)
+    b, _ = twin.step(point)
+    assert np.array_equal(a["mu"], b["mu"]) and twin.var_names == ("mu",)
+
+
+def test_device_choice_of_a_worker_process(monkeypatch):
+    import torch
+
+    from pymc_bart_amd import pgbart as pgb
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    picked = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: picked.append(i))
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert pgb._pick_device() == 5
+    monkeypatch.delenv("LOCAL_RANK")
+    monkeypatch.setenv("PGBART_DEVICE", "11")
+    assert pgb._pick_device() == 3          # modulo the visible devices
+    monkeypatch.delenv("PGBART_DEVICE")
+    import multiprocessing as mp
+
+    monkeypatch.setattr(mp.current_process(), "_identity", (3,), raising=False)
+    assert pgb._pick_device() == 2          # third worker of the pool -> GPU 2
+    assert picked == [5, 3, 2]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    assert pgb._pick_device() is None
+
+
+# ---- the family a model uses, decided from numeric probes (pymc_bart_amd/_pymc_bridge.py)
+def _probe_factory(kind, n=40, K=1, offset=None, **par):
+    from scipy.special import expit, ndtr
+
+    off = np.zeros(n) if offset is None else offset
+
+    def probe(x):
+        x = np.asarray(x, float)
+        if kind == "normal":
+            return "normal", [x + off, np.full(n, par.get("sigma", 0.7))]
+        if kind == "meanscale":
+            return "normal", [x[0], np.abs(x[1])]
+        if kind == "probit":
+            return "bernoulli", [ndtr(x + off)]
+        if kind == "logit":
+            return "bernoulli", [expit(x + off)]
+        if kind == "cloglog":
+            return "bernoulli", [1 - np.exp(-np.exp(x))]
+        if kind == "softmax":
+            e = np.exp(x - x.max(axis=0))
+            return "categorical", [(e / e.sum(axis=0)).T]       # (n, K) as the reference model writes it
+        if kind == "poisson":
+            return "poisson", [np.exp(x + off)]
+        if kind == "negbin":
+            return "negative_binomial", [np.exp(x + off), np.full(n, par.get("alpha", 2.0))]
+        if kind == "hetero":
+            return "normal", [x, np.exp(0.1 * x)]
+        return "gamma", [x]
+
+    return probe
+
+
+def test_likelihood_family_is_identified_numerically():
+    from pymc_bart_amd._pymc_bridge import identify
+
+    n = 40
+    off = np.linspace(-1, 1, n)
+    b = identify(_probe_factory("normal", sigma=0.7), (n,))
+    assert b.likelihood.family == "normal" and b.current() == ([0.7], None)
+    b = identify(_probe_factory("normal", offset=off, sigma=1.3), (n,))
+    params, o = b.current()
+    assert params == [1.3] and np.allclose(o, off)                 # the second BART term / a fixed effect
+    assert identify(_probe_factory("meanscale"), (2, n)).likelihood.family == "normal_meanscale"
+    b = identify(_probe_factory("probit", offset=off), (n,))
+    assert b.likelihood.family == "bernoulli_probit" and np.allclose(b.current()[1], off, atol=1e-9)
+    assert identify(_probe_factory("logit"), (n,)).likelihood.family == "bernoulli_logit"
+    b = identify(_probe_factory("softmax", K=3), (3, n))
+    assert b.likelihood.family == "categorical" and b.likelihood.n_outputs == 3
+    b = identify(_probe_factory("poisson", offset=np.log(np.linspace(0.5, 4, n))), (n,))
+    assert b.likelihood.family == "poisson_log" and b.current()[1] is not None
+    b = identify(_probe_factory("negbin", alpha=2.5), (n,))
+    assert b.likelihood.family == "negbin_log" and b.current()[0] == [2.5]
+    for bad in ("cloglog", "hetero", "gamma"):
+        with pytest.raises(NotImplementedError):
+            identify(_probe_factory(bad), (n,))
