@@ -1180,3 +1180,37 @@ void pgbo_loglik(int family, const double* y, const double* mu, int64_t n, doubl
 void pgbo_log_ndtr(const double* x, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = pgb_log_ndtr(x[i]);
 }
+
+/* ---- hooks for the oracle-INDEPENDENT checks of the shared numeric layer (tests/test_spec_independent.py:
+ *      every function below is compiled into both backends from include/pgbart_spec.h, so HIP == oracle says
+ *      nothing about it; these expose them to scipy / NumPy) */
+void pgbo_loglikq(int family, const double* y, const double* mu, int64_t n, double param, double param2,
+                  double* out) {
+  for (int64_t i = 0; i < n; ++i)
+    out[i] = pgb_loglik1q(family, y[i], mu[i], param, param2, pgb_ln_tn(), pgb_ln_tp());
+}
+void pgbo_loglik_multi(int family, int K, const double* y, const double* mu /* [n][K] */, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik(family, K, y[i], mu + i * K);
+}
+void pgbo_lin_fit(int64_t cnt, int64_t q_u, int64_t q_uu, int64_t q_us, int64_t q_st, double inv_c1, double inv_R,
+                  double m, double* out3) {
+  pgb_linfit f = pgb_lin_fit(cnt, q_u, q_uu, q_us, q_st, inv_c1, inv_R, m);
+  out3[0] = f.slope_u; out3[1] = f.ubar; out3[2] = f.var_u;
+}
+double pgbo_lin_sse(double sse_const, double slope_u, double ubar, double var_u, int64_t q_ur, int64_t q_r,
+                    double inv_c1) {
+  pgb_linfit f = {slope_u, ubar, var_u};
+  return pgb_lin_sse(sse_const, f, q_ur, q_r, inv_c1);
+}
+double pgbo_leaf_sse(int64_t cnt, int64_t q_r, int64_t q_r2, double v, double inv_c1, double inv_c2) {
+  return pgb_leaf_sse(cnt, q_r, q_r2, v, inv_c1, inv_c2);
+}
+double pgbo_leaf_value(int64_t cnt, int64_t q_st, double inv_c1, double m, double z, double leaf_sd) {
+  return pgb_leaf_value(cnt, q_st, inv_c1, m, z, leaf_sd);
+}
+int pgbo_sample_var(const int64_t* S, int p, double u) { return pgb_sample_var(S, p, u); }
+int64_t pgbo_alpha_init(double prior, double max_prior) { return pgb_alpha_init(prior, max_prior); }
+int64_t pgbo_alpha_unit(double max_prior) { return pgb_alpha_unit(max_prior); }
+double pgbo_subset_value(double u1, double x) { return pgb_subset_value(u1, x); }
+int pgbo_go_left(int rule, double x, double v) { return pgb_go_left(rule, x, v); }
+int pgbo_col_exponent(double amax) { return pgb_col_exponent(amax); }
