@@ -652,19 +652,27 @@ static int harvest_profile(pgb_handle* h) {
 // host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
 // are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
 #define BUNDLE 8
+#define BUNDLE_TAIL 2
+// Slots are enqueued in bundles of 8 with at most 3 bundles in flight; once the number of slots this
+// call has enqueued comes within 2 bundles of what such a call needed last time (running estimate per
+// astep), it switches to bundles of 2 with 2 in flight, so that only a few idle slots (~4 us each) are
+// queued behind the slot that completes the step -- the results of a synchronous astep wait for them.
 static int feed_until_flag(pgb_handle* h, int n_steps) {
   Dev& d = h->d;
-  long long start = h->slot;
+  const long long start = h->slot;
   long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
+  const long long expect = h->slots_per_step > 0.0 ? (long long)(h->slots_per_step * n_steps) : (1ll << 60);
   int rc;
   while (*h->flag < (unsigned long long)h->steps_target) {
+    const bool tail = (h->slot - start) + 2 * BUNDLE >= expect;
+    const int depth = tail ? 2 : 3;
     hipEvent_t ev = h->bundle_ev[h->bundles & 3];
-    if (h->bundles >= 3) {
-      // wait for bundle (bundles - 3) before reusing its event: keeps <= 3 bundles queued
-      HIPCHK(hipEventSynchronize(h->bundle_ev[(h->bundles - 3) & 3]));
+    if (h->bundles >= depth) {
+      // wait for an earlier bundle before queueing more (this also frees its event for reuse)
+      HIPCHK(hipEventSynchronize(h->bundle_ev[(h->bundles - depth) & 3]));
       if (*h->flag >= (unsigned long long)h->steps_target) break;
     }
-    if ((rc = enqueue_slots(h, BUNDLE)) != PGB_OK) return rc;
+    if ((rc = enqueue_slots(h, tail ? BUNDLE_TAIL : BUNDLE)) != PGB_OK) return rc;
     HIPCHK(hipEventRecord(ev, h->stream));
     h->bundles += 1;
     if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
@@ -717,6 +725,13 @@ static void counters_from(pgb_handle* h, const unsigned long long* c) {
   h->ctr.partitions = (int64_t)c[6];
 }
 
+// running estimate of the (working) slots one astep needs, from the device's own count
+static void note_step_slots(pgb_handle* h, long long slots_before, int n_steps) {
+  const double per = (double)(h->ctr.slots - slots_before) / (double)(n_steps > 0 ? n_steps : 1);
+  if (per <= 0.0) return;
+  h->slots_per_step = h->slots_per_step > 0.0 ? 0.5 * h->slots_per_step + 0.5 * per : per;
+}
+
 static int fetch_counters(pgb_handle* h, pgb_counters* out) {
   unsigned long long c[8];
   HIPCHK(hipMemcpyAsync(c, h->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
@@ -731,6 +746,7 @@ extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, 
   if (!h) return fail(PGB_E_INVALID, "null handle");
   JOIN_ASYNC(h);
   int rc;
+  const long long slots0 = h->ctr.slots;
   if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
   if ((rc = run_until_idle(h, 1)) != PGB_OK) return rc;
   if (sum_trees_dev_out)  // [K][n] out of the padded [K][n_pad] buffer
@@ -741,6 +757,7 @@ extern "C" int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, 
     HIPCHK(hipMemcpyAsync(vi_counts_host_out, h->d.vi, h->d.p * sizeof(int32_t), hipMemcpyDeviceToHost,
                           h->stream));
   if ((rc = fetch_counters(h, counters_out)) != PGB_OK) return rc;
+  note_step_slots(h, slots0, 1);
   return PGB_OK;
 }
 
@@ -754,6 +771,7 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   JOIN_ASYNC(h);
   Dev& d = h->d;
   int rc;
+  const long long slots0 = h->ctr.slots;
   if ((rc = begin_steps(h, tune, 1)) != PGB_OK) return rc;
   if ((rc = feed_until_flag(h, 1)) != PGB_OK) return rc;
   const int nt = h->last_n;
@@ -776,6 +794,7 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   h->st_cur = H->st_cur;
   h->alpha_cur = H->alpha_cur;
   counters_from(h, H->counters);
+  note_step_slots(h, slots0, 1);
   h->out_valid = 1;
   if (vi_counts_host_out) memcpy(vi_counts_host_out, h->out_host + h->out_layout.vi, (size_t)d.p * sizeof(int32_t));
   if (counters_out) *counters_out = h->ctr;
