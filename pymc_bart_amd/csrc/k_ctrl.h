@@ -478,7 +478,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       const DPart* A = &OT[anc];
       const Fin& f = s_fin[anc];
       const int nn = f.nn_old;
-      for (int i = tid; i < nn; i += BT) {
+      // (waves 1..3 copy: wave 0 goes straight on to the proposal -- it would otherwise sit out the
+      //  round trip of these loads before popping its node; nothing below reads the new table until
+      //  the workgroup barrier of a tree's last slot)
+      for (int i = tid - 64; i < nn; i += BT - 64) {
+        if (i < 0) continue;
         DNode z = A->nd[i];
         if (r1 && i == 0) {  // root statistics (see above)
           z.q_st = ia.A;

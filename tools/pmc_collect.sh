@@ -1,0 +1,35 @@
+#!/bin/bash
+# HBM traffic (cfg2) / VALU instruction counts (cfg4, cfg5) of the hot kernels, per launch, from separate
+# rocprofv3 --pmc passes (counters only: no trace domains), written to profiles/r02_pmc_<workload>.json,
+# the file bench.py reads `roofline.traffic` from.  Run on the GPU box from the repo root.
+# usage: tools/pmc_collect.sh cfg2|cfg4|cfg5
+W=${1:-cfg2}; R=$PWD; cd /tmp; export TMPDIR=/tmp
+if [ $W = cfg2 ]; then A="--steps 10 --warmup 2 --burnin 30 --repeats 1"; else A="--workload $W --steps 3 --warmup 1 --burnin 3 --repeats 1"; fi
+A="$A --no-extras --no-cpu-baseline --no-roofline --no-multichain"
+DIRS=""
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
+  rm -rf /tmp/pmc_${W}_$C
+  rocprofv3 --pmc $C -d /tmp/pmc_${W}_$C --output-format csv -- python3 $R/bench.py $A > /dev/null 2> /tmp/pmc_${W}_$C.err || tail -3 /tmp/pmc_${W}_$C.err
+  DIRS="$DIRS /tmp/pmc_${W}_$C"
+done
+python3 $R/tools/pmc_summary.py $DIRS > /tmp/pmc_${W}.json
+python3 - <<PY
+import json
+raw = json.load(open("/tmp/pmc_${W}.json"))
+out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged per launch by tools/pmc_summary.py)",
+       "workload": "$W",
+       "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): corrected x2; WRITE_SIZE taken as reported (calibrated exact on k_transpose in round 1); units KB per launch as the counters report them; SQ_INSTS_VALU counts wave-instructions",
+       "raw": raw}
+for k, v in raw.items():
+    short = k.split("<")[0]
+    f, w = v.get("FETCH_SIZE_avg_per_launch"), v.get("WRITE_SIZE_avg_per_launch")
+    e = out.setdefault(short, {})
+    if f is not None and w is not None and v.get("launches", 0) > e.get("launches", 0):
+        e.update(launches=v["launches"], hbm_bytes_per_launch_corrected=(2.0 * f + w) * 1024.0,
+                 fetch_KB_per_launch=f, write_KB_per_launch=w)
+    if v.get("SQ_INSTS_VALU_avg_per_launch") is not None and v.get("launches", 0) >= e.get("valu_launches", 0):
+        e.update(valu_launches=v["launches"], valu_wave_insts_per_launch=v["SQ_INSTS_VALU_avg_per_launch"],
+                 waves_per_launch=v.get("SQ_WAVES_avg_per_launch"))
+json.dump(out, open("$R/gpurun_out/r02_pmc_${W}.json", "w"), indent=1)
+print({k: v for k, v in out.items() if k.startswith("k_")})
+PY
