@@ -161,8 +161,10 @@ __device__ __forceinline__ void lin_children_x(const Dev& S, LinKids& lk, ChildX
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
-void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias) {
-  // ctrls / ias repeat S.ctrl / S.initacc as kernel arguments (see k_rows)
+void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias,
+            const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all) {
+  // ctrls / ias / jobs_all / acc_all / parts_all repeat S.ctrl / S.initacc / S.jobs / S.acc / S.parts as
+  // kernel arguments (preloaded into SGPRs): their first loads do not wait for the argument block S
   const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_i[16];
@@ -172,8 +174,18 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   __shared__ ChildX s_finx[MK ? MAXP : 1][KXMAX];     // K-vector leaves: children, outputs 1..K-1
   __shared__ double s_prior[PGB_MAX_DEPTH];           // P(leaf | depth): read once by the idle wave 3
   __shared__ DNode s_pop[MAXP];                       // node each OLD particle would pop next (prefetched)
+  __shared__ double s_ahead[2][4];                    // [set][z0, z1, u_res, u_fin]: draws made one slot ahead
 
   TR(0);
+  // The previous round's job record and split statistics of old particle q = lane (wave 0) are
+  // requested FIRST, together with the control word: their addresses depend on `par` alone.  Harmless
+  // in idle / first slots (the records exist).
+  Job j_pre;
+  Acc a_pre;
+  if (threadIdx.x < 64) {
+    j_pre = jobs_all[(size_t)(par ^ 1) * MAXP + threadIdx.x];
+    a_pre = load_acc(&acc_all[((size_t)(par ^ 1) * MAXP + threadIdx.x) * ACC_PER]);
+  }
   if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
   const Ctrl c = load_uniform(&ctrls[par]);
   Ctrl* co = &ctrls[par ^ 1];
@@ -237,7 +249,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   TR(1);
   const int r = c.round;  // >= 1 in PH_ROUND: round 0 is proposed by the slot that starts the tree
   const uint32_t it = (uint32_t)c.iter;
-  const DPart* OT = S.parts + (size_t)par * MAXP;
+  const DPart* OT = parts_all + (size_t)par * MAXP;
   DPart* NT = S.parts + (size_t)(par ^ 1) * MAXP;
   const Job* JP = S.jobs + (size_t)(par ^ 1) * MAXP;  // jobs (+ particle headers) of the previous slot
   Job* JN = S.jobs + (size_t)par * MAXP;
@@ -263,6 +275,25 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
     if (l == 0) s_i[8 + set] = jj;
     TRX(9 + set, blockIdx.x == 1 && l == 0);
+  }
+
+  // Wave 3: the draws the NEXT slot starts with -- the leaf noise of the children this slot's proposal may
+  // create (particle p), the resampling offset of the proposed round and the final-choice draw of its tree
+  // -- for both candidate proposals (set 0 / 1 as above).  They travel in the job record / control word.
+  if (tid >= 192 && tid < 198) {
+    const int l = tid - 192, set = l & 1, kind = l >> 1;  // kind 0: leaf noise, 1: resampling, 2: final choice
+    const uint32_t ita = set ? it + 1u : it, ra = set ? 0u : (uint32_t)r;
+    if (kind == 0) {
+      const pgb_u2 ul = pgb_draw2(S.seed, ita, ra, (uint32_t)p, PGB_RNG_LEAF, 0);
+      double z0, z1;
+      pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+      s_ahead[set][0] = z0;
+      s_ahead[set][1] = z1;
+    } else if (kind == 1) {
+      s_ahead[set][2] = pgb_draw2(S.seed, ita, ra, 0u, PGB_RNG_RESAMPLE, 0).u0;
+    } else {
+      s_ahead[set][3] = pgb_draw2(S.seed, ita, 0, 0, PGB_RNG_FINAL, 0).u0;
+    }
   }
 
   int anc = p;  // ancestor (old particle index) of new particle p
@@ -298,8 +329,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       lk.svarL = lk.svarR = -1;
       lk.linL = lk.linR = false;
       if (isp) {
-        j = JP[q];
-        a = load_acc(&S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER]);
+        j = j_pre;
+        a = a_pre;
         // requested as soon as the job header is here; consumed at the end of this phase
         if (j.h_next_pop < j.h_n_nodes) popn = OT[q].nd[j.h_next_pop];
         if (!normal) {
@@ -311,14 +342,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           }
         }
       }
-      // one Philox evaluation per lane: lane 0 draws the resampling offset, lane q the leaf noise
-      double z0, z1, u_res;
-      {
-        const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)(r - 1), (uint32_t)q,
-                                    q == 0 ? PGB_RNG_RESAMPLE : PGB_RNG_LEAF, 0);
-        u_res = readlane_d(ul.u0, 0);
-        pgb_normal2(ul.u0, ul.u1, &z0, &z1);
-      }
+      // the leaf noise of old particle q's pending split and the resampling offset were drawn one slot
+      // ahead (same addresses: (iter, r - 1, q, LEAF) and (iter, r - 1, 0, RESAMPLE)) and arrive with the
+      // job record / control word
+      const double z0 = isp ? j.z0 : 0.0, z1 = isp ? j.z1 : 0.0;
+      const double u_res = c.u_res;
       if (isp) {
         if (r1) {  // round-0 jobs were written before the root statistics existed
           j.p_q_st = ia.A;
@@ -432,8 +460,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
         if (q == 0) lw = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
-        const pgb_u2 u_fin = pgb_draw2(S.seed, it, 0, 0, PGB_RNG_FINAL, 0);
-        pick = wave_pick(lw, 0, P, u_fin.u0);
+        pick = wave_pick(lw, 0, P, c.u_fin);  // (iter, 0, 0, FINAL), drawn one slot ahead
       }
       if (tid == 0) {
         s_i[0] = stop ? 1 : 0;
@@ -964,6 +991,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       job.p_sse = nd.sse;
       job.p_value = nd.value;
       job.p_depth = nd.depth;
+      job.z0 = s_ahead[set][0];
+      job.z1 = s_ahead[set][1];
       atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
       atomicAdd(&S.counters[6], 1ull);
       if constexpr (MK)
@@ -1016,6 +1045,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     o.pend_leafsd = 0;
     o.lid_gen = (c.lid_gen + 1) % NGEN;
     o.sse0 = sse0;
+    o.u_res = s_ahead[set][2];
+    o.u_fin = s_ahead[set][3];
     o.phase = PH_ROUND;
     if (!fresh) {
       cmd->kind = CMD_PARTITION;

@@ -113,12 +113,8 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     if (tid >= 1 && tid < S.P) j = jobs[tid];
     const bool has = j.active != 0;
     const unsigned long long m = __ballot(has);
-    // one Philox evaluation per lane: the leaf noise of particle `tid` in this round
-    double z0, z1;
-    {
-      const pgb_u2 ul = pgb_draw2(S.seed, it, (uint32_t)round, (uint32_t)tid, PGB_RNG_LEAF, 0);
-      pgb_normal2(ul.u0, ul.u1, &z0, &z1);
-    }
+    // the leaf noise of particle `tid` in this round: drawn by the control kernel of this slot, in the job
+    const double z0 = has ? j.z0 : 0.0, z1 = has ? j.z1 : 0.0;
     if (has) {
       const int k = __popcll(m & ((1ull << tid) - 1ull));
       const Acc a = load_acc(&S.acc[((size_t)par * MAXP + tid) * ACC_PER]);

@@ -39,6 +39,11 @@ struct Job {  // one particle's work for a PARTITION row pass + what the next k_
   double h_sse_tot, h_sse_orph;
   int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
   int32_t pad_;
+  // leaf noise of the two children this split creates ([U] draw_leaf_value: the Box-Muller pair addressed
+  // by (iter, round, particle)): drawn by an idle wave of the slot that WRITES the job, so that the slot
+  // that finishes the round does not start with ~1.8 us of Philox + log + sqrt + sincos on its one
+  // critical wave
+  double z0, z1;
 };
 // (No unions / arrays in records that are copied by value in kernels: they defeat scalar
 //  replacement and the copies get demoted to LDS or scratch.)
@@ -117,6 +122,9 @@ struct Ctrl {
   double sse0;  // SSE of the reference particle (the current tree), fixed at round 0
   long long steps_done;  // asteps completed since creation (mirrored to the host flag)
   long long slot_no;     // k_ctrl launches so far
+  // draws the NEXT slot needs before it can do anything else, made one slot ahead (same addresses):
+  // the systematic-resampling offset of the round just proposed, the final-choice draw of its tree
+  double u_res, u_fin;
 };
 
 struct Dev {  // kernel argument block (by value)

@@ -571,7 +571,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
       h->slot += 1;
       continue;
     }
-#define CTRL_ARGS dd, par, d.ctrl, (const InitAcc*)d.initacc
+#define CTRL_ARGS dd, par, d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
     if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS);
     else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS);
     else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS);
