@@ -420,7 +420,7 @@ def main():
             name: {"pct": 100.0 * k["ms"] / tot_ms, "avg_us": k["ms"] * 1e3 / k["launches"],
                    "launches": k["launches"], "workgroups": k["workgroups"]}
             for name, k in kern.items()}
-        dom = "k_slot" if "k_slot" in kern else "k_rows"
+        dom = "k_rows"
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_{args.workload}.json")
         default_cfg = (args.workload != "cfg2") or (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40)

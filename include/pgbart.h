@@ -176,7 +176,7 @@ int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* l
  * pgb_profile(h, 0, ...).  CPU backends report 0. */
 int pgb_profile_clock(pgb_handle* h, double* kernel_ms_out, int64_t* launches_out);
 /* Per-kernel view of the last profiled region (valid after pgb_profile(h, 0, ...)): which = 0 the
- * control kernel, 1 the row pass, 2 the per-row log-likelihood pass, 3 the fused slot kernel.
+ * control kernel, 1 the row pass, 2 the per-row log-likelihood pass.
  * Total event time, launches, and the workgroups of one launch.  CPU backends report 0.          */
 int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int64_t* launches_out,
                        int32_t* workgroups_out);

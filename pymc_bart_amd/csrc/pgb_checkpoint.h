@@ -105,8 +105,8 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
 extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out, int64_t* launches_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   JOIN_ASYNC(h);
-  if (kernel_ms_out) *kernel_ms_out = h->prof_ms[PK_ROWS] + h->prof_ms[PK_SLOT];
-  if (launches_out) *launches_out = h->prof_launches[PK_ROWS] + h->prof_launches[PK_SLOT];
+  if (kernel_ms_out) *kernel_ms_out = h->prof_ms[PK_ROWS];
+  if (launches_out) *launches_out = h->prof_launches[PK_ROWS];
   if (enable && !h->prof) {
     for (int k = 0; k < PK_COUNT; ++k) {
       h->prof_ms[k] = 0.0;

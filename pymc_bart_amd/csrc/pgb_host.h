@@ -1,6 +1,6 @@
 // pgb_host.h -- part of pgbart_hip.hip (not a standalone header): host side: handles, the C ABI of include/pgbart.h, slot enqueueing.
 // ------------------------------------------------------------------ host side
-enum { PK_CTRL = 0, PK_ROWS = 1, PK_LL = 2, PK_SLOT = 3, PK_COUNT = 4 };
+enum { PK_CTRL = 0, PK_ROWS = 1, PK_LL = 2, PK_COUNT = 3 };
 static thread_local char g_err[512];
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
@@ -32,10 +32,8 @@ struct pgb_handle {
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
-  int fused;       // one launch per SMC round (k_slot) instead of {k_ctrl ; k_rows}
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int ll_grid;     // ... of the log-likelihood pass
-  int slot_grid;   // ... of the fused slot kernel: every workgroup runs the control phase, so never more than fit at once
   int sigma_dirty;
   double inv_sigma2;
   double lik_param2;
@@ -161,8 +159,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->prof_slot0 = 0;
   if (const char* e = getenv("PGB_ROWS_GRID")) h->rows_grid = atoi(e) > 0 ? atoi(e) : h->rows_grid;
   h->ll_grid = h->rows_grid;
-  h->slot_grid = 256;  // one workgroup of SLOT_TEAMS row teams per CU
-  if (const char* e = getenv("PGB_SLOT_GRID")) h->slot_grid = atoi(e) > 0 ? atoi(e) : h->slot_grid;
   if (const char* e = getenv("PGB_LL_GRID")) h->ll_grid = atoi(e) > 0 ? atoi(e) : h->ll_grid;
   h->st_cur = 0;
   h->alpha_cur = 0;
@@ -197,15 +193,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
   // One launch per SMC round where the round is latency-bound: Normal likelihood, one output, constant
   // leaves, and few enough (particle, chunk) pairs that a work item holds <= GMAXF particles.
-  {
-    const bool can = s->family == PGB_FAMILY_NORMAL && s->n_outputs == 1 && s->response == PGB_RESPONSE_CONSTANT &&
-                     s->p <= CDF_LDS;
-    // measured on MI355X at cfg2 (profiles/r02_*): the fused schedule is SLOWER than the two-kernel slot
-    // (22.5 vs 16.7 us per round: every workgroup repeats the control phase on a busy memory system),
-    // so it is opt-in: PGB_FUSED=1
-    h->fused = 0;
-    if (const char* e = getenv("PGB_FUSED")) h->fused = can && atoi(e) != 0;
-  }
   d.batch_tune = s->batch_tune;
   d.batch_draw = s->batch_draw;
   d.seed = s->seed;
@@ -253,10 +240,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
-  DA(d.acc, 3 * MAXP * ACC_PER);  // (the fused slot kernel keeps a ring of three)
+  DA(d.acc, 2 * MAXP * ACC_PER);
   DA(d.accl, 2 * MAXP * LL_PER);
   DA(d.jobl, 2 * MAXP);
-  DA(d.initacc, 3 * IA_SLOTS);
+  DA(d.initacc, 2 * IA_SLOTS);
   DA(d.cmd, 2);
   DA(d.ctrl, 2);
   DA(d.counters, 8);
@@ -349,10 +336,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
-  HC(hipMemsetAsync(d.acc, 0, 3 * MAXP * ACC_PER * sizeof(Acc), sm));
+  HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
   HC(hipMemsetAsync(d.accl, 0, 2 * MAXP * LL_PER * sizeof(AccL), sm));
   HC(hipMemsetAsync(d.jobl, 0, 2 * MAXP * sizeof(JobL), sm));
-  HC(hipMemsetAsync(d.initacc, 0, 3 * IA_SLOTS * sizeof(InitAcc), sm));
+  HC(hipMemsetAsync(d.initacc, 0, 2 * IA_SLOTS * sizeof(InitAcc), sm));
   HC(hipMemsetAsync(d.cmd, 0, 2 * sizeof(Cmd), sm));
   HC(hipMemsetAsync(d.counters, 0, 8 * sizeof(unsigned long long), sm));
   HC(hipMemsetAsync(vi, 0, d.p * sizeof(int32_t), sm));
@@ -561,16 +548,6 @@ static int enqueue_slots(pgb_handle* h, int count) {
   const bool lin = d.response != PGB_RESPONSE_CONSTANT;
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-    if (h->fused) {
-      const int s3 = (int)(h->slot % 3);
-      long long wg = (want + SLOT_TEAMS - 1) / SLOT_TEAMS;  // `want` row items, SLOT_TEAMS per workgroup
-      if (wg > h->slot_grid) wg = h->slot_grid;
-      dim3 gslot((unsigned)wg);
-      if (h->has_subset) LAUNCH_KT(PK_SLOT, (k_slot<true>), gslot, SLOT_BT, dd, par, s3, d.ctrl);
-      else LAUNCH_KT(PK_SLOT, (k_slot<false>), gslot, SLOT_BT, dd, par, s3, d.ctrl);
-      h->slot += 1;
-      continue;
-    }
 #define CTRL_ARGS dd, par, d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
     if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS);
     else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS);
@@ -937,7 +914,7 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
   Ctrl c;
   InitAcc ia[IA_SLOTS];
   HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
-  const size_t ia_read = h->fused ? (size_t)((h->slot + 2) % 3) : (size_t)((h->slot & 1) ^ 1);  // the last slot's sums
+  const size_t ia_read = (size_t)((h->slot & 1) ^ 1);  // the last slot's sums
   HIPCHK(hipMemcpyAsync(ia, &d.initacc[ia_read * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   double leaf_sd = c.leaf_sd;

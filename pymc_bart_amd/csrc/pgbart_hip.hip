@@ -53,7 +53,6 @@
 #include "pgb_leaf_values.h"
 #include "k_ctrl.h"
 #include "k_rows.h"
-#include "k_slot.h"
 #include "k_rows_mk.h"
 #include "k_loglik.h"
 #include "k_setup_predict.h"

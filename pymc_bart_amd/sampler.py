@@ -328,7 +328,7 @@ class PySampler:
         ``{name: {"ms", "launches", "workgroups"}}`` for the kernels that ran."""
         lib = self.backend.lib
         out = {}
-        for which, name in enumerate(("k_ctrl", "k_rows", "k_loglik", "k_slot")):
+        for which, name in enumerate(("k_ctrl", "k_rows", "k_loglik")):
             ms, nl, wg = C.c_double(), C.c_int64(), C.c_int32()
             lib.check(lib.lib.pgb_profile_kernel(self._h, which, C.byref(ms), C.byref(nl), C.byref(wg)),
                       "pgb_profile_kernel")

@@ -454,32 +454,6 @@ def test_results_do_not_depend_on_launch_geometry(hip, name, monkeypatch):
         assert digest(run_case(c, hip)) == GOLD[name], env
 
 
-@pytest.mark.parametrize("name", ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
-                                  "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "subset_rule"])
-def test_fused_slot_kernel_and_two_kernel_slot_agree(hip, name, monkeypatch):
-    """k_slot (one launch per SMC round) and {k_ctrl ; k_rows} are two schedules of the same contract:
-    both reproduce the committed fingerprint, under the default geometry and under odd ones (tiny grids
-    make a workgroup loop over several groups, tiny targets force the 16-particle cap of a work item)."""
-    c = make_case(name)
-    for fused in ("1", "0"):
-        monkeypatch.setenv("PGB_FUSED", fused)
-        for env in ({}, {"PGB_ROWS_GRID": "7", "PGB_ROWS_TARGET": "3", "PGB_ROWS_TARGET_INIT": "5"},
-                    {"PGB_ROWS_GRID": "333", "PGB_ROWS_TARGET": "100000", "PGB_ROWS_TARGET_INIT": "1"}):
-            for k in ("PGB_ROWS_GRID", "PGB_ROWS_TARGET", "PGB_ROWS_TARGET_INIT"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            g = run_case(c, hip)
-            assert digest(g) == GOLD[name], (fused, env)
-            assert g["counters"]["saturations"] == 0
-            # ... and it really was the schedule asked for
-            s = g["sampler"]
-            s.profile(True)
-            s.step(False)
-            s.profile(False)
-            assert set(s.profile_kernels()) == ({"k_slot"} if fused == "1" else {"k_ctrl", "k_rows"})
-
-
 def test_partial_dependence_sweep_on_gpu_matches_the_oracle(hip, oracle):
     """The PDP / ICE sweeps (all-but-one covariate excluded, k_predict) give the oracle's numbers."""
     from pymc_bart_amd import individual_conditional_expectation, partial_dependence
