@@ -124,6 +124,18 @@ int pgb_set_offset(pgb_handle* h, const double* offset_dev);
  * (upstream evaluates model.datalogp; here a closed family).  NORMAL: {sigma}.  */
 int pgb_set_likelihood(pgb_handle* h, const double* params_host, int32_t n_params);
 
+/* Likelihoods outside the closed family (family PGB_FAMILY_CALLBACK, one output, constant leaves):
+ * `fn` receives n (row index, observed value, linear predictor = sum of trees + offset) triples and writes
+ * the n per-row log-likelihoods; it returns 0 on success.  A batch lists one particle after the other, each
+ * with ascending row indices (a row may occur once per particle).  Upstream evaluates model.datalogp through PyTensor
+ * for every particle; here the device produces the predictors of the rows each round re-labelled, the
+ * host evaluates them in one call per round and the fixed-point sums go back to the device -- the slow
+ * fallback SURVEY.md section 7 asks for (a slot then costs a device round trip instead of ~17 us).
+ * `fn` must be a pure function of each (row, y_i, mu_i). */
+typedef int (*pgb_loglik_fn)(void* ctx, const int64_t* row, const double* y, const double* mu, int64_t n,
+                             double* loglik_out);
+int pgb_set_loglik_callback(pgb_handle* h, pgb_loglik_fn fn, void* ctx);
+
 /* One PGBART.astep: re-sample the next batch of trees.
  *   sum_trees_dev_out  K*n doubles (layout [K][n]), may be NULL
  *   vi_counts_host_out p int32: split-variable counts of the accepted trees of

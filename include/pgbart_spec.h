@@ -79,6 +79,11 @@
 #define PGB_FAMILY_ASYMLAPLACE 7      /* y ~ AsymmetricLaplace(b, q, mu): quantile regression   params: b, q */
 #define PGB_FAMILY_STUDENT_T 8        /* y ~ StudentT(nu, mu, sigma)         params: sigma, nu */
 #define PGB_FAMILY_GAMMA_LOG 9        /* y ~ Gamma(alpha, mean exp(mu)), y > 0   params: alpha */
+#define PGB_FAMILY_CALLBACK 10        /* log p(y_i | mu_i) evaluated by a HOST callback (pgb_set_loglik_callback):
+                                         the slow fallback for likelihoods outside the closed family -- upstream
+                                         evaluates the model's datalogp through PyTensor for every particle.
+                                         Per-row values are clamped to [-2047, 2047] like the built-in families
+                                         and enter the particle weights through the same fixed-point sums. */
 
 /* RNG purposes (high half of counter word 3) */
 #define PGB_RNG_PROPOSE 1u  /* u0: prior coin, u1: split variable            */
@@ -531,6 +536,7 @@ PGB_HD double pgb_softplus(double t) {
 PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double param2, const double* tn,
                            const double* tp) {
   double ll;
+  if (family == PGB_FAMILY_CALLBACK) return 0.0; /* evaluated on the host, never here */
   if (family == PGB_FAMILY_POISSON_LOG || family == PGB_FAMILY_NEGBIN_LOG) {
     const double yy = y > 0.0 ? y : 0.0;
     const double em = pgb_exp(mu);
@@ -595,6 +601,13 @@ PGB_HD double pgb_loglik_meanscale(double y, const double* mu) {
   if (sd < 1e-8) sd = 1e-8;
   const double z = (y - mu[0]) / sd;
   double ll = -pgb_log(sd) - 0.5 * (z * z);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 2047.0) ll = 2047.0;
+  return ll;
+}
+
+/* the contract's range for a callback's per-row value (NaN -> the lower bound) */
+PGB_HD double pgb_clamp_loglik(double ll) {
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 2047.0) ll = 2047.0;
   return ll;

@@ -124,6 +124,9 @@ struct pgb_handle {
   double sse0; /* reference particle (Normal) */
   int64_t ll0; /* reference particle (Bernoulli families) */
   int have_data, have_y;
+  pgb_loglik_fn cb_fn; /* PGB_FAMILY_CALLBACK */
+  void* cb_ctx;
+  int cb_failed;
 };
 
 /* ------------------------------------------------------------------ helpers */
@@ -181,8 +184,11 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
              s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
-             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG) {
+             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG ||
+             s->family == PGB_FAMILY_CALLBACK) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
+    if (s->family == PGB_FAMILY_CALLBACK && s->response != PGB_RESPONSE_CONSTANT)
+      return fail(PGB_E_UNSUPPORTED, "the callback family has constant leaves");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
@@ -335,7 +341,15 @@ int pgb_set_likelihood(pgb_handle* h, const double* params, int32_t n_params) {
 
 /* ------------------------------------------------------------------ one tree update */
 /* per-row log-likelihood of the non-Normal families at linear predictor(s) mu[0..K-1] */
-static double o_loglik(const pgb_handle* h, double y, const double* mu) {
+static double o_loglik(const pgb_handle* h, int64_t row, double y, const double* mu) {
+  if (h->s.family == PGB_FAMILY_CALLBACK) { /* the host callback, one row at a time */
+    double out = 0.0;
+    if (!h->cb_fn || h->cb_fn(h->cb_ctx, &row, &y, mu, 1, &out) != 0) {
+      ((pgb_handle*)h)->cb_failed = 1;
+      return -2047.0;
+    }
+    return pgb_clamp_loglik(out);
+  }
   /* inv_sigma2 doubles as "the family's scalar parameter" for the non-Normal families */
   return pgb_loglikq(h->s.family, h->s.n_outputs, y, mu, h->inv_sigma2, h->lik_param2);
 }
@@ -401,8 +415,8 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
         mu_cur[k] = stk;
       }
       h->r[i] = 0.0;
-      C += pgb_quant(o_loglik(h, h->y[i], mu_stump), h->sc.cl, &sat);
-      E0 += pgb_quant(o_loglik(h, h->y[i], mu_cur), h->sc.cl, &sat);
+      C += pgb_quant(o_loglik(h, i, h->y[i], mu_stump), h->sc.cl, &sat);
+      E0 += pgb_quant(o_loglik(h, i, h->y[i], mu_cur), h->sc.cl, &sat);
     }
   }
   h->ctr.saturations += sat;
@@ -461,7 +475,7 @@ static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, 
       if (svar >= 0) vi = pgb_leaf_pred(vi, slope, xbar, h->X[(size_t)svar * n + i]);
       mu[0] = ((h->st[i] - h->oldv[i]) + h->off[i]) + vi;
     }
-    acc += pgb_quant(o_loglik(h, h->y[i], mu), h->sc.cl, &sat);
+    acc += pgb_quant(o_loglik(h, i, h->y[i], mu), h->sc.cl, &sat);
   }
   h->ctr.saturations += sat;
   return acc;
@@ -800,6 +814,8 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
 static int o_step(pgb_handle* h, int tune) {
   const pgb_settings* s = &h->s;
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  if (s->family == PGB_FAMILY_CALLBACK && !h->cb_fn) return fail(PGB_E_INVALID, "pgb_set_loglik_callback first");
+  h->cb_failed = 0;
   memset(h->vi, 0, sizeof(int32_t) * s->p);
   int bs = tune ? s->batch_tune : s->batch_draw;
   int upper = h->lower + bs;
@@ -824,11 +840,20 @@ static int o_step(pgb_handle* h, int tune) {
   return PGB_OK;
 }
 
+int pgb_set_loglik_callback(pgb_handle* h, pgb_loglik_fn fn, void* ctx) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  if (h->s.family != PGB_FAMILY_CALLBACK) return fail(PGB_E_INVALID, "the sampler was not created with the callback family");
+  h->cb_fn = fn;
+  h->cb_ctx = ctx;
+  return PGB_OK;
+}
+
 int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_out, int32_t* vi_out,
              pgb_counters* counters_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   int rc = o_step(h, tune);
   if (rc) return rc;
+  if (h->cb_failed) return fail(PGB_E_STATE, "the log-likelihood callback reported an error");
   if (sum_trees_out) memcpy(sum_trees_out, h->st, sizeof(double) * h->s.n * h->s.n_outputs);
   if (vi_out) memcpy(vi_out, h->vi, sizeof(int32_t) * h->s.p);
   if (counters_out) *counters_out = h->ctr;

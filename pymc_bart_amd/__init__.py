@@ -6,7 +6,7 @@ Public names mirror what the reference imports from the external ``bartrs`` whee
 """
 
 from . import _abi
-from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikelihood, GammaLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
+from .pgbart import (PGBART, AsymmetricLaplaceLikelihood, BARTOp, BernoulliLikelihood, CallbackLikelihood, GammaLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
                      NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood, StudentTLikelihood)
 from .sampler import PyBartSettings, PySampler
 from .trees import PosteriorSampler, TreeArrays
@@ -32,7 +32,7 @@ _register_step_method()
 
 __version__ = "0.1.0"
 __all__ = [
-    "PGBART", "BARTOp", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood", "GammaLikelihood",
+    "PGBART", "BARTOp", "CallbackLikelihood", "NormalLikelihood", "BernoulliLikelihood", "CategoricalLikelihood", "NormalMeanScaleLikelihood", "PoissonLikelihood", "NegativeBinomialLikelihood", "AsymmetricLaplaceLikelihood", "StudentTLikelihood", "GammaLikelihood",
     "PyBartSettings", "PySampler", "TreeArrays", "PosteriorSampler", "compute_variable_importance", "get_variable_inclusion", "vi_to_kulprit",
     "partial_dependence", "individual_conditional_expectation", "_abi",
 ]

@@ -49,6 +49,7 @@ FAMILIES = {
     "asymmetric_laplace": 7,
     "student_t": 8,
     "gamma_log": 9,
+    "callback": 10,
 }
 
 #: every symbol ``include/pgbart.h`` declares (checked by tests/test_abi.py)
@@ -61,6 +62,7 @@ SYMBOLS = (
     "pgb_set_response",
     "pgb_set_offset",
     "pgb_set_likelihood",
+    "pgb_set_loglik_callback",
     "pgb_step",
     "pgb_step_host",
     "pgb_step_async",
@@ -137,6 +139,11 @@ class TreeArraysC(C.Structure):
     ]
 
 
+#: ``pgb_loglik_fn``: int fn(void* ctx, const int64_t* row, const double* y, const double* mu, int64_t n, double* out)
+LOGLIK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                        C.c_int64, C.POINTER(C.c_double))
+
+
 class PGBError(RuntimeError):
     pass
 
@@ -165,6 +172,7 @@ class PGBLibrary:
         lib.pgb_set_response.argtypes = [vp, vp]
         lib.pgb_set_offset.argtypes = [vp, vp]
         lib.pgb_set_likelihood.argtypes = [vp, vp, C.c_int32]
+        lib.pgb_set_loglik_callback.argtypes = [vp, LOGLIK_FN, vp]
         lib.pgb_step.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_host.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]

@@ -13,8 +13,9 @@ reference ``tests/test_bart.py:211-241``; a log-exposure) and the scalar paramet
 
 ``identify`` / ``Binding`` are plain NumPy and tested without PyMC.  ``bind_model`` builds ``probe``
 from a real model with PyTensor; PyMC is not installable on the build box, so that function follows the
-public PyMC API from memory (marked [P]) and fails with a clear ``NotImplementedError`` whenever the
-model is outside the closed family.
+public PyMC API from memory (marked [P]).  A single-output model outside the closed family is not refused:
+it runs through the host-callback family on the model's own elementwise logp (``FullVectorLogp``, tested
+here with a NumPy stand-in for the compiled function) -- slowly, like upstream, but unchanged.
 """
 
 from __future__ import annotations
@@ -22,8 +23,8 @@ from __future__ import annotations
 import numpy as np
 from scipy.special import expit, ndtr, ndtri
 
-from .pgbart import (BernoulliLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood, NormalLikelihood,
-                     NormalMeanScaleLikelihood, PoissonLikelihood)
+from .pgbart import (BernoulliLikelihood, CallbackLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
+                     NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood)
 
 _TOL = 1e-8
 
@@ -124,6 +125,49 @@ def identify(probe, shape, seed=0) -> Binding:
         "pass likelihood= explicitly if it is one of them in disguise")
 
 
+class FullVectorLogp:
+    """A callback for family "callback" built from a function of the WHOLE BART vector:
+    ``full_logp(bart_value) -> per-observation log-likelihood`` (what a compiled PyMC model gives: the
+    observed variable's elementwise logp with every other variable at its current shared value).
+
+    The sampler asks for (row, y, mu) triples, one particle after the other with ascending rows inside a
+    particle; each particle's rows are scattered into a copy of the current BART value, the model function
+    is evaluated on that vector -- exactly what upstream's PGBART does per particle -- and the requested
+    rows are read back.  Rows outside the particle's leaf keep the base value; their results are ignored."""
+
+    def __init__(self, full_logp, base_value):
+        self.full_logp = full_logp
+        self.base = np.array(base_value, np.float64).ravel()
+
+    def set_base(self, value):
+        self.base = np.array(value, np.float64).ravel()
+
+    def __call__(self, y, mu, rows):
+        out = np.empty(mu.size)
+        cuts = np.flatnonzero(np.diff(rows) <= 0) + 1          # a row index that does not increase: next particle
+        for seg in np.split(np.arange(mu.size), cuts):
+            if seg.size == 0:
+                continue
+            full = self.base.copy()
+            full[rows[seg]] = mu[seg]
+            out[seg] = np.asarray(self.full_logp(full), np.float64).ravel()[rows[seg]]
+        return out
+
+
+class CallbackBinding:
+    """The fallback binding: any single-output observed distribution, through the model's own logp."""
+
+    has_offset = False
+    kind = "callback"
+
+    def __init__(self, likelihood, shape):
+        self.likelihood = likelihood
+        self.shape = shape
+
+    def current(self):
+        return [], None
+
+
 def bind_model(vars, model=None, initial_point=None, compile_kwargs=None):  # noqa: A002  [P]
     """Everything ``PGBART.__init__`` takes from a PyMC model: the BART value variable and its op, the
     shared replacements ``ArrayStepShared`` keeps current, the observed response, and ``probe``.
@@ -163,5 +207,18 @@ def bind_model(vars, model=None, initial_point=None, compile_kwargs=None):  # no
 
     y_obs = np.asarray(model.rvs_to_values[rv].data if hasattr(model.rvs_to_values[rv], "data")
                        else model.rvs_to_values[rv].eval(), dtype=np.float64)
+    try:
+        binding = identify(probe, shape)
+    except NotImplementedError:
+        if len(shape) != 1:
+            raise
+        # outside the closed family: the model's own elementwise logp of the observed variable, as a
+        # function of the whole BART vector (slow host-callback path, CallbackLikelihood)
+        logp_el = model.logp(vars=[rv], sum=False)[0]
+        lp_list, lp_in = join_nonshared_inputs(initial_point, [logp_el], [value_bart], shared)
+        lp_fn = compile_pymc([lp_in], lp_list[0], **(compile_kwargs or {}))
+        lp_fn.trust_input = True
+        full = FullVectorLogp(lambda v: lp_fn(np.asarray(v, dtype=lp_in.dtype)), initial_point[value_bart.name])
+        binding = CallbackBinding(CallbackLikelihood(full), shape)
     return {"value_var": value_bart, "op": bart_rv.owner.op, "shared": shared, "observed": y_obs,
-            "binding": identify(probe, shape), "initial_point": initial_point}
+            "binding": binding, "initial_point": initial_point}

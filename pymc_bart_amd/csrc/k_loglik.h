@@ -272,6 +272,23 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         nid_n = *(const uint32_t*)(newl + (size_t)ln.p * S.n_pad + base);
       }
       long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
+      if constexpr (FAM == PGB_FAMILY_CALLBACK) {
+        // the host evaluates this family (pgb_set_loglik_callback): hand it every row's side and the
+        // linear predictor of the rows of the split leaf
+        uint32_t sides = 0;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          uint32_t side = 3;
+          if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+            const uint32_t nl = (nid >> (8 * e)) & 255u;
+            side = nl == (uint32_t)lj.label ? 0u : (nl == (uint32_t)lj.new_label ? 1u : 2u);
+            S.cb_mu[(size_t)lj.p * S.n_pad + base + e] = nv[e] + (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0);
+          }
+          sides |= side << (8 * e);
+        }
+        *(uint32_t*)(S.cb_side + (size_t)lj.p * S.n_pad + base) = sides;
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
@@ -300,6 +317,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
       if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
     }
+    if constexpr (FAM == PGB_FAMILY_CALLBACK) continue;  // nothing to reduce: the host sums
     __syncthreads();
     for (int t = tid; t < (g1 - g0) * 3; t += BT) {
       const int gi = t / 3, i = t % 3;

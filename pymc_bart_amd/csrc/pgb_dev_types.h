@@ -190,6 +190,10 @@ struct Dev {  // kernel argument block (by value)
   double* tsx;            // [m][MAXN][KX]        accepted trees' leaf slopes
   double* lsx;            // [2][2][256][KX]      label -> slope tables: [par][0 new | 1 next]
   long long* accux;       // [2][MAXP][AX_SLOTS][AX_REC]  row-pass sums of u st_k: left [k], right [KX + k]
+  // callback family only (null otherwise): what k_loglik hands to the host instead of evaluating it --
+  // per particle and row, the linear predictor and the side (0 left, 1 right, 2 dropped, 3 not in the leaf)
+  double* cb_mu;      // [MAXP][n_pad]
+  uint8_t* cb_side;   // [MAXP][n_pad]
   // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
   long long* prof_stamps;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps

@@ -56,6 +56,10 @@ struct pgb_handle {
   double* st_dense;          // [K][n] staging of sum_trees in HBM
   int out_valid;             // the block holds the trees of the last step (pgb_export_trees(0) reads it)
   // pgb_step_async: a worker thread feeds the state machine while the caller goes on
+  // callback family: the host evaluates the per-row log-likelihood once per slot
+  pgb_loglik_fn cb_fn;
+  void* cb_ctx;
+  std::vector<double> y_host, off_host;
   int device;
   std::thread worker;
   int job_running, job_rc;
@@ -116,8 +120,11 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
              s->family == PGB_FAMILY_BERNOULLI_LOGIT || s->family == PGB_FAMILY_POISSON_LOG ||
              s->family == PGB_FAMILY_NEGBIN_LOG || s->family == PGB_FAMILY_ASYMLAPLACE ||
-             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG) {
+             s->family == PGB_FAMILY_STUDENT_T || s->family == PGB_FAMILY_GAMMA_LOG ||
+             s->family == PGB_FAMILY_CALLBACK) {
     if (s->n_outputs != 1) return fail(PGB_E_INVALID, "this family has a single output");
+    if (s->family == PGB_FAMILY_CALLBACK && s->response != PGB_RESPONSE_CONSTANT)
+      return fail(PGB_E_UNSUPPORTED, "the callback family has constant leaves");
   } else {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
@@ -147,6 +154,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     h->prof_launches[k] = 0;
     h->prof_wgs[k] = 0;
   }
+  h->cb_fn = nullptr;
+  h->cb_ctx = nullptr;
   h->out_host = h->out_dev = nullptr;
   h->st_dense = nullptr;
   h->out_valid = 0;
@@ -237,6 +246,14 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
   transient(h);  // particle labels live for one tree update only
   DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
+  if (s->family == PGB_FAMILY_CALLBACK) {
+    DA(d.cb_mu, (size_t)MAXP * d.n_pad);
+    transient(h);
+    DA(d.cb_side, (size_t)MAXP * d.n_pad);
+    transient(h);
+    h->y_host.assign((size_t)d.n, 0.0);
+    h->off_host.assign((size_t)d.n, 0.0);
+  }
   DA(d.trees, d.m);
   DA(d.parts, 2 * MAXP);
   DA(d.jobs, 2 * MAXP);
@@ -454,6 +471,8 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
   if (!h || !y_dev) return fail(PGB_E_INVALID, "null argument");
   JOIN_ASYNC(h);
   HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->s.family == PGB_FAMILY_CALLBACK)
+    HIPCHK(hipMemcpyAsync(h->y_host.data(), y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_y = 1;
   return PGB_OK;
@@ -468,6 +487,12 @@ extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
     HIPCHK(hipMemcpyAsync((void*)h->d.off, offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   else
     HIPCHK(hipMemsetAsync((void*)h->d.off, 0, h->d.n * sizeof(double), h->stream));
+  if (h->s.family == PGB_FAMILY_CALLBACK) {
+    if (offset_dev)
+      HIPCHK(hipMemcpyAsync(h->off_host.data(), offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    else
+      h->off_host.assign((size_t)h->d.n, 0.0);
+  }
   if (h->d.has_off != (offset_dev ? 1 : 0)) {
     h->d.has_off = offset_dev ? 1 : 0;
     HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
@@ -600,6 +625,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
           case PGB_FAMILY_NEGBIN_LOG: LAUNCH_LL(1, PGB_FAMILY_NEGBIN_LOG); break;
           case PGB_FAMILY_ASYMLAPLACE: LAUNCH_LL(1, PGB_FAMILY_ASYMLAPLACE); break;
           case PGB_FAMILY_GAMMA_LOG: LAUNCH_LL(1, PGB_FAMILY_GAMMA_LOG); break;
+          case PGB_FAMILY_CALLBACK: LAUNCH_LL(1, PGB_FAMILY_CALLBACK); break;
           default: LAUNCH_LL(1, PGB_FAMILY_STUDENT_T);
         }
       }
@@ -628,6 +654,89 @@ static int harvest_profile(pgb_handle* h) {
 // The device publishes its progress in a pinned host word (k_ctrl, final slot of a step); the
 // host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
 // are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
+// ---- callback family: the host half of a slot (after {k_ctrl ; k_rows ; k_loglik<callback>} have run)
+// k_loglik left, per active particle, every row's side and the linear predictor of the rows of the split
+// leaf; the callback evaluates them in ONE call, the values are clamped and quantised like the built-in
+// families' and their sums per (particle, side) go where k_loglik would have put them.  A slot that
+// starts a tree also needs the log-likelihood of a fresh stump and of the current tree over all rows
+// (what the INIT part of k_rows computes for the built-in families).
+static int callback_host_phase(pgb_handle* h, int par) {
+  Dev& d = h->d;
+  const size_t n = (size_t)d.n;
+  struct CmdHead { int32_t kind, tree_old, tree_new, sel_gen, sel_slot, tune, dst_gen, st_cur; } ch;
+  HIPCHK(hipMemcpy(&ch, &d.cmd[par], sizeof ch, hipMemcpyDeviceToHost));
+  if (!(ch.kind & CMD_PARTITION)) return PGB_OK;
+  std::vector<Job> jobs(MAXP);
+  HIPCHK(hipMemcpy(jobs.data(), d.jobs + (size_t)par * MAXP, sizeof(Job) * MAXP, hipMemcpyDeviceToHost));
+  std::vector<double> yy, mm, out;
+  std::vector<int64_t> rows;
+  std::vector<int> owner;  // (particle << 2) | side of every gathered row
+  std::vector<uint8_t> side(n);
+  std::vector<double> mu(n);
+  for (int p = 1; p < d.P; ++p) {
+    if (!jobs[p].active) continue;
+    HIPCHK(hipMemcpy(side.data(), d.cb_side + (size_t)p * d.n_pad, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mu.data(), d.cb_mu + (size_t)p * d.n_pad, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+      if (side[i] < 3) {
+        rows.push_back((int64_t)i);
+        yy.push_back(h->y_host[i]);
+        mm.push_back(mu[i]);
+        owner.push_back((p << 2) | side[i]);
+      }
+  }
+  size_t n_part = yy.size();
+  const bool init = (ch.kind & CMD_INIT) != 0;
+  if (init) {  // stump and current tree over all rows: [n_part, n_part + n) stump, [n_part + n, n_part + 2n) current
+    std::vector<double2> pack(n);
+    std::vector<double> noi(n);
+    HIPCHK(hipMemcpy(pack.data(), d.pack, n * sizeof(double2), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(noi.data(), d.st + (size_t)(ch.st_cur ^ 1) * d.n_pad, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+      rows.push_back((int64_t)i);
+      yy.push_back(h->y_host[i]);
+      mm.push_back((noi[i] + h->off_host[i]) + d.init_leaf);
+    }
+    for (size_t i = 0; i < n; ++i) {
+      rows.push_back((int64_t)i);
+      yy.push_back(h->y_host[i]);
+      mm.push_back(pack[i].x + h->off_host[i]);
+    }
+  }
+  if (yy.empty()) return PGB_OK;
+  out.assign(yy.size(), 0.0);
+  if (h->cb_fn(h->cb_ctx, rows.data(), yy.data(), mm.data(), (int64_t)yy.size(), out.data()) != 0)
+    return fail(PGB_E_STATE, "the log-likelihood callback reported an error");
+  unsigned sat = 0;
+  std::vector<AccL> sums(MAXP, AccL{0, 0, 0, 0});
+  for (size_t i = 0; i < n_part; ++i) {
+    const long long q = pgb_quant(pgb_clamp_loglik(out[i]), d.sc.cl, &sat);
+    AccL& a = sums[owner[i] >> 2];
+    const int sd = owner[i] & 3;
+    if (sd == 0) a.llL += q; else if (sd == 1) a.llR += q; else a.llN += q;
+  }
+  for (int p = 1; p < d.P; ++p)
+    if (jobs[p].active)  // copy 0 of the particle's record (k_ctrl zeroed all copies in this slot)
+      HIPCHK(hipMemcpy(&d.accl[((size_t)par * MAXP + p) * LL_PER], &sums[p], sizeof(AccL), hipMemcpyHostToDevice));
+  if (init) {
+    long long C = 0, E0 = 0;
+    for (size_t i = 0; i < n; ++i) C += pgb_quant(pgb_clamp_loglik(out[n_part + i]), d.sc.cl, &sat);
+    for (size_t i = 0; i < n; ++i) E0 += pgb_quant(pgb_clamp_loglik(out[n_part + n + i]), d.sc.cl, &sat);
+    InitAcc ia;
+    HIPCHK(hipMemcpy(&ia, &d.initacc[(size_t)par * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost));
+    ia.C += C;
+    ia.E0 += E0;
+    HIPCHK(hipMemcpy(&d.initacc[(size_t)par * IA_SLOTS], &ia, sizeof ia, hipMemcpyHostToDevice));
+  }
+  if (sat) {
+    unsigned long long cs = 0;
+    HIPCHK(hipMemcpy(&cs, &d.counters[4], sizeof cs, hipMemcpyDeviceToHost));
+    cs += sat;
+    HIPCHK(hipMemcpy(&d.counters[4], &cs, sizeof cs, hipMemcpyHostToDevice));
+  }
+  return PGB_OK;
+}
+
 #define BUNDLE 8
 #define BUNDLE_TAIL 2
 // Slots are enqueued in bundles of 8 with at most 3 bundles in flight; once the number of slots this
@@ -640,6 +749,17 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
   long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
   const long long expect = h->slots_per_step > 0.0 ? (long long)(h->slots_per_step * n_steps) : (1ll << 60);
   int rc;
+  if (h->s.family == PGB_FAMILY_CALLBACK) {  // one slot at a time, the host evaluates between slots
+    if (!h->cb_fn) return fail(PGB_E_INVALID, "pgb_set_loglik_callback first");
+    while (*h->flag < (unsigned long long)h->steps_target) {
+      const int par = (int)(h->slot & 1);
+      if ((rc = enqueue_slots(h, 1)) != PGB_OK) return rc;
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if ((rc = callback_host_phase(h, par)) != PGB_OK) return rc;
+      if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
+    }
+    return PGB_OK;
+  }
   while (*h->flag < (unsigned long long)h->steps_target) {
     const bool tail = (h->slot - start) + 2 * BUNDLE >= expect;
     const int depth = tail ? 2 : 3;
@@ -715,6 +835,16 @@ static int fetch_counters(pgb_handle* h, pgb_counters* out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   counters_from(h, c);
   if (out) *out = h->ctr;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_loglik_callback(pgb_handle* h, pgb_loglik_fn fn, void* ctx) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
+  if (h->s.family != PGB_FAMILY_CALLBACK)
+    return fail(PGB_E_INVALID, "the sampler was not created with the callback family");
+  h->cb_fn = fn;
+  h->cb_ctx = ctx;
   return PGB_OK;
 }
 

@@ -155,6 +155,25 @@ class StudentTLikelihood:
         return [_from_point(self.sigma, point), _from_point(self.nu, point)]
 
 
+class CallbackLikelihood:
+    """Any per-observation likelihood: ``logp(y, mu) -> log p(y_i | mu_i)`` evaluated on the HOST (NumPy
+    arrays in and out, elementwise).  This is the slow fallback for models outside the closed family --
+    upstream evaluates the model's ``datalogp`` through PyTensor for every particle (``SURVEY.md`` section 7);
+    here the GPU still does the tree work, but every SMC round costs a device round trip and a Python call,
+    so expect it to run two orders of magnitude below the built-in families.  ``params`` may return scalars
+    the callable closes over; they are not sent to the device."""
+
+    family = "callback"
+
+    def __init__(self, logp):
+        if not callable(logp):
+            raise TypeError("logp must be callable: logp(y, mu) -> array of per-row log-likelihoods")
+        self.logp = logp
+
+    def params(self, point=None):
+        return []
+
+
 class CategoricalLikelihood:
     """``y ~ Categorical(softmax(BART[0..K-1]))`` -- K-vector leaves sharing one tree structure
     (reference ``tests/test_bart.py:140-164``: ``shape=(3, 9)``; cfg5 of BASELINE.json)."""
@@ -313,6 +332,8 @@ class PGBART(_Base):
         )
         self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
         self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
+        if self.likelihood.family == "callback":
+            self.sampler.set_loglik_callback(self.likelihood.logp)
         # the op is a mailbox: utils.py:125 reads op.n_outputs, which the step method sets
         op.n_outputs = n_outputs
         op._rule_ids = rule_ids
@@ -343,6 +364,8 @@ class PGBART(_Base):
         _pick_device()
         self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
                                  self._split_prior, backend=None)
+        if self.likelihood.family == "callback":
+            self.sampler.set_loglik_callback(self.likelihood.logp)
         self.sampler.restore(blob)
         if self._offset is not None:  # the image carries the chain, not the caller-owned response
             self._apply_offset(self._offset)

@@ -223,6 +223,36 @@ class PySampler:
         lib = self.backend.lib
         lib.check(lib.lib.pgb_set_likelihood(self._h, keep.ctypes.data, a.size), "pgb_set_likelihood")
 
+    def set_loglik_callback(self, fn) -> None:
+        """Family "callback": ``fn(y, mu)`` or ``fn(y, mu, rows)`` -> per-row log-likelihood (NumPy arrays in,
+        array out): a function of each row's observed value, linear predictor and -- if it takes a third
+        argument -- row index (per-row covariates of the likelihood).  The native library calls it once per
+        SMC round with all the rows that round re-labelled, one particle after the other, ascending rows
+        within a particle (``pgb_set_loglik_callback``)."""
+        import inspect
+
+        lib = self.backend.lib
+        try:
+            wants_rows = len(inspect.signature(fn).parameters) >= 3
+        except (TypeError, ValueError):
+            wants_rows = False
+
+        def trampoline(_ctx, row_ptr, y_ptr, mu_ptr, n, out_ptr):
+            try:
+                n = int(n)
+                y = np.ctypeslib.as_array(y_ptr, shape=(n,))
+                mu = np.ctypeslib.as_array(mu_ptr, shape=(n,))
+                val = fn(y, mu, np.ctypeslib.as_array(row_ptr, shape=(n,))) if wants_rows else fn(y, mu)
+                np.ctypeslib.as_array(out_ptr, shape=(n,))[:] = np.asarray(val, dtype=np.float64).reshape(n)
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the ABI's error code
+                self._callback_error = e
+                return 1
+
+        self._callback_error = None
+        self._callback = _abi.LOGLIK_FN(trampoline)  # keep it alive as long as the sampler
+        lib.check(lib.lib.pgb_set_loglik_callback(self._h, self._callback, None), "pgb_set_loglik_callback")
+
     # -- one astep -----------------------------------------------------------------
     def step(self, tune: bool, fetch: bool = True):
         """One astep.  ``fetch=True`` (what ``PGBART.astep`` does): ``sum_trees`` comes back as a host
@@ -236,12 +266,12 @@ class PySampler:
             st = mem.host_result(K * n)
             rc = lib.lib.pgb_step_host(self._h, int(bool(tune)), st.ctypes.data, self._vi.ctypes.data,
                                        C.byref(self.counters))
-            lib.check(rc, "pgb_step_host")
+            self._check(rc, "pgb_step_host")
             self._check_saturation()
             return (st.reshape(K, n) if K > 1 else st), self._vi.copy()
         rc = lib.lib.pgb_step(self._h, int(bool(tune)), mem.ptr(self._out), self._vi.ctypes.data,
                               C.byref(self.counters))
-        lib.check(rc, "pgb_step")
+        self._check(rc, "pgb_step")
         self._check_saturation()
         return None, self._vi.copy()
 
@@ -253,9 +283,17 @@ class PySampler:
 
     def sync(self) -> dict:
         lib = self.backend.lib
-        lib.check(lib.lib.pgb_sync(self._h, C.byref(self.counters)), "pgb_sync")
+        self._check(lib.lib.pgb_sync(self._h, C.byref(self.counters)), "pgb_sync")
         self._check_saturation()
         return self.counters.as_dict()
+
+    def _check(self, rc: int, what: str) -> None:
+        """``lib.check`` that re-raises an exception a Python log-likelihood callback raised."""
+        err = getattr(self, "_callback_error", None)
+        if rc != _abi.PGB_OK and err is not None:
+            self._callback_error = None
+            raise _abi.PGBError(f"{what}: the log-likelihood callback raised {type(err).__name__}: {err}") from err
+        self.backend.lib.check(rc, what)
 
     def _check_saturation(self) -> None:
         """Fixed-point sums are exact only inside the declared range (PyBartSettings.range_exp);

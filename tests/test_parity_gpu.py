@@ -454,6 +454,27 @@ def test_results_do_not_depend_on_launch_geometry(hip, name, monkeypatch):
         assert digest(run_case(c, hip)) == GOLD[name], env
 
 
+def test_host_callback_likelihood_on_gpu_reproduces_the_builtin_family(hip):
+    """Family "callback" (pgb_set_loglik_callback): the device hands the host every re-labelled row's
+    linear predictor, the callback evaluates them, the sums go back.  With the check loss spelt out in
+    exact IEEE arithmetic it reproduces the built-in asymmetric-Laplace fingerprint bit for bit, and
+    the step method built on it runs through checkpoints."""
+    from test_callback_family import callback_case, run_callback_case
+
+    g = run_callback_case(callback_case(), hip)
+    assert digest(g) == GOLD["quantile_asymlaplace"]
+    assert g["counters"]["saturations"] == 0
+
+
+def test_host_callback_with_offset_matches_the_oracle(hip, oracle):
+    from test_callback_family import run_callback_case
+
+    c = dict(make_case("poisson_exposure"))
+    c["family"] = "callback"
+    c["callback"] = lambda y, mu: y * mu - 2.0 * mu * mu       # any elementwise function of exact arithmetic
+    _assert_same(run_callback_case(c, hip), run_callback_case(c, oracle))
+
+
 def test_partial_dependence_sweep_on_gpu_matches_the_oracle(hip, oracle):
     """The PDP / ICE sweeps (all-but-one covariate excluded, k_predict) give the oracle's numbers."""
     from pymc_bart_amd import individual_conditional_expectation, partial_dependence
