@@ -114,10 +114,10 @@ int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t*
 /* Observed response of the likelihood, n doubles (class index for categorical). */
 int pgb_set_response(pgb_handle* h, const double* y_dev);
 
-/* Per-row offset of the linear predictor for the single-output per-row families (everything but
- * NORMAL, where the caller subtracts the other terms from the response instead): the likelihood
- * sees offset + sum_trees -- the contribution of the other additive terms of the model at the
- * current point (a second BART variable, a log-exposure, ...).  n doubles; NULL resets to 0.   */
+/* Per-row offset of the linear predictor(s) for the per-row families (everything but NORMAL, where
+ * the caller subtracts the other terms from the response instead): the likelihood sees
+ * offset + sum_trees -- the contribution of the other additive terms of the model at the current
+ * point (a second BART variable, a log-exposure, ...).  K*n doubles, layout [K][n]; NULL resets to 0. */
 int pgb_set_offset(pgb_handle* h, const double* offset_dev);
 
 /* Likelihood parameters at the current point of the other model variables

@@ -205,7 +205,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   int p = s->p, m = s->m, P = s->num_particles, K = s->n_outputs;
   h->X = (double*)malloc(sizeof(double) * (size_t)n * p);
   h->y = (double*)malloc(sizeof(double) * n);
-  h->off = (double*)calloc((size_t)n, sizeof(double));
+  h->off = (double*)calloc((size_t)n * (size_t)s->n_outputs, sizeof(double)); /* [K][n] */
   h->rules = (int32_t*)calloc(p, sizeof(int32_t));
   h->alpha_vec = (int64_t*)malloc(sizeof(int64_t) * p);
   h->cdf = (int64_t*)malloc(sizeof(int64_t) * p);
@@ -308,10 +308,10 @@ int pgb_set_response(pgb_handle* h, const double* y) {
 
 int pgb_set_offset(pgb_handle* h, const double* off) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
-  if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
-    return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
-  if (off) memcpy(h->off, off, sizeof(double) * h->s.n);
-  else memset(h->off, 0, sizeof(double) * h->s.n);
+  if (h->s.family == PGB_FAMILY_NORMAL)
+    return fail(PGB_E_UNSUPPORTED, "offsets are for the per-row families (a Normal model fits observed - offset)");
+  if (off) memcpy(h->off, off, sizeof(double) * h->s.n * h->s.n_outputs);
+  else memset(h->off, 0, sizeof(double) * h->s.n * h->s.n_outputs);
   return PGB_OK;
 }
 
@@ -411,8 +411,8 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
         const double noik = stk - ok;
         h->oldv[(size_t)k * n + i] = ok;
         Ax[k - 1] += pgb_quant(stk, h->sc.c1, &sat);
-        mu_stump[k] = noik + s->init_leaf;
-        mu_cur[k] = stk;
+        mu_stump[k] = (noik + h->off[(size_t)k * n + i]) + s->init_leaf;
+        mu_cur[k] = stk + h->off[(size_t)k * n + i];
       }
       h->r[i] = 0.0;
       C += pgb_quant(o_loglik(h, i, h->y[i], mu_stump), h->sc.cl, &sat);
@@ -468,7 +468,7 @@ static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, 
     for (int o = 0; o < K; ++o) {
       double vo = v[o];
       if (svar >= 0) vo = pgb_leaf_pred(vo, o ? slopex[o - 1] : slope, xbar, h->X[(size_t)svar * n + i]);
-      mu[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + vo;
+      mu[o] = ((h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + h->off[(size_t)o * n + i]) + vo;
     }
     if (K == 1) {
       double vi = v[0];

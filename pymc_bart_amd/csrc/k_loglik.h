@@ -224,14 +224,15 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
                 v0k = pgb_leaf_pred(v0k, side == 0 ? lj.slopeL : lj.slopeR, xb, xv);
               }
             }
-            mu[0] = nv[e] + v0k;
+            mu[0] = (S.has_off ? nv[e] + S.off[base + e] : nv[e]) + v0k;
 #pragma unroll
             for (int k = 1; k < KB; ++k)
               if (k < K) {
                 double vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
                 if constexpr (LIN)
                   if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
-                mu[k] = noi[(size_t)k * S.n_pad + base + e] + vk;
+                const double nk = noi[(size_t)k * S.n_pad + base + e];
+                mu[k] = (S.has_off ? nk + S.off[(size_t)k * S.n_pad + base + e] : nk) + vk;
               }
             double llv;
             if constexpr (KT >= 2) {

@@ -148,8 +148,9 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
             const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][k], 1, (ids_next >> (8 * e)) & 255u, k, row);
             const double noi = st - o;
             stv[e][k] = st;
-            mu_stump[k] = noi + S.init_leaf;
-            mu_cur[k] = st;
+            const double offk = S.has_off ? S.off[(size_t)k * n_pad + row] : 0.0;  // (x + 0.0 == x bit for bit)
+            mu_stump[k] = (noi + offk) + S.init_leaf;
+            mu_cur[k] = st + offk;
             if (writer) {
               if (k == 0) S.pack[row] = make_double2(st, 0.0);
               else S.packx[(size_t)(k - 1) * n_pad + row] = st;

@@ -140,7 +140,7 @@ struct Dev {  // kernel argument block (by value)
   const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
   const double* XT;  // [p][n_pad]
   const double* y;   // [n_pad]
-  const double* off; // [n_pad] offset of the linear predictor (single-output per-row families; 0 by default)
+  const double* off; // [K][n_pad] offset of the linear predictor (per-row families; 0 by default)
   double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
   double2* pack;     // [n_pad] {sum_trees, y - noi}
   double* rs_mean;

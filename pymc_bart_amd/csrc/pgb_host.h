@@ -222,7 +222,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   DA(y, d.n_pad);
   transient(h);
   double* off;
-  DA(off, d.n_pad);
+  DA(off, (size_t)d.K * d.n_pad);
   transient(h);
   d.off = off;
   const int K = d.K, KX = d.K - 1;
@@ -331,7 +331,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   }
   HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
-  HC(hipMemsetAsync(off, 0, d.n_pad * sizeof(double), sm));
+  HC(hipMemsetAsync(off, 0, (size_t)d.K * d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(pack, 0, d.n_pad * sizeof(double2), sm));
   HC(hipMemsetAsync(rs_mean, 0, (size_t)K * d.n_pad * sizeof(double), sm));
   HC(hipMemsetAsync(rs_m2, 0, (size_t)K * d.n_pad * sizeof(double), sm));
@@ -481,12 +481,13 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
 extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   JOIN_ASYNC(h);
-  if (h->s.family == PGB_FAMILY_NORMAL || h->s.n_outputs != 1)
-    return fail(PGB_E_UNSUPPORTED, "offsets are for the single-output per-row families");
-  if (offset_dev)
-    HIPCHK(hipMemcpyAsync((void*)h->d.off, offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->s.family == PGB_FAMILY_NORMAL)
+    return fail(PGB_E_UNSUPPORTED, "offsets are for the per-row families (a Normal model fits observed - offset)");
+  if (offset_dev)  // [K][n] -> the padded [K][n_pad] rows
+    HIPCHK(hipMemcpy2DAsync((void*)h->d.off, h->d.n_pad * sizeof(double), offset_dev, h->d.n * sizeof(double),
+                            h->d.n * sizeof(double), (size_t)h->d.K, hipMemcpyDeviceToDevice, h->stream));
   else
-    HIPCHK(hipMemsetAsync((void*)h->d.off, 0, h->d.n * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync((void*)h->d.off, 0, (size_t)h->d.K * h->d.n_pad * sizeof(double), h->stream));
   if (h->s.family == PGB_FAMILY_CALLBACK) {
     if (offset_dev)
       HIPCHK(hipMemcpyAsync(h->off_host.data(), offset_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));

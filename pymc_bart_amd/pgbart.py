@@ -414,10 +414,10 @@ class PGBART(_Base):
         offset = np.asarray(offset, np.float64)
         if self.likelihood.family == "normal":      # additive Normal model: fit what is left
             self.sampler.set_response(self._y_obs - offset)
-        elif self.shape == (self.num_observations,):  # per-row families: offset of the predictor
+        else:                                        # per-row families: offset of the linear predictor(s)
+            if offset.shape != self.shape:
+                raise ValueError(f"offset must have the BART variable's shape {self.shape}, got {offset.shape}")
             self.sampler.set_offset(offset)
-        else:
-            raise NotImplementedError("offsets are not implemented for multi-output families")
         self._offset = np.array(offset, copy=True)
 
     if _Base is object:  # without PyMC: the part of ArrayStepShared.step this class needs

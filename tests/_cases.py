@@ -173,6 +173,15 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=8, P=12, steps=24, family="categorical", K=K, response="mix")
+    elif name == "categorical_k3_offset":  # additive multi-output model: per-row, per-output offsets of the predictors
+        n, p, K = 2500, 4, 3
+        X = rng.normal(size=(n, p))
+        Z = rng.normal(size=n)                                   # a covariate handled by another model term
+        off = np.stack([0.8 * Z, -0.8 * Z, np.zeros(n)])
+        F = np.stack([X[:, 0], -X[:, 0], 0.7 * X[:, 1]]) + off
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=8, P=10, steps=24, family="categorical", K=K, offset=off)
     elif name == "onehot_fail_nan":  # failed one-hot splits that shed NaN rows (Normal family)
         n, p = 2500, 3
         X = rng.normal(size=(n, p))
@@ -203,7 +212,7 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
-         "meanscale_k2_linear", "categorical_k3_mix"]
+         "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -328,6 +337,8 @@ def random_case(seed):
         extra["lik_params"] = [float(rng.uniform(0.1, 2.0)), float(rng.uniform(1.0, 30.0))]
     if fam not in ("normal", "categorical", "normal_meanscale") and rng.random() < 0.3:
         extra["offset"] = rng.normal(0, 0.3, n)  # another additive term of the linear predictor
+    elif fam in ("categorical", "normal_meanscale") and rng.random() < 0.3:
+        extra["offset"] = rng.normal(0, 0.3, (K, n))  # ... of every linear predictor of a K-vector model
     return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

@@ -152,3 +152,38 @@ def test_gather_without_dense_draws():
            "history": (None, []), "counters": {}, "step": object()}
     out = gather_chains(res)
     assert out[0]["mu"] is None and "step" not in out[0]
+
+
+def test_multi_output_offsets(oracle):
+    """Offsets of the linear predictors for K-vector leaves ([K][n]): zeros change nothing (bit for bit),
+    a real offset moves the chain, and the step method checks the shape."""
+    from pymc_bart_amd.pgbart import CategoricalLikelihood
+
+    rng = np.random.default_rng(4)
+    n, K = 300, 3
+    X = rng.normal(size=(n, 3))
+    Z = rng.normal(size=n)
+    off = np.stack([1.5 * Z, -1.5 * Z, np.zeros(n)])
+    F = np.stack([X[:, 0], -X[:, 0], 0 * X[:, 0]]) + off
+    pr = np.exp(F) / np.exp(F).sum(0)
+    Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+
+    def run(offset, steps=30):
+        st = PGBART([BARTOp(X, Y, m=6)], num_particles=6, likelihood=CategoricalLikelihood(K), random_seed=3,
+                    backend=oracle)
+        outs = []
+        for it in range(steps):
+            if it == steps // 2:
+                st.stop_tuning()
+            outs.append(st.astep(None, offset=offset if it == 0 else None)[0])
+        return np.array(outs)
+
+    base = run(None)
+    assert np.array_equal(base, run(np.zeros((K, n))))
+    with_off = run(off)
+    assert not np.array_equal(base, with_off)
+    # with the Z-driven part handled by the offset, the trees need less of the class-0-vs-1 contrast
+    assert np.abs(with_off[-10:, 0] - with_off[-10:, 1]).mean() < np.abs(base[-10:, 0] - base[-10:, 1]).mean() + 0.5
+    with pytest.raises(ValueError, match="shape"):
+        PGBART([BARTOp(X, Y, m=6)], num_particles=6, likelihood=CategoricalLikelihood(K), random_seed=3,
+               backend=oracle).astep(None, offset=np.zeros(n))
