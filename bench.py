@@ -461,7 +461,12 @@ def main():
             kl = kern["k_loglik"]
             insts = pmc.get("k_loglik", {}).get("valu_wave_insts_per_launch")
             ginst = (insts * kl["launches"] / (kl["ms"] * 1e-3) / 1e9) if insts else None
-            line["roofline_dominant"] = {
+            # for these workloads the row pass is NOT the dominant kernel and its algorithmic-byte rate can
+            # exceed the HBM peak (the layout moves far fewer bytes than the reference's index lists): the
+            # line's `roofline` is the dominant kernel's, the row pass keeps its figures under `roofline_rows`
+            if "roofline" in line:
+                line["roofline_rows"] = line.pop("roofline")
+            line["roofline"] = {
                 "bound": "valu-f64-issue", "kernel": "k_loglik", "pct_of_gpu_time": 100.0 * kl["ms"] / tot_ms,
                 "achieved": ginst, "peak": VALU_F64_PEAK_GINST, "unit": "G wave-instructions/s",
                 "frac": (ginst / VALU_F64_PEAK_GINST) if ginst else None,
