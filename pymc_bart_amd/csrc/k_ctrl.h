@@ -273,7 +273,13 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     }
     const double u1 = readlane_d(u.u1, 0);
     const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
-    if (l == 0) s_i[8 + set] = jj;
+    if (l == 0) {
+      s_i[8 + set] = jj;
+      // the column's rule and NaN flag: fetched here, off the critical path (they used to be two dependent
+      // global loads right before the job record is written)
+      s_i[10 + set] = S.rules[jj];
+      s_i[12 + set] = S.col_nan[jj];
+    }
     TRX(9 + set, blockIdx.x == 1 && l == 0);
   }
 
@@ -885,7 +891,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     if (tid < 64) {
       const int j = s_i[8 + set];
       const double* xc = S.XT + (size_t)j * S.n_pad;
-      const bool subset_rule = S.rules[j] == PGB_RULE_SUBSET;
+      const bool subset_rule = s_i[10 + set] == PGB_RULE_SUBSET;
       const uint8_t* lid =
           job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
       const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
@@ -968,8 +974,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       job.label = nlabel;
       job.new_label = F.n_leaves;
       job.var = j;
-      job.rule = S.rules[j];
-      job.check_nan = S.col_nan[j];
+      job.rule = s_i[10 + set];
+      job.check_nan = s_i[12 + set];
       job.ccL = ((rr * MAXP + p) * 2);
       job.ccR = job.ccL + 1;
       job.cnt = ncnt;
