@@ -176,6 +176,14 @@ extern "C" int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_m
 }
 
 #ifdef PGB_TRACE
+// raw device-clock stamps of the row pass (first / last reading of every workgroup, per launch)
+extern "C" int pgb_debug_stamps(pgb_handle* h, long long* out, long long slot0, int n_slots) {
+  if (!h->prof_buf) return fail(PGB_E_INVALID, "profiling was never enabled");
+  for (int i = 0; i < n_slots; ++i)
+    HIPCHK(hipMemcpy(out + (size_t)i * PROF_BLOCKS * 2, h->prof_buf + (size_t)((slot0 + i) % PROF_RING) * PROF_BLOCKS * 2,
+                     (size_t)PROF_BLOCKS * 2 * sizeof(long long), hipMemcpyDeviceToHost));
+  return PGB_OK;
+}
 extern "C" int pgb_debug_trace(pgb_handle* h, long long* out, int n_slots) {
   HIPCHK(hipMemcpy(out, h->d.trace, (size_t)n_slots * 16 * sizeof(long long), hipMemcpyDeviceToHost));
   return PGB_OK;
