@@ -210,6 +210,11 @@ _HIP_LIB: PGBLibrary | None = None
 
 
 def hip_library_path() -> str:
+    """The in-tree gfx950 build; ``PGBART_HIP_LIB`` names another build of the same library (profiling /
+    experiment builds -- it must still be the HIP backend, see :func:`load_hip_library`)."""
+    override = os.environ.get("PGBART_HIP_LIB")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpgbart_hip.so")
 
 
@@ -229,4 +234,6 @@ def load_hip_library() -> PGBLibrary:
         import torch  # noqa: F401
 
         _HIP_LIB = PGBLibrary(path)
+        if _HIP_LIB.backend_name != "hip-gfx950":
+            raise PGBError(f"{path} is not the HIP backend (it reports {_HIP_LIB.backend_name!r})")
     return _HIP_LIB

@@ -158,6 +158,91 @@ __device__ __forceinline__ void lin_children_x(const Dev& S, LinKids& lk, ChildX
   }
 }
 
+
+// [U] get_split_value: the k-th row (ascending) of a leaf, k = floor(u * cnt), on ONE wave (all 64 lanes
+// call this with wave-uniform arguments; no workgroup barrier): the per-chunk row counts the node got
+// when it was created are scanned to find the chunk, then the chunk's 1024 label bytes (16 per lane).
+// A missing value at the chosen row redraws the row (<= PGB_SELECT_TRIES).  pre0 / pre1: the
+// pre-drawn uniforms of the tries ([1 + try]).  Returns found and the split value in every lane.
+struct SplitRow {
+  int found;
+  double v;
+};
+__device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool subset_rule, int src_gen, int src_slot,
+                                                     int ncnt, int ncc, int nlabel, const double* pre0,
+                                                     const double* pre1) {
+  const double* xc = S.XT + (size_t)j * S.n_pad;
+  const uint8_t* lid = src_slot >= 0 ? S.lid + ((size_t)src_gen * MAXP + src_slot) * S.n_pad : nullptr;
+  const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
+  SplitRow out;
+  out.found = 0;
+  out.v = 0.0;
+  // per-lane partial sums of the node's per-chunk row counts (independent of the retry)
+  const int per = (S.nchunks + 63) / 64;
+  const int c0 = lane_id() * per;
+  int c1 = c0 + per;
+  if (c1 > S.nchunks) c1 = S.nchunks;
+  int part = 0, pre = 0;
+  if (lid != nullptr) {
+    for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
+    pre = wave_incl_scan(part) - part;
+  }
+  for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !out.found; ++tr) {
+    long long k = (long long)(pre0[1 + tr] * (double)ncnt);
+    if (k > ncnt - 1) k = ncnt - 1;
+    long long row;
+    if (lid == nullptr) {
+      row = k;  // untouched root: every row belongs to it
+    } else {
+      // (1) which chunk holds the k-th row
+      const bool own = (long long)pre <= k && k < (long long)pre + part;
+      int cstar = 0, kk = 0;
+      if (own) {
+        kk = (int)(k - pre);
+        cstar = c0;
+        while (kk >= ccr[cstar]) {
+          kk -= ccr[cstar];
+          ++cstar;
+        }
+      }
+      const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
+      cstar = __builtin_amdgcn_readlane(cstar, ol);
+      kk = __builtin_amdgcn_readlane(kk, ol);
+      // (2) which row inside the chunk: 16 label bytes per lane
+      const uint4 ids = *(const uint4*)(lid + (size_t)cstar * CH + lane_id() * 16);
+      const uint32_t wds[4] = {ids.x, ids.y, ids.z, ids.w};
+      int mcnt = 0;
+#pragma unroll
+      for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mcnt += (((wds[wd] >> (8 * e)) & 255u) == (uint32_t)nlabel);
+      const int pre2 = wave_incl_scan(mcnt) - mcnt;
+      const bool own2 = pre2 <= kk && kk < pre2 + mcnt;
+      int off = 0;
+      if (own2) {
+        int rem = kk - pre2;
+        for (int bb = 0; bb < 16; ++bb) {
+          if (((wds[bb >> 2] >> (8 * (bb & 3))) & 255u) == (uint32_t)nlabel) {
+            if (rem == 0) {
+              off = bb;
+              break;
+            }
+            --rem;
+          }
+        }
+      }
+      const int ol2 = (int)__ffsll((long long)__ballot(own2)) - 1;
+      off = __builtin_amdgcn_readlane(off, ol2);
+      row = (long long)cstar * CH + ol2 * 16 + off;
+    }
+    const double x = xc[row];
+    out.found = (x == x) ? 1 : 0;
+    out.v = x;
+    if (out.found && subset_rule) out.v = pgb_subset_value(pre1[1 + tr], x);
+  }
+  return out;
+}
+
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
@@ -176,7 +261,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   __shared__ DNode s_pop[MAXP];                       // node each OLD particle would pop next (prefetched)
   __shared__ double s_ahead[2][4];                    // [set][z0, z1, u_res, u_fin]: draws made one slot ahead
 
-  TR(0);
+  TR_DECL();
+  TR0();
   // The previous round's job record and split statistics of old particle q = lane (wave 0) are
   // requested FIRST, together with the control word: their addresses depend on `par` alone.  Harmless
   // in idle / first slots (the records exist).
@@ -188,6 +274,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   }
   if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
   const Ctrl c = load_uniform(&ctrls[par]);
+  TR_BIND(c.slot_no);
   Ctrl* co = &ctrls[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
   const int P = S.P, Lc = P - 1;
@@ -303,6 +390,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   }
 
   int anc = p;  // ancestor (old particle index) of new particle p
+  int pick0 = p;  // ... as wave 0 itself picked it (scalar; the other waves read it from LDS)
   bool stop = false;
   int sel = 0;
   double sse0 = c.sse0;
@@ -451,12 +539,25 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
               f.svarR = lk.svarR; f.slopeR = lk.slopeR; f.xbarR = lk.xbarR;
             }
         }
-        s_pop[q] = popn;
         pending = f.next_pop < f.n_nodes;
         lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
                     : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
       }
       TR(2);
+      if (b == 0) {
+        // particle steps / partitions / rows touched of the round the previous slot proposed, counted here
+        // from its job records: 39 workgroups adding to one line at the end of a kernel serialise (~12 ns
+        // each) and the kernel does not end before the last one is acknowledged
+        const unsigned long long mp = __ballot(isp && j.popped), ma = __ballot(isp && j.active);
+        const long long rt = wave_sum_dpp(isp && j.active ? (long long)j.cnt : 0ll);
+        if (tid == 63) {
+          if (mp) atomicAdd(&S.counters[0], (unsigned long long)__popcll(mp));
+          if (ma) {
+            atomicAdd(&S.counters[6], (unsigned long long)__popcll(ma));
+            atomicAdd(&S.counters[2], (unsigned long long)rt);
+          }
+        }
+      }
       stop = __ballot(pending) == 0ull;
       int pick;
       if (!stop) {
@@ -468,6 +569,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         if (q == 0) lw = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
         pick = wave_pick(lw, 0, P, c.u_fin);  // (iter, 0, 0, FINAL), drawn one slot ahead
       }
+      // (stored only now: the load was requested when the job header arrived and its round trip runs
+      //  under the weights, the scan and the pick instead of ending the finish stage)
+      if (isp) s_pop[q] = popn;
+      pick0 = pick;
       if (tid == 0) {
         s_i[0] = stop ? 1 : 0;
         s_i[1] = pick;
@@ -583,6 +688,146 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         z.cc_row = isL ? f.ccL : f.ccR;
         me->nd[nn + (isL ? 0 : 1)] = z;
       }
+    }
+    if (!stop) {
+      // =============================================================== plain round: propose on wave 0
+      // Waves 1..3 are done once their copy is issued.  Wave 0 proposes round r for new particle p
+      // ([U] ParticleTree.sample_tree / grow_tree) with wave-uniform values only: every lane reads the
+      // ancestor's record from LDS (the reads go out together), no value travels through lane 0, LDS and
+      // a workgroup barrier.  The slots that end or start a tree take the general path further down.
+      if (tid >= 64) return;
+      const int a0 = pick0;  // the ancestor, in a scalar register (s_i[1] holds the same value)
+      const Fin& F = s_fin[a0];
+      const int np = F.next_pop, nn_old = F.nn_old, f_nodes = F.n_nodes, f_leaves = F.n_leaves;
+      const int f_gen = F.loc_gen, f_slot = F.loc_slot;
+      const double f_sse_tot = F.sse_tot, f_sse_orph = F.sse_orph;
+      const double u_coin = s_pre[0][0];
+      const int jvar = s_i[8], jrule = s_i[10], jnan = s_i[12];
+      const bool has = np < f_nodes;
+      DNode nd;
+      memset(&nd, 0, sizeof nd);
+      if (has) {
+        if (np < nn_old) {  // an old node of the ancestor (prefetched by lane a0 of the finish stage)
+          nd = s_pop[a0];
+          if (r1 && np == 0) nd.q_st = ia.A, nd.q_r = normal ? ia.B : ia.C, nd.q_r2 = ia.C, nd.sse = root_sse;
+        } else {  // one of the children the ancestor's pending split just created
+          const bool isL = np == nn_old;
+          nd.var = -1;
+          nd.depth = F.depth + 1;
+          nd.label = isL ? F.label : (uint8_t)F.new_label;
+          nd.cnt = isL ? F.cL : F.cR;
+          nd.q_st = isL ? F.aL : F.aR;
+          nd.q_r = normal ? (isL ? F.bL : F.bR) : (isL ? F.llL : F.llR);
+          nd.q_r2 = isL ? F.c2L : F.c2R;
+          nd.sse = isL ? F.sseL : F.sseR;
+          nd.value = isL ? F.vL : F.vR;
+          nd.cc_row = isL ? F.ccL : F.ccR;
+        }
+      }
+      const double pl = (has && nd.depth < PGB_MAX_DEPTH) ? s_prior[nd.depth] : 1.0;
+      const bool attempt = has && (pl < u_coin) && (f_nodes + 2 <= MAXN) && (nd.cnt >= 2);
+      TR(5);
+      SplitRow sr;
+      sr.found = 0;
+      sr.v = 0.0;
+      if (attempt) {
+        TR(6);
+        sr = select_split_row(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
+                              s_pre1[0]);
+      }
+      TR(7);
+      Job job;
+      memset(&job, 0, sizeof job);
+      job.src_gen = f_gen;
+      job.src_slot = f_slot;
+      job.h_n_nodes = f_nodes;
+      job.h_n_leaves = f_leaves;
+      job.h_next_pop = np + (has ? 1 : 0);
+      job.h_sse_tot = f_sse_tot;
+      job.h_sse_orph = f_sse_orph;
+      job.popped = has ? 1 : 0;
+      if (sr.found) {
+        job.active = 1;
+        job.node = np;
+        job.label = nd.label;
+        job.new_label = f_leaves;
+        job.var = jvar;
+        job.rule = jrule;
+        job.check_nan = jnan;
+        job.ccL = ((r * MAXP + p) * 2);
+        job.ccR = job.ccL + 1;
+        job.cnt = nd.cnt;
+        job.v = sr.v;
+        // parent statistics and the children's leaf noise travel with the job
+        job.p_q_st = nd.q_st;
+        job.p_q_r = nd.q_r;
+        job.p_q_r2 = nd.q_r2;
+        job.p_sse = nd.sse;
+        job.p_value = nd.value;
+        job.p_depth = nd.depth;
+        job.z0 = s_ahead[0][0];
+        job.z1 = s_ahead[0][1];
+      }
+      {
+        const int dst = (c.lid_gen + 1) % NGEN;
+        job.copy = (!job.active && f_slot >= 0 && f_gen == (dst + 1) % NGEN) ? 1 : 0;
+      }
+      if (tid == 0) {
+        if constexpr (MK)
+        if (job.active)
+        for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
+          long long pq;
+          double pv;
+          if (np < nn_old) {
+            const size_t so = ((size_t)par * MAXP + a0) * MAXN * KX + (size_t)np * KX + k;
+            pq = (r1 && np == 0) ? root_A_x(S, par ^ 1, k) : S.pqx[so];
+            pv = S.pvx[so];
+            if (F.ok == -1 && np == F.node) pq = s_finx[a0][k].aL;
+          } else {
+            const bool isL = np == nn_old;
+            pq = isL ? s_finx[a0][k].aL : s_finx[a0][k].aR;
+            pv = isL ? s_finx[a0][k].vL : s_finx[a0][k].vR;
+          }
+          S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
+          S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
+        }
+        JN[p] = job;
+        if (!normal)  // the node's log-likelihood lives in q_r for these families
+          S.jobl[par * MAXP + p] = JobL{job.active ? nd.q_r : 0, F.ll_tot, F.ll_orph, 0};
+        me->n_nodes = f_nodes;
+        me->n_leaves = f_leaves;
+        me->next_pop = job.h_next_pop;
+        me->loc_gen = f_gen;
+        me->loc_slot = f_slot;
+        me->sse_tot = f_sse_tot;
+        me->sse_orph = f_sse_orph;
+      }
+      TRV(17, r);
+      TRV(16, attempt);
+      TRV(18, 0);
+      TRV(19, 0);
+      TR(8);
+      if (b == 0 && tid == 0) {
+        cmd->dst_gen = (c.lid_gen + 1) % NGEN;
+        cmd->st_cur = c.st_cur;
+        cmd->kind = CMD_PARTITION;
+        Ctrl o = c;
+        o.slot_no = c.slot_no + 1;
+        o.leaf_sd = leaf_sd;
+        if constexpr (MK)
+          for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
+        o.pend_leafsd = 0;
+        o.lid_gen = (c.lid_gen + 1) % NGEN;
+        o.sse0 = sse0;
+        o.u_res = s_ahead[0][2];
+        o.u_fin = s_ahead[0][3];
+        o.phase = PH_ROUND;
+        o.round = r + 1;
+        atomicAdd(&S.counters[3], 1ull);  // round r-1 is complete
+        *co = o;
+        TRX(11, true);
+      }
+      return;
     }
   } else {
     __syncthreads();  // waves 1/2 have published their draws
@@ -844,7 +1089,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   if (tid == 0) {
     const int np = F.next_pop;
     if (np < F.n_nodes) {
-      atomicAdd(&S.counters[0], 1ull);
       node = np;
       // the popped node: the root of a fresh stump, an old node of the ancestor, or one of the
       // children just created
@@ -886,88 +1130,18 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   TR(5);
   if (attempt) {
     const int ncnt = s_i[5], ncc = s_i[6], nlabel = s_i[7];
-    // Everything below runs on wave 0 only (no workgroup barriers): the k-th row (ascending) of
-    // the leaf, k = floor(u * cnt)   ([U] get_split_value)
+    // runs on wave 0 only (no workgroup barriers)
     if (tid < 64) {
-      const int j = s_i[8 + set];
-      const double* xc = S.XT + (size_t)j * S.n_pad;
-      const bool subset_rule = s_i[10 + set] == PGB_RULE_SUBSET;
-      const uint8_t* lid =
-          job.src_slot >= 0 ? S.lid + ((size_t)job.src_gen * MAXP + job.src_slot) * S.n_pad : nullptr;
-      const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
-      int found = 0;
-      double v = 0.0;
       TR(6);
-      // per-lane partial sums of the node's per-chunk row counts (independent of the retry)
-      const int per = (S.nchunks + 63) / 64;
-      const int c0 = lane_id() * per;
-      int c1 = c0 + per;
-      if (c1 > S.nchunks) c1 = S.nchunks;
-      int part = 0, pre = 0;
-      if (lid != nullptr) {
-        for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
-        pre = wave_incl_scan(part) - part;
-      }
-      for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !found; ++tr) {
-        long long k = (long long)(s_pre[set][1 + tr] * (double)ncnt);
-        if (k > ncnt - 1) k = ncnt - 1;
-        long long row;
-        if (lid == nullptr) {
-          row = k;  // untouched root: every row belongs to it
-        } else {
-          // (1) which chunk holds the k-th row
-          const bool own = (long long)pre <= k && k < (long long)pre + part;
-          int cstar = 0, kk = 0;
-          if (own) {
-            kk = (int)(k - pre);
-            cstar = c0;
-            while (kk >= ccr[cstar]) {
-              kk -= ccr[cstar];
-              ++cstar;
-            }
-          }
-          const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
-          cstar = __builtin_amdgcn_readlane(cstar, ol);
-          kk = __builtin_amdgcn_readlane(kk, ol);
-          // (2) which row inside the chunk: 16 label bytes per lane
-          const uint4 ids = *(const uint4*)(lid + (size_t)cstar * CH + lane_id() * 16);
-          const uint32_t wds[4] = {ids.x, ids.y, ids.z, ids.w};
-          int mcnt = 0;
-#pragma unroll
-          for (int wd = 0; wd < 4; ++wd)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mcnt += (((wds[wd] >> (8 * e)) & 255u) == (uint32_t)nlabel);
-          const int pre2 = wave_incl_scan(mcnt) - mcnt;
-          const bool own2 = pre2 <= kk && kk < pre2 + mcnt;
-          int off = 0;
-          if (own2) {
-            int rem = kk - pre2;
-            for (int bb = 0; bb < 16; ++bb) {
-              if (((wds[bb >> 2] >> (8 * (bb & 3))) & 255u) == (uint32_t)nlabel) {
-                if (rem == 0) {
-                  off = bb;
-                  break;
-                }
-                --rem;
-              }
-            }
-          }
-          const int ol2 = (int)__ffsll((long long)__ballot(own2)) - 1;
-          off = __builtin_amdgcn_readlane(off, ol2);
-          row = (long long)cstar * CH + ol2 * 16 + off;
-        }
-        const double x = xc[row];
-        found = (x == x) ? 1 : 0;
-        v = x;
-        if (found && subset_rule) v = pgb_subset_value(s_pre1[set][1 + tr], x);
-      }
+      const SplitRow sr = select_split_row(S, s_i[8 + set], s_i[10 + set] == PGB_RULE_SUBSET, job.src_gen, job.src_slot,
+                                           ncnt, ncc, nlabel, s_pre[set], s_pre1[set]);
       if (tid == 0) {
-        s_i[0] = found;
-        s_d[0] = v;
+        s_i[14] = sr.found;  // (not s_i[0]: waves 1..3 read s_i[0..1] after the resampling barrier and no later barrier orders them)
+        s_d[0] = sr.v;
       }
     }
     __syncthreads();
-    if (s_i[0]) {
+    if (s_i[14]) {
       const int j = s_i[8 + set];
       job.active = 1;
       job.node = node;
@@ -999,8 +1173,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       job.p_depth = nd.depth;
       job.z0 = s_ahead[set][0];
       job.z1 = s_ahead[set][1];
-      atomicAdd(&S.counters[2], (unsigned long long)nd.cnt);
-      atomicAdd(&S.counters[6], 1ull);
       if constexpr (MK)
       for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
         long long pq;
@@ -1022,6 +1194,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
       }
     }
+    job.popped = node >= 0 ? 1 : 0;
     JN[p] = job;
     if (!normal)  // the node's log-likelihood lives in q_r for these families
       S.jobl[par * MAXP + p] = JobL{job.active ? nd.q_r : 0, F.ll_tot, F.ll_orph, 0};
@@ -1033,13 +1206,11 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
     me->sse_tot = F.sse_tot;
     me->sse_orph = F.sse_orph;
   }
-#ifdef PGB_TRACE
-  if (b == 1 && tid == 0) {
-    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 15] = r;
-    S.trace[(size_t)(c.slot_no % TRACE_SLOTS) * 16 + 14] = attempt;
-    TR(8);
-  }
-#endif
+  TRV(17, r);
+  TRV(16, attempt);
+  TRV(18, fresh);
+  TRV(19, stop);
+  TR(8);
   if (b == 0 && tid == 0) {
     cmd->dst_gen = (c.lid_gen + 1) % NGEN;
     cmd->st_cur = c.st_cur;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   __shared__ int s_n[2];
   const Cmd* cmd = &cmds[par];
   const int kind = cmd->kind;
-  TRR(12, 0);
+  TRR_BIND(S.ctrl[par ^ 1].slot_no - 1);  // (stamp 12: entry)
   // profiling: every workgroup leaves its first and last device-clock reading; the host takes
   // min(start) .. max(end) per launch -- the interval rocprofv3 reports for the dispatch
   long long* pstamp = nullptr;

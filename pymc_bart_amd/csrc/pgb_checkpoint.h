@@ -185,7 +185,7 @@ extern "C" int pgb_debug_stamps(pgb_handle* h, long long* out, long long slot0, 
   return PGB_OK;
 }
 extern "C" int pgb_debug_trace(pgb_handle* h, long long* out, int n_slots) {
-  HIPCHK(hipMemcpy(out, h->d.trace, (size_t)n_slots * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, h->d.trace, (size_t)n_slots * TRACE_W * sizeof(long long), hipMemcpyDeviceToHost));
   return PGB_OK;
 }
 #endif

@@ -38,7 +38,7 @@ struct Job {  // one particle's work for a PARTITION row pass + what the next k_
   // particle header after this round's pop (so that the next k_ctrl needs one load per particle)
   double h_sse_tot, h_sse_orph;
   int32_t h_n_nodes, h_n_leaves, h_next_pop, p_depth;
-  int32_t pad_;
+  int32_t popped;  // a node was popped for this particle in the round this record proposes (a particle step)
   // leaf noise of the two children this split creates ([U] draw_leaf_value: the Box-Muller pair addressed
   // by (iter, round, particle)): drawn by an idle wave of the slot that WRITES the job, so that the slot
   // that finishes the round does not start with ~1.8 us of Philox + log + sqrt + sincos on its one
@@ -197,29 +197,35 @@ struct Dev {  // kernel argument block (by value)
   // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
   long long* prof_stamps;
   unsigned long long* host_flag;  // pinned host word: number of completed asteps
-  long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][16] wall_clock64 stamps
+  long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][TRACE_W] wall_clock64 stamps
 };
 
 #ifdef PGB_TRACE
 #define TRACE_SLOTS 4096
-#define TR(i)                                                                              \
-  do {                                                                                     \
-    if (blockIdx.x == 1 && threadIdx.x == 0)                                               \
-      S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64();         \
-  } while (0)
-#define TRX(i, cond)                                                                       \
-  do {                                                                                     \
-    if (cond) S.trace[(size_t)(S.ctrl[par].slot_no % TRACE_SLOTS) * 16 + (i)] = wall_clock64(); \
-  } while (0)
+#define TRACE_W 24 /* stamps 0..15, 16: attempt, 17: round of the proposal, 18: fresh (this slot starts a tree), 19: stop */
+// The record of a slot is addressed through `tr_rec` (set once per kernel from the slot number the kernel
+// has in registers anyway): a stamp is one clock read and one store, no load.  TR0() keeps the entry
+// reading in a register until the slot number is known.
+#define TR_DECL() long long tr_t0 = 0; long long* tr_rec = nullptr
+#define TR0() do { tr_t0 = wall_clock64(); } while (0)
+#define TR_BIND(slot_no) do { tr_rec = S.trace + (size_t)((slot_no) % TRACE_SLOTS) * TRACE_W; if (blockIdx.x == 1 && threadIdx.x == 0) tr_rec[0] = tr_t0; } while (0)
+#define TR(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) tr_rec[(i)] = wall_clock64(); } while (0)
+#define TRX(i, cond) do { if (cond) tr_rec[(i)] = wall_clock64(); } while (0)
+#define TRV(i, val) do { if (blockIdx.x == 1 && threadIdx.x == 0) tr_rec[(i)] = (val); } while (0)
 // stamps of the row pass (entries 12..15 of the slot's record), taken by one chosen workgroup
-#define TRR(i, blk)                                                                                  \
-  do {                                                                                               \
-    if (blockIdx.x == (blk) && threadIdx.x == 0)                                                     \
-      S.trace[(size_t)((S.ctrl[par ^ 1].slot_no - 1) % TRACE_SLOTS) * 16 + (i)] = wall_clock64();    \
-  } while (0)
+#define TRR_BIND(slot_no)                                                                   \
+  const long long tr_t12 = wall_clock64();                                                   \
+  long long* tr_rec = S.trace + (size_t)((slot_no) % TRACE_SLOTS) * TRACE_W;                 \
+  if (blockIdx.x == 0 && threadIdx.x == 0) tr_rec[12] = tr_t12
+#define TRR(i, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) tr_rec[(i)] = wall_clock64(); } while (0)
 #else
+#define TR_DECL() ((void)0)
+#define TR0() ((void)0)
+#define TR_BIND(slot_no) ((void)0)
 #define TR(i) ((void)0)
 #define TRX(i, cond) ((void)0)
+#define TRV(i, val) ((void)0)
+#define TRR_BIND(slot_no) ((void)0)
 #define TRR(i, blk) ((void)0)
 #endif
 

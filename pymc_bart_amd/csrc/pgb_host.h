@@ -302,9 +302,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipHostGetDevicePointer(&dp, hp, 0));
     d.host_flag = (unsigned long long*)dp;
 #ifdef PGB_TRACE
-    if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * 16)) != PGB_OK) { pgb_destroy(h); return rc; }
+    if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * TRACE_W)) != PGB_OK) { pgb_destroy(h); return rc; }
     transient(h);
-    HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * 16 * sizeof(long long), sm));
+    HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * TRACE_W * sizeof(long long), sm));
 #endif
     {  // host-facing results of pgb_step_host: mapped pinned block + dense sum_trees staging
       int cap_trees = s->batch_tune > s->batch_draw ? s->batch_tune : s->batch_draw;

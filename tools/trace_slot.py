@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Slot anatomy from the in-kernel device-clock stamps (-DPGB_TRACE build of the HIP library).
+
+Builds pymc_bart_amd/csrc/libpgbart_hip_trace.so (same flags as __graft_entry__.build plus
+-DPGB_TRACE) when run with --build (no GPU needed), and on a GPU box runs cfg2 for a few asteps
+and prints, per stage stamp, the median offset from the entry of k_ctrl (workgroup 1), for plain
+SMC rounds and for the slots that start a tree.  Stamps (k_ctrl.h / k_rows.h):
+  0 entry | 1 control word here | 2 finish stage done (wave 0) | 3 ancestor known by all waves
+  4 node-table copy issued / end-of-tree bookkeeping done | 5 popped, prior coin | 6 split-row selection starts
+  7 split row found | 8 job written | 9,10 pre-draw waves done | 11 control word written (workgroup 0)
+  12 k_rows entry (workgroup 0) | 13 jobs listed | 14 rows loaded + quantised (last item) | 15 item loop done
+usage: python tools/trace_slot.py --build            (here)
+       python tools/trace_slot.py [--asteps 10]      (GPU box)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TRACE_SO = os.path.join(ROOT, "pymc_bart_amd", "csrc", "libpgbart_hip_trace.so")
+
+
+def build(extra=(), out=TRACE_SO):
+    import __graft_entry__ as g
+
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *g.HIPCC_FLAGS, "-DPGB_TRACE", *extra, g.HIP_SRC, "-o", out]
+    subprocess.check_call(cmd)
+    print("built", out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--asteps", type=int, default=10)
+    ap.add_argument("--burnin", type=int, default=40)
+    ap.add_argument("--define", action="append", default=[])
+    ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
+    a = ap.parse_args()
+    if a.build:
+        build([f"-D{d}" for d in a.define], a.lib)
+        return
+    import torch  # noqa: F401  (one HIP runtime per process)
+
+    from pymc_bart_amd import _abi, workloads
+    from pymc_bart_amd._device import TorchHipMemory
+    from pymc_bart_amd.sampler import Backend, PyBartSettings, PySampler
+
+    lib = _abi.PGBLibrary(a.lib)
+    lib.lib.pgb_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    be = Backend(lib=lib, mem=TorchHipMemory(0))
+    w = workloads.cfg2()
+    X, Y = w["X"], w["Y"]
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=3415)
+    s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
+    s.set_likelihood([1.0])
+    for _ in range(a.burnin):
+        s.step(True)
+    c0 = s.counters.as_dict()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(a.asteps):
+        s.step(False)
+    dt = time.perf_counter() - t0
+    c1 = s.counters.as_dict()
+    print({k: c1[k] - c0[k] for k in c1}, "sync astep ms", 1e3 * dt / a.asteps)
+    NS = 4096
+    buf = np.zeros((NS, 24), np.int64)
+    lib.check(lib.lib.pgb_debug_trace(s._h, buf.ctypes.data, NS), "trace")
+    # keep slots with a full set of k_ctrl stamps; stamp 15 = round of the proposal, 14 = attempt
+    t = buf.astype(np.float64) * 0.01  # 100 MHz ticks -> us
+    ok = (buf[:, 0] > 0) & (buf[:, 8] > buf[:, 0])
+    order = np.argsort(buf[:, 0])
+    order = order[ok[order]]
+    t = t[order]
+    rnd = buf[order, 17]
+    att = buf[order, 16]
+    nxt = np.roll(t[:, 0], -1) - t[:, 0]
+    nxt[-1] = np.nan
+
+    def show(name, sel):
+        if sel.sum() < 5:
+            print(name, "too few slots", int(sel.sum()))
+            return
+        parts = []
+        for i in (1, 9, 10, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15):
+            d = t[sel, i] - t[sel, 0]
+            d = d[(t[sel, i] > 0) & (d > -1) & (d < 200)]
+            if d.size:
+                parts.append(f"{i}:{np.median(d):.2f}")
+        v = nxt[sel]
+        v = v[np.isfinite(v) & (v < 200)]
+        print(f"{name:28s} n={int(sel.sum()):5d}  " + " ".join(parts) + f"  | next k_ctrl {np.median(v):.2f} (mean {v.mean():.2f})")
+
+    fresh = buf[order, 18] != 0
+    stop = buf[order, 19] != 0
+    show("plain round, attempt", (rnd >= 2) & (att == 1) & ~fresh & ~stop)
+    show("plain round, no attempt", (rnd >= 2) & (att == 0) & ~fresh & ~stop)
+    show("round 1 (after tree start)", (rnd == 1) & ~fresh & ~stop)
+    show("tree end + next tree start", fresh & stop)
+    show("step start (begin)", fresh & ~stop)
+    v = nxt[np.isfinite(nxt) & (nxt < 200)]
+    print("all slots: mean period %.2f us, median %.2f us, n=%d" % (v.mean(), np.median(v), v.size))
+
+
+if __name__ == "__main__":
+    main()
