@@ -170,23 +170,35 @@ struct SplitRow {
 };
 __device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool subset_rule, int src_gen, int src_slot,
                                                      int ncnt, int ncc, int nlabel, const double* pre0,
-                                                     const double* pre1) {
+                                                     const double* pre1, long long* tr_rec = nullptr) {
   const double* xc = S.XT + (size_t)j * S.n_pad;
   const uint8_t* lid = src_slot >= 0 ? S.lid + ((size_t)src_gen * MAXP + src_slot) * S.n_pad : nullptr;
   const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
   SplitRow out;
   out.found = 0;
   out.v = 0.0;
-  // per-lane partial sums of the node's per-chunk row counts (independent of the retry)
+  // per-lane partial sums of the node's per-chunk row counts (independent of the retry); the counts of a
+  // lane's chunks stay in registers (<= 4 chunks per lane, i.e. n <= 262144: one 8-byte load, no re-read
+  // when the k-th row is located; longer columns walk the counts in memory)
   const int per = (S.nchunks + 63) / 64;
   const int c0 = lane_id() * per;
   int c1 = c0 + per;
   if (c1 > S.nchunks) c1 = S.nchunks;
   int part = 0, pre = 0;
+  unsigned cw[4] = {0u, 0u, 0u, 0u};  // counts of chunks c0 .. c0 + 3
+  const bool inreg = per <= 4;
   if (lid != nullptr) {
-    for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
+    if (inreg) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < per && c0 + i < S.nchunks) cw[i] = ccr[c0 + i];
+      part = (int)(cw[0] + cw[1] + cw[2] + cw[3]);
+    } else {
+      for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
+    }
     pre = wave_incl_scan(part) - part;
   }
+  TRS(20);
   for (uint32_t tr = 0; tr < PGB_SELECT_TRIES && !out.found; ++tr) {
     long long k = (long long)(pre0[1 + tr] * (double)ncnt);
     if (k > ncnt - 1) k = ncnt - 1;
@@ -200,43 +212,56 @@ __device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool s
       if (own) {
         kk = (int)(k - pre);
         cstar = c0;
-        while (kk >= ccr[cstar]) {
-          kk -= ccr[cstar];
-          ++cstar;
+        if (inreg) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            if (kk >= (int)cw[i] && cstar == c0 + i) {
+              kk -= (int)cw[i];
+              ++cstar;
+            }
+        } else {
+          while (kk >= ccr[cstar]) {
+            kk -= ccr[cstar];
+            ++cstar;
+          }
         }
       }
       const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
       cstar = __builtin_amdgcn_readlane(cstar, ol);
       kk = __builtin_amdgcn_readlane(kk, ol);
-      // (2) which row inside the chunk: 16 label bytes per lane
+      TRS(23);
+      // (2) which row inside the chunk: 16 label bytes per lane.  Matches as a 16-bit mask: a byte of
+      // (word xor label-in-every-byte) is zero exactly where the label matches; the exact zero-byte test
+      // ~(((x & 0x7f7f7f7f) + 0x7f7f7f7f) | x | 0x7f7f7f7f) leaves 0x80 in those bytes and nothing else.
       const uint4 ids = *(const uint4*)(lid + (size_t)cstar * CH + lane_id() * 16);
       const uint32_t wds[4] = {ids.x, ids.y, ids.z, ids.w};
-      int mcnt = 0;
+      const uint32_t lab4 = (uint32_t)nlabel * 0x01010101u;
+      uint32_t mask = 0;
 #pragma unroll
-      for (int wd = 0; wd < 4; ++wd)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mcnt += (((wds[wd] >> (8 * e)) & 255u) == (uint32_t)nlabel);
+      for (int wd = 0; wd < 4; ++wd) {
+        const uint32_t x = wds[wd] ^ lab4;
+        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);  // 0x80 per matching byte
+        // gather the four flag bits (bits 7, 15, 23, 31) into a nibble
+        const uint32_t nib = ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+        mask |= nib << (4 * wd);
+      }
+      const int mcnt = __popc(mask);
       const int pre2 = wave_incl_scan(mcnt) - mcnt;
       const bool own2 = pre2 <= kk && kk < pre2 + mcnt;
       int off = 0;
-      if (own2) {
-        int rem = kk - pre2;
-        for (int bb = 0; bb < 16; ++bb) {
-          if (((wds[bb >> 2] >> (8 * (bb & 3))) & 255u) == (uint32_t)nlabel) {
-            if (rem == 0) {
-              off = bb;
-              break;
-            }
-            --rem;
-          }
-        }
+      if (own2) {  // position of the (kk - pre2)-th set bit: clear that many low set bits, count trailing zeros
+        uint32_t mm = mask;
+        for (int rem = kk - pre2; rem > 0; --rem) mm &= mm - 1u;
+        off = __ffs((int)mm) - 1;
       }
       const int ol2 = (int)__ffsll((long long)__ballot(own2)) - 1;
       off = __builtin_amdgcn_readlane(off, ol2);
       row = (long long)cstar * CH + ol2 * 16 + off;
     }
+    TRS(21);
     const double x = xc[row];
     out.found = (x == x) ? 1 : 0;
+    TRS(22);
     out.v = x;
     if (out.found && subset_rule) out.v = pgb_subset_value(pre1[1 + tr], x);
   }
@@ -733,7 +758,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       if (attempt) {
         TR(6);
         sr = select_split_row(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
-                              s_pre1[0]);
+                              s_pre1[0], TR_REC);
       }
       TR(7);
       Job job;

@@ -202,7 +202,7 @@ struct Dev {  // kernel argument block (by value)
 
 #ifdef PGB_TRACE
 #define TRACE_SLOTS 4096
-#define TRACE_W 24 /* stamps 0..15, 16: attempt, 17: round of the proposal, 18: fresh (this slot starts a tree), 19: stop */
+#define TRACE_W 24 /* stamps 0..15, 16: attempt, 17: round of the proposal, 18: fresh (this slot starts a tree), 19: stop, 20..23: inside the split-row selection */
 // The record of a slot is addressed through `tr_rec` (set once per kernel from the slot number the kernel
 // has in registers anyway): a stamp is one clock read and one store, no load.  TR0() keeps the entry
 // reading in a register until the slot number is known.
@@ -212,6 +212,8 @@ struct Dev {  // kernel argument block (by value)
 #define TR(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) tr_rec[(i)] = wall_clock64(); } while (0)
 #define TRX(i, cond) do { if (cond) tr_rec[(i)] = wall_clock64(); } while (0)
 #define TRV(i, val) do { if (blockIdx.x == 1 && threadIdx.x == 0) tr_rec[(i)] = (val); } while (0)
+#define TRS(i) do { if (tr_rec != nullptr && blockIdx.x == 1 && threadIdx.x == 0) tr_rec[(i)] = wall_clock64(); } while (0)
+#define TR_REC tr_rec
 // stamps of the row pass (entries 12..15 of the slot's record), taken by one chosen workgroup
 #define TRR_BIND(slot_no)                                                                   \
   const long long tr_t12 = wall_clock64();                                                   \
@@ -225,6 +227,8 @@ struct Dev {  // kernel argument block (by value)
 #define TR(i) ((void)0)
 #define TRX(i, cond) ((void)0)
 #define TRV(i, val) ((void)0)
+#define TRS(i) ((void)0)
+#define TR_REC nullptr
 #define TRR_BIND(slot_no) ((void)0)
 #define TRR(i, blk) ((void)0)
 #endif

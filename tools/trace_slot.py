@@ -7,6 +7,7 @@ and prints, per stage stamp, the median offset from the entry of k_ctrl (workgro
 SMC rounds and for the slots that start a tree.  Stamps (k_ctrl.h / k_rows.h):
   0 entry | 1 control word here | 2 finish stage done (wave 0) | 3 ancestor known by all waves
   4 node-table copy issued / end-of-tree bookkeeping done | 5 popped, prior coin | 6 split-row selection starts
+  20 chunk counts scanned | 23 chunk known | 21 row known | 22 split value here
   7 split row found | 8 job written | 9,10 pre-draw waves done | 11 control word written (workgroup 0)
   12 k_rows entry (workgroup 0) | 13 jobs listed | 14 rows loaded + quantised (last item) | 15 item loop done
 usage: python tools/trace_slot.py --build            (here)
@@ -41,6 +42,7 @@ def main():
     ap.add_argument("--asteps", type=int, default=10)
     ap.add_argument("--burnin", type=int, default=40)
     ap.add_argument("--define", action="append", default=[])
+    ap.add_argument("--stamps", action="store_true", help="also per-workgroup first/last clock readings of the row pass")
     ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
     a = ap.parse_args()
     if a.build:
@@ -63,6 +65,8 @@ def main():
     for _ in range(a.burnin):
         s.step(True)
     c0 = s.counters.as_dict()
+    if a.stamps:
+        s.profile(True)
     import time
     t0 = time.perf_counter()
     for _ in range(a.asteps):
@@ -89,7 +93,7 @@ def main():
             print(name, "too few slots", int(sel.sum()))
             return
         parts = []
-        for i in (1, 9, 10, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15):
+        for i in (1, 9, 10, 2, 3, 4, 5, 6, 20, 23, 21, 22, 7, 8, 11, 12, 13, 14, 15):
             d = t[sel, i] - t[sel, 0]
             d = d[(t[sel, i] > 0) & (d > -1) & (d < 200)]
             if d.size:
@@ -105,6 +109,65 @@ def main():
     show("round 1 (after tree start)", (rnd == 1) & ~fresh & ~stop)
     show("tree end + next tree start", fresh & stop)
     show("step start (begin)", fresh & ~stop)
+    if a.stamps:
+        s.profile(False)
+        lib.lib.pgb_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
+        sb = np.zeros((NS, 1024, 2), np.int64)
+        lib.check(lib.lib.pgb_debug_stamps(s._h, sb.ctypes.data, 0, NS), "stamps")
+        sb = sb[order].astype(np.float64) * 0.01  # same ring index as the trace records
+
+        def rows(name, sel):
+            idx = np.nonzero(sel)[0]
+            out = []
+            for i in idx:
+                st, en = sb[i, :, 0], sb[i, :, 1]
+                m = (st > 0) & (en > st)
+                if m.sum() < 8 or abs(st[m].min() - t[i, 12]) > 50:
+                    continue  # stale ring entry
+                t0 = st[m].min()
+                dur = en[m] - st[m]
+                work = dur > 0.6  # workgroups that had an item
+                nx = t[i + 1, 0] if i + 1 < t.shape[0] else np.nan
+                out.append((m.sum(), work.sum(), st[m].max() - t0, en[m].max() - t0, np.median(dur[work]) if work.any() else 0,
+                            dur.max(), t[i, 15] - t0, nx - en[m].max(), t0 - t[i, 8]))
+            if len(out) < 3:
+                print(name, "too few launches with stamps", len(out))
+                return
+            o = np.array(out)
+            md = np.nanmedian(o, axis=0)
+            print(f"{name:28s} n={len(out):4d} wgs {md[0]:.0f} with work {md[1]:.0f} | last start +{md[2]:.2f} | span {md[3]:.2f} | "
+                  f"wg median {md[4]:.2f} longest {md[5]:.2f} | wg0 done +{md[6]:.2f} | end -> next k_ctrl {md[7]:.2f} | k_ctrl wg1 job -> first wg {md[8]:.2f}")
+
+        def by_block(name, sel):
+            idx = np.nonzero(sel)[0]
+            acc_d, acc_s, acc_e, cnt = np.zeros(1024), np.zeros(1024), np.zeros(1024), 0
+            for i in idx:
+                st, en = sb[i, :, 0], sb[i, :, 1]
+                m = (st > 0) & (en > st)
+                if m.sum() < 1024 or abs(st[m].min() - t[i, 12]) > 50:
+                    continue
+                t0 = st.min()
+                acc_d += en - st
+                acc_s += st - t0
+                acc_e += en - t0
+                cnt += 1
+            if cnt == 0:
+                return
+            d, st_, en_ = acc_d / cnt, acc_s / cnt, acc_e / cnt
+            print(f"{name}: mean per block over {cnt} launches")
+            print("  blocks 0..15 duration", np.round(d[:16], 2))
+            print("  blocks 0..15 start   ", np.round(st_[:16], 2))
+            for lo in (0, 64, 128, 256, 384, 512, 640, 768, 896):
+                hi = lo + (64 if lo < 128 else 128)
+                print(f"  blocks {lo:4d}..{hi - 1:4d}: start {st_[lo:hi].mean():.2f}  duration {d[lo:hi].mean():.2f} (max {d[lo:hi].max():.2f})  end {en_[lo:hi].mean():.2f} (max {en_[lo:hi].max():.2f})")
+            print("  by blockIdx % 8: duration", np.round([d[k::8].mean() for k in range(8)], 2), "end", np.round([en_[k::8].max() for k in range(8)], 2))
+
+        by_block("plain round", (rnd >= 2) & ~fresh & ~stop)
+        by_block("tree start", fresh & stop)
+        print("-- row pass, per-workgroup stamps (us)")
+        rows("plain round", (rnd >= 2) & ~fresh & ~stop)
+        rows("round 1", (rnd == 1) & ~fresh & ~stop)
+        rows("tree end + next tree start", fresh & stop)
     v = nxt[np.isfinite(nxt) & (nxt < 200)]
     print("all slots: mean period %.2f us, median %.2f us, n=%d" % (v.mean(), np.median(v), v.size))
 
