@@ -984,13 +984,17 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         }
         for (int j = tid; j < S.p; j += BT) alpha_o[j] = alpha[j];
         __syncthreads();
-        if (tid == 0)
-          for (int i = 0; i < nn; ++i)
-            if (snd[i].var >= 0) alpha_o[snd[i].var] += S.alpha_unit;
+        // (one thread per node, integer atomics: a serial loop of dependent global read-modify-writes on
+        //  one thread cost this workgroup -- and with it the slot -- a few microseconds per tree)
+        for (int i = tid; i < nn; i += BT) {
+          const int v = snd[i].var;
+          if (v >= 0) atomicAdd((unsigned long long*)&alpha_o[v], (unsigned long long)S.alpha_unit);
+        }
       } else {
-        if (tid == 0)
-          for (int i = 0; i < nn; ++i)
-            if (snd[i].var >= 0) S.vi[snd[i].var] += 1;
+        for (int i = tid; i < nn; i += BT) {
+          const int v = snd[i].var;
+          if (v >= 0) atomicAdd(&S.vi[v], 1);
+        }
       }
       if (tree_new == tree_old && has_init) {  // m == 1 corner: next update is this very tree
         __syncthreads();
