@@ -304,6 +304,28 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
   const int P = S.P, Lc = P - 1;
   Cmd* cmd = &S.cmd[par];
+  // One workgroup more than there are particles to propose for (single-output constant leaves): it builds
+  // the label -> value tables the row pass of THIS slot needs if the slot turns out to end the tree -- of
+  // the tree as it stands (the update may keep it) and of the tree that would be updated next.  Both depend
+  // on the control word alone, so they are built here, next to the workgroups that decide; a slot that does
+  // not end the tree leaves them unused.  (The other instances build their tables where the tree ends.)
+  constexpr bool SPEC_LV = !MK && !LIN;
+  if constexpr (SPEC_LV) {
+    if (b == P - 1) {
+      if (c.phase != PH_ROUND) return;
+      const int t_old = c.lower + c.k;
+      int t_next;
+      if (c.k + 1 < c.batch_n) {
+        t_next = t_old + 1;
+      } else {
+        const int upper = c.lower + c.batch_n;
+        t_next = upper < S.m ? upper : 0;
+      }
+      build_lv(S.trees[t_old].nd, S.trees[t_old].n_nodes, cmd->lv_keep);
+      if (t_next != t_old) build_lv(S.trees[t_next].nd, S.trees[t_next].n_nodes, cmd->lv_next);
+      return;
+    }
+  }
   InitAcc ia;  // statistics of the previous FINAL/INIT row pass (integer sums over IA_SLOTS lines)
   {
     const InitAcc* src = ias + (size_t)(par ^ 1) * IA_SLOTS;
@@ -953,11 +975,12 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           cmd->sel_slot = -2;
           cmd->sel_gen = 0;
         }
-        build_lv(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, cmd->lv_new);
+        if constexpr (!SPEC_LV) build_lv(S.trees[tree_old].nd, S.trees[tree_old].n_nodes, cmd->lv_new);
       }
       // label table of the next tree to update (a different tree unless m == 1)
-      if (has_init && tree_new != tree_old)
-        build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
+      if constexpr (!SPEC_LV)
+        if (has_init && tree_new != tree_old)
+          build_lv(S.trees[tree_new].nd, S.trees[tree_new].n_nodes, cmd->lv_next);
     }
     // Bookkeeping that needs the accepted tree's split variables is done by the workgroup
     // that owns a complete copy of that tree.

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
 
   if (do_final || do_init) {
     for (int i = tid; i < 256; i += BT) {
-      s_lv[0][i] = cmd->lv_new[i];
+      s_lv[0][i] = (!LIN && cmd->sel_slot == -2) ? cmd->lv_keep[i] : cmd->lv_new[i];
       s_lv[1][i] = cmd->lv_next[i];
       if constexpr (LIN) {
         s_ll[0][i] = S.lvl[((size_t)par * 2 + 0) * 256 + i];

@@ -108,6 +108,9 @@ struct Cmd {
   int32_t tune, dst_gen, st_cur;
   long long rs_count;
   double lv_new[256], lv_next[256];
+  // label -> value table of the tree being updated as it stands (used instead of lv_new when the update
+  // keeps the old tree, sel_slot == -2): built ahead by an idle wave, see k_ctrl (single-output, constant leaves)
+  double lv_keep[256];
 };
 
 struct Ctrl {

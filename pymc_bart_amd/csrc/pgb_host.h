@@ -578,7 +578,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
     if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS);
     else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS);
     else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS);
-    else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), gctrl, CTRL_ARGS);
+    else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), dim3((unsigned)d.P), CTRL_ARGS);  // + the workgroup that builds the label tables ahead
 #undef CTRL_ARGS
 #define ROWS_ARGS dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
