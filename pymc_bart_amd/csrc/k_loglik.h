@@ -59,6 +59,14 @@ __device__ __forceinline__ double loglik_cat_fast(double y, const double* mu) {
   return ll;
 }
 
+// pgb_quant of a per-row log-likelihood that has already been clamped to the contract's range
+// (|ll| <= 2047, never NaN: every pgb_loglik* routine ends with that clamp): |ll * cl| < 2^50, so none of
+// pgb_quant's NaN / saturation branches can fire and what is left of it is the rounding itself.  Same bits.
+__device__ __forceinline__ long long quant_ll(double ll, double cl) {
+  const double mg = ll * cl + 6755399441055744.0; /* 1.5 * 2^52 */
+  return (long long)(pgb_d2u(mg) - 0x4338000000000000ull);
+}
+
 // KT: 1 = single output; 2, 3, 4 = that many outputs, loops unrolled; 0 = any K <= PGB_MAX_OUTPUTS
 // FAM: the likelihood family when known at compile time (single-output kernels: the per-row
 // evaluation then contains one family's code only), -1: read S.family.
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
             } else {
               llv = pgb_loglik(S.family, K, yv[e], mu);
             }
-            const long long q = pgb_quant(llv, cl, &sat);
+            const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
         }
@@ -273,6 +281,10 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         nid_n = *(const uint32_t*)(newl + (size_t)ln.p * S.n_pad + base);
       }
       long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
+      // (the particle's fields in registers: read through the LDS record they cost three LDS reads per ROW)
+      const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
+      const double vL = lj.vL, vR = lj.vR;
+      const bool drops = lj.check_nan != 0;  // only a column with missing values drops rows
       if constexpr (FAM == PGB_FAMILY_CALLBACK) {
         // the host evaluates this family (pgb_set_loglik_callback): hand it every row's side and the
         // linear predictor of the rows of the split leaf
@@ -290,14 +302,15 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         *(uint32_t*)(S.cb_side + (size_t)lj.p * S.n_pad + base) = sides;
         continue;
       }
+      long long vt = 0;  // all rows of the split leaf: the right child is what the other two leave
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
-        if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+        if (((ids >> (8 * e)) & 255u) == lab) {
           // ONE evaluation per row: the side only selects the leaf value and the accumulator
           // (separate calls per side would run one after the other on a divergent wave)
           const uint32_t nl = (nid >> (8 * e)) & 255u;
-          const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
-          double vleaf = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;  // dropped: predicts 0
+          const int side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
+          double vleaf = side == 0 ? vL : side == 1 ? vR : 0.0;  // dropped: predicts 0
           if constexpr (LIN) {
             const int sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
             if (sv >= 0) {
@@ -306,14 +319,15 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
             }
           }
           const double mu = nv[e] + vleaf;
-          const long long q = pgb_quant(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2,
-                                                      PROBIT ? s_ln : pgb_ln_tn(),
-                                                      PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl, &sat);
+          const long long q = quant_ll(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2,
+                                                    PROBIT ? s_ln : pgb_ln_tn(),
+                                                    PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl);
+          vt += q;
           v0 += side == 0 ? q : 0;
-          v1 += side == 1 ? q : 0;
-          v2 += side == 2 ? q : 0;
+          if (drops) v2 += side == 2 ? q : 0;
         }
       }
+      v1 = vt - v0 - v2;
       const int slot = (g - g0) * 3;
       const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
       if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Parity hunt on a GPU box: random configurations (tests/_cases.random_case) through the HIP library and
+the CPU oracle, bit-for-bit digests compared.  usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from _cases import digest, random_case, run_case  # noqa: E402
+from _oracle import oracle_backend  # noqa: E402
+from pymc_bart_amd.sampler import default_backend  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+hip, orc = default_backend(0), oracle_backend()
+t0, bad, done = time.time(), [], 0
+fam = {}
+for seed in range(first, first + count):
+    if time.time() - t0 > budget:
+        break
+    c = random_case(seed)
+    g, o = digest(run_case(c, hip)), digest(run_case(c, orc))
+    done += 1
+    key = (c["family"], int(c["K"]), str(c.get("response", "constant")))
+    fam[key] = fam.get(key, 0) + 1
+    if g != o:
+        bad.append(seed)
+        print("MISMATCH", seed, c["family"], c["X"].shape, c["m"], c["P"], c["K"], c["rules"].tolist(), flush=True)
+print(f"fuzz: seeds {first}..{first + done - 1}: {done} configurations, {len(bad)} mismatches {bad}, {time.time() - t0:.0f} s")
+print("by (family, K, response):", sorted(fam.items(), key=lambda kv: -kv[1])[:12])
+sys.exit(1 if bad else 0)
