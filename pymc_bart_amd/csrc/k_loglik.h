@@ -181,6 +181,40 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     if (tid == 0) s_n[0] = __popcll(m);
   }
   __syncthreads();
+  if constexpr (!MK && FAM != PGB_FAMILY_CALLBACK) {
+    // A slot that starts a tree ([U] init_particles): the log-likelihood of a fresh stump (C) and of the
+    // tree as it stands, the reference particle (E0), over ALL rows -- from the {sum_trees, sum_trees_noi}
+    // the INIT part of this slot's row pass just wrote.  Evaluated here, in the kernel that is compiled per
+    // family, and not in the row pass: with every family's evaluation inlined twice the per-row-family
+    // instance of k_rows needed 163 VGPRs for a loop that does not use any of it.
+    const int fam = FAM >= 0 ? FAM : S.family;
+    if ((cmd->kind & CMD_INIT) && fam != PGB_FAMILY_CALLBACK) {
+      const double* __restrict__ const noi0 = S.st + (size_t)cn.st_cur * S.n_pad;
+      long long ce[2] = {0, 0};
+      for (int chunk = blockIdx.x; chunk < S.nchunks; chunk += gridDim.x) {
+        const long long base = (long long)chunk * CH + tid * RPT;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          const long long row = base + e;
+          if (row >= S.n) continue;
+          const double yr = S.y[row];
+          const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
+          ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noi0[row] + offv) + S.init_leaf, cn.inv_sigma2, cn.lik_param2,
+                                         PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
+                            S.sc.cl);
+          ce[1] += quant_ll(pgb_loglik1q(fam, yr, S.pack[row].x + offv, cn.inv_sigma2, cn.lik_param2,
+                                         PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
+                            S.sc.cl);
+        }
+      }
+      block_sum<2>(ce, s_red);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (ce[0]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)ce[0]);
+        if (ce[1]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)ce[1]);
+      }
+    }
+  }
   const int nact = s_n[0];
   if (nact == 0) return;
   int G = (nact * S.nchunks + S.ll_target - 1) / S.ll_target;

@@ -220,13 +220,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               iv[2] += qc[e];
               const double er = r - o;
               iv[3] += pgb_quant(er * er, c2, &sat);
-            } else {
-              // C: log-likelihood of a fresh stump, E0: of the current tree (reference particle)
-              const double lp = S.ctrl[par ^ 1].inv_sigma2, lp2 = S.ctrl[par ^ 1].lik_param2;  // family parameters
-              const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
-              iv[2] += pgb_quant(pgb_loglik1q(S.family, yv, (noi + offv) + S.init_leaf, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
-              iv[3] += pgb_quant(pgb_loglik1q(S.family, yv, st + offv, lp, lp2, pgb_ln_tn(), pgb_ln_tp()), S.sc.cl, &sat);
             }
+            // (per-row families: C, the log-likelihood of a fresh stump, and E0, of the current tree, are
+            //  summed by k_loglik, which runs after this pass and is compiled per family)
           }
         }
       } else {
@@ -236,8 +232,10 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           strow[e] = sr.x;
           rrow[e] = sr.y;
           qa[e] = pgb_quant(sr.x, c1, nullptr);
-          qb[e] = pgb_quant(sr.y, c1, nullptr);
-          qc[e] = pgb_quant(sr.y * sr.y, c2, nullptr);
+          // (per-row families carry no residual algebra: r is 0 in `pack`, and the constants let the
+          //  compiler drop the two sums from every particle's reduction)
+          qb[e] = normal ? pgb_quant(sr.y, c1, nullptr) : 0;
+          qc[e] = normal ? pgb_quant(sr.y * sr.y, c2, nullptr) : 0;
         }
       }
       TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
