@@ -181,15 +181,16 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
     if (tid == 0) s_n[0] = __popcll(m);
   }
   __syncthreads();
-  if constexpr (!MK && FAM != PGB_FAMILY_CALLBACK) {
+  if constexpr (FAM != PGB_FAMILY_CALLBACK) {
     // A slot that starts a tree ([U] init_particles): the log-likelihood of a fresh stump (C) and of the
     // tree as it stands, the reference particle (E0), over ALL rows -- from the {sum_trees, sum_trees_noi}
     // the INIT part of this slot's row pass just wrote.  Evaluated here, in the kernel that is compiled per
-    // family, and not in the row pass: with every family's evaluation inlined twice the per-row-family
-    // instance of k_rows needed 163 VGPRs for a loop that does not use any of it.
+    // family / number of outputs, and not in the row pass: with the evaluation inlined twice the row pass
+    // needed 163 (single output) / 256 (K = 4) VGPRs for a loop that does not use any of it.
     const int fam = FAM >= 0 ? FAM : S.family;
     if ((cmd->kind & CMD_INIT) && fam != PGB_FAMILY_CALLBACK) {
-      const double* __restrict__ const noi0 = S.st + (size_t)cn.st_cur * S.n_pad;
+      const int Kn = KT > 0 ? KT : S.K;
+      const double* __restrict__ const noi0 = S.st + (size_t)cn.st_cur * Kn * S.n_pad;
       long long ce[2] = {0, 0};
       for (int chunk = blockIdx.x; chunk < S.nchunks; chunk += gridDim.x) {
         const long long base = (long long)chunk * CH + tid * RPT;
@@ -198,13 +199,33 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
           const long long row = base + e;
           if (row >= S.n) continue;
           const double yr = S.y[row];
-          const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
-          ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noi0[row] + offv) + S.init_leaf, cn.inv_sigma2, cn.lik_param2,
-                                         PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
-                            S.sc.cl);
-          ce[1] += quant_ll(pgb_loglik1q(fam, yr, S.pack[row].x + offv, cn.inv_sigma2, cn.lik_param2,
-                                         PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
-                            S.sc.cl);
+          if constexpr (MK) {
+            double mu_stump[KB], mu_cur[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+              if (k < Kn) {
+                const double offk = S.has_off ? S.off[(size_t)k * S.n_pad + row] : 0.0;  // (x + 0.0 == x bit for bit)
+                const double stk = k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row];
+                mu_stump[k] = (noi0[(size_t)k * S.n_pad + row] + offk) + S.init_leaf;
+                mu_cur[k] = stk + offk;
+              }
+            if constexpr (KT >= 2) {
+              const bool cat = S.family == PGB_FAMILY_CATEGORICAL;
+              ce[0] += quant_ll(cat ? loglik_cat_fast<KT>(yr, mu_stump) : pgb_loglik(S.family, Kn, yr, mu_stump), S.sc.cl);
+              ce[1] += quant_ll(cat ? loglik_cat_fast<KT>(yr, mu_cur) : pgb_loglik(S.family, Kn, yr, mu_cur), S.sc.cl);
+            } else {
+              ce[0] += quant_ll(pgb_loglik(S.family, Kn, yr, mu_stump), S.sc.cl);
+              ce[1] += quant_ll(pgb_loglik(S.family, Kn, yr, mu_cur), S.sc.cl);
+            }
+          } else {
+            const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
+            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noi0[row] + offv) + S.init_leaf, cn.inv_sigma2, cn.lik_param2,
+                                           PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
+                              S.sc.cl);
+            ce[1] += quant_ll(pgb_loglik1q(fam, yr, S.pack[row].x + offv, cn.inv_sigma2, cn.lik_param2,
+                                           PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
+                              S.sc.cl);
+          }
         }
       }
       block_sum<2>(ce, s_red);

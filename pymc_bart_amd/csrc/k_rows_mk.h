@@ -127,7 +127,6 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
           const long long row = base + e;
           for (int k = 0; k < K; ++k) stv[e][k] = 0.0;
           if (row >= n) continue;
-          double mu_stump[KB], mu_cur[KB];
           for (int k = 0; k < K; ++k) {
             double st = st_in[(size_t)k * n_pad + row];
             if (do_final) {
@@ -148,9 +147,6 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
             const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][k], 1, (ids_next >> (8 * e)) & 255u, k, row);
             const double noi = st - o;
             stv[e][k] = st;
-            const double offk = S.has_off ? S.off[(size_t)k * n_pad + row] : 0.0;  // (x + 0.0 == x bit for bit)
-            mu_stump[k] = (noi + offk) + S.init_leaf;
-            mu_cur[k] = st + offk;
             if (writer) {
               if (k == 0) S.pack[row] = make_double2(st, 0.0);
               else S.packx[(size_t)(k - 1) * n_pad + row] = st;
@@ -158,11 +154,8 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
               iv[2 + k] += pgb_quant(st, c1, &sat);
             }
           }
-          if (writer) {
-            const double yv = S.y[row];
-            iv[0] += pgb_quant(pgb_loglik(S.family, K, yv, mu_stump), S.sc.cl, &sat);  // C: fresh stump
-            iv[1] += pgb_quant(pgb_loglik(S.family, K, yv, mu_cur), S.sc.cl, &sat);    // E0: current tree
-          }
+          // (C, the log-likelihood of a fresh stump, and E0, of the current tree, are summed by k_loglik,
+          //  which runs after this pass and is compiled per number of outputs)
         }
       } else {
         for (int e = 0; e < RPT; ++e) {
