@@ -272,6 +272,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         }
         uint32_t out = ids;
         uint8_t* __restrict__ const dp = dst0 + (size_t)rj.p * n_pad + base;
+        // (the particle's split in registers: read through the LDS record, the value, the rule and the labels
+        //  were fetched again for every ROW -- the compiler cannot keep LDS reads across the stores of the
+        //  reduction -- with a wait for the LDS each time)
+        const double r_v = rj.v, r_uscale = rj.uscale;
+        const int r_rule = rj.rule;
+        const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
         if (!rj.active) {  // forced refresh only
           *(uint32_t*)dp = out;
           continue;
@@ -282,12 +288,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
-              if (go_left_t<SUB>(rj.rule, x[e], rj.v)) {
+            if (((ids >> (8 * e)) & 255u) == r_label) {
+              if (go_left_t<SUB>(r_rule, x[e], r_v)) {
                 v0 += 1;
                 v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
               } else {
-                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+                out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
                 v0 += 1ll << 20;
               }
             }
@@ -299,17 +305,17 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+            if (((ids >> (8 * e)) & 255u) == r_label) {
               const double xv = x[e];
               if (xv != xv) {
                 out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
                 v[0] += 1ll << 40;
                 v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
-              } else if (go_left_t<SUB>(rj.rule, xv, rj.v)) {
+              } else if (go_left_t<SUB>(r_rule, xv, r_v)) {
                 v[0] += 1;
                 v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
               } else {
-                out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+                out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
                 v[0] += 1ll << 20;
               }
             }
@@ -325,13 +331,13 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
             const double xv = x[e];
-            if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label && xv == xv) {
-              const double uu = xv * rj.uscale;
+            if (((ids >> (8 * e)) & 255u) == r_label && xv == xv) {
+              const double uu = xv * r_uscale;
               const long long q0 = pgb_quant(uu * S.lin_R, c1, nullptr);
               const long long q1 = pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
               const long long q2 = pgb_quant(uu * strow[e], c1, nullptr);
               const long long q3 = pgb_quant(uu * rrow[e], c1, nullptr);
-              const bool gl = go_left_t<SUB>(rj.rule, xv, rj.v);
+              const bool gl = go_left_t<SUB>(r_rule, xv, r_v);
               ul[0] += gl ? q0 : 0; ul[1] += gl ? q1 : 0; ul[2] += gl ? q2 : 0; ul[3] += gl ? q3 : 0;
               ur[0] += gl ? 0 : q0; ur[1] += gl ? 0 : q1; ur[2] += gl ? 0 : q2; ur[3] += gl ? 0 : q3;
             }

@@ -182,24 +182,28 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
           continue;
         }
         const double2* xp = (const double2*)(S.XT + rj.xoff + base);
+        // (the particle's split in registers instead of LDS reads per row, see k_rows)
+        const double r_v = rj.v;
+        const int r_rule = rj.rule;
+        const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
         const double2 t0 = xp[0], t1 = xp[1];
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
         int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
         long long cnts = 0;
         for (int e = 0; e < RPT; ++e) {
           side[e] = 0;
-          if (((ids >> (8 * e)) & 255u) == (uint32_t)rj.label) {
+          if (((ids >> (8 * e)) & 255u) == r_label) {
             const double xv = x[e];
             if (xv != xv) {
               side[e] = 3;
               out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
               cnts += 1ll << 40;
-            } else if (go_left(rj.rule, xv, rj.v)) {
+            } else if (go_left(r_rule, xv, r_v)) {
               side[e] = 1;
               cnts += 1;
             } else {
               side[e] = 2;
-              out = (out & ~(255u << (8 * e))) | ((uint32_t)rj.new_label << (8 * e));
+              out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
               cnts += 1ll << 20;
             }
           }
