@@ -270,13 +270,25 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
         const LJob& lj = s_job[g];
         const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
         const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
+        // (the particle's labels and leaf values in registers instead of LDS reads per row)
+        const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
+        double vLr[KT >= 2 ? KT : 1], vRr[KT >= 2 ? KT : 1];
+        vLr[0] = lj.vL;
+        vRr[0] = lj.vR;
+        if constexpr (KT >= 2) {
+#pragma unroll
+          for (int k = 1; k < KT; ++k) {
+            vLr[k] = lj.vLx[k - 1];
+            vRr[k] = lj.vRx[k - 1];
+          }
+        }
         long long v0 = 0, v1 = 0, v2 = 0;
         for (int e = 0; e < RPT; ++e) {
-          if (((ids >> (8 * e)) & 255u) == (uint32_t)lj.label) {
+          if (((ids >> (8 * e)) & 255u) == lab) {
             const uint32_t nl = (nid >> (8 * e)) & 255u;
-            const int side = nl == (uint32_t)lj.label ? 0 : (nl == (uint32_t)lj.new_label ? 1 : 2);
+            const int side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
             double mu[KB];
-            double v0k = side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0;
+            double v0k = side == 0 ? vLr[0] : side == 1 ? vRr[0] : 0.0;
             int sv = -1;
             double xv = 0.0, xb = 0.0;
             if constexpr (LIN) {
@@ -291,7 +303,9 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
 #pragma unroll
             for (int k = 1; k < KB; ++k)
               if (k < K) {
-                double vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
+                double vk;
+                if constexpr (KT >= 2) vk = side == 0 ? vLr[k < KT ? k : 0] : side == 1 ? vRr[k < KT ? k : 0] : 0.0;
+                else vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
                 if constexpr (LIN)
                   if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
                 const double nk = noi[(size_t)k * S.n_pad + base + e];
