@@ -293,7 +293,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   // in idle / first slots (the records exist).
   Job j_pre;
   Acc a_pre;
-  if (threadIdx.x < 64) {
+  // (only the lanes that can be particles: the grid has P - 1 or P workgroups, so lanes 1 .. gridDim.x cover
+  //  particles 1 .. P - 1 -- at P = 40 the other 23 lanes made 37 % of this batch for nothing)
+  if (threadIdx.x >= 1 && threadIdx.x <= gridDim.x) {
     j_pre = jobs_all[(size_t)(par ^ 1) * MAXP + threadIdx.x];
     a_pre = load_acc(&acc_all[((size_t)(par ^ 1) * MAXP + threadIdx.x) * ACC_PER]);
   }
