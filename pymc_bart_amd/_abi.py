@@ -233,7 +233,8 @@ def load_hip_library() -> PGBLibrary:
         # buffers: import torch first so that its libamdhip64.so.7 is the one already loaded.
         import torch  # noqa: F401
 
-        _HIP_LIB = PGBLibrary(path)
-        if _HIP_LIB.backend_name != "hip-gfx950":
-            raise PGBError(f"{path} is not the HIP backend (it reports {_HIP_LIB.backend_name!r})")
+        lib = PGBLibrary(path)
+        if lib.backend_name != "hip-gfx950":
+            raise PGBError(f"{path} is not the HIP backend (it reports {lib.backend_name!r})")
+        _HIP_LIB = lib
     return _HIP_LIB

@@ -64,3 +64,16 @@ def test_product_package_never_references_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "libpgbart_oracle" not in text and "from _oracle" not in text, f
                 assert "import oracle" not in text, f
+
+
+def test_library_override_must_still_be_the_hip_backend(oracle, monkeypatch):
+    """PGBART_HIP_LIB names another BUILD of the HIP library (profiling / experiment builds); pointing it
+    at anything that is not the gfx950 backend -- the CPU checker, say -- is refused: the product has
+    no CPU path, by override or otherwise."""
+    monkeypatch.setenv("PGBART_HIP_LIB", oracle.lib.path)
+    monkeypatch.setattr(_abi, "_HIP_LIB", None)
+    with pytest.raises(_abi.PGBError, match="not the HIP backend"):
+        _abi.load_hip_library()
+    assert _abi._HIP_LIB is None  # a refused library is not kept
+    monkeypatch.delenv("PGBART_HIP_LIB")
+    assert _abi.load_hip_library().backend_name == "hip-gfx950"
