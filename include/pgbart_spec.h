@@ -315,10 +315,10 @@ PGB_HD void pgb_normal2(double u0, double u1, double* z0, double* z1) {
  *           for e = -3..9, s = 0..7 -- so the row index and the local variable come straight from
  *           the exponent and the top three mantissa bits of z: no division, no exp, no log.
  *           z >= 1024: -log z - log sqrt(2 pi) - w + 2.5 w^2, w = z^-2 (next term < 1e-17).
- *   x >= 0: log Phi(z) itself, 34 pieces of width 1/4 on [0, 8.5); 0 beyond (|.| < 1e-17).
- * Both signs share ONE Horner evaluation (the sign only selects the table row and the local
- * variable), so a wave with mixed signs runs one polynomial path.  Tables: tools/fit_log_ndtr.py
- * (Chebyshev-node interpolation against mpmath at 60 digits; absolute error 4e-15 / 5e-16).
+ *   x >= 0: log Phi(z) itself on the SAME dyadic intervals, up to 8.5; 0 beyond (|.| < 1e-17).
+ * Both signs share the interval arithmetic AND the Horner evaluation: the sign only selects the
+ * table, so a wave with mixed signs runs one path.  Tables: tools/fit_log_ndtr.py
+ * (Chebyshev-node interpolation against mpmath at 60 digits; absolute error 4e-15 / 7.5e-15).
  * Absolute error of the function < 4e-13 against scipy.special.log_ndtr on [-38, 38] (the
  * rounding of z^2 at |x| ~ 38), < 1e-14 on [-5, 5] (tests/test_spec.py). */
 /* the tables live in accessor functions so that a kernel can stage them in LDS (per-lane rows
@@ -434,15 +434,40 @@ PGB_HD const double* pgb_ln_tn(void) {
   return &t[0][0];
 }
 PGB_HD const double* pgb_ln_tp(void) {
-  static const double t[34][9] = {
-    {-0x1.3256172f7f1bep-1, 0x1.70aa14147e559p-4, -0x1.3789f7df5bd50p-8, 0x1.3d21436888496p-14, 0x1.3464f17fbfa71p-20, -0x1.bf1c1c2260febp-28, -0x1.0e61fb5735579p-30, -0x1.b296e7a7e0028p-36, 0x1.3482c461d6327p-43},
-    {-0x1.bf2c740535475p-2, 0x1.26a4c52e2ce76p-4, -0x1.180d396af5f9ap-8, 0x1.61df01422a853p-14, 0x1.114d199b40162p-20, -0x1.5c1a53d31f0afp-26, -0x1.6326c23229253p-30, -0x1.30a16f2adb08bp-36, 0x1.d4dfaa4cdd552p-41},
-    {-0x1.3ca5e181de6b4p-2, 0x1.c9ce8bd89f145p-5, -0x1.eacddce394bc3p-9, 0x1.7fbbd102ff368p-14, 0x1.8a2f50dc14b01p-21, -0x1.3bc8a3053e538p-25, -0x1.83d5038031323p-30, 0x1.8cd24374cc4f0p-39, 0x1.d897ff6a1f8bap-40},
-    {-0x1.b18c203eca063p-3, 0x1.584406b6daa59p-5, -0x1.a0f93ee7be814p-9, 0x1.9146918d4ef73p-14, 0x1.31c17459af12cp-22, -0x1.c41c4248c14d0p-25, -0x1.3ea90c2bc1a1cp-30, 0x1.30cc3788cb556p-35, 0x1.3452ea0d7dfd0p-39},
-    {-0x1.1de6f2151f49ap-3, 0x1.f2ee6ff575b83p-6, -0x1.556c6794c7badp-9, 0x1.9151f141d5e42p-14, -0x1.41071b0b5d1efp-22, -0x1.0d20f77a279d4p-24, -0x1.dd86c1aee2a88p-32, 0x1.290df995d79bdp-34, 0x1.e2cd06bb6552ap-40},
-    {-0x1.69e8b8a516e7fp-4, 0x1.5acab4beea7e1p-6, -0x1.0bc7e5549dd8ep-9, 0x1.7ca7682d0b659p-14, -0x1.f3ddbbc70c9b4p-21, -0x1.08714d8fb461bp-24, 0x1.66b01761e3ec1p-31, 0x1.6b9c949b129dfp-34, 0x1.9423871260a3cp-54},
-    {-0x1.b6295bcbdfd74p-5, 0x1.cc5b5188a23c1p-7, -0x1.8fe8f4abb42bap-10, 0x1.53b65dc4f0174p-14, -0x1.8e9a062d3eed2p-20, -0x1.93f060ce62161p-25, 0x1.db6ea26f17bdap-30, 0x1.1c585879119dfp-34, -0x1.38fff73e216a1p-39},
-    {-0x1.f9bd6774eea48p-6, 0x1.2294c953210bdp-7, -0x1.1aba2832bd042p-10, 0x1.1b4ab36dbee57p-14, -0x1.ece0699416bccp-20, -0x1.7a321a4b122b0p-26, 0x1.3f9c9d8c66e78p-29, 0x1.25e70b188cd29p-36, -0x1.ec9a2e5df7a77p-39},
+  static const double t[105][9] = {
+    {-0x1.49fdb8239277dp-1, 0x1.845d8f1d630c8p-5, -0x1.3edbb6f305fdbp-10, 0x1.336f39cd291b8p-17, 0x1.37ccb4ad14d39p-24, -0x1.fa9c942d19b25p-34, -0x1.ecbfca37ae037p-37, -0x1.b87b592fdaa63p-43, 0x1.5bbcb0e37cd90p-55},
+    {-0x1.2f77317c8eb32p-1, 0x1.6e3bee4ac297dp-8, -0x1.369bab58aa2fap-16, 0x1.3e556129ddbfdp-26, 0x1.33d53f55348f7p-36, -0x1.d8981a3bd8be9p-48, -0x1.115b6ad0eb368p-54, -0x1.b284f214272efp-64, 0x1.5692c50adceeep-75},
+    {-0x1.29c7f1a501b73p-1, 0x1.69653d049704cp-8, -0x1.34bc5e1ec175ap-16, 0x1.40bbd98d105ecp-26, 0x1.329dbe41a066dp-36, -0x1.0633c18677858p-47, -0x1.1747358acca92p-54, -0x1.af88c53d000e8p-64, 0x1.a612d78c264aap-75},
+    {-0x1.242bfd8e8c34cp-1, 0x1.649610243cf98p-8, -0x1.32d97913cc89fp-16, 0x1.431fc2515f9d7p-26, 0x1.314582f2a1a44p-36, -0x1.20a90accca80ap-47, -0x1.1d2774335deefp-54, -0x1.abeab71dec4b1p-64, 0x1.f87355fe41fa7p-75},
+    {-0x1.1ea3370ae2dd8p-1, 0x1.5fce760107fd5p-8, -0x1.30f30040a96acp-16, 0x1.4580d951d39cdp-26, 0x1.2fcbdd26821cep-36, -0x1.3baab8efe2665p-47, -0x1.22f9e62a11f63p-54, -0x1.a7a50bed4b6f8p-64, 0x1.26d76dfca9771p-74},
+    {-0x1.192d7fb27e65fp-1, 0x1.5b0e7ce16050fp-8, -0x1.2f08f81275265p-16, 0x1.47dedb0a83cacp-26, 0x1.2e301e39ba759p-36, -0x1.573764ef84289p-47, -0x1.28bc36d24a825p-54, -0x1.a2b214c23aa14p-64, 0x1.52def45b493b0p-74},
+    {-0x1.13cab8e4e259ep-1, 0x1.565632f92dd8ap-8, -0x1.2d1b655c97b3ap-16, 0x1.4a39829c18c6cp-26, 0x1.2c71996cdbfa8p-36, -0x1.734d6eeef39f7p-47, -0x1.2e6bfdc7ec38fp-54, -0x1.9d0c33e86dc9ap-64, 0x1.804b61fe35695p-74},
+    {-0x1.0e7ac3c8ea55ap-1, 0x1.51a5a6683ae28p-8, -0x1.2b2a4d5aca1f1p-16, 0x1.4c9089cfdc6b8p-26, 0x1.2a8fa42ccbafep-36, -0x1.8feafc5d512a4p-47, -0x1.3406bf2376b0fp-54, -0x1.96ade169f8587p-64, 0x1.af16b1a40412cp-74},
+    {-0x1.093d814d1dc44p-1, 0x1.4cfce5388ee04p-8, -0x1.2935b5b31630ep-16, 0x1.4ee3a91c5c9a5p-26, 0x1.2889965d46a08p-36, -0x1.ad0df6251b1abp-47, -0x1.3989ebce5c4f6p-54, -0x1.8f91afce69cb0p-64, 0x1.df39a7aacf0ccp-74},
+    {-0x1.018467ffdb9f9p-1, 0x1.460e7f4348fd8p-7, -0x1.26405046a3a61p-14, 0x1.5258658d8371ep-23, 0x1.253b6abbf638ap-32, -0x1.d9b76bc45eb77p-42, -0x1.419cb0e405a2dp-48, -0x1.837310ff7982cp-57, 0x1.14f2bfc2c67b9p-65},
+    {-0x1.eef1234068943p-2, 0x1.3cec6b2692c0ep-7, -0x1.2242713deeb34p-14, 0x1.56e3ad506e801p-23, 0x1.204eee02f2126p-32, -0x1.0b7f8f441f10dp-41, -0x1.4bf4b04222166p-48, -0x1.70878c5c94fa6p-57, 0x1.48e29401c095dp-65},
+    {-0x1.db6a972994017p-2, 0x1.33ea7c384eddcp-7, -0x1.1e370f1daa101p-14, 0x1.5b5a0d892c174p-23, 0x1.1ac6dc3674b4cp-32, -0x1.2b15177b777b9p-41, -0x1.55bcb89f17d15p-48, -0x1.5a4a5aff07bb2p-57, 0x1.7f1f293611a90p-65},
+    {-0x1.c873260ced812p-2, 0x1.2b091d8c935c2p-7, -0x1.1a1e6c4b40b77p-14, 0x1.5fb90ea16bd08p-23, 0x1.149ea07fd42cap-32, -0x1.4b8db4a4483c7p-41, -0x1.5edd1191b327fp-48, -0x1.4098920d43950p-57, 0x1.b76a5ef2ed5f8p-65},
+    {-0x1.b608c39c200eap-2, 0x1.2248b80667bfep-7, -0x1.15f8d2adc6002p-14, 0x1.63fe274901ce6p-23, 0x1.0dd1f4ab9ee4ep-32, -0x1.6cd8888d42ed7p-41, -0x1.673d1cb551873p-48, -0x1.23538ae4dc0f3p-57, 0x1.f179b771ce27bp-65},
+    {-0x1.a4295d0dc3533p-2, 0x1.19a9b21ae827ap-7, -0x1.11c693e1347c2p-14, 0x1.6826bdc764176p-23, 0x1.065cecb294dcep-32, -0x1.8ee25ca464675p-41, -0x1.6ec3764534abfp-48, -0x1.0261ad1277df8p-57, 0x1.167aec3ac4f70p-64},
+    {-0x1.92d2d9462b992p-2, 0x1.112c6f92df003p-7, -0x1.0d880965726a0p-14, 0x1.6c30297c09f73p-23, 0x1.fc78053ddb580p-33, -0x1.b19591354496ap-41, -0x1.75561b571cbfap-48, -0x1.bb5e7e59f5999p-58, 0x1.34bd17871c027p-64},
+    {-0x1.820319042b81ap-2, 0x1.08d1514af9591p-7, -0x1.093d94c88d08ep-14, 0x1.7017b48efba38p-23, 0x1.ead84577fc8d0p-33, -0x1.d4da1081fe787p-41, -0x1.7ada95dd4b289p-48, -0x1.6a5e78638c862p-58, 0x1.534a5e637a280p-64},
+    {-0x1.69c37441c2b8fp-2, 0x1.f912e7b18768cp-7, -0x1.02b8787b21d46p-12, 0x1.75ad76d0b8250p-20, 0x1.cdcd8b5363f45p-29, -0x1.054b33fbbb93ap-35, -0x1.80ec4897753fep-42, -0x1.c4b50c12c447fp-52, 0x1.811c20180d6fap-56},
+    {-0x1.4b320f5951cd0p-2, 0x1.d948db56d33bfp-7, -0x1.f3c2d60c4ac19p-13, 0x1.7c8f3ffcb0a40p-20, 0x1.a2250a168e3adp-29, -0x1.2995d16c6bc01p-35, -0x1.84594ec3d278cp-42, -0x1.2ca8044717f0ep-55, 0x1.bcb08038c1442p-56},
+    {-0x1.2e9466bf1b223p-2, 0x1.ba9c2ecc3e5b0p-7, -0x1.e1c66aee9f1ecp-13, 0x1.82b70ae7ecb87p-20, 0x1.70ce203414badp-29, -0x1.4deb5473bcae9p-35, -0x1.81b306229c79cp-42, 0x1.b34a78720e1d5p-52, 0x1.f427912632431p-56},
+    {-0x1.13d87ecd5b5f9p-2, 0x1.9d117e7ed5cb7p-7, -0x1.cf84efc0fbf52p-13, 0x1.880e2a34b9062p-20, 0x1.39d2f9d048255p-29, -0x1.71b0b6cf233bep-35, -0x1.783816e191aedp-42, 0x1.e02f23b49f1d3p-51, 0x1.124d020efab12p-55},
+    {-0x1.f5d82dc999791p-3, 0x1.80acca6096ba6p-7, -0x1.bd08b30c0b3f3p-13, 0x1.8c7e4b7dda7c2p-20, 0x1.faaeb1a31187ep-30, -0x1.9439e44b2ec3cp-35, -0x1.673fc8ead6ca0p-42, 0x1.7e453b89a5bacp-50, 0x1.2573ad9e9c7fbp-55},
+    {-0x1.c7796775409e1p-3, 0x1.657165315a6a9p-7, -0x1.aa5d0aff2d39ap-13, 0x1.8ff1e2bdad4f7p-20, 0x1.773614503f7ffp-30, -0x1.b4cc8b8363e53p-35, -0x1.4e44ebfe64f9cp-42, 0x1.0a35cb100450ap-49, 0x1.31ecc6debd603p-55},
+    {-0x1.9c6f555b5beafp-3, 0x1.4b61e45d17ddfp-7, -0x1.978e4972431f9p-13, 0x1.92549e8d9b67dp-20, 0x1.d3ef5705c4157p-31, -0x1.d2a3f8e9ca1b1p-35, -0x1.2cf1089363e80p-42, 0x1.576786f1e8f97p-49, 0x1.362928c62ee18p-55},
+    {-0x1.74945c2da9da6p-3, 0x1.328010c684471p-7, -0x1.84a9aa4b271abp-13, 0x1.9393e2d5081d1p-20, 0x1.4fb5fb05aeb16p-32, -0x1.ecf5fbbecb1d7p-35, -0x1.03273b666931dp-42, 0x1.a47a7cb11e94cp-49, 0x1.30c0462371208p-55},
+    {-0x1.3e718d02d6b2fp-3, 0x1.0f64c2f92e6f2p-6, -0x1.6848ae45df348p-11, 0x1.932d1d1a97a42p-17, -0x1.35c2bf6451d85p-27, -0x1.060f8e9261686p-29, -0x1.6a0812970a7cdp-37, 0x1.0904019c4e95ep-41, 0x1.13eeb84b07000p-47},
+    {-0x1.000734fb251f7p-3, 0x1.c96d2ad95a591p-7, -0x1.42ae4089a631fp-11, 0x1.8e26ad6c41187p-17, -0x1.eaa812923b487p-26, -0x1.112648f0a38c9p-29, -0x1.9927fe816226ep-39, 0x1.45142f8e9845ap-41, 0x1.89d5a35f236a3p-48},
+    {-0x1.9765935cec1a3p-4, 0x1.7d630e0d5d897p-7, -0x1.1dcc011b3fda6p-11, 0x1.83d009a4bd2e4p-17, -0x1.a01bcc0220fb2p-25, -0x1.0efbe20c9f30bp-29, 0x1.8f919a8b34cd9p-38, 0x1.67c778736dca7p-41, 0x1.29467c173db8fp-49},
+    {-0x1.409b1cbf09397p-4, 0x1.3a6d2d3fff8a0p-7, -0x1.f442f13e11417p-12, 0x1.74349c7eb22fap-17, -0x1.227f90a26574fp-24, -0x1.fc573b1d1fc7fp-30, 0x1.02cc030b938f2p-36, 0x1.67a80e64e87d7p-41, -0x1.3a9c703df9af3p-49},
+    {-0x1.f2ea0451cba5dp-5, 0x1.002e0deadf4bep-7, -0x1.b0537a42d4de5p-12, 0x1.5fa87634409ebp-17, -0x1.6d61a570713a7p-24, -0x1.bd7583e508619p-30, 0x1.990832c9dddf5p-36, 0x1.3fcb8f9fbd2d0p-41, -0x1.de8378f153980p-48},
+    {-0x1.7fa8bab7b746cp-5, 0x1.9c556b3f0bfbdp-8, -0x1.70a92aeaccb72p-12, 0x1.46c81cd6f88b8p-17, -0x1.ac584de2c8833p-24, -0x1.649547d0f02c1p-30, 0x1.0aa2d5800d27fp-35, 0x1.e384c09858b77p-42, -0x1.7b508e2ec03e3p-47},
+    {-0x1.2378b318ff16cp-5, 0x1.479ca233b912cp-8, -0x1.35ffff30917dep-12, 0x1.2a706c9184c97p-17, -0x1.dbc942cda8695p-24, -0x1.f01f07cf3a9afp-31, 0x1.3436f9d0af5efp-35, 0x1.0c522475cb155p-42, -0x1.d7d3fdb1fb815p-47},
+    {-0x1.b5603055b1f0dp-6, 0x1.00deb302ea883p-8, -0x1.00e5aea8d98e9p-12, 0x1.0baedeb89db09p-17, -0x1.f94b1ff7d0fe6p-24, -0x1.01413f907f198p-31, 0x1.4445bc4c8ba19p-35, 0x1.6e52392169ce1p-46, -0x1.f2325e79e88f4p-47},
     {-0x1.157a5dee91099p-6, 0x1.5b9dadb9c7363p-8, -0x1.78b79bedb59d8p-11, 0x1.b71fecb427b29p-15, -0x1.0128380705364p-19, 0x1.89afa81c54286p-28, 0x1.2a739d30bfb37p-29, -0x1.4478731412747p-35, -0x1.9647a0b544f86p-39},
     {-0x1.20ca757a34e1fp-7, 0x1.88ed3235e31bfp-9, -0x1.d74fda2b16a4ep-12, 0x1.3b2b6c4a5bd9cp-15, -0x1.d383a8b61622ap-20, 0x1.d9b07730b5b3dp-26, 0x1.7f9db27f3af48p-30, -0x1.2b85413a4e092p-34, -0x1.fb4a2d262068bp-41},
     {-0x1.1c8c5555ca7bfp-8, 0x1.a2c29f114ef41p-10, -0x1.1426387512681p-12, 0x1.a22c5e96a0d52p-16, -0x1.784d8d855b555p-20, 0x1.49f3f23eaf574p-25, 0x1.c98a95b53b75ap-32, -0x1.2310d98580c16p-34, 0x1.1e3a0d3e003bbp-40},
@@ -451,48 +476,89 @@ PGB_HD const double* pgb_ln_tp(void) {
     {-0x1.831407d9a7e95p-12, 0x1.5fb2319af6024p-13, -0x1.28dc8c7cb5a72p-15, 0x1.30ed3d54f37edp-18, -0x1.a077a2c63670ep-22, 0x1.7d616cfd4f0f5p-26, -0x1.a5fbd8cbd010ep-31, 0x1.ba9f1d55a8167p-38, 0x1.d8edbbb70b11ap-41},
     {-0x1.2f051a65b3d72p-13, 0x1.2526cf65a8058p-14, -0x1.09b5a982f7387p-16, 0x1.28bc4bdbfa22dp-19, -0x1.c19bd6f9449e3p-23, 0x1.dad0e480145e5p-27, -0x1.4fe619e5a98a9p-31, 0x1.f250f857a0bb4p-37, 0x1.a254a18b03c74p-43},
     {-0x1.bf3a7383e9134p-15, 0x1.cb284b6aaed81p-16, -0x1.bcd578224e819p-18, 0x1.0c307f4661eb7p-20, -0x1.bd99854278de6p-24, 0x1.090f23bbda894p-27, -0x1.bfe47b708375cp-32, 0x1.e909f4d424483p-37, -0x1.7a2fb5c004d4bp-43},
-    {-0x1.36ff6bb50c785p-16, 0x1.51d1404fd6a3dp-17, -0x1.5c61881af1878p-19, 0x1.c2e41fb428156p-22, -0x1.96f495830ed93p-25, 0x1.0c29a24e7a25ep-28, -0x1.0458f4d04f923p-32, 0x1.66da0a6c2be6ep-37, -0x1.26fa461c824b9p-42},
-    {-0x1.9776056d2b406p-18, 0x1.d2fafe190dfacp-19, -0x1.fec35ae17520ep-21, 0x1.60fa892d34f0ep-23, -0x1.578453c252567p-26, 0x1.ef4ae6a91e86fp-30, -0x1.0d97bcf4fd0f8p-33, 0x1.b6f466d1f4431p-38, -0x1.f0face457d2e0p-43},
-    {-0x1.f6c726add6fb5p-20, 0x1.2f3620549181ap-20, -0x1.5e96c246aabf9p-22, 0x1.019ce4d54ba3dp-24, -0x1.0ca6c970ebfdap-27, 0x1.a3b9d86dbcde2p-31, -0x1.f7d3785839cecp-35, 0x1.d348182495df9p-39, -0x1.432b921258c68p-43},
-    {-0x1.24149f101743cp-21, 0x1.71e584a210d0ap-22, -0x1.c2cfca5b57716p-24, 0x1.5edf60e9e9b74p-26, -0x1.860f2c6b7ae26p-29, 0x1.47ac5d1986b7dp-32, -0x1.ac7736f830f3ep-36, 0x1.baa1c1bbd3b40p-40, -0x1.624cd541a30dfp-44},
-    {-0x1.3f7a8f1d851a2p-23, 0x1.a7e88bb593778p-24, -0x1.0f90fc40b1fa3p-25, 0x1.be4360a91c8a7p-28, -0x1.0741c98cf2ccfp-30, 0x1.d8b9c661e3f71p-34, -0x1.4d97d73fd0fedp-37, 0x1.7a08c0017d66dp-41, -0x1.53cafe93bcf8bp-45},
-    {-0x1.48eb8d145ee8ep-25, 0x1.c85f9f230afc8p-26, -0x1.32a03fbbcba82p-27, 0x1.092d95485f3e7p-29, -0x1.4ac7e634a10bcp-32, 0x1.3bcd032c02912p-35, -0x1.dd9dac96830b1p-39, 0x1.25995c414ac93p-42, -0x1.22b8601249114p-46},
-    {-0x1.3eb3453d3c8a3p-27, 0x1.cd8ea2eded5d1p-28, -0x1.44884acbe4240p-29, 0x1.26a228f3cf755p-31, -0x1.8348a8fa8ae9ep-34, 0x1.877a911c32df8p-37, -0x1.3b62a89e4bdedp-40, 0x1.a12afe702e527p-44, -0x1.c116a6194cae5p-48},
-    {-0x1.2293637cac591p-29, 0x1.b6848b23da0b2p-30, -0x1.42095647af517p-31, 0x1.3231154dcfb55p-33, -0x1.a6e1f17ca2737p-36, 0x1.c2ed40fa86fabp-39, -0x1.812a8f95dd8d3p-42, 0x1.1045e9013d921p-45, -0x1.3b96f2e76ec82p-49},
-    {-0x1.f289d488f4b4ap-32, 0x1.8762da1505798p-32, -0x1.2ba7af0dfa534p-33, 0x1.29be7ff351b08p-35, -0x1.aef302855fc04p-38, 0x1.e3351ce109f56p-41, -0x1.b3d6f542b560cp-44, 0x1.4791b32b37495p-47, -0x1.95c90d4507bbfp-51},
-    {-0x1.9256fc313e2bdp-34, 0x1.4827ed6585235p-34, -0x1.057fd146dc184p-35, 0x1.0f01b3cf7414dp-37, -0x1.9a1ffe478c8f9p-40, 0x1.e233f96a481aep-43, -0x1.c9b08d2c5c2dep-46, 0x1.6c242c6ca08dcp-49, -0x1.df45bdabe2ebfp-53},
-    {-0x1.317156a78b172p-36, 0x1.0278910bce75fp-36, -0x1.ac17b078cf0cap-38, 0x1.cdea9be54260bp-40, -0x1.6cafe247b7aa3p-42, 0x1.c080a7d3642e8p-45, -0x1.bea26b6ebe380p-48, 0x1.76c7fadaf8d6cp-51, -0x1.04cae14c22892p-54},
-    {-0x1.b437009ea5552p-39, 0x1.7e7fa1d6c4a83p-39, -0x1.48b5af57bc7acp-40, 0x1.70adac47de6b3p-42, -0x1.2f22ecb80c9b2p-44, 0x1.8517f460a42f2p-47, -0x1.957580b5d94a0p-50, 0x1.65b6c334cda2ep-53, -0x1.062691b004d2bp-56},
-    {-0x1.24f60a258d773p-41, 0x1.09df85a841032p-41, -0x1.d996269b9630cp-43, 0x1.13a74f72ca4acp-44, -0x1.d74640ed928c5p-47, 0x1.3b0acee4795f4p-49, -0x1.56bc26efc0f41p-52, 0x1.3d0d65e2f55afp-55, -0x1.e7c0cec960cb4p-59},
-    {-0x1.721278ef40c2ap-44, 0x1.5b388401e4e2ap-44, -0x1.40181a30a344bp-45, 0x1.823762373f137p-47, -0x1.56b48db748b03p-49, 0x1.dc6731b57a198p-52, -0x1.0dfad40d75551p-54, 0x1.053fe02422c06p-57, -0x1.a49c251042fccp-61},
-    {-0x1.b79cff2b8cae9p-47, 0x1.a9fbf63b12f7ep-47, -0x1.9604278b757b1p-48, 0x1.fb1b25b6aa39ep-50, -0x1.d26ac01335795p-52, 0x1.50866d849d162p-54, -0x1.8ca2fc715b887p-57, 0x1.90a49f0f53758p-60, -0x1.50aaa3e4f9640p-63},
-    {-0x1.eb0fed119b109p-50, 0x1.eaf36542b8ca6p-50, -0x1.e347990c39ea9p-51, 0x1.380a22390f9fdp-52, -0x1.291841c7f2d8ap-54, 0x1.bc5d2264506d2p-57, -0x1.0fdb9e8de5302p-59, 0x1.1e1cb4c8b1ecep-62, -0x1.f4d1f404086cbp-66},
-    {-0x1.01e30a1d54c78p-52, 0x1.09c5972f5074ep-52, -0x1.0decae900b470p-53, 0x1.67fce4ea8ea40p-55, -0x1.625d50c385d1ep-57, 0x1.124ee1cc13d16p-59, -0x1.5be8a1ae7023cp-62, 0x1.7cdb7df3dbf96p-65, -0x1.5a7c048cf453fp-68},
-    {-0x1.fd59ae3f7142ep-56, 0x1.0e5011ed79d14p-55, -0x1.1afbd42aa4a19p-56, 0x1.855e848815345p-58, -0x1.8bd3fed38282ap-60, 0x1.3cc0b1c690573p-62, -0x1.9fd8b74267e10p-65, 0x1.d8cccd4785191p-68, -0x1.be4ce2cee174dp-71},
+    {-0x1.66a63a5c5cc49p-17, 0x1.904c162c84690p-17, -0x1.a95210a91597ap-18, 0x1.1c98b610b61e5p-19, -0x1.0af44b1efc902p-21, 0x1.707aa65a04dd9p-24, -0x1.7bc711138eba0p-27, 0x1.1eb5238787c5cp-30, -0x1.18d6922f113cep-34},
+    {-0x1.110576b9a1bf4p-20, 0x1.51865c55fccecp-20, -0x1.90cfaabd9ba93p-21, 0x1.2f3f372037de0p-22, -0x1.46b494506230dp-24, 0x1.08d50c9cae195p-26, -0x1.4c463c6aa52c1p-29, 0x1.496f12aab779ap-32, -0x1.e966b3e1b833fp-36},
+    {-0x1.46a16da817198p-24, 0x1.bb4a8814ac789p-24, -0x1.22e8ee50b33a4p-24, 0x1.eaa07713fd7d4p-26, -0x1.29ba9ccc4b6f1p-27, 0x1.13ad6c553d831p-29, -0x1.93350bb02e56ap-32, 0x1.e59644da7c079p-35, -0x1.c7ae965fd44a4p-38},
+    {-0x1.32a35e3ed86a6p-28, 0x1.c56b1317dacbdp-28, -0x1.45e500ec51ae7p-28, 0x1.2ee06c98e6b39p-29, -0x1.98383c9448a0bp-31, 0x1.a79a3ca3c1f89p-33, -0x1.5fc37d45c562dp-35, 0x1.eee9e35f86d60p-38, -0x1.12598805f9e7bp-40},
+    {-0x1.c34c28f42587cp-33, 0x1.693085d27541ep-32, -0x1.1a2dff9ba12cep-32, 0x1.1e6d2ed6581a4p-33, -0x1.a802c9fd66d54p-35, 0x1.e63c5db2c425ap-37, -0x1.c26edae7fac1dp-39, 0x1.69aa8a12b2a99p-41, -0x1.c973bd4cf2878p-44},
+    {-0x1.041789eb78bb0p-37, 0x1.c0277054d597bp-37, -0x1.7a218946b1d2ep-37, 0x1.a019554fab7cdp-38, -0x1.4f4e5597a6146p-39, 0x1.a45b07a98cbd1p-41, -0x1.acd897a1850c9p-43, 0x1.82fcf54125cc0p-45, -0x1.1135acc074208p-47},
+    {-0x1.d53e3e82dad22p-43, 0x1.b10ea310b66a1p-42, -0x1.8875ccf9a1cdap-42, 0x1.d146489f854a6p-43, -0x1.9541f29933f33p-44, 0x1.134c2a508f171p-45, -0x1.32498914a51d2p-47, 0x1.333e452a94dadp-49, -0x1.dd0ffaaba83f9p-52},
+    {-0x1.4b13ea9a9f5d0p-48, 0x1.45e730ce79a5bp-47, -0x1.3bb8c58d95591p-47, 0x1.911f4bae0e0c1p-48, -0x1.775d7ac54ff52p-49, 0x1.125ad8986a8fdp-50, -0x1.4a4f09804e4e0p-52, 0x1.6d57c1e286a4dp-54, -0x1.347523c1fc7a4p-56},
+    {-0x1.5dbbaccf1a4e0p-57, 0x1.75474ab08fab4p-55, -0x1.8f8d7573271cep-54, 0x1.227db36d8b34bp-53, -0x1.2485c73998cefp-53, 0x1.8874777f85b81p-54, -0x1.1e0eacf944552p-54, 0x1.11e9961103e86p-54, -0x1.e1177bdb5958dp-56},
+    {-0x1.3d2d60a5c14aap-70, 0x1.72e892a332377p-68, -0x1.c226c43a4d6d8p-67, 0x1.825ad1b4a76f7p-66, -0x1.a7ecb02437186p-66, 0x1.07f1231375e15p-66, -0x1.de48ecf979d38p-67, 0x1.428237c06c977p-66, -0x1.3bce89806b570p-67},
+    {-0x1.abbbd1ab8143dp-85, 0x1.080351f7f294ep-82, -0x1.6f6d57dbee1ccp-81, 0x1.8161a5e51ca11p-80, -0x1.bb7051d9c78b8p-80, 0x1.9a5db6886ea6fp-81, -0x1.02cee884700cap-80, 0x1.04efe571c1e85p-79, -0x1.178a1389d2bd9p-80},
+    {-0x1.ac170cfdee0fcp-101, 0x1.03253fb444d98p-98, -0x1.b136afceaff8ep-97, 0x1.273dc4cb76442p-95, -0x1.54adf532645c0p-95, 0x1.9257cd2cfca66p-98, -0x1.57daf93a4fcfep-96, 0x1.26ff61f2ffc39p-94, -0x1.54cfba37dc1a0p-95},
+    {-0x1.3d880d577329bp-118, 0x1.3947c0190a32dp-116, -0x1.6d9796d042c2ap-114, 0x1.61e0ac4b7b4ccp-112, -0x1.878f34ce4c54bp-112, -0x1.127f512731b9dp-113, -0x1.bcbf1a6d59ccap-114, 0x1.d76225ffa7073p-111, -0x1.225bbd4e515b1p-111},
+    {-0x1.5cbaff5bbf4b5p-137, 0x1.cedb5c260159ep-137, -0x1.b0478edf146d6p-133, 0x1.4d943e8b425f7p-130, -0x1.567d12f7b5b14p-130, -0x1.5b3263d471628p-130, 0x1.0b8131edd1b32p-133, 0x1.0c5f9b1053b2fp-128, -0x1.5d5dbe357aec3p-129},
+    {-0x1.1b4c176e39cf0p-157, -0x1.5813a471f8eecp-155, -0x1.534225c0a6560p-153, 0x1.e9f3dcfd0cbf7p-150, -0x1.cd792482815dfp-150, -0x1.964415cb4db14p-149, 0x1.1962c6be470c6p-150, 0x1.b634f57ad3f77p-148, -0x1.2b29084f66bf7p-148},
+    {-0x1.543b1842c894ep-179, -0x1.830b2d85e725cp-175, -0x1.260ed7172af27p-175, 0x1.1360c04c11d98p-170, -0x1.e0581e43b5af3p-171, -0x1.28e84f37b9446p-169, 0x1.1a19a937e0301p-170, 0x1.01b73ec694d52p-168, -0x1.6ec943d8a79d4p-169},
+    {-0x1.14be5c581bcb8p-214, -0x1.349d1d9d09abdp-194, 0x1.1ae1279485f2ap-194, 0x1.e28d195a1d6f3p-191, -0x1.bb90a2921388bp-191, -0x1.6abf4a2cc9dd8p-189, 0x1.4f972175f107dp-189, 0x1.384aeedc6a8b8p-189, -0x1.26a295a1b5c05p-189},
+    {-0x1.02d64a74714f3p-266, -0x1.2b00881b79976p-243, 0x1.19dff59ebc4eap-243, 0x1.d18d06aea4e24p-240, -0x1.b7c212a1d2ab2p-240, -0x1.59f4118bd67f0p-238, 0x1.4888dbbc63414p-238, 0x1.21ce93a13588ap-238, -0x1.16d58209ff3e0p-238},
+    {-0x1.1ee774feb43cdp-324, -0x1.49da6139a5334p-298, 0x1.3d19b8760e219p-298, 0x1.000066cc88281p-294, -0x1.ecefd80deb9c7p-295, -0x1.7934acb7b78d0p-293, 0x1.6ca887422c48ep-293, 0x1.362fa828a49dfp-293, -0x1.2e96e9876d6a2p-293},
+    {-0x1.78249810921d5p-388, -0x1.a29b68aca9f69p-359, 0x1.980ef2d38a01ap-359, 0x1.4425437979948p-355, -0x1.3c53ed9963f67p-355, -0x1.da92e2f7b8d42p-354, 0x1.d09273d73eba1p-354, 0x1.8136666676149p-354, -0x1.7b86613f2f095p-354},
+    {-0x1.2334bd061877ep-457, -0x1.33928486a0099p-425, 0x1.2eda134345b8ap-425, 0x1.db877d6b514dfp-422, -0x1.d49f1e4b9605bp-422, -0x1.5a75e52eded72p-420, 0x1.563a751d3cd9cp-420, 0x1.169a22e59c8a3p-420, -0x1.147ca0e703511p-420},
+    {-0x1.09f504c96d386p-532, -0x1.06cf01c63eabep-497, 0x1.04b10db1d1f5dp-497, 0x1.95cf128733ef1p-494, -0x1.92cb0d4daf182p-494, -0x1.269e9647e5b9cp-492, 0x1.24f26be727ca1p-492, 0x1.d695745f31197p-493, -0x1.d5879dde12783p-493},
+    {-0x1.1e485467b3945p-613, -0x1.05e646fdaf8bcp-575, 0x1.0537d5efb7c1dp-575, 0x1.94057214248a3p-572, -0x1.932982a2fcc40p-572, -0x1.248aa896c96c1p-570, 0x1.244f75a5b8431p-570, 0x1.d0e093c5133b0p-571, -0x1.d1b6330817bb6p-571},
+    {-0x1.6af0e389373a7p-700, -0x1.30fd46d78dc36p-659, 0x1.31737aa335f40p-659, 0x1.d627da7f2230cp-656, -0x1.d709d2e6a5524p-656, -0x1.53bdc65a4a820p-654, 0x1.54b9e996ffad0p-654, 0x1.0ce66b52a5132p-654, -0x1.0e352426ab25bp-654},
+    {-0x1.a22175280770ep-841, -0x1.12cec0a25e3cbp-749, 0x1.16fca6c747089p-749, 0x1.a69c2b6524a5ap-746, -0x1.ad0a15930c435p-746, -0x1.2f52ac54110c0p-744, 0x1.33f12f6812aa7p-744, 0x1.d9fbe35c6c453p-745, -0x1.e1374074c0179p-745},
+    {-0x0.00000037b23b8p-1022, -0x1.7768a0d8235bcp-946, 0x1.7d2b13de407b1p-946, 0x1.20a70070274bap-942, -0x1.2514dc9232aaep-942, -0x1.9e534e92669f3p-941, 0x1.a4af7254e95f7p-941, 0x1.43adcf492b575p-941, -0x1.48a6ac773c7a1p-941},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {-0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
+    {0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0, -0x0.0p+0, 0x0.0p+0, 0x0.0p+0, -0x0.0p+0},
   };
   return &t[0][0];
 }
 #define PGB_LN_TN_ROWS 105
-#define PGB_LN_TP_ROWS 34
+#define PGB_LN_TP_ROWS 105
 PGB_HD double pgb_log_ndtr_t(double x, const double* tn, const double* tp) {
   if (!(x == x)) return x;
   const int neg = x < 0.0;
   const double z = neg ? -x : x;
-  /* x >= 0: equal intervals of z */
-  const double zc = z < 8.5 ? z : 8.5; /* keeps the conversion below in range */
-  int ip = (int)(zc * 4.0);
-  if (ip > 33) ip = 33;
-  const double up = zc * 8.0 - (double)(2 * ip + 1);
-  /* x < 0: dyadic intervals from the bits of z (every step below is exact) */
+  /* dyadic interval and local variable from the bits of z (every step below is exact); the same
+   * for both signs -- the sign only selects the table */
   const uint64_t zb = pgb_d2u(z);
   const int e = (int)((zb >> 52) & 0x7FF) - 1023;
   const int ec = e > 9 ? 9 : e;
   const int sub = (int)((zb >> 49) & 7);
   const double m = pgb_u2d((zb & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull); /* [1, 2) */
   const int in = e < -3 ? 0 : 1 + (ec + 3) * 8 + sub;
-  const double un = e < -3 ? z * 16.0 - 1.0 : (m - (1.0 + (double)sub * 0.125)) * 16.0 - 1.0;
-  const double* c = neg ? tn + in * 9 : tp + ip * 9;
-  const double u = neg ? un : up; /* local variable in [-1, 1] */
+  const double u = e < -3 ? z * 16.0 - 1.0 : (m - (1.0 + (double)sub * 0.125)) * 16.0 - 1.0; /* [-1, 1] */
+  const double* c = (neg ? tn : tp) + in * 9;
   double g = c[8];
   g = PGB_FMA(g, u, c[7]);
   g = PGB_FMA(g, u, c[6]);
