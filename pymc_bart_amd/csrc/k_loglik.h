@@ -194,11 +194,28 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
       long long ce[2] = {0, 0};
       for (int chunk = blockIdx.x; chunk < S.nchunks; chunk += gridDim.x) {
         const long long base = (long long)chunk * CH + tid * RPT;
+        // (single output: the four rows' inputs are requested together -- the arrays are padded to whole
+        //  chunks -- instead of one dependent round trip per row and evaluation)
+        double yrr[RPT], noir[RPT], str_[RPT], offr[RPT];
+        const double init_leaf = S.init_leaf;
+        if constexpr (!MK) {
+          const double* __restrict__ const yp = S.y;
+          const double2* __restrict__ const pk = S.pack;
+          const double* __restrict__ const op = S.off;
+          const bool ho = S.has_off != 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            yrr[e] = yp[base + e];
+            noir[e] = noi0[base + e];
+            str_[e] = pk[base + e].x;
+            offr[e] = ho ? op[base + e] : 0.0;  // (x + 0.0 == x bit for bit)
+          }
+        }
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
           const long long row = base + e;
           if (row >= S.n) continue;
-          const double yr = S.y[row];
+          const double yr = MK ? S.y[row] : yrr[e];
           if constexpr (MK) {
             double mu_stump[KB], mu_cur[KB];
 #pragma unroll
@@ -218,11 +235,11 @@ __global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int p
               ce[1] += quant_ll(pgb_loglik(S.family, Kn, yr, mu_cur), S.sc.cl);
             }
           } else {
-            const double offv = S.has_off ? S.off[row] : 0.0;  // (x + 0.0 == x bit for bit)
-            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noi0[row] + offv) + S.init_leaf, cn.inv_sigma2, cn.lik_param2,
+            const double offv = offr[e];
+            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noir[e] + offv) + init_leaf, cn.inv_sigma2, cn.lik_param2,
                                            PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
                               S.sc.cl);
-            ce[1] += quant_ll(pgb_loglik1q(fam, yr, S.pack[row].x + offv, cn.inv_sigma2, cn.lik_param2,
+            ce[1] += quant_ll(pgb_loglik1q(fam, yr, str_[e] + offv, cn.inv_sigma2, cn.lik_param2,
                                            PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
                               S.sc.cl);
           }
