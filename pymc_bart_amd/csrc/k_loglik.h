@@ -72,7 +72,9 @@ __device__ __forceinline__ long long quant_ll(double ll, double cl) {
 // evaluation then contains one family's code only), -1: read S.family.
 // LIN: linear response (single-output families): the children predict value + slope (x - xbar).
 template <int KT, int FAM, bool LIN>
-__global__ __launch_bounds__(BT) void k_loglik(const Dev* __restrict__ Sp, int par) {
+// (compiled for 3 workgroups per CU, i.e. <= 168 VGPRs: the K = 4 instance sits right at that edge, and one
+//  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5)
+__global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
