@@ -821,10 +821,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         const int dst = (c.lid_gen + 1) % NGEN;
         job.copy = (!job.active && f_slot >= 0 && f_gen == (dst + 1) % NGEN) ? 1 : 0;
       }
-      if (tid == 0) {
-        if constexpr (MK)
-        if (job.active)
-        for (int k = 0; k < KX; ++k) {  // extension outputs of the node being split
+      if constexpr (MK)
+      if (job.active && tid < KX) {  // extension outputs of the node being split: output k on lane k
+        const int k = tid;           // (one lane after the other paid two dependent global loads per output)
+        {
           long long pq;
           double pv;
           if (np < nn_old) {
@@ -840,6 +840,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
           S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
         }
+      }
+      if (tid == 0) {
         JN[p] = job;
         if (!normal)  // the node's log-likelihood lives in q_r for these families
           S.jobl[par * MAXP + p] = JobL{job.active ? nd.q_r : 0, F.ll_tot, F.ll_orph, 0};
