@@ -34,6 +34,7 @@ struct pgb_handle {
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int ll_grid;     // ... of the log-likelihood pass
+  void (*ll_kernel)(const Dev*, int);  // the instance of k_loglik this sampler launches (family / outputs / response)
   int sigma_dirty;
   double inv_sigma2;
   double lik_param2;
@@ -105,6 +106,32 @@ static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
 
 extern "C" const char* pgb_last_error(void) { return g_err; }
 extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
+
+// The instance of k_loglik a sampler launches, chosen once: per number of outputs (loops unrolled for
+// K = 2, 3, 4), per family for single-output constant leaves (one family's code per instance).
+typedef void (*ll_kernel_t)(const Dev*, int);
+static ll_kernel_t select_ll_kernel(int K, bool lin, int family) {
+  if (K > 1 && lin) return k_loglik<0, -1, true>;
+  if (K > 1) {
+    switch (K) {
+      case 2: return k_loglik<2, -1, false>;
+      case 3: return k_loglik<3, -1, false>;
+      case 4: return k_loglik<4, -1, false>;
+      default: return k_loglik<0, -1, false>;
+    }
+  }
+  if (lin) return k_loglik<1, -1, true>;  // linear leaves: one instance, family read at run time
+  switch (family) {
+    case PGB_FAMILY_BERNOULLI_PROBIT: return k_loglik<1, PGB_FAMILY_BERNOULLI_PROBIT, false>;
+    case PGB_FAMILY_BERNOULLI_LOGIT: return k_loglik<1, PGB_FAMILY_BERNOULLI_LOGIT, false>;
+    case PGB_FAMILY_POISSON_LOG: return k_loglik<1, PGB_FAMILY_POISSON_LOG, false>;
+    case PGB_FAMILY_NEGBIN_LOG: return k_loglik<1, PGB_FAMILY_NEGBIN_LOG, false>;
+    case PGB_FAMILY_ASYMLAPLACE: return k_loglik<1, PGB_FAMILY_ASYMLAPLACE, false>;
+    case PGB_FAMILY_GAMMA_LOG: return k_loglik<1, PGB_FAMILY_GAMMA_LOG, false>;
+    case PGB_FAMILY_CALLBACK: return k_loglik<1, PGB_FAMILY_CALLBACK, false>;
+    default: return k_loglik<1, PGB_FAMILY_STUDENT_T, false>;
+  }
+}
 
 extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (!s || !out) return fail(PGB_E_INVALID, "null argument");
@@ -199,6 +226,22 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.ll_target = d.rows_target;
   d.ll_pad = 0;
   if (const char* e = getenv("PGB_LL_TARGET")) d.ll_target = atoi(e) > 0 ? atoi(e) : d.ll_target;
+  // The likelihood pass is a persistent grid too, and its instances differ a lot in registers (probit 88
+  // VGPRs, K = 4 softmax 154): the grid is what the chosen instance can keep resident -- 5 workgroups per
+  // CU for probit, 3 for K = 4 -- so that no workgroup waits for another to finish; the pass aims for at
+  // least as many work items.  (cfg4: 1024 -> 1280 workgroups, k_loglik 40.3 -> 37.5 us.)
+  h->ll_kernel = select_ll_kernel(d.K, d.response != PGB_RESPONSE_CONSTANT, d.family);
+  if (d.family != PGB_FAMILY_NORMAL && !getenv("PGB_LL_GRID")) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->ll_kernel, BT, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && per_cu > 0 && cus > 0) {
+      long long g = (long long)per_cu * cus;
+      if (g < 256) g = 256;
+      if (g > 2048) g = 2048;
+      h->ll_grid = (int)g;
+      if (!getenv("PGB_LL_TARGET")) d.ll_target = h->ll_grid > 1024 ? h->ll_grid : 1024;
+    }
+  }
   if (const char* e = getenv("PGB_ROWS_TARGET_INIT")) d.rows_target_init = atoi(e) > 0 ? atoi(e) : d.rows_target_init;
   // One launch per SMC round where the round is latency-bound: Normal likelihood, one output, constant
   // leaves, and few enough (particle, chunk) pairs that a work item holds <= GMAXF particles.
@@ -605,33 +648,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
       }
     }
 #undef ROWS_ARGS
-    if (d.family != PGB_FAMILY_NORMAL) {  // per-row log-likelihood of the rows this round re-labelled
-#define LAUNCH_LL(KT_, FAM_) LAUNCH_K(PK_LL, (k_loglik<KT_, FAM_, false>), gll, dd, par)
-      if (d.K > 1 && lin) {
-        LAUNCH_K(PK_LL, (k_loglik<0, -1, true>), gll, dd, par);
-      } else if (d.K > 1) {
-        switch (d.K) {
-          case 2: LAUNCH_LL(2, -1); break;
-          case 3: LAUNCH_LL(3, -1); break;
-          case 4: LAUNCH_LL(4, -1); break;
-          default: LAUNCH_LL(0, -1);
-        }
-      } else if (lin) {  // linear leaves: one instance, family read at run time
-        LAUNCH_K(PK_LL, (k_loglik<1, -1, true>), gll, dd, par);
-      } else {
-        switch (d.family) {
-          case PGB_FAMILY_BERNOULLI_PROBIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_PROBIT); break;
-          case PGB_FAMILY_BERNOULLI_LOGIT: LAUNCH_LL(1, PGB_FAMILY_BERNOULLI_LOGIT); break;
-          case PGB_FAMILY_POISSON_LOG: LAUNCH_LL(1, PGB_FAMILY_POISSON_LOG); break;
-          case PGB_FAMILY_NEGBIN_LOG: LAUNCH_LL(1, PGB_FAMILY_NEGBIN_LOG); break;
-          case PGB_FAMILY_ASYMLAPLACE: LAUNCH_LL(1, PGB_FAMILY_ASYMLAPLACE); break;
-          case PGB_FAMILY_GAMMA_LOG: LAUNCH_LL(1, PGB_FAMILY_GAMMA_LOG); break;
-          case PGB_FAMILY_CALLBACK: LAUNCH_LL(1, PGB_FAMILY_CALLBACK); break;
-          default: LAUNCH_LL(1, PGB_FAMILY_STUDENT_T);
-        }
-      }
-#undef LAUNCH_LL
-    }
+    if (d.family != PGB_FAMILY_NORMAL)  // per-row log-likelihood of the rows this round re-labelled
+      LAUNCH_K(PK_LL, h->ll_kernel, gll, dd, par);
     h->slot += 1;
   }
   HIPCHK(hipGetLastError());
