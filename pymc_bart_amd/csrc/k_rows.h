@@ -25,7 +25,12 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
 
 // LIN: linear response (Normal family only): leaves predict value + slope (x[svar] - xbar); the
 // partition additionally reduces the sums pgb_lin_fit needs for both children.
-template <bool SUB, bool NORMAL, bool LIN>
+// F32: the split column is read from a float32 shadow of the design matrix -- half the bytes of the
+// pass's largest stream when the matrix does not fit the Infinity Cache (cfg4: 800 MB).  Rounding to
+// float32 is monotone, so x32 < v32 implies x < v and x32 > v32 implies x > v; only a float32 TIE needs the
+// float64 value, which that lane then fetches.  Same decisions, bit for bit.  (Continuous / one-hot rules,
+// constant leaves.)
+template <bool SUB, bool NORMAL, bool LIN, bool F32 = false>
 __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
                                                               const Cmd* __restrict__ cmds,
                                                               const Job* __restrict__ jobs_all) {
@@ -248,26 +253,36 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       // particle g + 1 are requested before particle g is relabelled and reduced
       uint32_t nx_ids = root_ids;
       double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
+      float4 nxf = {0.f, 0.f, 0.f, 0.f};
       if (g0 < g1) {
         const RJob& rn = s_job[g0];
         if (rn.src >= 0) nx_ids = *(const uint32_t*)(lid0 + rn.src + base);
         if (rn.active) {
-          const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
-          nx0 = xn[0];
-          nx1 = xn[1];
+          if constexpr (F32) {
+            nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+          } else {
+            const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+            nx0 = xn[0];
+            nx1 = xn[1];
+          }
         }
       }
       for (int g = g0; g < g1; ++g) {
         const RJob& rj = s_job[g];
         const uint32_t ids = nx_ids;
         const double2 t0 = nx0, t1 = nx1;
+        const float4 tf = nxf;
         if (g + 1 < g1) {
           const RJob& rn = s_job[g + 1];
           nx_ids = rn.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rn.src + base);
           if (rn.active) {
-            const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
-            nx0 = xn[0];
-            nx1 = xn[1];
+            if constexpr (F32) {
+              nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+            } else {
+              const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
+              nx0 = xn[0];
+              nx1 = xn[1];
+            }
           }
         }
         uint32_t out = ids;
@@ -283,13 +298,25 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           continue;
         }
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        const float xf[RPT] = {tf.x, tf.y, tf.z, tf.w};
+        const float r_vf = (float)r_v;
+        const double* __restrict__ const xcol = XT + rj.xoff + base;  // (F32: float32 ties only)
+        // go left?  F32: decided on the float32 values unless they tie (see the template comment)
+        auto left_of = [&](int e) -> bool {
+          if constexpr (F32) {
+            if (xf[e] != r_vf) return r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
+            return go_left_t<SUB>(r_rule, xcol[e], r_v);
+          } else {
+            return go_left_t<SUB>(r_rule, x[e], r_v);
+          }
+        };
         const int slot = (g - g0) * NRED;
         if (!rj.check_nan) {  // common case: the split column has no missing values
           long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
             if (((ids >> (8 * e)) & 255u) == r_label) {
-              if (go_left_t<SUB>(r_rule, x[e], r_v)) {
+              if (left_of(e)) {
                 v0 += 1;
                 v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
               } else {
@@ -306,12 +333,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
             if (((ids >> (8 * e)) & 255u) == r_label) {
-              const double xv = x[e];
-              if (xv != xv) {
+              const bool missing = F32 ? (xf[e] != xf[e]) : (x[e] != x[e]);  // (NaN stays NaN in float32)
+              if (missing) {
                 out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
                 v[0] += 1ll << 40;
                 v[4] += qa[e]; v[5] += qb[e]; v[6] += qc[e];
-              } else if (go_left_t<SUB>(r_rule, xv, r_v)) {
+              } else if (left_of(e)) {
                 v[0] += 1;
                 v[1] += qa[e]; v[2] += qb[e]; v[3] += qc[e];
               } else {

@@ -2,6 +2,12 @@
 // ------------------------------------------------------------------ setup kernels
 // X row-major [n][ldx] -> XT column-major [p][n_pad]; LDS-tiled 32x32 transpose so that both
 // the read and the write are coalesced.  Also flags columns that contain NaN.
+// float32 shadow of the column-major design matrix (see k_rows<..., F32>)
+__global__ __launch_bounds__(BT) void k_f32_shadow(const double* __restrict__ XT, float* __restrict__ XT32, long long count) {
+  for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < count; i += (long long)gridDim.x * BT)
+    XT32[i] = (float)XT[i];
+}
+
 __global__ __launch_bounds__(BT) void k_transpose(const double* __restrict__ X, long long ldx,
                                                   double* __restrict__ XT, long long n,
                                                   long long n_pad, int p, int32_t* col_nan) {

@@ -142,6 +142,7 @@ struct Dev {  // kernel argument block (by value)
   pgb_scales sc;
   const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
   const double* XT;  // [p][n_pad]
+  const float* XT32; // [p][n_pad] float32 shadow of XT (null unless the matrix is larger than the Infinity Cache)
   const double* y;   // [n_pad]
   const double* off; // [K][n_pad] offset of the linear predictor (per-row families; 0 by default)
   double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)

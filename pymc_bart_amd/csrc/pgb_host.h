@@ -481,6 +481,24 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   dim3 grid((unsigned)(d.n_pad / 32), (unsigned)((d.p + 31) / 32));
   hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
                      d.n_pad, d.p, (int32_t*)d.col_nan);
+  // A design matrix that does not fit the 256 MiB Infinity Cache streams from HBM in every row pass: the
+  // single-output row pass then reads a float32 shadow of the split column (k_rows<..., F32>); smaller
+  // matrices stay on the float64 path (cache-resident, latency-bound: the shadow only adds conversions).
+  {
+    size_t min_bytes = (size_t)192 << 20;
+    if (const char* e = getenv("PGB_X32_MIN_MB")) min_bytes = (size_t)atoll(e) << 20;
+    const size_t count = (size_t)d.p * d.n_pad;
+    if (d.K == 1 && d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
+      if (!d.XT32) {
+        float* x32 = nullptr;
+        int rc32 = dalloc(h, &x32, count);
+        if (rc32 != PGB_OK) return rc32;
+        transient(h);
+        d.XT32 = x32;
+      }
+      hipLaunchKernelGGL(k_f32_shadow, dim3(2048), dim3(BT), 0, sm, d.XT, (float*)d.XT32, (long long)count);
+    }
+  }
   double* prior_stage = nullptr;
   if (d.p >= d.n_pad) {  // more columns than padded rows: stage through a temporary
     HIPCHK(hipMalloc((void**)&prior_stage, d.p * sizeof(double)));
@@ -642,6 +660,9 @@ static int enqueue_slots(pgb_handle* h, int count) {
       } else if (h->has_subset) {
         if (nrm) LAUNCH_K(PK_ROWS, (k_rows<true, true, false>), grows, ROWS_ARGS);
         else LAUNCH_K(PK_ROWS, (k_rows<true, false, false>), grows, ROWS_ARGS);
+      } else if (d.XT32 != nullptr) {  // float32 shadow of the split columns (matrix larger than the Infinity Cache)
+        if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, false, true>), grows, ROWS_ARGS);
+        else LAUNCH_K(PK_ROWS, (k_rows<false, false, false, true>), grows, ROWS_ARGS);
       } else {
         if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, false>), grows, ROWS_ARGS);
         else LAUNCH_K(PK_ROWS, (k_rows<false, false, false>), grows, ROWS_ARGS);
