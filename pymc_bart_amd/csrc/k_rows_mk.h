@@ -11,8 +11,11 @@ __device__ __forceinline__ double loglik_any(const Dev& S, double y, const doubl
 // in registers), 0: any K <= PGB_MAX_OUTPUTS.
 // LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory
 // (lvl for output 0 and the shared parts, lsx for the slopes of outputs 1..K-1)
-template <int KT, bool LIN>
-__global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+// F32: the split column from the float32 shadow of the design matrix (see k_rows<..., F32>); continuous /
+// one-hot rules only.
+// (the compile-time-K instances are held to 4 workgroups per CU, <= 128 VGPRs: K = 4 sits at that edge)
+template <int KT, bool LIN, bool F32 = false>
+__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 1) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops
@@ -186,19 +189,35 @@ __global__ __launch_bounds__(BT) void k_rows_mk(const Dev* __restrict__ Sp, int 
         const double r_v = rj.v;
         const int r_rule = rj.rule;
         const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
-        const double2 t0 = xp[0], t1 = xp[1];
-        const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
+        double x[RPT] = {0.0, 0.0, 0.0, 0.0};
+        float xf[RPT] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (F32) {
+          const float4 tf = *(const float4*)(S.XT32 + rj.xoff + base);
+          xf[0] = tf.x; xf[1] = tf.y; xf[2] = tf.z; xf[3] = tf.w;
+        } else {
+          const double2 t0 = xp[0], t1 = xp[1];
+          x[0] = t0.x; x[1] = t0.y; x[2] = t1.x; x[3] = t1.y;
+        }
+        const float r_vf = (float)r_v;
         int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
         long long cnts = 0;
         for (int e = 0; e < RPT; ++e) {
           side[e] = 0;
           if (((ids >> (8 * e)) & 255u) == r_label) {
-            const double xv = x[e];
-            if (xv != xv) {
+            bool missing, left;
+            if constexpr (F32) {  // decided on the float32 values unless they tie
+              missing = xf[e] != xf[e];
+              if (xf[e] != r_vf) left = r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
+              else left = go_left(r_rule, ((const double*)xp)[e], r_v);
+            } else {
+              missing = x[e] != x[e];
+              left = !missing && go_left(r_rule, x[e], r_v);
+            }
+            if (missing) {
               side[e] = 3;
               out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
               cnts += 1ll << 40;
-            } else if (go_left(r_rule, xv, r_v)) {
+            } else if (left) {
               side[e] = 1;
               cnts += 1;
             } else {

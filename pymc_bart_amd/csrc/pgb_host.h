@@ -482,13 +482,13 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
                      d.n_pad, d.p, (int32_t*)d.col_nan);
   // A design matrix that does not fit the 256 MiB Infinity Cache streams from HBM in every row pass: the
-  // single-output row pass then reads a float32 shadow of the split column (k_rows<..., F32>); smaller
+  // row pass (single output, K = 2..4) then reads a float32 shadow of the split column (k_rows<..., F32>); smaller
   // matrices stay on the float64 path (cache-resident, latency-bound: the shadow only adds conversions).
   {
     size_t min_bytes = (size_t)192 << 20;
     if (const char* e = getenv("PGB_X32_MIN_MB")) min_bytes = (size_t)atoll(e) << 20;
     const size_t count = (size_t)d.p * d.n_pad;
-    if (d.K == 1 && d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
+    if (d.K <= 4 && d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
       if (!d.XT32) {
         float* x32 = nullptr;
         int rc32 = dalloc(h, &x32, count);
@@ -645,11 +645,14 @@ static int enqueue_slots(pgb_handle* h, int count) {
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
       LAUNCH_K(PK_ROWS, (k_rows_mk<0, true>), grows, dd, par);
     } else if (d.K == 2) {
-      LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par);
+      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<2, false, true>), grows, dd, par);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par);
     } else if (d.K == 3) {
-      LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par);
+      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<3, false, true>), grows, dd, par);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par);
     } else if (d.K == 4) {
-      LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
+      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
     } else if (d.K > 1) {
       LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
     } else {
