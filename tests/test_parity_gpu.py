@@ -44,6 +44,20 @@ def test_hip_equals_oracle_and_golden(hip, oracle, name):
     assert g["counters"]["saturations"] == 0
 
 
+@pytest.mark.parametrize("name", ["cfg1_friedman", "nan_onehot_prior", "duplicates", "onehot_fail_nan",
+                                  "probit_cfg4_small", "logit_nan_onehot", "categorical_k3_reference",
+                                  "categorical_k4_cfg5_small", "meanscale_k2_reference"])
+def test_float32_shadow_of_the_split_columns_changes_nothing(hip, monkeypatch, name):
+    """A design matrix larger than the Infinity Cache is partitioned on a float32 shadow of its columns
+    (k_rows / k_rows_mk <F32>: monotone rounding decides, float32 ties fetch the float64 value).  Forced on
+    at test sizes (PGB_X32_MIN_MB=0, read when the data are set): missing values, one-hot columns, heavy
+    ties, every row-pass instance that has the variant -- the committed fingerprints still hold."""
+    monkeypatch.setenv("PGB_X32_MIN_MB", "0")
+    g = run_case(make_case(name), hip)
+    assert digest(g) == GOLD[name]
+    assert g["counters"]["saturations"] == 0
+
+
 def test_hip_is_deterministic_across_runs(hip):
     c = make_case("nan_onehot_prior")
     assert digest(run_case(c, hip)) == digest(run_case(c, hip))
