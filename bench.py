@@ -437,11 +437,14 @@ def main():
             # (1 B each) and the split column (8 B per row); each particle group re-reads {sum_trees, r}
             # (16 B per row); a tree-boundary pass adds the INIT/FINAL streams (~26 B read per row and
             # group, 25 B written per row)
-            impl = parts * 10.0 * n + launches * ngroups * 16.0 * n + tu * (ngroups * 26.0 + 25.0) * n
+            # (a matrix beyond the Infinity Cache is partitioned on its float32 shadow: 4 B per row)
+            shadow = K_out <= 4 and args.response == "constant" and X.shape[1] * (nchunks * 1024) * 8 >= (192 << 20)
+            xbytes = 4.0 if shadow else 8.0
+            impl = parts * (2.0 + xbytes) * n + launches * ngroups * 16.0 * n + tu * (ngroups * 26.0 + 25.0) * n
             line["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc.get(dom, {}).get("hbm_bytes_per_launch_corrected"),
+                "traffic": (pmc.get(dom) or pmc.get("k_rows_mk") or {}).get("hbm_bytes_per_launch_corrected"),
                 "traffic_source": (f"profiles/{ROUND}_pmc_{args.workload}.json: " + pmc.get("command", "")) if pmc else None,
                 "launches": launches, "avg_launch_us": ms_rows * 1e3 / max(launches, 1),
                 "avg_kernel_us_device_clock": (clk_ms * 1e3 / clk_launches) if clk_launches else None,
@@ -454,8 +457,9 @@ def main():
                         "dominant kernel from HIP events attached to each dispatch; it is a work rate, not HBM "
                         "utilisation -- at cfg2 the working set lives in L2 / Infinity Cache and `traffic` (PMC, "
                         "per launch) is far below it.  implementation_* is a byte model of what this layout "
-                        "actually streams per launch (labels 1 B in + 1 B out and the 8-B split column per row "
-                        "of every ACTIVE particle, 16 B per row and particle group), most of it served by L2.",
+                        "actually streams per launch (labels 1 B in + 1 B out and the split column, 8 B per row -- "
+                        "4 B from the float32 shadow when the matrix exceeds the Infinity Cache -- of every ACTIVE "
+                        "particle, 16 B per row and particle group), most of it served by L2 at cfg2.",
             }
         if args.workload in ("cfg4", "cfg5") and "k_loglik" in kern:
             kl = kern["k_loglik"]
