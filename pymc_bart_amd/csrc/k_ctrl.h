@@ -285,6 +285,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   __shared__ double s_prior[PGB_MAX_DEPTH];           // P(leaf | depth): read once by the idle wave 3
   __shared__ DNode s_pop[MAXP];                       // node each OLD particle would pop next (prefetched)
   __shared__ double s_ahead[2][4];                    // [set][z0, z1, u_res, u_fin]: draws made one slot ahead
+  __shared__ double s_aheadx[2][MK ? KXMAX : 1][2];   // ... leaf noise of outputs 1..K-1
 
   TR_DECL();
   TR0();
@@ -437,6 +438,16 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       s_ahead[set][3] = pgb_draw2(S.seed, ita, 0, 0, PGB_RNG_FINAL, 0).u0;
     }
   }
+  if constexpr (MK) {  // ... and the leaf noise of outputs 1..K-1 (sub = output), same two candidate proposals
+    if (tid >= 198 && tid < 198 + 2 * KX) {
+      const int l = tid - 198, set = l & 1, k = l >> 1;
+      const pgb_u2 ul = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p, PGB_RNG_LEAF, (uint32_t)(k + 1));
+      double z0, z1;
+      pgb_normal2(ul.u0, ul.u1, &z0, &z1);
+      s_aheadx[set][k][0] = z0;
+      s_aheadx[set][k][1] = z1;
+    }
+  }
 
   int anc = p;  // ancestor (old particle index) of new particle p
   int pick0 = p;  // ... as wave 0 itself picked it (scalar; the other waves read it from LDS)
@@ -574,9 +585,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           for (int k = 0; k < KX; ++k) {
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            const double* zz = S.jzx + (((size_t)(par ^ 1) * MAXP + q) * KX + k) * 2;
             s_finx[q][k] = child_values_x(S, f.ok, f.cL, f.cR, load_accx(S.accx, par ^ 1, q, k),
-                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
-                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
+                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, zz[0], zz[1],
+                                          leaf_sd_x(S, c, par, par ^ 1, k));
             if constexpr (LIN)
               if (f.ok == 1)
                 lin_children_x(S, lk, s_finx[q][k], j.var, f.cL, f.cR, load_accx(S.accux, par ^ 1, q, k),
@@ -644,9 +656,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           for (int k = wv - 1; k < KX; k += 3) {
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
+            const double* zz = S.jzx + (((size_t)(par ^ 1) * MAXP + q) * KX + k) * 2;
             s_finx[q][k] = child_values_x(S, ok, cL, cR, load_accx(S.accx, par ^ 1, q, k),
-                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, it,
-                                          (uint32_t)(r - 1), (uint32_t)q, k, leaf_sd_x(S, c, par, par ^ 1, k));
+                                          load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, zz[0], zz[1],
+                                          leaf_sd_x(S, c, par, par ^ 1, k));
           }
         }
       }
@@ -839,6 +852,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           }
           S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
           S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
+          S.jzx[(((size_t)par * MAXP + p) * KX + k) * 2] = s_aheadx[0][k][0];
+          S.jzx[(((size_t)par * MAXP + p) * KX + k) * 2 + 1] = s_aheadx[0][k][1];
         }
       }
       if (tid == 0) {
@@ -1248,6 +1263,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
         }
         S.jqx[((size_t)par * MAXP + p) * KX + k] = pq;
         S.jvx[((size_t)par * MAXP + p) * KX + k] = pv;
+        S.jzx[(((size_t)par * MAXP + p) * KX + k) * 2] = s_aheadx[set][k][0];
+        S.jzx[(((size_t)par * MAXP + p) * KX + k) * 2 + 1] = s_aheadx[set][k][1];
       }
     }
     job.popped = node >= 0 ? 1 : 0;

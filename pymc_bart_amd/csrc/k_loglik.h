@@ -160,9 +160,10 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
         const int KX = (KT > 0 ? KT : S.K) - 1;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
         const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
+        const double* zz = S.jzx + (((size_t)par * MAXP + tid) * KX + kx) * 2;  // drawn by this slot's control kernel
         ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
-                                   load_accx(S.accx, par, tid, KX + kx), pq, pv,
-                                   it, (uint32_t)round, (uint32_t)tid, kx, leaf_sd_x(S, cn, par ^ 1, par, kx));
+                                   load_accx(S.accx, par, tid, KX + kx), pq, pv, zz[0], zz[1],
+                                   leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
         if constexpr (LIN) {

@@ -179,6 +179,7 @@ struct Dev {  // kernel argument block (by value)
   double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
   long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
   double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
+  double* jzx;        // [2][MAXP][KX][2]       per job: leaf noise of the children, outputs 1..K-1 (drawn one slot ahead like Job::z0 / z1)
   double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
   // ---- linear response (Normal family, K = 1, continuous columns)
   int32_t response, has_off;  // has_off: an offset of the linear predictor is set (else the array is all 0)

@@ -283,6 +283,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.lvx, (size_t)2 * 2 * 256 * KX);
     DA(d.jqx, (size_t)2 * MAXP * KX);
     DA(d.jvx, (size_t)2 * MAXP * KX);
+    DA(d.jzx, (size_t)2 * MAXP * KX * 2);
     DA(d.lsdx, (size_t)2 * KXMAX);
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
@@ -387,6 +388,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipMemsetAsync(d.lvx, 0, (size_t)2 * 2 * 256 * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
     HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
+    HC(hipMemsetAsync(d.jzx, 0, (size_t)2 * MAXP * KX * 2 * sizeof(double), sm));
     hipLaunchKernelGGL(k_fill_f64, dim3(1), dim3(256), 0, sm, d.lsdx, (long long)2 * KXMAX, s->init_leaf_sd);
     // every accepted tree starts as a stump whose K-vector leaf is init_leaf
     hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,

@@ -77,17 +77,17 @@ struct ChildX {
   long long aL, aR;
   double sL, sR;  // linear response: slopes on the shared regressor (0 for a constant leaf)
 };
+// z0 / z1: the Box-Muller pair addressed by (iter, round, particle, LEAF, sub = k + 1), drawn one slot ahead by
+// the control kernel that proposed the split (Dev::jzx) -- the consumers (the next control kernel and this
+// slot's likelihood pass, in EVERY workgroup's prologue) used to redo Philox + log + sqrt + sincos per output.
 __device__ __forceinline__ ChildX child_values_x(const Dev& S, int ok, int cL, int cR, long long aLk,
-                                                 long long aNk, long long pq, double pv, uint32_t it,
-                                                 uint32_t round, uint32_t particle, int k, double lsd) {
+                                                 long long aNk, long long pq, double pv, double z0, double z1,
+                                                 double lsd) {
   ChildX c;
   c.sL = c.sR = 0.0;
   c.aL = aLk;
   c.aR = pq - aLk - aNk;
   if (ok == 1) {
-    const pgb_u2 u = pgb_draw2(S.seed, it, round, particle, PGB_RNG_LEAF, (uint32_t)(k + 1));
-    double z0, z1;
-    pgb_normal2(u.u0, u.u1, &z0, &z1);
     c.vL = pgb_leaf_value(cL, c.aL, S.sc.inv_c1, S.mdouble, z0, lsd);
     c.vR = pgb_leaf_value(cR, c.aR, S.sc.inv_c1, S.mdouble, z1, lsd);
   } else {
