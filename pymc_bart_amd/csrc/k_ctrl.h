@@ -716,7 +716,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       }
       if constexpr (MK) {  // extension outputs of the node table
         const size_t so = ((size_t)par * MAXP + anc) * MAXN * KX, dn = ((size_t)(par ^ 1) * MAXP + p) * MAXN * KX;
-        for (int e = tid; e < nn * KX; e += BT) {
+        // (waves 1..3 only, like the node table itself: wave 0 goes on to the proposal)
+        for (int e = tid - 64; e < nn * KX; e += BT - 64) {
+          if (e < 0) continue;
           const int i = e / KX, k = e % KX;
           double v = S.pvx[so + e];
           long long qv = S.pqx[so + e];
@@ -727,7 +729,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
           if constexpr (LIN) S.psx[dn + e] = S.psx[so + e];
         }
         if (f.ok == 1)
-          for (int e = tid; e < 2 * KX; e += BT) {
+          for (int e = tid - 128; e < 2 * KX; e += BT) {
+            if (e < 0) continue;
             const int ch = e / KX, k = e % KX;
             S.pvx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].vR : s_finx[anc][k].vL;
             S.pqx[dn + (size_t)(nn + ch) * KX + k] = ch ? s_finx[anc][k].aR : s_finx[anc][k].aL;
