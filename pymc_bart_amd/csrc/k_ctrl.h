@@ -219,7 +219,7 @@ __device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool s
               kk -= (int)cw[i];
               ++cstar;
             }
-        } else {
+        } else if (per > 64) {  // (more than 64 chunks per lane, n > 4M rows: walk the counts)
           while (kk >= ccr[cstar]) {
             kk -= ccr[cstar];
             ++cstar;
@@ -229,6 +229,17 @@ __device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool s
       const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
       cstar = __builtin_amdgcn_readlane(cstar, ol);
       kk = __builtin_amdgcn_readlane(kk, ol);
+      if (!inreg && per <= 64) {
+        // the owning lane's chunks, one per lane: a second scan instead of a serial walk of dependent loads
+        // (at n = 1M a lane owns 16 chunks)
+        const int cl = cstar + lane_id();
+        const int cv = (lane_id() < per && cl < S.nchunks) ? (int)ccr[cl] : 0;
+        const int inc = wave_incl_scan(cv);
+        const bool hit = lane_id() < per && kk < inc && kk >= inc - cv;
+        const int hl = (int)__ffsll((long long)__ballot(hit)) - 1;
+        kk -= __builtin_amdgcn_readlane(inc - cv, hl);
+        cstar += hl;
+      }
       TRS(23);
       // (2) which row inside the chunk: 16 label bytes per lane.  Matches as a 16-bit mask: a byte of
       // (word xor label-in-every-byte) is zero exactly where the label matches; the exact zero-byte test
