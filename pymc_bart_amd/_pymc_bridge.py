@@ -33,28 +33,36 @@ class Binding:
     """The likelihood of a model as the sampler sees it: a family object plus, per step, the scalar
     parameters and the offset of the linear predictor, both read from ``probe`` at ``x = 0``."""
 
-    def __init__(self, likelihood, probe, shape, kind, has_offset):
+    #: kinds whose linear predictor may carry other additive terms of the model
+    OFFSET_KINDS = ("normal", "bernoulli_probit", "bernoulli_logit", "poisson", "negbin")
+
+    def __init__(self, likelihood, probe, shape, kind, has_offset=None):
         self.likelihood = likelihood
         self.probe = probe
         self.shape = shape
         self.kind = kind
-        self.has_offset = has_offset
+        # Whether the model HAS other additive terms is never inferred from a value: `b * x` with
+        # b ~ Normal starts at b = 0, so a zero offset at bind time says nothing about later steps
+        # (round-2 ADVICE).  Every kind that can carry an offset reports it on every step; the step
+        # method uploads it only when it changed.  (`has_offset` is accepted for older callers.)
+        self.has_offset = kind in self.OFFSET_KINDS
 
     def current(self):
-        """(params, offset) at the current values of the other variables."""
+        """(params, offset) at the current values of the other variables; ``offset`` is an array for
+        every kind in ``OFFSET_KINDS`` (zeros when the model has no other terms), else ``None``."""
         _, p = self.probe(np.zeros(self.shape))
         k = self.kind
         if k == "normal":
-            return [_scalar(p[1], "sigma")], (np.asarray(p[0], float) if self.has_offset else None)
+            return [_scalar(p[1], "sigma")], np.broadcast_to(np.asarray(p[0], float), self.shape)
         if k == "bernoulli_probit":
-            return [], (ndtri(np.clip(p[0], 1e-300, 1 - 1e-16)) if self.has_offset else None)
+            return [], np.broadcast_to(ndtri(np.clip(p[0], 1e-300, 1 - 1e-16)), self.shape)
         if k == "bernoulli_logit":
             pc = np.clip(p[0], 1e-300, 1 - 1e-16)
-            return [], (np.log(pc) - np.log1p(-pc) if self.has_offset else None)
+            return [], np.broadcast_to(np.log(pc) - np.log1p(-pc), self.shape)
         if k == "poisson":
-            return [], (np.log(p[0]) if self.has_offset else None)
+            return [], np.broadcast_to(np.log(p[0]), self.shape)
         if k == "negbin":
-            return [_scalar(p[1], "alpha")], (np.log(p[0]) if self.has_offset else None)
+            return [_scalar(p[1], "alpha")], np.broadcast_to(np.log(p[0]), self.shape)
         return [], None  # categorical / mean-scale: no free parameters, no offsets
 
 
@@ -87,19 +95,18 @@ def identify(probe, shape, seed=0) -> Binding:
                 raise NotImplementedError("Normal likelihood whose mean is not (BART + other terms)")
             if not _close(pr[1], p0[1]):
                 raise NotImplementedError("Normal likelihood whose sigma depends on the BART variable")
-            has_off = bool(np.any(np.asarray(p0[0]) != 0.0))
-            return Binding(NormalLikelihood(_scalar(p0[1], "sigma")), probe, shape, "normal", has_off)
+            return Binding(NormalLikelihood(_scalar(p0[1], "sigma")), probe, shape, "normal")
         if shape[0] == 2 and _close(pr[0], xr[0]) and _close(pr[1], np.abs(xr[1])):
-            return Binding(NormalMeanScaleLikelihood(), probe, shape, "meanscale", False)
+            return Binding(NormalMeanScaleLikelihood(), probe, shape, "meanscale")
         raise NotImplementedError("multi-output Normal likelihood other than Normal(BART[0], |BART[1]|)")
     if name in ("bernoulli", "bernoulli_rv"):
         p_0, p_r = np.asarray(p0[0], float), np.asarray(pr[0], float)
         o = ndtri(np.clip(p_0, 1e-300, 1 - 1e-16))
         if _close(p_r, ndtr(xr + o)):
-            return Binding(BernoulliLikelihood("probit"), probe, shape, "bernoulli_probit", bool(np.any(np.abs(o) > 1e-12)))
+            return Binding(BernoulliLikelihood("probit"), probe, shape, "bernoulli_probit")
         o = np.log(p_0) - np.log1p(-p_0)
         if _close(p_r, expit(xr + o)):
-            return Binding(BernoulliLikelihood("logit"), probe, shape, "bernoulli_logit", bool(np.any(np.abs(o) > 1e-12)))
+            return Binding(BernoulliLikelihood("logit"), probe, shape, "bernoulli_logit")
         raise NotImplementedError("Bernoulli likelihood whose link is neither probit nor logit")
     if name in ("categorical", "categorical_rv"):
         K = shape[0]
@@ -108,16 +115,15 @@ def identify(probe, shape, seed=0) -> Binding:
             pm_ = pm_.T
         e = np.exp(xr - xr.max(axis=0))
         if pm_.shape == shape and _close(pm_, e / e.sum(axis=0)):
-            return Binding(CategoricalLikelihood(K), probe, shape, "categorical", False)
+            return Binding(CategoricalLikelihood(K), probe, shape, "categorical")
         raise NotImplementedError("Categorical likelihood whose probabilities are not softmax(BART)")
     if name in ("poisson", "poisson_rv"):
         if _close(np.log(pr[0]) - np.log(p0[0]), xr):
-            return Binding(PoissonLikelihood(), probe, shape, "poisson", bool(np.any(np.log(p0[0]) != 0.0)))
+            return Binding(PoissonLikelihood(), probe, shape, "poisson")
         raise NotImplementedError("Poisson likelihood whose rate is not exp(BART + other terms)")
     if name in ("negative_binomial", "negativebinomial", "nbinom", "negative_binomial_rv"):
         if _close(np.log(pr[0]) - np.log(p0[0]), xr) and _close(pr[1], p0[1]):
-            return Binding(NegativeBinomialLikelihood(_scalar(p0[1], "alpha")), probe, shape, "negbin",
-                           bool(np.any(np.log(p0[0]) != 0.0)))
+            return Binding(NegativeBinomialLikelihood(_scalar(p0[1], "alpha")), probe, shape, "negbin")
         raise NotImplementedError("NegativeBinomial likelihood outside mu = exp(BART + other terms), alpha free")
     raise NotImplementedError(
         f"observed distribution {name!r} is not in this sampler's closed likelihood family (Normal, "
@@ -176,8 +182,16 @@ def bind_model(vars, model=None, initial_point=None, compile_kwargs=None):  # no
     ``make_shared_replacements``, ``join_nonshared_inputs``, ``model.replace_rvs_by_values``), the
     calls upstream's PGBART made to compile its log-likelihood; not runnable on the build box."""
     from pymc.model import modelcontext
-    from pymc.pytensorf import compile_pymc, inputvars, join_nonshared_inputs, make_shared_replacements
-    from pytensor.graph.traversal import ancestors
+    from pymc.pytensorf import inputvars, join_nonshared_inputs, make_shared_replacements
+
+    try:  # PyMC >= 5.22 renamed compile_pymc to compile (the old name is deprecated, then removed)
+        from pymc.pytensorf import compile as compile_pymc
+    except ImportError:
+        from pymc.pytensorf import compile_pymc
+    try:  # newer PyTensor moved the graph walkers
+        from pytensor.graph.traversal import ancestors
+    except ImportError:
+        from pytensor.graph.basic import ancestors
 
     model = modelcontext(model)
     if initial_point is None:

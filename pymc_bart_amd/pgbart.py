@@ -210,6 +210,38 @@ def _op_of(var):
 _PUBLISH_LOCK = __import__("threading").Lock()
 
 
+def _managed_list_beside(proxy):
+    """A new, empty managed list on the manager server that serves ``proxy``.
+
+    In the process that owns the manager this is ``manager.list()``.  A PyMC worker process only has the
+    proxy it was given (``_manager`` is ``None`` after a fork or an unpickle), so the list is created the
+    way ``BaseManager._create`` does it: a ``create`` request for the registered type ``"list"`` on the
+    proxy's server, a proxy for the returned id, and the server-side creation reference dropped.  Nested
+    managed lists are supported by ``multiprocessing.managers`` (the server keeps an object alive while
+    another managed object refers to it, also after the creating process has gone).  Raises for anything
+    that is not a ``multiprocessing`` list proxy."""
+    from multiprocessing import managers
+
+    mgr = getattr(proxy, "_manager", None)
+    if mgr is not None:
+        return mgr.list()
+    token, authkey, serializer = proxy._token, proxy._authkey, proxy._serializer
+    client = managers.listener_client[serializer][1]
+
+    def request(method, args):
+        conn = client(token.address, authkey=authkey)
+        try:
+            return managers.dispatch(conn, None, method, args)
+        finally:
+            conn.close()
+
+    ident, exposed = request("create", ("list",))
+    new = managers.ListProxy(managers.Token("list", token.address, ident), serializer, authkey=authkey,
+                             exposed=exposed)
+    request("decref", (ident,))  # the proxy holds its own reference now
+    return new
+
+
 def _pick_device():
     """A step method unpickled in a worker process (PyMC runs chains as processes and is not told which
     chain it carries) picks its GPU: LOCAL_RANK (torch.distributed launchers), PGBART_DEVICE, else the
@@ -397,7 +429,7 @@ class PGBART(_Base):
                 offset = model_offset
         else:
             params = self.likelihood.params(point)
-        if offset is not None:
+        if offset is not None and not self._same_offset(offset):
             self._apply_offset(offset)
         self.sampler.set_likelihood(params)
         if not self.tune and self._baseline is None:
@@ -409,6 +441,14 @@ class PGBART(_Base):
             self._publish()
         stats = {"variable_inclusion": _encode_vi(vi), "tune": self.tune}
         return sum_trees, [stats]
+
+    def _same_offset(self, offset) -> bool:
+        """True when ``offset`` is what the device already holds (no offset yet = zeros): the model's
+        other terms are reported on every step, but uploaded only when they moved."""
+        offset = np.asarray(offset, np.float64)
+        if self._offset is None:
+            return not offset.any()
+        return offset.shape == self._offset.shape and np.array_equal(offset, self._offset)
 
     def _apply_offset(self, offset):
         offset = np.asarray(offset, np.float64)
@@ -430,32 +470,50 @@ class PGBART(_Base):
             return out, stats
 
     def _publish(self):
-        """Hand this chain's history to the op (reference ``bart.py:134-135`` -> ``utils.py:124-127``).
+        """Hand this chain's history to the op (reference ``bart.py:134-135`` -> ``utils.py:124-127``):
+        ONE ``(baseline_forest, batches)`` entry per chain, current after every draw, O(1) per draw.
 
-        A plain list holds ``(baseline, batches)`` by reference: it is appended once (under the op's
-        lock: PyMC-style worker threads of several chains share the op) and grows with
-        ``self._batches``.  A ``multiprocessing.Manager().list()`` proxy pickles what it is given, so
-        re-assigning the whole history every draw would move O(draws^2) bytes: there the entry is
-        re-sent every ``_PROXY_EVERY`` draws and by :meth:`flush_history` (called by ``stop`` /
-        the end of sampling)."""
+        * A plain ``list`` (this package's :class:`BARTOp`) holds ``self._batches`` by reference.
+        * The reference's op carries a ``multiprocessing.Manager().list()`` proxy, which pickles what it is
+          given: there ``batches`` is a second managed list on the SAME manager server
+          (:func:`_managed_list_beside`) and every draw appends its batch to it -- one small message per
+          draw, nothing to flush when the worker process ends (PyMC gives a step method no end-of-sampling
+          hook), and the parent sees exactly as many batches as the trace has draws.
+        * Any other list-like gets its entry re-assigned on every draw (always current, O(draws^2) bytes)."""
         trees = self.bart.all_trees
         if not self._registered:
+            self._shared = None
+            self._is_proxy = not isinstance(trees, list)
+            if self._is_proxy:
+                try:
+                    self._shared = _managed_list_beside(trees)
+                    self._shared.extend(self._batches)
+                except Exception:  # noqa: BLE001 - not a manager proxy: fall back to re-assignment
+                    self._shared = None
+            entry = (self._baseline, self._batches if self._shared is None else self._shared)
             with _PUBLISH_LOCK:
-                trees.append((self._baseline, self._batches))
+                trees.append(entry)
                 self._slot = len(trees) - 1
             self._registered = True
-            self._is_proxy = not isinstance(trees, list)
             self._published = len(self._batches)
             return
-        if self._is_proxy and len(self._batches) - self._published >= self._PROXY_EVERY:
+        if self._shared is not None:
+            for b in self._batches[self._published:]:
+                self._shared.append(b)
+            self._published = len(self._batches)
+        elif self._is_proxy:
             self.flush_history()
 
-    _PROXY_EVERY = 64
-
     def flush_history(self):
-        """Make the op's history entry current (needed for proxy lists only; a no-op otherwise)."""
-        if self._registered and getattr(self, "_is_proxy", False) and self._published < len(self._batches):
-            self.bart.all_trees[self._slot] = (self._baseline, self._batches)
+        """Make the op's history entry current.  Every draw already does (see :meth:`_publish`); kept for
+        callers of earlier versions and as the re-assignment of the list-like fallback."""
+        if not self._registered or not getattr(self, "_is_proxy", False):
+            return
+        if self._published < len(self._batches):
+            if getattr(self, "_shared", None) is not None:
+                self._shared.extend(self._batches[self._published:])
+            else:
+                self.bart.all_trees[self._slot] = (self._baseline, self._batches)
             self._published = len(self._batches)
 
     @property

@@ -120,6 +120,12 @@ class TreeArrays:
         )
 
 
+def _as_list(batches) -> list:
+    """The batches of one chain as a list.  Under PyMC they arrive as a ``multiprocessing`` list proxy
+    (``PGBART._publish``): one slice request fetches them all instead of one round trip per draw."""
+    return batches if isinstance(batches, list) else list(batches[:])
+
+
 _HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "slope", "xbar", "svar")
 
 
@@ -134,7 +140,7 @@ def save_history(path, all_trees, m: int, rules=None) -> None:
     out = {"format": np.array("pgbart-history-1"), "n_chains": np.array(len(all_trees)), "m": np.array(int(m)),
            "rules": np.asarray([] if rules is None else rules, np.int32)}
     for i, (baseline, batches) in enumerate(all_trees):
-        parts = [baseline] + list(batches)
+        parts = [baseline] + _as_list(batches)
         cat = TreeArrays.concat(parts)
         out[f"c{i}_n_outputs"] = np.array(cat.n_outputs)
         out[f"c{i}_sizes"] = np.array([p.n_trees for p in parts], np.int64)
@@ -243,7 +249,8 @@ class PosteriorSampler:
     @classmethod
     def from_history(cls, batches, baseline_forest: TreeArrays, m: int, n_outputs: int,
                      rules=None, backend=None) -> "PosteriorSampler":
-        parts = [baseline_forest] + list(batches)
+        batches = _as_list(batches)
+        parts = [baseline_forest] + batches
         pool = TreeArrays.concat(parts)
         cur = np.empty(m, np.int64)
         cur[baseline_forest.tree_id] = np.arange(baseline_forest.n_trees)

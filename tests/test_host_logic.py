@@ -72,8 +72,10 @@ def test_history_is_published_once_and_grows_in_place(oracle):
     assert len(op.all_trees[a._slot][1]) == 5 and op.all_trees[a._slot][1] is a._batches
 
 
-def test_proxy_history_is_sent_in_strides_not_every_draw(oracle):
-    class Proxy:  # the part of multiprocessing.Manager().list() the step method uses
+def test_list_like_history_is_current_after_every_draw(oracle):
+    """A history container that is neither a list nor a manager proxy: the entry is re-assigned on every
+    draw, so a reader never sees fewer batches than draws (round-2 ADVICE: no flush call exists in PyMC)."""
+    class Proxy:  # pickles what it is given, like multiprocessing.Manager().list()
         def __init__(self):
             self.items, self.sets = [], 0
 
@@ -93,13 +95,47 @@ def test_proxy_history_is_sent_in_strides_not_every_draw(oracle):
     X, Y = _data(n=120)
     op = BARTOp(X, Y, m=4, all_trees=Proxy())
     s = PGBART([op], num_particles=4, random_seed=1, backend=oracle)
-    s._PROXY_EVERY = 8
     s.stop_tuning()
-    for _ in range(20):
+    for d in range(20):
         s.astep(None)
-    assert op.all_trees.sets == 2            # draws 9 and 17, not 19 re-sends
-    s.flush_history()
-    assert op.all_trees.sets == 3 and len(op.all_trees[0][1]) == 20
+        assert len(op.all_trees[0][1]) == d + 1
+    s.flush_history()                        # harmless, nothing left to send
+    assert len(op.all_trees) == 1 and len(op.all_trees[0][1]) == 20
+
+
+@pytest.mark.parametrize("start_method", ["fork", "spawn"])
+def test_manager_list_history_is_complete_when_the_worker_just_exits(oracle, start_method):
+    """Reference ``bart.py:134-135``: ``all_trees`` is a ``Manager().list()``; PyMC worker processes run
+    their draws and exit without telling the step method (``tests/test_bart.py:84-104``: 100 draws x 2
+    chains, then predictions from the parent).  Every draw must be in the parent's history."""
+    import multiprocessing as mp
+
+    from _workers import run_chain_and_exit
+    from pymc_bart_amd.utils import _get_posterior_sampler, _sample_posterior
+
+    X, Y = _data(n=150)
+    with mp.Manager() as manager:
+        op = BARTOp(X, Y, m=5, all_trees=manager.list())
+        ctx = mp.get_context(start_method)
+        procs = [ctx.Process(target=run_chain_and_exit, args=(op, c, 7, 100)) for c in range(2)]
+        for pr in procs:
+            pr.start()
+        for pr in procs:
+            pr.join(120)
+        assert [pr.exitcode for pr in procs] == [0, 0]
+        assert len(op.all_trees) == 2                      # one entry per chain, as utils.py:124-127 reads it
+        assert [len(batches) for _, batches in op.all_trees] == [100, 100]
+        op.n_outputs = 1                                   # (set by the step method in the worker's copy)
+        ps = _get_posterior_sampler(op, backend=oracle)
+        assert ps.n_draws == 200
+        pred = _sample_posterior(ps, X[:7], np.random.default_rng(0), size=(2, 3))
+        assert pred.shape == (2, 3, 7, 1) and np.all(np.isfinite(pred))
+        # ... and in the process that owns the manager (sequential sampling): same mailbox, same rule
+        s = PGBART([op], num_particles=4, random_seed=1, chain=2, backend=oracle)
+        s.stop_tuning()
+        for _ in range(3):
+            s.astep(None)
+        assert [len(batches) for _, batches in op.all_trees] == [100, 100, 3]
 
 
 def test_predictor_rejects_malformed_histories(oracle):

@@ -252,7 +252,8 @@ def test_likelihood_family_is_identified_numerically():
     n = 40
     off = np.linspace(-1, 1, n)
     b = identify(_probe_factory("normal", sigma=0.7), (n,))
-    assert b.likelihood.family == "normal" and b.current() == ([0.7], None)
+    params, o = b.current()
+    assert b.likelihood.family == "normal" and params == [0.7] and o.shape == (n,) and not o.any()
     b = identify(_probe_factory("normal", offset=off, sigma=1.3), (n,))
     params, o = b.current()
     assert params == [1.3] and np.allclose(o, off)                 # the second BART term / a fixed effect
@@ -269,3 +270,55 @@ def test_likelihood_family_is_identified_numerically():
     for bad in ("cloglog", "hetero", "gamma"):
         with pytest.raises(NotImplementedError):
             identify(_probe_factory(bad), (n,))
+
+
+def test_an_offset_that_is_zero_at_bind_time_is_still_followed(fake_pymc, oracle):
+    """Round-2 ADVICE (high): ``y ~ Normal(BART + b * x, sigma)`` with ``b ~ Normal`` starts at b = 0, so the
+    probe at the model's initial point sees no offset; NUTS then moves ``b``.  The binding must keep reporting
+    the other terms and the step method must fit ``y - b * x``, not the raw response."""
+    from pymc_bart_amd._pymc_bridge import identify
+
+    _, pgb = fake_pymc
+    rng = np.random.default_rng(8)
+    n = 200
+    X = rng.normal(size=(n, 2))
+    z = rng.normal(size=n)
+    f = np.where(X[:, 0] > 0, 1.0, -1.0)
+    Y = f + 3.0 * z + rng.normal(0, 0.1, n)
+    b_now = {"b": 0.0}
+
+    def probe(x):
+        return "normal", [np.asarray(x, float) + b_now["b"] * z, np.full(n, 0.3)]
+
+    binding = identify(probe, (n,))                        # bound while b == 0
+    assert binding.has_offset and not binding.current()[1].any()
+
+    def make():
+        st = pgb.PGBART([pgb.BARTOp(X, Y, m=8)], num_particles=6, batch=(1.0, 1.0), likelihood=binding.likelihood,
+                        observed=Y, random_seed=4, backend=oracle)
+        st._binding = binding
+        return st
+
+    st = make()
+    uploads = []
+    orig = st._apply_offset
+    st._apply_offset = lambda o: (uploads.append(np.array(o)), orig(o))[1]
+    st.astep(None)
+    assert uploads == []                                    # zero offset, nothing held: nothing to upload
+    b_now["b"] = 3.0                                        # the other sampler moved b
+    for it in range(30):
+        if it == 15:
+            st.stop_tuning()
+        mu, _ = st.astep(None)
+    assert len(uploads) == 1 and np.allclose(uploads[0], 3.0 * z)   # uploaded once, when it changed
+    assert np.corrcoef(mu, f)[0, 1] > 0.9                   # BART explains f, not f + 3 z
+    assert abs(np.corrcoef(mu, z)[0, 1]) < 0.3
+    # the same chain with the offset handed in explicitly: bit-identical
+    ref = make()
+    ref._binding = None
+    ref.astep(None)
+    for it in range(30):
+        if it == 15:
+            ref.stop_tuning()
+        mu_ref, _ = ref.astep(None, offset=3.0 * z)
+    assert np.array_equal(mu, mu_ref)
