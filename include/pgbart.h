@@ -117,7 +117,8 @@ int pgb_set_response(pgb_handle* h, const double* y_dev);
 /* Per-row offset of the linear predictor(s) for the per-row families (everything but NORMAL, where
  * the caller subtracts the other terms from the response instead): the likelihood sees
  * offset + sum_trees -- the contribution of the other additive terms of the model at the current
- * point (a second BART variable, a log-exposure, ...).  K*n doubles, layout [K][n]; NULL resets to 0. */
+ * point (a second BART variable, a log-exposure, ...).  EXACTLY K*n doubles, layout [K][n] (the call takes
+ * no size: the caller guarantees it, as the ctypes stub does); NULL resets to 0. */
 int pgb_set_offset(pgb_handle* h, const double* offset_dev);
 
 /* Likelihood parameters at the current point of the other model variables
@@ -131,7 +132,10 @@ int pgb_set_likelihood(pgb_handle* h, const double* params_host, int32_t n_param
  * for every particle; here the device produces the predictors of the rows each round re-labelled, the
  * host evaluates them in one call per round and the fixed-point sums go back to the device -- the slow
  * fallback SURVEY.md section 7 asks for (a slot then costs a device round trip instead of ~17 us).
- * `fn` must be a pure function of each (row, y_i, mu_i). */
+ * `fn` must be a pure function of each (row, y_i, mu_i).
+ * A non-zero return abandons the astep half-way: that call returns PGB_E_STATE and the handle is POISONED --
+ * every later pgb_step* / pgb_export_trees returns PGB_E_STATE (the chain's state is undefined) until
+ * pgb_checkpoint_load restores an idle image, or the handle is destroyed. */
 typedef int (*pgb_loglik_fn)(void* ctx, const int64_t* row, const double* y, const double* mu, int64_t n,
                              double* loglik_out);
 int pgb_set_loglik_callback(pgb_handle* h, pgb_loglik_fn fn, void* ctx);
@@ -199,7 +203,8 @@ int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int6
  * specific to the backend that wrote it.  To resume: pgb_create with the SAME settings,
  * pgb_set_data / pgb_set_response with the same data, then pgb_checkpoint_load; the chain then
  * continues bit-identically (the random numbers are addressed by (seed, iter, ...), so the image
- * carries no generator state beyond the iteration counter). */
+ * carries no generator state beyond the iteration counter).  An image carries a layout version and is
+ * refused by a build whose records differ.  Loading also clears a poisoned handle (see the callback). */
 int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out);
 int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes);
 int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes);

@@ -815,7 +815,11 @@ static int o_step(pgb_handle* h, int tune) {
   const pgb_settings* s = &h->s;
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   if (s->family == PGB_FAMILY_CALLBACK && !h->cb_fn) return fail(PGB_E_INVALID, "pgb_set_loglik_callback first");
-  h->cb_failed = 0;
+  /* include/pgbart.h: a step abandoned on a callback error poisons the handle until a checkpoint is loaded */
+  if (h->cb_failed)
+    return fail(PGB_E_STATE, "an earlier step of this sampler was abandoned half-way (log-likelihood "
+                             "callback error or stuck state machine): its state is undefined; restore a "
+                             "checkpoint (pgb_checkpoint_load) or create a new sampler");
   memset(h->vi, 0, sizeof(int32_t) * s->p);
   int bs = tune ? s->batch_tune : s->batch_draw;
   int upper = h->lower + bs;
@@ -883,6 +887,7 @@ int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
 
 int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
+  if (h->cb_failed) return fail(PGB_E_STATE, "an earlier step of this sampler was abandoned half-way; restore a checkpoint");
   int nt = which == 0 ? h->n_last : h->s.m;
   int total = 0;
   for (int t = 0; t < nt; ++t) total += h->trees[which == 0 ? h->last_ids[t] : t].n_nodes;
@@ -1156,6 +1161,7 @@ int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
   h->inv_sigma2 = hd.inv_sigma2;
   h->lik_param2 = hd.lik_param2;
   h->ctr = hd.ctr;
+  h->cb_failed = 0;
   return PGB_OK;
 }
 

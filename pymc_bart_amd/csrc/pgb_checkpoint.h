@@ -1,7 +1,13 @@
 // pgb_checkpoint.h -- part of pgbart_hip.hip (not a standalone header): checkpoint / resume, profiling and debug entry points.
 // ---- checkpoint / resume ------------------------------------------------------------------
+// Layout version of the image: bump when a device record that travels in the payload (Job, Ctrl, Cmd, DPart,
+// Acc, DTree ...) or this header changes.  The record sizes are stored as well, so an image written by a
+// build with other records is refused by name rather than by a payload-size coincidence.
+#define PGB_CKPT_VERSION 2
 struct CkptHeader {
-  char magic[8];       // "PGBCKPT1"
+  char magic[8];       // "PGBCKPT2"
+  int32_t version;     // PGB_CKPT_VERSION
+  int32_t rec_bytes[7];  // sizeof Job, Ctrl, Cmd, DPart, Acc, DTree, pgb_counters of the writing build
   char backend[16];    // pgb_backend_name()
   pgb_settings s;      // must equal the loading handle's settings
   long long n_allocs, payload_bytes;
@@ -11,6 +17,14 @@ struct CkptHeader {
   double inv_sigma2, lik_param2;
   pgb_counters ctr;
 };
+
+static void ckpt_stamp(CkptHeader* hd) {
+  memcpy(hd->magic, "PGBCKPT2", 8);
+  hd->version = PGB_CKPT_VERSION;
+  const int32_t rb[7] = {(int32_t)sizeof(Job), (int32_t)sizeof(Ctrl), (int32_t)sizeof(Cmd), (int32_t)sizeof(DPart),
+                         (int32_t)sizeof(Acc), (int32_t)sizeof(DTree), (int32_t)sizeof(pgb_counters)};
+  memcpy(hd->rec_bytes, rb, sizeof rb);
+}
 
 static long long ckpt_payload(const pgb_handle* h, long long* n_allocs) {
   long long tot = 0, cnt = 0;
@@ -36,7 +50,7 @@ extern "C" int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes)
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
   CkptHeader hd;
   memset(&hd, 0, sizeof hd);
-  memcpy(hd.magic, "PGBCKPT1", 8);
+  ckpt_stamp(&hd);
   snprintf(hd.backend, sizeof hd.backend, "%s", pgb_backend_name());
   hd.s = h->s;
   hd.payload_bytes = ckpt_payload(h, &hd.n_allocs);
@@ -71,7 +85,12 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
   if (bytes < (int64_t)sizeof(CkptHeader)) return fail(PGB_E_INVALID, "checkpoint truncated");
   CkptHeader hd;
   memcpy(&hd, host_buf, sizeof hd);
-  if (memcmp(hd.magic, "PGBCKPT1", 8) != 0) return fail(PGB_E_INVALID, "not a pgbart checkpoint");
+  if (memcmp(hd.magic, "PGBCKPT", 7) != 0) return fail(PGB_E_INVALID, "not a pgbart checkpoint");
+  CkptHeader mine;
+  ckpt_stamp(&mine);
+  if (hd.magic[7] != mine.magic[7] || hd.version != mine.version ||
+      memcmp(hd.rec_bytes, mine.rec_bytes, sizeof mine.rec_bytes) != 0)
+    return fail(PGB_E_INVALID, "checkpoint layout version differs from this build's (written by another release)");
   if (strncmp(hd.backend, pgb_backend_name(), sizeof hd.backend) != 0)
     return fail(PGB_E_INVALID, "checkpoint was written by a different backend");
   if (memcmp(&hd.s, &h->s, sizeof(pgb_settings)) != 0)
@@ -99,6 +118,8 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
   h->inv_sigma2 = hd.inv_sigma2;
   h->lik_param2 = hd.lik_param2;
   h->ctr = hd.ctr;
+  h->out_valid = 0;  // the mapped block still holds the trees of the step before the load
+  h->poisoned = 0;   // an idle image replaces whatever an abandoned step left behind
   return PGB_OK;
 }
 

@@ -56,6 +56,8 @@ struct pgb_handle {
   StepOutLayout out_layout;
   double* st_dense;          // [K][n] staging of sum_trees in HBM
   int out_valid;             // the block holds the trees of the last step (pgb_export_trees(0) reads it)
+  int poisoned;              // a step was abandoned half-way (callback error, stuck state machine): the device
+                             // state is undefined until pgb_checkpoint_load restores an idle image
   // pgb_step_async: a worker thread feeds the state machine while the caller goes on
   // callback family: the host evaluates the per-row log-likelihood once per slot
   pgb_loglik_fn cb_fn;
@@ -88,6 +90,14 @@ static int join_async(pgb_handle* h) {
   do {                                         \
     int rcj_ = join_async(h);                  \
     if (rcj_ != PGB_OK) return rcj_;           \
+  } while (0)
+// Entry points that run or read the chain refuse a poisoned handle (see pgb_handle::poisoned).
+#define REFUSE_POISONED(h)                                                                                  \
+  do {                                                                                                      \
+    if ((h)->poisoned)                                                                                      \
+      return fail(PGB_E_STATE, "an earlier step of this sampler was abandoned half-way (log-likelihood "    \
+                               "callback error or stuck state machine): its state is undefined; restore a " \
+                               "checkpoint (pgb_checkpoint_load) or create a new sampler");                 \
   } while (0)
 
 template <typename T>
@@ -186,6 +196,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->out_host = h->out_dev = nullptr;
   h->st_dense = nullptr;
   h->out_valid = 0;
+  h->poisoned = 0;
   h->job_running = 0;
   h->job_rc = PGB_OK;
   h->device = 0;
@@ -458,6 +469,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
                             const double* split_prior_host) {
   if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
   JOIN_ASYNC(h);
+  h->out_valid = 0;
   Dev& d = h->d;
   if (ldx < d.p) return fail(PGB_E_INVALID, "ldx < p");
   double mx = 0.0;
@@ -533,6 +545,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
 extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
   if (!h || !y_dev) return fail(PGB_E_INVALID, "null argument");
   JOIN_ASYNC(h);
+  h->out_valid = 0;
   HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (h->s.family == PGB_FAMILY_CALLBACK)
     HIPCHK(hipMemcpyAsync(h->y_host.data(), y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -544,6 +557,7 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
 extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   JOIN_ASYNC(h);
+  h->out_valid = 0;
   if (h->s.family == PGB_FAMILY_NORMAL)
     return fail(PGB_E_UNSUPPORTED, "offsets are for the per-row families (a Normal model fits observed - offset)");
   if (offset_dev)  // [K][n] -> the padded [K][n_pad] rows
@@ -800,8 +814,14 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
       const int par = (int)(h->slot & 1);
       if ((rc = enqueue_slots(h, 1)) != PGB_OK) return rc;
       HIPCHK(hipStreamSynchronize(h->stream));
-      if ((rc = callback_host_phase(h, par)) != PGB_OK) return rc;
-      if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
+      if ((rc = callback_host_phase(h, par)) != PGB_OK) {
+        h->poisoned = 1;  // steps_target is ahead of the flag and the device sits in the middle of a round
+        return rc;
+      }
+      if (h->slot > cap) {
+        h->poisoned = 1;
+        return fail(PGB_E_STATE, "sampler state machine did not finish");
+      }
     }
     return PGB_OK;
   }
@@ -817,7 +837,10 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
     if ((rc = enqueue_slots(h, tail ? BUNDLE_TAIL : BUNDLE)) != PGB_OK) return rc;
     HIPCHK(hipEventRecord(ev, h->stream));
     h->bundles += 1;
-    if (h->slot > cap) return fail(PGB_E_STATE, "sampler state machine did not finish");
+    if (h->slot > cap) {
+      h->poisoned = 1;
+      return fail(PGB_E_STATE, "sampler state machine did not finish");
+    }
   }
   return PGB_OK;
 }
@@ -839,6 +862,7 @@ static int run_until_idle(pgb_handle* h, int n_steps) {
 static int begin_steps(pgb_handle* h, int tune, int n_steps) {
   Dev& d = h->d;
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  REFUSE_POISONED(h);
   int par = (int)(h->slot & 1);
   h->out_valid = 0;
   hipLaunchKernelGGL(k_begin, dim3(1), dim3(256), 0, h->stream, h->d_dev, par, tune, n_steps,
@@ -957,6 +981,7 @@ extern "C" int pgb_step_async(pgb_handle* h, int32_t tune, int32_t n_steps) {
   if (!h || n_steps < 1) return fail(PGB_E_INVALID, "bad argument");
   JOIN_ASYNC(h);
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
+  REFUSE_POISONED(h);
   h->job_running = 1;
   h->job_rc = PGB_OK;
   h->job_err[0] = 0;
@@ -1015,6 +1040,7 @@ static int export_from_block(pgb_handle* h, pgb_tree_arrays* out) {
 extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");
   JOIN_ASYNC(h);
+  REFUSE_POISONED(h);
   Dev& d = h->d;
   if (which == 0 && h->out_valid) return export_from_block(h, out);
   int first = which == 0 ? h->last_lower : 0;

@@ -213,7 +213,11 @@ class PySampler:
         if offset is None:
             lib.check(lib.lib.pgb_set_offset(self._h, None), "pgb_set_offset")
             return
-        self._off = mem.from_host(np.ascontiguousarray(offset, dtype=np.float64))
+        offset = np.ascontiguousarray(offset, dtype=np.float64)
+        want = self.settings.n_outputs * self.settings.n  # the ABI takes no size: it reads exactly K*n doubles
+        if offset.size != want:
+            raise ValueError(f"offset must hold n_outputs * n = {want} values ([K][n]), got {offset.size}")
+        self._off = mem.from_host(offset)
         lib.check(lib.lib.pgb_set_offset(self._h, mem.ptr(self._off)), "pgb_set_offset")
 
     # -- likelihood parameters at the current point -------------------------------

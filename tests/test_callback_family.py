@@ -90,9 +90,25 @@ def test_a_raising_callback_surfaces_as_an_error(oracle):
     s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
     with pytest.raises(_abi.PGBError, match="pgb_set_loglik_callback first"):
         s.step(True)
+    good = s.checkpoint()
     s.set_loglik_callback(bad)
     with pytest.raises(_abi.PGBError, match="model logp blew up"):
         s.step(True)
+    # the step was abandoned half-way: the handle refuses to go on (include/pgbart.h) ...
+    s.set_loglik_callback(lambda y, mu: -0.5 * (y - mu) ** 2)
+    for call in (lambda: s.step(True), lambda: s.step_async(True, 1), lambda: s.export_trees(0)):
+        with pytest.raises(_abi.PGBError, match="abandoned half-way"):
+            call()
+    # ... until an idle image is restored; the chain then equals one that never saw the bad callback
+    s.restore(good)
+    twin = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    twin.set_loglik_callback(lambda y, mu: -0.5 * (y - mu) ** 2)
+    for _ in range(3):
+        a, _ = s.step(True)
+        b, _ = twin.step(True)
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError, match="n_outputs \\* n"):
+        s.set_offset(np.zeros(7))
     with pytest.raises(_abi.PGBError, match="callback family"):
         PySampler(PyBartSettings.from_data(X, Y, m=4, num_particles=4), X, Y, np.zeros(2, np.int32), np.ones(2),
                   backend=oracle).set_loglik_callback(bad)
