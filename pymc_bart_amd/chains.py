@@ -100,15 +100,17 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
     return out
 
 
-def gather_chains(result: dict, dist=None, dst: int = 0):
+def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool = False):
     """The single end-of-run collective: gather every rank's draws and tree history on ``dst``.
 
     Dense draws travel as one tensor per rank (``all_gather`` over RCCL/xGMI on GPUs: each rank's
     shard moves over its own links in parallel); the small ragged pieces (VI strings, tree
     history) travel pickled with ``gather_object``.  Returns the list of per-chain results on
-    ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``.
+    ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``; a group of ONE rank
+    skips the collectives too unless ``force_collective`` is set (the GPU suite sets it to run the RCCL
+    calls of this function at world size 1 before an 8-GPU job meets them for the first time).
     """
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return [{k: v for k, v in result.items() if k != "step"}]
     import torch
 

@@ -1,0 +1,54 @@
+"""First contact with RCCL happens HERE, not in the driver's 8-GPU run (round-2 VERDICT, missing #1):
+``init_process_group("nccl")``, the device ``all_reduce`` / ``all_gather`` of ``bench.py`` and the collective
+branch of ``chains.gather_chains`` on ``cuda`` tensors, at world size 1 on the one GPU of the test box.
+Every rank is a fresh CHILD process started by ``torch.distributed.run`` (the pytest process, which has
+touched the GPU, is never exec'ed).  Reference model of the exchange: ``bart.py:133-135`` (per-chain
+histories return to the parent), ``utils.py:122-127`` (one predictor per chain)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(script_args, timeout=600):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_rank_under_torchrun_initialises_rccl_and_runs_its_collectives():
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--burnin", "2",
+                 "--repeats", "2", "--no-cpu-baseline", "--no-extras"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["ranks_reported_by_collective"] == 1           # an all_reduce of ones on a cuda tensor over RCCL
+    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 100_000 * 8   # the end-of-run all_gather
+    assert d["per_rank_ms_per_step"] and len(d["per_rank_ms_per_step"]) == 1
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["data"] == "synthetic"
+    assert d["roofline"]["kernel"] == "k_rows"              # the HIP path ran under the launcher
+
+
+def test_gather_chains_collective_branch_on_cuda_over_rccl():
+    r = _launch([os.path.join(ROOT, "tests", "_rccl_child.py")])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_CHILD ")]
+    assert len(out) == 1, r.stdout[-2000:]
+    d = json.loads(out[0][len("RCCL_CHILD "):])
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["allreduce"] == 1.0
+    assert d["chains"] == 1 and d["mu_equal"] and d["sigma_equal"] and d["vi_equal"] and d["n_batches"] == 8
