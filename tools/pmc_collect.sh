@@ -1,10 +1,10 @@
 #!/bin/bash
 # HBM traffic (cfg2) / VALU instruction counts (cfg4, cfg5) of the hot kernels, per launch, from separate
-# rocprofv3 --pmc passes (counters only: no trace domains), written to profiles/r02_pmc_<workload>.json,
+# rocprofv3 --pmc passes (counters only: no trace domains), written to profiles/r03_pmc_<workload>.json,
 # the file bench.py reads `roofline.traffic` from.  Run on the GPU box from the repo root.
 # usage: tools/pmc_collect.sh cfg2|cfg4|cfg5
 W=${1:-cfg2}; R=$PWD; cd /tmp; export TMPDIR=/tmp
-if [ $W = cfg2 ]; then A="--steps 10 --warmup 2 --burnin 30 --repeats 1"; else A="--workload $W --steps 3 --warmup 1 --burnin 3 --repeats 1"; fi
+if [ $W = cfg2 ]; then A="--steps 10 --warmup 2 --burnin 30 --repeats 1 --no-workloads"; else A="--workload $W --steps 3 --warmup 1 --burnin 3 --repeats 1"; fi
 A="$A --no-extras --no-cpu-baseline --no-roofline --no-multichain"
 DIRS=""
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
@@ -30,6 +30,6 @@ for k, v in raw.items():
     if v.get("SQ_INSTS_VALU_avg_per_launch") is not None and v.get("launches", 0) >= e.get("valu_launches", 0):
         e.update(valu_launches=v["launches"], valu_wave_insts_per_launch=v["SQ_INSTS_VALU_avg_per_launch"],
                  waves_per_launch=v.get("SQ_WAVES_avg_per_launch"))
-json.dump(out, open("$R/gpurun_out/r02_pmc_${W}.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r03_pmc_${W}.json", "w"), indent=1)
 print({k: v for k, v in out.items() if k.startswith("k_")})
 PY
