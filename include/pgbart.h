@@ -168,6 +168,13 @@ int pgb_sync(pgb_handle* h, pgb_counters* counters_out);
  * last step (a "batch"); which = 1: all m current trees (a "baseline forest").  */
 int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out);
 
+/* The same export as ONE self-describing record in a caller buffer, in one call (include/pgbart_pack.h
+ * documents the record: a 4-int header, the int32 arrays, the 8-byte arrays; the linear-response arrays only
+ * when the sampler has linear leaves).  *bytes_out receives the record size; when cap_bytes is too small
+ * (or host_buf is NULL) the call returns PGB_E_NOMEM and *bytes_out says how much is needed.  This is the
+ * form the per-draw batches of the tree history travel in (utils.py:124-127).                          */
+int pgb_export_trees_packed(pgb_handle* h, int32_t which, void* host_buf, int64_t cap_bytes, int64_t* bytes_out);
+
 /* Current sampler scalars: leaf_sd[K], iter, lower cursor. */
 int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out);
 /* Current split-variable weights alpha_vec[p] (prior + tuning counts). */

@@ -49,6 +49,7 @@
 #include <string.h>
 
 #include "pgbart.h"
+#include "pgbart_pack.h"
 #include "pgbart_spec.h"
 
 #define MAXN PGB_MAX_NODES
@@ -926,6 +927,13 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
   }
   out->node_off[nt] = off;
   return PGB_OK;
+}
+
+int pgb_export_trees_packed(pgb_handle* h, int32_t which, void* host_buf, int64_t cap_bytes, int64_t* bytes_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  int rc = pgb_export_trees_packed_via(h, which, host_buf, cap_bytes, bytes_out, h->s.response != PGB_RESPONSE_CONSTANT);
+  if (rc == PGB_E_NOMEM) return fail(rc, "packed tree record does not fit the buffer (*bytes_out has the size)");
+  return rc;
 }
 
 int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {

@@ -15,6 +15,7 @@ import os
 import numpy as np
 
 PGB_OK = 0
+PGB_E_NOMEM = -3
 MAX_DEPTH = 64
 MAX_PARTICLES = 64
 MAX_NODES = 255
@@ -68,6 +69,7 @@ SYMBOLS = (
     "pgb_step_async",
     "pgb_sync",
     "pgb_export_trees",
+    "pgb_export_trees_packed",
     "pgb_get_state",
     "pgb_get_split_weights",
     "pgb_predict",
@@ -178,6 +180,7 @@ class PGBLibrary:
         lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]
         lib.pgb_sync.argtypes = [vp, C.POINTER(Counters)]
         lib.pgb_export_trees.argtypes = [vp, C.c_int32, C.POINTER(TreeArraysC)]
+        lib.pgb_export_trees_packed.argtypes = [vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
         lib.pgb_get_state.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         lib.pgb_get_split_weights.argtypes = [vp, vp]
         lib.pgb_predict.argtypes = [

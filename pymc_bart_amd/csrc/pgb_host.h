@@ -1108,6 +1108,15 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
   return PGB_OK;
 }
 
+extern "C" int pgb_export_trees_packed(pgb_handle* h, int32_t which, void* host_buf, int64_t cap_bytes,
+                                       int64_t* bytes_out) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  const int rc = pgb_export_trees_packed_via(h, which, host_buf, cap_bytes, bytes_out,
+                                             h->s.response != PGB_RESPONSE_CONSTANT);
+  if (rc == PGB_E_NOMEM) return fail(rc, "packed tree record does not fit the buffer (*bytes_out has the size)");
+  return rc;
+}
+
 extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   JOIN_ASYNC(h);

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "pgbart.h"
+#include "pgbart_pack.h"
 #include "pgbart_spec.h"
 
 #define CH 1024 /* rows per chunk = rows per k_rows workgroup */

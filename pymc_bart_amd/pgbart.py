@@ -447,7 +447,7 @@ class PGBART(_Base):
         other terms are reported on every step, but uploaded only when they moved."""
         offset = np.asarray(offset, np.float64)
         if self._offset is None:
-            return not offset.any()
+            return offset.shape == self.shape and not offset.any()
         return offset.shape == self._offset.shape and np.array_equal(offset, self._offset)
 
     def _apply_offset(self, offset):

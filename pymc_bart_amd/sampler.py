@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _abi
-from .trees import TreeArrays
+from .trees import PackedTrees, TreeArrays  # noqa: F401
 
 
 @dataclass
@@ -188,6 +188,7 @@ class PySampler:
         lib.check(lib.lib.pgb_set_response(self._h, mem.ptr(self._y)), "pgb_set_response")
         self._out = mem.empty((settings.n_outputs * settings.n,), np.float64)
         self._vi = np.zeros(settings.p, np.int32)
+        self._pack_buf = np.empty(64 << 10, np.uint8)  # packed tree records land here (grown on demand)
         self.counters = _abi.Counters()
         self._sat_seen = 0   # saturation events already reported
         self._steps = 0      # asteps issued (to name the one that overflowed)
@@ -317,14 +318,19 @@ class PySampler:
         return self._out
 
     # -- tree export -----------------------------------------------------------------
-    def export_trees(self, which: int) -> TreeArrays:
+    def export_trees(self, which: int):
+        """The trees of the last step (``which=0``: a per-draw batch) or all m current trees (``which=1``: a
+        baseline forest) as ONE packed record (``pgb_export_trees_packed``), decoded lazily: a
+        :class:`~pymc_bart_amd.trees.PackedTrees`, which behaves like :class:`TreeArrays`."""
         lib = self.backend.lib
-        c = _abi.TreeArraysC()
-        lib.check(lib.lib.pgb_export_trees(self._h, which, C.byref(c)), "pgb_export_trees(size)")
-        ta = TreeArrays.empty(c.n_trees, c.total_nodes, c.n_outputs)
-        c2 = ta.as_c()
-        lib.check(lib.lib.pgb_export_trees(self._h, which, C.byref(c2)), "pgb_export_trees")
-        return ta
+        buf = self._pack_buf
+        nb = C.c_int64()
+        rc = lib.lib.pgb_export_trees_packed(self._h, which, buf.ctypes.data, buf.size, C.byref(nb))
+        if rc == _abi.PGB_E_NOMEM:  # first baseline forest / an unusually bushy batch: grow once, retry
+            self._pack_buf = buf = np.empty(int(nb.value) * 2, np.uint8)
+            rc = lib.lib.pgb_export_trees_packed(self._h, which, buf.ctypes.data, buf.size, C.byref(nb))
+        lib.check(rc, "pgb_export_trees_packed")
+        return PackedTrees(buf[: int(nb.value)].tobytes())
 
     def state(self) -> dict:
         lib = self.backend.lib

@@ -95,6 +95,32 @@ class TreeArrays:
         v = self.var[a:b]
         return v[v >= 0]
 
+    @classmethod
+    def from_packed(cls, raw) -> "TreeArrays":
+        """Decode the record of ``pgb_export_trees_packed`` (``include/pgbart_pack.h``): zero-copy views of
+        ``raw`` (read-only when ``raw`` is ``bytes``)."""
+        hdr = np.frombuffer(raw, np.int32, 4)
+        nt, K, N, flags = (int(v) for v in hdr)
+        lin = bool(flags & 1)
+        o = 16
+
+        def take(dtype, count):
+            nonlocal o
+            a = np.frombuffer(raw, dtype, count, o)
+            o += a.nbytes
+            return a
+
+        tree_id, node_off = take(np.int32, nt), take(np.int32, nt + 1)
+        var, left, right = take(np.int32, N), take(np.int32, N), take(np.int32, N)
+        svar = take(np.int32, N) if lin else None
+        o = (o + 7) & ~7
+        split, count = take(np.float64, N), take(np.int64, N)
+        value = take(np.float64, N * K).reshape(N, K)
+        slope = take(np.float64, N * K).reshape(N, K) if lin else None
+        xbar = take(np.float64, N) if lin else None
+        return cls(n_outputs=K, tree_id=tree_id, node_off=node_off, var=var, split=split, left=left, right=right,
+                   count=count, value=value, slope=slope, xbar=xbar, svar=svar)
+
     @staticmethod
     def concat(parts: list["TreeArrays"]) -> "TreeArrays":
         K = parts[0].n_outputs
@@ -118,6 +144,32 @@ class TreeArrays:
             xbar=np.concatenate([p.xbar for p in parts]).astype(np.float64),
             svar=np.concatenate([p.svar for p in parts]).astype(np.int32),
         )
+
+
+class PackedTrees:
+    """One tree export kept as the packed record the native library wrote (``pgb_export_trees_packed``) and
+    decoded into a :class:`TreeArrays` on first use.  ``PGBART.astep`` stores one per draw: the step pays for
+    a single small copy, the decoding happens when (and if) predictions are made, and the history travels
+    through the reference's ``Manager().list()`` mailbox (``bart.py:134-135``) as a few KB of bytes."""
+
+    __slots__ = ("raw", "_ta")
+
+    def __init__(self, raw: bytes):
+        self.raw = raw
+        self._ta = None
+
+    def decoded(self) -> TreeArrays:
+        if self._ta is None:
+            self._ta = TreeArrays.from_packed(self.raw)
+        return self._ta
+
+    def __getattr__(self, name):  # every TreeArrays attribute / method, through the decoded arrays
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.decoded(), name)
+
+    def __reduce__(self):
+        return (PackedTrees, (self.raw,))
 
 
 def _as_list(batches) -> list:

@@ -21,14 +21,23 @@ def _encode_vi(vec) -> str:
     7 value bits per byte, least significant group first, bit 7 set on all but the last byte of a
     count -- and the byte string base64-encoded.  Golden vectors: ``tests/golden/vi_codec.json``."""
     counts = np.asarray(vec, dtype=np.int64).ravel()
-    if counts.size and int(counts.min()) < 0:
+    if counts.size == 0:
+        return ""
+    lo, hi = int(counts.min()), int(counts.max())
+    if lo < 0:
         raise ValueError("variable inclusion counts must be non-negative")
-    payload = bytearray()
-    for value in counts.tolist():
-        groups = [(value >> shift) & 0x7F for shift in range(0, max(value.bit_length(), 1), 7)]
-        payload.extend(g | 0x80 for g in groups[:-1])
-        payload.append(groups[-1])
-    return base64.b64encode(bytes(payload)).decode("ascii")
+    if hi < 0x80:  # what a step produces: every count is its own single byte
+        return base64.b64encode(counts.astype(np.uint8).tobytes()).decode("ascii")
+    # general case, vectorised: septet k of every count, kept while the count still has bits at or above it
+    n_groups = max(1, -(-hi.bit_length() // 7))
+    shifts = 7 * np.arange(n_groups, dtype=np.int64)
+    groups = (counts[:, None] >> shifts) & 0x7F
+    used = (counts[:, None] >> shifts) > 0
+    used[:, 0] = True
+    more = np.zeros_like(used)
+    more[:, :-1] = used[:, 1:]                      # a continuation bit on all but a count's last septet
+    payload = (groups | (more.astype(np.int64) << 7))[used].astype(np.uint8)  # row-major: counts in order
+    return base64.b64encode(payload.tobytes()).decode("ascii")
 
 
 def _decode_vi(s: str, length: int) -> list[int]:

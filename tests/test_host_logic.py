@@ -223,3 +223,64 @@ def test_multi_output_offsets(oracle):
     with pytest.raises(ValueError, match="shape"):
         PGBART([BARTOp(X, Y, m=6)], num_particles=6, likelihood=CategoricalLikelihood(K), random_seed=3,
                backend=oracle).astep(None, offset=np.zeros(n))
+
+
+def _export_unpacked(s, which):
+    """The two-call array export of the ABI (``pgb_export_trees``): what ``export_trees`` used before."""
+    import ctypes as C
+
+    from pymc_bart_amd.trees import TreeArrays
+
+    lib = s.backend.lib
+    c = _abi.TreeArraysC()
+    lib.check(lib.lib.pgb_export_trees(s._h, which, C.byref(c)), "size")
+    ta = TreeArrays.empty(c.n_trees, c.total_nodes, c.n_outputs)
+    c2 = ta.as_c()
+    lib.check(lib.lib.pgb_export_trees(s._h, which, C.byref(c2)), "fill")
+    return ta
+
+
+TREE_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "slope", "xbar", "svar")
+
+
+@pytest.mark.parametrize("response,K", [("constant", 1), ("linear", 1), ("constant", 3)])
+def test_packed_tree_record_equals_the_array_export(oracle, response, K):
+    """``pgb_export_trees_packed`` (one call, one record, decoded lazily) carries exactly what the array export
+    does, for batches and baseline forests, constant and linear leaves, K-vector leaves; it survives pickling as
+    its raw bytes; a buffer that is too small reports the size it needs."""
+    import ctypes as C
+    import warnings
+
+    from pymc_bart_amd.pgbart import CategoricalLikelihood
+    from pymc_bart_amd.trees import PackedTrees
+
+    rng = np.random.default_rng(6)
+    X = rng.normal(size=(400, 3))
+    Y = X[:, 0] + rng.normal(0, 0.3, 400) if K == 1 else rng.integers(0, K, 400).astype(float)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        op = BARTOp(X, Y, m=7, response=response)
+    lik = NormalLikelihood(1.0) if K == 1 else CategoricalLikelihood(K)
+    st = PGBART([op], num_particles=6, likelihood=lik, observed=Y, random_seed=2, backend=oracle, batch=(3, 3))
+    for it in range(8):
+        if it == 4:
+            st.stop_tuning()
+        st.astep(None)
+    s = st.sampler
+    for which in (0, 1):
+        packed, plain = s.export_trees(which), _export_unpacked(s, which)
+        assert isinstance(packed, PackedTrees) and packed._ta is None          # not decoded yet
+        assert packed.n_trees == plain.n_trees == (3 if which == 0 else 7) and packed.n_outputs == K
+        for f in TREE_FIELDS:
+            assert np.array_equal(getattr(packed, f), getattr(plain, f)), f
+        twin = pickle.loads(pickle.dumps(packed))
+        assert twin.raw == packed.raw and np.array_equal(twin.value, plain.value)
+        assert len(packed.raw) < 0.7 * sum(getattr(plain, f).nbytes for f in TREE_FIELDS) or response != "constant"
+    if response == "linear":
+        assert (s.export_trees(1).svar >= 0).any()
+    nb = C.c_int64()
+    rc = s.backend.lib.lib.pgb_export_trees_packed(s._h, 1, None, 0, C.byref(nb))
+    assert rc == _abi.PGB_E_NOMEM and nb.value == len(s.export_trees(1).raw)
+    # the history a step publishes is made of these records and the predictor reads them
+    ps = PosteriorSampler.from_history(st._batches, st._baseline, 7, K, backend=oracle)
+    assert ps.n_draws == 4 and ps.sample_posterior(X[:5], [0, 3], []).shape == (2, K, 5)
