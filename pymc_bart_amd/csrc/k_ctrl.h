@@ -313,6 +313,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   }
   if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
   const Ctrl c = load_uniform(&ctrls[par]);
+  // the credit the host enqueues against: slots whose control kernel has started (a posted store, no wait)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(S.host_flag + 2, (unsigned long long)(c.slot_no + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   TR_BIND(c.slot_no);
   Ctrl* co = &ctrls[par ^ 1];
   const int b = blockIdx.x, p = b + 1, tid = threadIdx.x;
@@ -386,8 +389,12 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
       if constexpr (MK)
         for (int k = 0; k < KX; ++k) S.lsdx[(par ^ 1) * KXMAX + k] = leaf_sd_x(S, c, par, par ^ 1, k);
       o.pend_leafsd = 0;
+      o.done_pub = c.steps_done;
       *co = o;
       cmd->kind = CMD_NOOP;
+      if (c.done_pub != c.steps_done)  // first idle slot after a step: every row pass of the step has run
+        __hip_atomic_store(S.host_flag + 1, (unsigned long long)c.steps_done, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);  // (release: the control word above is visible first)
     }
     return;
   }

@@ -3,7 +3,7 @@
 // Layout version of the image: bump when a device record that travels in the payload (Job, Ctrl, Cmd, DPart,
 // Acc, DTree ...) or this header changes.  The record sizes are stored as well, so an image written by a
 // build with other records is refused by name rather than by a payload-size coincidence.
-#define PGB_CKPT_VERSION 2
+#define PGB_CKPT_VERSION 3
 struct CkptHeader {
   char magic[8];       // "PGBCKPT2"
   int32_t version;     // PGB_CKPT_VERSION
@@ -108,7 +108,9 @@ extern "C" int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t 
     }
   h->slot = hd.slot;
   h->steps_target = hd.steps_target;
-  *h->flag = (unsigned long long)hd.flag;
+  h->flag[0] = (unsigned long long)hd.flag;
+  h->flag[1] = (unsigned long long)hd.flag;  // an idle image: every recorded step is complete
+  h->flag[2] = (unsigned long long)hd.slot;  // ... and every enqueued slot has run
   h->st_cur = hd.st_cur;
   h->alpha_cur = hd.alpha_cur;
   h->lower_host = hd.lower_host;

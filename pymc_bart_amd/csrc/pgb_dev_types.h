@@ -128,6 +128,9 @@ struct Ctrl {
   // draws the NEXT slot needs before it can do anything else, made one slot ahead (same addresses):
   // the systematic-resampling offset of the round just proposed, the final-choice draw of its tree
   double u_res, u_fin;
+  // steps whose LAST row pass has run, as published to the host (host_flag[1]) by the first idle slot after
+  // the step: the host then fetches the step's results without waiting for the idle slots queued behind it
+  long long done_pub;
 };
 
 struct Dev {  // kernel argument block (by value)

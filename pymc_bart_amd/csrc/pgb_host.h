@@ -22,9 +22,8 @@ struct pgb_handle {
   Dev* d_dev;                          // device-resident copy passed to every kernel
   volatile unsigned long long* flag;   // pinned host word written by k_ctrl (completed asteps)
   long long steps_target;              // asteps requested so far
-  std::vector<hipEvent_t> bundle_ev;   // throttle: at most 3 bundles of slots in flight
-  long long bundles;
   hipStream_t stream;
+  hipStream_t stream_out;              // pgb_step_host: the step's results leave on this stream, past the idle slots
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;     // per allocation: payload size ...
   std::vector<char> alloc_persist;     // ... and whether a checkpoint carries it
@@ -40,7 +39,8 @@ struct pgb_handle {
   double lik_param2;
   int lower_host;      // mirror of the batch cursor
   int last_lower, last_n;
-  double slots_per_step;  // running estimate
+  double slots_per_step;  // running estimate of the working slots one astep needs ...
+  double slots_var;       // ... and of their variance
   pgb_counters ctr;
   // profiling: events attached to the dispatches of a region, per kernel (PK_*); the row pass is
   // the dominant kernel pgb_profile reports
@@ -180,6 +180,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   pgb_handle* h = new pgb_handle();
   h->s = *s;
   h->stream = (hipStream_t)stream;
+  h->stream_out = nullptr;
   h->slot = 0;
   h->has_subset = 0;
   h->rows_grid = 1024;
@@ -212,11 +213,11 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->d_dev = nullptr;
   h->flag = nullptr;
   h->steps_target = 0;
-  h->bundles = 0;
   h->inv_sigma2 = 1.0;
   h->lik_param2 = 1.0;
   h->sigma_dirty = 1;
   h->slots_per_step = 0.0;
+  h->slots_var = 0.0;
   memset(&h->ctr, 0, sizeof h->ctr);
   Dev& d = h->d;
   memset(&d, 0, sizeof d);
@@ -352,7 +353,10 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     void* hp = nullptr;
     HC(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
     h->flag = (volatile unsigned long long*)hp;
-    *h->flag = 0;
+    h->flag[0] = 0;  // asteps whose last tree has been accepted (its FINAL row pass may still be running)
+    h->flag[1] = 0;  // asteps that are complete on the device (published by the first idle slot after them)
+    h->flag[2] = 0;  // slots whose control kernel has started (the credit the host enqueues against)
+    HC(hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
     void* dp = nullptr;
     HC(hipHostGetDevicePointer(&dp, hp, 0));
     d.host_flag = (unsigned long long*)dp;
@@ -378,11 +382,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
     transient(h);  // holds device pointers
     HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
-    for (int i = 0; i < 4; ++i) {
-      hipEvent_t ev;
-      HC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      h->bundle_ev.push_back(ev);
-    }
   }
   HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
   HC(hipMemsetAsync(y, 0, d.n_pad * sizeof(double), sm));
@@ -457,7 +456,7 @@ extern "C" int pgb_destroy(pgb_handle* h) {
   if (h->worker.joinable()) h->worker.join();
   for (int k = 0; k < PK_COUNT; ++k)
     for (hipEvent_t e : h->ev[k]) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->bundle_ev) (void)hipEventDestroy(e);
+  if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
   if (h->flag) (void)hipHostFree((void*)h->flag);
   if (h->out_host) (void)hipHostFree((void*)h->out_host);
   for (void* p : h->allocs) (void)hipFree(p);
@@ -709,10 +708,6 @@ static int harvest_profile(pgb_handle* h) {
   return PGB_OK;
 }
 
-// Enqueue bundles of slots until the device reports that all requested asteps are complete.
-// The device publishes its progress in a pinned host word (k_ctrl, final slot of a step); the
-// host polls it between bundles -- no stream synchronisation inside a step.  At most 3 bundles
-// are in flight, so the overshoot after completion is bounded (idle slots cost ~2 x 1.3 us).
 // ---- callback family: the host half of a slot (after {k_ctrl ; k_rows ; k_loglik<callback>} have run)
 // k_loglik left, per active particle, every row's side and the linear predictor of the rows of the split
 // leaf; the callback evaluates them in ONE call, the values are clamped and quantised like the built-in
@@ -796,17 +791,19 @@ static int callback_host_phase(pgb_handle* h, int par) {
   return PGB_OK;
 }
 
-#define BUNDLE 8
-#define BUNDLE_TAIL 2
-// Slots are enqueued in bundles of 8 with at most 3 bundles in flight; once the number of slots this
-// call has enqueued comes within 2 bundles of what such a call needed last time (running estimate per
-// astep), it switches to bundles of 2 with 2 in flight, so that only a few idle slots (~4 us each) are
-// queued behind the slot that completes the step -- the results of a synchronous astep wait for them.
+// ---- feeding the state machine ---------------------------------------------------------------------------
+// The device publishes two progress words besides the step count: flag[2] = slots whose control kernel has
+// started (Ctrl::slot_no, one posted store per slot) and flag[1] = steps that are complete.  The host
+// enqueues against flag[2] like against a credit: up to FEED_AHEAD slots beyond the executed one while the
+// step is expected to need them (running mean - 1 sd of the slots such a call took), FEED_MIN beyond it
+// after that -- so a finished step leaves at most a few idle slots (~2.6 us each) behind it.  No events, no
+// bundles: the throttle costs the device nothing and the host one read of pinned memory.
+#define FEED_AHEAD 24
+#define FEED_MIN 6
 static int feed_until_flag(pgb_handle* h, int n_steps) {
   Dev& d = h->d;
   const long long start = h->slot;
   long long cap = start + (long long)n_steps * (PGB_MAX_NODES + 3) * (d.m + 1) + 64;
-  const long long expect = h->slots_per_step > 0.0 ? (long long)(h->slots_per_step * n_steps) : (1ll << 60);
   int rc;
   if (h->s.family == PGB_FAMILY_CALLBACK) {  // one slot at a time, the host evaluates between slots
     if (!h->cb_fn) return fail(PGB_E_INVALID, "pgb_set_loglik_callback first");
@@ -825,21 +822,42 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
     }
     return PGB_OK;
   }
+  static const int feed_ahead = getenv("PGB_FEED_AHEAD") ? atoi(getenv("PGB_FEED_AHEAD")) : FEED_AHEAD;
+  static const int feed_min = getenv("PGB_FEED_MIN") ? atoi(getenv("PGB_FEED_MIN")) : FEED_MIN;
+  static const double feed_sd = getenv("PGB_FEED_SD") ? atof(getenv("PGB_FEED_SD")) : 1.0;
+  // slots this call is expected to need at least: mean - feed_sd * sd of the running per-step estimate
+  long long expect_end = 1ll << 60;
+  if (h->slots_per_step > 0.0) {
+    const double sd = h->slots_var > 0.0 ? __builtin_sqrt(h->slots_var) : 0.15 * h->slots_per_step;
+    double e = h->slots_per_step * n_steps - feed_sd * sd * __builtin_sqrt((double)n_steps);
+    expect_end = start + (long long)(e > 1.0 ? e : 1.0);
+  }
+  long long idle_polls = 0;
   while (*h->flag < (unsigned long long)h->steps_target) {
-    const bool tail = (h->slot - start) + 2 * BUNDLE >= expect;
-    const int depth = tail ? 2 : 3;
-    hipEvent_t ev = h->bundle_ev[h->bundles & 3];
-    if (h->bundles >= depth) {
-      // wait for an earlier bundle before queueing more (this also frees its event for reuse)
-      HIPCHK(hipEventSynchronize(h->bundle_ev[(h->bundles - depth) & 3]));
-      if (*h->flag >= (unsigned long long)h->steps_target) break;
-    }
-    if ((rc = enqueue_slots(h, tail ? BUNDLE_TAIL : BUNDLE)) != PGB_OK) return rc;
-    HIPCHK(hipEventRecord(ev, h->stream));
-    h->bundles += 1;
-    if (h->slot > cap) {
-      h->poisoned = 1;
-      return fail(PGB_E_STATE, "sampler state machine did not finish");
+    const long long executed = (long long)h->flag[2];
+    long long limit = executed + feed_ahead;
+    if (limit > expect_end) limit = expect_end;
+    if (limit < executed + feed_min) limit = executed + feed_min;
+    if (h->slot < limit) {
+      if ((rc = enqueue_slots(h, 1)) != PGB_OK) return rc;
+      if (h->slot > cap) {
+        h->poisoned = 1;
+        return fail(PGB_E_STATE, "sampler state machine did not finish");
+      }
+      idle_polls = 0;
+    } else {
+      for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+      // a device that stops publishing progress (lost GPU, a kernel that faulted) ends the call, not the process
+      if ((++idle_polls & 0xFFFF) == 0) {
+        if ((long long)h->flag[2] != executed) {
+          idle_polls = 0;
+        } else if (idle_polls >= (1ll << 26)) {  // ~10 s of polling without a single slot starting
+          hipError_t e = hipStreamQuery(h->stream);
+          h->poisoned = 1;
+          if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "device stopped making progress");
+          return fail(PGB_E_STATE, "device stopped publishing slot progress");
+        }
+      }
     }
   }
   return PGB_OK;
@@ -895,7 +913,14 @@ static void counters_from(pgb_handle* h, const unsigned long long* c) {
 static void note_step_slots(pgb_handle* h, long long slots_before, int n_steps) {
   const double per = (double)(h->ctr.slots - slots_before) / (double)(n_steps > 0 ? n_steps : 1);
   if (per <= 0.0) return;
-  h->slots_per_step = h->slots_per_step > 0.0 ? 0.5 * h->slots_per_step + 0.5 * per : per;
+  if (h->slots_per_step <= 0.0) {
+    h->slots_per_step = per;
+    return;
+  }
+  // exponentially weighted mean / variance (weight 1/8); a batch of n steps averages n of them
+  const double dev = per - h->slots_per_step;
+  h->slots_per_step += 0.125 * dev;
+  h->slots_var = 0.875 * (h->slots_var + 0.125 * dev * dev * (n_steps > 0 ? n_steps : 1));
 }
 
 static int fetch_counters(pgb_handle* h, pgb_counters* out) {
@@ -952,18 +977,37 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   if ((rc = feed_until_flag(h, 1)) != PGB_OK) return rc;
   const int nt = h->last_n;
   if (nt > h->out_layout.cap_trees) return fail(PGB_E_STATE, "step batch exceeds the export block");
+  // The progress word fires when the last tree is accepted; its FINAL row pass runs in that same slot, and the
+  // first idle slot behind it publishes "step complete" (flag[1]).  From there the results leave on a stream of
+  // their own: the idle slots still queued on the sampler's stream (a few, ~2.6 us each) drain
+  // while the export, the DMA and the caller's host work go on.
+  hipStream_t so = h->stream;
+  const bool early = h->s.family != PGB_FAMILY_CALLBACK && !h->prof && h->stream_out != nullptr;
+  if (early) {
+    int extra = 0;
+    while (h->flag[1] < (unsigned long long)h->steps_target) {
+      // every enqueued slot has started and none of them was an idle one behind the finishing slot: one more
+      if ((long long)h->flag[2] >= h->slot) {
+        if (h->flag[1] >= (unsigned long long)h->steps_target) break;
+        if (++extra > 16) { h->poisoned = 1; return fail(PGB_E_STATE, "the step-complete word never fired"); }
+        if ((rc = enqueue_slots(h, 1)) != PGB_OK) return rc;
+      }
+      for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+    }
+    so = h->stream_out;
+  }
   const long long dense_blocks = sum_trees_host_out ? ((long long)d.K * d.n + BT - 1) / BT : 0;
   long long grid = dense_blocks < 512 ? dense_blocks : 512;
   if (grid < nt) grid = nt;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_export_step, dim3((unsigned)grid), dim3(BT), 0, h->stream, (const Dev*)h->d_dev,
+  hipLaunchKernelGGL(k_export_step, dim3((unsigned)grid), dim3(BT), 0, so, (const Dev*)h->d_dev,
                      (int)(h->slot & 1), h->last_lower, nt, h->out_dev, h->out_layout,
                      sum_trees_host_out ? h->st_dense : nullptr);
   if (sum_trees_host_out)
     HIPCHK(hipMemcpyAsync(sum_trees_host_out, h->st_dense, (size_t)d.K * d.n * sizeof(double),
-                          hipMemcpyDeviceToHost, h->stream));
+                          hipMemcpyDeviceToHost, so));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(so));
   if (h->prof && (rc = harvest_profile(h)) != PGB_OK) return rc;
   const StepOutHdr* H = (const StepOutHdr*)h->out_host;
   if (H->phase != PH_IDLE) return fail(PGB_E_STATE, "device not idle after the progress flag fired");
