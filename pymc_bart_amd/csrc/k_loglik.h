@@ -5,17 +5,28 @@
 // evaluates the per-row log-likelihood of the rows of the leaf that was split -- left / right /
 // dropped by a missing value -- and reduces it in fixed point.  Same work items as PARTITION.
 // (a template: the single-output kernels keep 64 of these in LDS and carry none of the arrays)
+struct LJobLin {  // linear response: the children's linear parts
+  double slopeL, xbarL, slopeR, xbarR;
+  int32_t svarL, svarR;
+};
+struct LJobNone {};
 template <bool MK, bool LIN>
-struct LJobT {
+struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant leaves: none of the linear fields in LDS)
   long long src, xoff;
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
   double vLx[MK ? KXMAX : 1], vRx[MK ? KXMAX : 1];  // K-vector leaves: outputs 1..K-1
-  // linear response: the children's linear parts
-  double slopeL, xbarL, slopeR, xbarR;
-  int32_t svarL, svarR;
-  double sLx[MK && LIN ? KXMAX : 1], sRx[MK && LIN ? KXMAX : 1];  // ... slopes of outputs 1..K-1
+  double sLx[MK && LIN ? KXMAX : 0], sRx[MK && LIN ? KXMAX : 0];  // ... slopes of outputs 1..K-1
 };
+
+// Dense evaluation of sparse leaves (single output, constant leaves): a wave owns 256 rows, 4 per lane, and the
+// per-row evaluation is issued once per row slot e = 0..3 for the whole wave however few lanes have a row of
+// the split leaf there -- from the second round on a leaf holds a half, a quarter, ... of the rows, scattered,
+// so most of the issued lanes were masked off (round-2 profile: ~127 lane-instructions per touched row against
+// ~70 per evaluated row).  When a wave finds at most LL_DENSE_MAX of its 256 rows in the leaf it lists them
+// (ballot + mbcnt rank, {sum_trees_noi + offset, side, y}) in a wave-private LDS list and evaluates the list
+// 64 at a time: 1-2 evaluations instead of 4.  Order within a side does not matter (integer sums).
+#define LL_DENSE_MAX 128
 
 // Categorical-softmax with K known at compile time: pgb_loglik_cat's arithmetic with K - 1
 // exponentials instead of K.  The largest predictor contributes exp(0), which pgb_exp returns as
@@ -73,8 +84,10 @@ __device__ __forceinline__ long long quant_ll(double ll, double cl) {
 // LIN: linear response (single-output families): the children predict value + slope (x - xbar).
 template <int KT, int FAM, bool LIN>
 // (compiled for 3 workgroups per CU, i.e. <= 168 VGPRs: the K = 4 instance sits right at that edge, and one
-//  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5)
-__global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, int par) {
+//  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5;
+//  the probit instance -- cfg4's dominant kernel -- for 5: <= 96 VGPRs, where a 97th costs it a fifth)
+__global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : 3)
+void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Dev& S = *Sp;
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
@@ -86,6 +99,17 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
   // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
   constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
   __shared__ double s_ln[PROBIT ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
+  // wave-private lists of the dense path (see LL_DENSE_MAX); Bernoulli responses travel as a flag bit
+  // (the evaluation is inlined a second time: the families whose instance would cross an occupancy edge with
+  //  it -- Poisson, NegativeBinomial, Gamma: two exp / log chains each -- keep the plain path;
+  //  tools/occupancy_guard.py holds the line)
+  constexpr bool DENSE = KT == 1 && !LIN &&
+                         (FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_BERNOULLI_LOGIT ||
+                          FAM == PGB_FAMILY_ASYMLAPLACE || FAM == PGB_FAMILY_STUDENT_T);
+  constexpr bool YBIT = FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_BERNOULLI_LOGIT;
+  __shared__ double s_lnv[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
+  __shared__ double s_ly[DENSE && !YBIT ? BT / 64 : 1][DENSE && !YBIT ? LL_DENSE_MAX : 1];
+  __shared__ uint8_t s_lfl[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
   // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
   // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
   // SLOWER at cfg4, 184 k / 171 k vs 223 k particle-steps/s: with a quarter of the lanes active the
@@ -142,8 +166,10 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
       lj.vR = cv.vR;
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
-      lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
-      lj.svarL = lj.svarR = -1;
+      if constexpr (LIN) {
+        lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
+        lj.svarL = lj.svarR = -1;
+      }
       LinKids lk;
       lk.svarL = lk.svarR = -1;
       lk.linL = lk.linR = false;
@@ -258,38 +284,47 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
   }
   const int nact = s_n[0];
   if (nact == 0) return;
-  int G = (nact * S.nchunks + S.ll_target - 1) / S.ll_target;
-  if (G < 1) G = 1;
-  const int ngroups = (nact + G - 1) / G;
-  const int nitems = S.nchunks * ngroups;
+  // (arrays of the argument block as GLOBAL pointers -- see as_global: a flat load also counts in lgkmcnt, so
+  //  the first LDS table read of an evaluation waited for the label words requested for the NEXT particle)
+  const gptr<const double> gy = as_global(S.y), goff = as_global(S.off);
+  const gptr<const uint8_t> glid = as_global((const uint8_t*)S.lid);
+  // Work = nchunks x nact (chunk, particle) units.  The persistent grid takes them as ONE linear range cut into
+  // gridDim.x equal spans (chunk-major): a workgroup gets a run of particles of one chunk and, if its span
+  // crosses a chunk boundary, the first particles of the next.  (Whole items of G particles left the grid
+  // unbalanced: cfg4, round 0: 977 chunks x 2 groups over 1280 workgroups = 674 workgroups with 39 units,
+  // 606 with 30 or 9 -- 76 % of the pass's lanes.)
+  const int W = S.nchunks * nact;  // (< 2^31: n < 2^31 rows, at most 63 particles)
+  const int per = W / (int)gridDim.x, rem = W - per * (int)gridDim.x, bx = (int)blockIdx.x;
+  const int u_lo = bx * per + (bx < rem ? bx : rem), u_hi = u_lo + per + (bx < rem ? 1 : 0);
   const int K = KT > 0 ? KT : S.K;
-  const double* __restrict__ const noi = S.st + (size_t)cn.st_cur * K * S.n_pad;
+  const gptr<const double> noi = as_global((const double*)S.st + (size_t)cn.st_cur * K * S.n_pad);
   const double cl = S.sc.cl;
   // The row pass of this slot has already sorted the rows of every split leaf: left rows kept the
   // leaf's label, right rows carry the new one, dropped rows the orphan label.  Reading those
   // bytes back (1 B per row) replaces a second read of the split column (8 B per row).
-  const uint8_t* __restrict__ const newl = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
+  const gptr<const uint8_t> newl = as_global((const uint8_t*)S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad);
   const long long n = S.n;
   unsigned sat = 0;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int chunk = item % S.nchunks, grp = item / S.nchunks;
+  for (int u = u_lo; u < u_hi;) {
+    const int chunk = u / nact, g0 = u - chunk * nact;
+    const int g1 = nact - g0 < u_hi - u ? nact : g0 + (u_hi - u);
+    u += g1 - g0;
     const long long base = (long long)chunk * CH + tid * RPT;
     double yv[RPT], nv[RPT];
     uint32_t root_ids = 0;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
-      yv[e] = S.y[base + e];
+      yv[e] = gy[base + e];
       nv[e] = noi[base + e];
       if constexpr (KT == 1)
-        if (S.has_off) nv[e] = nv[e] + S.off[base + e];  // (adding the default 0.0 would give the same bits)
+        if (S.has_off) nv[e] = nv[e] + goff[base + e];  // (adding the default 0.0 would give the same bits)
       if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
     }
     if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
-      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
-        const uint32_t ids = lj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + lj.src + base);
-        const uint32_t nid = *(const uint32_t*)(newl + (size_t)lj.p * S.n_pad + base);
+        const uint32_t ids = lj.src < 0 ? root_ids : *gcast<const uint32_t>(glid + lj.src + base);
+        const uint32_t nid = *gcast<const uint32_t>(newl + (size_t)lj.p * S.n_pad + base);
         // (the particle's labels and leaf values in registers instead of LDS reads per row)
         const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
         double vLr[KT >= 2 ? KT : 1], vRr[KT >= 2 ? KT : 1];
@@ -319,7 +354,7 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
                 v0k = pgb_leaf_pred(v0k, side == 0 ? lj.slopeL : lj.slopeR, xb, xv);
               }
             }
-            mu[0] = (S.has_off ? nv[e] + S.off[base + e] : nv[e]) + v0k;
+            mu[0] = (S.has_off ? nv[e] + goff[base + e] : nv[e]) + v0k;
 #pragma unroll
             for (int k = 1; k < KB; ++k)
               if (k < K) {
@@ -329,7 +364,7 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
                 if constexpr (LIN)
                   if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
                 const double nk = noi[(size_t)k * S.n_pad + base + e];
-                mu[k] = (S.has_off ? nk + S.off[(size_t)k * S.n_pad + base + e] : nk) + vk;
+                mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + base + e] : nk) + vk;
               }
             double llv;
             if constexpr (KT >= 2) {
@@ -357,17 +392,16 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
       __syncthreads();
       continue;
     }
-    const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
     // the label words of the next particle are requested before this one is evaluated
-    uint32_t ids_n = s_job[g0].src < 0 ? root_ids : *(const uint32_t*)(S.lid + s_job[g0].src + base);
-    uint32_t nid_n = *(const uint32_t*)(newl + (size_t)s_job[g0].p * S.n_pad + base);
+    uint32_t ids_n = s_job[g0].src < 0 ? root_ids : *gcast<const uint32_t>(glid + s_job[g0].src + base);
+    uint32_t nid_n = *gcast<const uint32_t>(newl + (size_t)s_job[g0].p * S.n_pad + base);
     for (int g = g0; g < g1; ++g) {
       const LJob& lj = s_job[g];
       const uint32_t ids = ids_n, nid = nid_n;
       if (g + 1 < g1) {
         const LJob& ln = s_job[g + 1];
-        ids_n = ln.src < 0 ? root_ids : *(const uint32_t*)(S.lid + ln.src + base);
-        nid_n = *(const uint32_t*)(newl + (size_t)ln.p * S.n_pad + base);
+        ids_n = ln.src < 0 ? root_ids : *gcast<const uint32_t>(glid + ln.src + base);
+        nid_n = *gcast<const uint32_t>(newl + (size_t)ln.p * S.n_pad + base);
       }
       long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
       // (the particle's fields in registers: read through the LDS record they cost three LDS reads per ROW)
@@ -392,6 +426,53 @@ __global__ __launch_bounds__(BT, 3) void k_loglik(const Dev* __restrict__ Sp, in
         continue;
       }
       long long vt = 0;  // all rows of the split leaf: the right child is what the other two leave
+      if constexpr (DENSE) {
+        unsigned long long mk[RPT];
+        int M = 0;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          mk[e] = __ballot(((ids >> (8 * e)) & 255u) == lab);
+          M += __popcll(mk[e]);
+        }
+        if (M <= LL_DENSE_MAX) {  // (wave-uniform)
+          int off = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == lab) {
+              const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u));
+              const uint32_t nl = (nid >> (8 * e)) & 255u;
+              const uint32_t side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
+              s_lnv[w][pos] = nv[e];
+              if constexpr (YBIT) s_lfl[w][pos] = (uint8_t)(side | (yv[e] > 0.5 ? 4u : 0u));
+              else { s_lfl[w][pos] = (uint8_t)side; s_ly[w][pos] = yv[e]; }
+            }
+            off += __popcll(mk[e]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (int k = lane; k < M; k += 64) {
+            const uint32_t fl = s_lfl[w][k];
+            const int side = (int)(fl & 3u);
+            // (Bernoulli: the evaluation only asks whether y > 0.5)
+            const double yk = YBIT ? ((fl & 4u) ? 1.0 : 0.0) : s_ly[w][k];
+            const double mu = s_lnv[w][k] + (side == 0 ? vL : side == 1 ? vR : 0.0);
+            const long long q = quant_ll(pgb_loglik1q(FAM, yk, mu, cn.inv_sigma2, cn.lik_param2,
+                                                      PROBIT ? s_ln : pgb_ln_tn(),
+                                                      PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl);
+            vt += q;
+            v0 += side == 0 ? q : 0;
+            if (drops) v2 += side == 2 ? q : 0;
+          }
+          __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
+          v1 = vt - v0 - v2;
+          const int slot = (g - g0) * 3;
+          const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+          if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+          continue;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < RPT; ++e) {
         if (((ids >> (8 * e)) & 255u) == lab) {

@@ -71,15 +71,18 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       }
     }
   }
-  uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
-  const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
-  const uint8_t* sel_lid =
-      (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
+  // (arrays of the argument block as GLOBAL pointers: see as_global)
+  const gptr<uint8_t> tl_old = as_global(do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr);
+  const gptr<const uint8_t> tl_new = as_global(do_init ? (const uint8_t*)S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr);
+  const gptr<const uint8_t> sel_lid = as_global(
+      (do_final && cmd->sel_slot >= 0) ? (const uint8_t*)S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr);
+  const gptr<double> rs_mean = as_global(S.rs_mean), rs_m2 = as_global(S.rs_m2);
+  const gptr<double> pack = as_global((double*)S.pack);  // [n_pad] pairs {sum_trees, r}
   const double cntf = (double)cmd->rs_count;
   // sum_trees buffers: an INIT reads st_in and writes sum_trees_noi to st_out (other workgroups of
   // the same chunk still read st_in); a lone FINAL updates st_in in place
-  double* const st_in = S.st + (size_t)cmd->st_cur * S.n_pad;
-  double* const st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad;
+  const gptr<double> st_in = as_global(S.st + (size_t)cmd->st_cur * S.n_pad);
+  const gptr<double> st_out = as_global(S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad);
 
   if (do_part) {
     const Job* jobs = jobs_all + (size_t)par * MAXP;
@@ -122,9 +125,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     int ngroups = (nact + G - 1) / G;
     if (ngroups < 1) ngroups = 1;  // an INIT must run even if no particle splits
     const int nitems = S.nchunks * ngroups;
-    uint8_t* __restrict__ const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
-    const uint8_t* __restrict__ const lid0 = S.lid;
-    const double* __restrict__ const XT = S.XT;
+    const gptr<uint8_t> __restrict__ dst0 = as_global(S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad);
+    const gptr<const uint8_t> __restrict__ lid0 = as_global((const uint8_t*)S.lid);
+    const gptr<const double> __restrict__ XT = as_global(S.XT);
+    const gptr<const float> __restrict__ XT32 = as_global(S.XT32);
+    const gptr<const double> __restrict__ yarr = as_global(S.y);
+    const gptr<uint16_t> ccp = as_global(S.cc);
     const double c1 = S.sc.c1, c2 = S.sc.c2;
     const long long n = S.n, n_pad = S.n_pad;
     long long iv[5] = {0, 0, 0, 0, 0};  // INIT/FINAL statistics: A, B, C, E0, QSTD
@@ -141,20 +147,20 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         // ---- this slot starts a tree: finish the previous tree (FINAL) and compute the new
         // residuals (INIT) on the fly; the first group of each chunk also writes them back
         const bool writer = grp == 0;
-        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+        uint32_t ids_next = *gcast<const uint32_t>(tl_new + base);
         uint32_t ids_sel = 0;
         if (do_final) {
           if (cmd->sel_slot == -2) {
-            ids_sel = *(const uint32_t*)(tl_old + base);  // old tree kept
+            ids_sel = *gcast<const uint32_t>(tl_old + base);  // old tree kept
           } else {
             if (sel_lid) {
-              ids_sel = *(const uint32_t*)(sel_lid + base);
+              ids_sel = *gcast<const uint32_t>(sel_lid + base);
             } else {  // untouched root: label 0 (pad rows: orphan)
 #pragma unroll
               for (int e = 0; e < RPT; ++e)
                 if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
             }
-            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+            if (writer) *gcast<uint32_t>(tl_old + base) = ids_sel;
           }
           if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
         }
@@ -163,16 +169,15 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         // the loop would be issued one row (one memory round trip) at a time
         double st4[RPT], y4[RPT], mean4[RPT], m24[RPT];
         {
-          const double2* __restrict__ sp = (const double2*)(st_in + base);
-          const double2* __restrict__ yp = (const double2*)(S.y + base);
-          const double2 s01 = sp[0], s23 = sp[1], y01 = yp[0], y23 = yp[1];
+          const gptr<const double> sp = st_in + base, yp = yarr + base;
+          const double2 s01 = gload_d2(sp), s23 = gload_d2(sp + 2), y01 = gload_d2(yp), y23 = gload_d2(yp + 2);
           st4[0] = s01.x; st4[1] = s01.y; st4[2] = s23.x; st4[3] = s23.y;
           y4[0] = y01.x; y4[1] = y01.y; y4[2] = y23.x; y4[3] = y23.y;
           const bool upd = do_final && cmd->tune && writer;
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
-            mean4[e] = upd ? S.rs_mean[base + e] : 0.0;
-            m24[e] = upd ? S.rs_m2[base + e] : 0.0;
+            mean4[e] = upd ? rs_mean[base + e] : 0.0;
+            m24[e] = upd ? rs_m2[base + e] : 0.0;
           }
         }
 #pragma unroll
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               const double mean = mean0 + delta / cntf;
               const double delta2 = nv - mean;
               const double m2 = m20 + delta * delta2;
-              S.rs_mean[row] = mean;
-              S.rs_m2[row] = m2;
+              rs_mean[row] = mean;
+              rs_m2[row] = m2;
               iv[4] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
             }
           }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           strow[e] = st;
           rrow[e] = r;
           if (writer) {  // saturation is counted where the values are produced, once
-            S.pack[row] = make_double2(st, r);
+            gstore_d2(pack + 2 * row, st, r);
             st_out[row] = noi;
             sat += sat1;
             iv[0] += qa[e];
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       } else {
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
-          const double2 sr = S.pack[base + e];
+          const double2 sr = gload_d2(pack + 2 * (base + e));
           strow[e] = sr.x;
           rrow[e] = sr.y;
           qa[e] = pgb_quant(sr.x, c1, nullptr);
@@ -256,14 +261,14 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       float4 nxf = {0.f, 0.f, 0.f, 0.f};
       if (g0 < g1) {
         const RJob& rn = s_job[g0];
-        if (rn.src >= 0) nx_ids = *(const uint32_t*)(lid0 + rn.src + base);
+        if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
         if (rn.active) {
           if constexpr (F32) {
-            nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+            nxf = gload_f4(XT32 + rn.xoff + base);
           } else {
-            const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
-            nx0 = xn[0];
-            nx1 = xn[1];
+            const gptr<const double> xn = XT + rn.xoff + base;
+            nx0 = gload_d2(xn);
+            nx1 = gload_d2(xn + 2);
           }
         }
       }
@@ -274,19 +279,19 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         const float4 tf = nxf;
         if (g + 1 < g1) {
           const RJob& rn = s_job[g + 1];
-          nx_ids = rn.src < 0 ? root_ids : *(const uint32_t*)(lid0 + rn.src + base);
+          nx_ids = rn.src < 0 ? root_ids : *gcast<const uint32_t>(lid0 + rn.src + base);
           if (rn.active) {
             if constexpr (F32) {
-              nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+              nxf = gload_f4(XT32 + rn.xoff + base);
             } else {
-              const double2* __restrict__ xn = (const double2*)(XT + rn.xoff + base);
-              nx0 = xn[0];
-              nx1 = xn[1];
+              const gptr<const double> xn = XT + rn.xoff + base;
+              nx0 = gload_d2(xn);
+              nx1 = gload_d2(xn + 2);
             }
           }
         }
         uint32_t out = ids;
-        uint8_t* __restrict__ const dp = dst0 + (size_t)rj.p * n_pad + base;
+        const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)rj.p * n_pad + base;
         // (the particle's split in registers: read through the LDS record, the value, the rule and the labels
         //  were fetched again for every ROW -- the compiler cannot keep LDS reads across the stores of the
         //  reduction -- with a wait for the LDS each time)
@@ -294,13 +299,13 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         const int r_rule = rj.rule;
         const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
         if (!rj.active) {  // forced refresh only
-          *(uint32_t*)dp = out;
+          *gcast<uint32_t>(dp) = out;
           continue;
         }
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
         const float xf[RPT] = {tf.x, tf.y, tf.z, tf.w};
         const float r_vf = (float)r_v;
-        const double* __restrict__ const xcol = XT + rj.xoff + base;  // (F32: float32 ties only)
+        const gptr<const double> __restrict__ xcol = XT + rj.xoff + base;  // (F32: float32 ties only)
         // go left?  F32: decided on the float32 values unless they tie (see the template comment)
         auto left_of = [&](int e) -> bool {
           if constexpr (F32) {
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               }
             }
           }
-          *(uint32_t*)dp = out;
+          *gcast<uint32_t>(dp) = out;
           const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
           if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
         } else {
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
               }
             }
           }
-          *(uint32_t*)dp = out;
+          *gcast<uint32_t>(dp) = out;
           const long long ta = wave_sum4(v[0], v[1], v[2], v[3]);
           const long long tb = wave_sum4(v[4], v[5], v[6], 0);
           if (lane < 4) s_red[(slot + lane) * 4 + w] = ta;
@@ -394,8 +399,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
-          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
-          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+          ccp[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+          ccp[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
           if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
         } else if (s != 0) {
           long long* dst = i == 1 ? &a->aL : i == 2 ? &a->bL : i == 3 ? &a->c2L : i == 4 ? &a->aN : i == 5 ? &a->bN : &a->c2N;
@@ -445,13 +450,13 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     }
     st = st + nv;
     if (cmd->tune) {  // [U] RunningSd.update (Welford)
-      const double mean0 = S.rs_mean[row], m20 = S.rs_m2[row];
+      const double mean0 = rs_mean[row], m20 = rs_m2[row];
       const double delta = nv - mean0;
       const double mean = mean0 + delta / cntf;
       const double delta2 = nv - mean;
       const double m2 = m20 + delta * delta2;
-      S.rs_mean[row] = mean;
-      S.rs_m2[row] = m2;
+      rs_mean[row] = mean;
+      rs_m2[row] = m2;
       v[4] += pgb_quant(PGB_SQRT(m2 / cntf), S.sc.c1, &sat);
     }
     st_out[row] = st;

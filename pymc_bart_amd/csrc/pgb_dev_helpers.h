@@ -1,4 +1,35 @@
 // pgb_dev_helpers.h -- part of pgbart_hip.hip (not a standalone header): wave / workgroup primitives and the label -> value table builders.
+// ---- global address space ------------------------------------------------------------------------------
+// A pointer LOADED from memory (every array of the argument block `Dev`) is a generic pointer to the compiler,
+// and a load through it is a FLAT instruction: it counts in lgkmcnt as well as vmcnt, so every wait for an LDS
+// read (`s_waitcnt lgkmcnt(0)`) also drains the global loads in flight -- the software pipelines of the row
+// passes were serialised by their own LDS job records.  as_global() states what the host knows (these arrays
+// live in HBM): loads become global_load (vmcnt only, SGPR base + VGPR offset).
+template <typename T>
+using gptr = T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
+template <typename U, typename T>
+__device__ __forceinline__ gptr<U> gcast(gptr<T> p) { return (gptr<U>)p; }
+// (HIP's double2 / float4 are classes whose copy constructors take generic references: wide loads and stores
+//  through a global pointer go through the native vector types)
+typedef double pgb_v2f64 __attribute__((ext_vector_type(2)));
+typedef float pgb_v4f32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 gload_d2(gptr<const double> p) {
+  const pgb_v2f64 v = *(gptr<const pgb_v2f64>)p;
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ float4 gload_f4(gptr<const float> p) {
+  const pgb_v4f32 v = *(gptr<const pgb_v4f32>)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore_d2(gptr<double> p, double a, double b) {
+  pgb_v2f64 v;
+  v.x = a;
+  v.y = b;
+  *(gptr<pgb_v2f64>)p = v;
+}
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long wave_sum(long long v) {
 #pragma unroll

@@ -24,6 +24,18 @@ def main():
     print(f"{'kernel':60s} {'calls':>8s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for name, n, s, a, mn, mx in rows:
         print(f"{name[:60]:60s} {n:8d} {s/1e6:10.3f} {a/1e3:9.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.1f}")
+    if "--hist" in sys.argv:  # where each hot kernel's time goes: launches and time by duration bucket
+        edges = [0, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 1 << 30]
+        for name, n, s_, a, mn, mx in rows[:4]:
+            durs = [r[0] / 1e3 for r in c.execute(
+                f"select d.end-d.start from {kd} d join {ks} s on d.kernel_id = s.id where s.{namecol} = ?", (name,))]
+            tot_k = sum(durs) or 1.0
+            print(f"histogram {name[:50]}")
+            for lo, hi in zip(edges[:-1], edges[1:]):
+                sel = [d for d in durs if lo <= d < hi]
+                if sel:
+                    print(f"   [{lo:4d},{hi if hi < 1 << 30 else 9999:5d}) us: {len(sel):6d} launches {100 * len(sel) / len(durs):5.1f} %  "
+                          f"time {100 * sum(sel) / tot_k:5.1f} %  avg {sum(sel) / len(sel):7.2f} us")
     if "--gaps" in sys.argv:
         ev = list(c.execute(f"select d.start, d.end from {kd} d order by d.start"))
         gaps = [ev[i + 1][0] - ev[i][1] for i in range(len(ev) - 1)]
