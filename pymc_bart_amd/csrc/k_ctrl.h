@@ -91,7 +91,7 @@ struct LinKids {
   bool linL, linR;
   double uscale, xs;
 };
-__device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __restrict__ copies, int var, int cL, int cR,
+__device__ __forceinline__ LinKids lin_children(const DevG& S, const AccU* __restrict__ copies, int var, int cL, int cR,
                                                 long long aL, long long aR, uint32_t it, uint32_t round, uint32_t q) {
   LinKids k;
   k.slopeL = k.xbarL = k.slopeR = k.xbarR = 0.0;
@@ -136,7 +136,7 @@ __device__ __forceinline__ LinKids lin_children(const Dev& S, const AccU* __rest
 }
 // K-vector leaves: the slopes of extension output kx of both children (sums of u st_k from accux,
 // the sums of u / u^2 are shared with output 0); a leaf is linear when ANY output has a slope.
-__device__ __forceinline__ void lin_children_x(const Dev& S, LinKids& lk, ChildX& cx, int var, int cL, int cR,
+__device__ __forceinline__ void lin_children_x(const DevG& S, LinKids& lk, ChildX& cx, int var, int cL, int cR,
                                                long long usL, long long usR) {
   if (lk.linL) {
     const pgb_linfit f = pgb_lin_fit(cL, lk.u0L, lk.u1L, usL, cx.aL, S.sc.inv_c1, S.inv_R, S.mdouble);
@@ -168,7 +168,7 @@ struct SplitRow {
   int found;
   double v;
 };
-__device__ __forceinline__ SplitRow select_split_row(const Dev& S, int j, bool subset_rule, int src_gen, int src_slot,
+__device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool subset_rule, int src_gen, int src_slot,
                                                      int ncnt, int ncc, int nlabel, const double* pre0,
                                                      const double* pre1, long long* tr_rec = nullptr) {
   const double* xc = S.XT + (size_t)j * S.n_pad;
@@ -286,7 +286,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
             const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all) {
   // ctrls / ias / jobs_all / acc_all / parts_all repeat S.ctrl / S.initacc / S.jobs / S.acc / S.parts as
   // kernel arguments (preloaded into SGPRs): their first loads do not wait for the argument block S
-  const Dev& S = *Sp;  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
   __shared__ Fin s_fin[MAXP];
   __shared__ int s_i[16];
   __shared__ double s_d[4];

@@ -43,7 +43,7 @@ __host__ __device__ inline StepOutLayout stepout_layout(int p, int cap_trees, in
 __global__ __launch_bounds__(BT) void k_export_step(const Dev* __restrict__ Sp, int par, int first, int n_trees,
                                                     unsigned char* __restrict__ blob, StepOutLayout L,
                                                     double* __restrict__ st_dense /* [K][n] or null */) {
-  const Dev& S = *Sp;
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   const int tid = threadIdx.x, b = blockIdx.x;
   const Ctrl c = S.ctrl[par];
   const int K = S.K, KX = S.K - 1;

@@ -27,6 +27,9 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
 // (ballot + mbcnt rank, {sum_trees_noi + offset, side, y}) in a wave-private LDS list and evaluates the list
 // 64 at a time: 1-2 evaluations instead of 4.  Order within a side does not matter (integer sums).
 #define LL_DENSE_MAX 128
+#ifndef PGB_LLK_WGS
+#define PGB_LLK_WGS 3  // workgroups per CU the K = 2, 3, 4 instances are compiled for (experiment knob)
+#endif
 
 // Categorical-softmax with K known at compile time: pgb_loglik_cat's arithmetic with K - 1
 // exponentials instead of K.  The largest predictor contributes exp(0), which pgb_exp returns as
@@ -86,9 +89,9 @@ template <int KT, int FAM, bool LIN>
 // (compiled for 3 workgroups per CU, i.e. <= 168 VGPRs: the K = 4 instance sits right at that edge, and one
 //  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5;
 //  the probit instance -- cfg4's dominant kernel -- for 5: <= 96 VGPRs, where a 97th costs it a fifth)
-__global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : 3)
+__global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : (KT >= 2 && !LIN) ? PGB_LLK_WGS : 3)
 void k_loglik(const Dev* __restrict__ Sp, int par) {
-  const Dev& S = *Sp;
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
   typedef LJobT<MK, LIN> LJob;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
                                                               const Job* __restrict__ jobs_all) {
   // cmds / jobs_all repeat S.cmd / S.jobs as kernel arguments: their first loads then do not wait
   // for the load of the argument block S itself (one dependent memory round trip less)
-  const Dev& S = *Sp;
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   constexpr int NRED = LIN ? 15 : 7;  // values reduced per particle
   __shared__ long long s_red[MAXP * NRED * 4];
   __shared__ double s_lv[2][256];

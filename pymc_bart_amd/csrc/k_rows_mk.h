@@ -3,7 +3,7 @@
 // K-vector leaves (K > 1, Categorical-softmax): the same slot logic as k_rows with sum_trees, leaf
 // values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
 // the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
-__device__ __forceinline__ double loglik_any(const Dev& S, double y, const double* mu) {
+__device__ __forceinline__ double loglik_any(const DevG& S, double y, const double* mu) {
   return pgb_loglik(S.family, S.K, y, mu);
 }
 
@@ -16,7 +16,7 @@ __device__ __forceinline__ double loglik_any(const Dev& S, double y, const doubl
 // (the compile-time-K instances are held to 4 workgroups per CU, <= 128 VGPRs: K = 4 sits at that edge)
 template <int KT, bool LIN, bool F32 = false>
 __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 1) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
-  const Dev& S = *Sp;
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops
   __shared__ long long s_red[MAXP * (1 + 2 * KB) * 4];

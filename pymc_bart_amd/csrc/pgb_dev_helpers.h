@@ -1,14 +1,11 @@
 // pgb_dev_helpers.h -- part of pgbart_hip.hip (not a standalone header): wave / workgroup primitives and the label -> value table builders.
-// ---- global address space ------------------------------------------------------------------------------
-// A pointer LOADED from memory (every array of the argument block `Dev`) is a generic pointer to the compiler,
-// and a load through it is a FLAT instruction: it counts in lgkmcnt as well as vmcnt, so every wait for an LDS
-// read (`s_waitcnt lgkmcnt(0)`) also drains the global loads in flight -- the software pipelines of the row
-// passes were serialised by their own LDS job records.  as_global() states what the host knows (these arrays
-// live in HBM): loads become global_load (vmcnt only, SGPR base + VGPR offset).
-template <typename T>
-using gptr = T __attribute__((address_space(1)))*;
+// ---- global address space (see DevG in pgb_dev_types.h) ----------------------------------------------------
 template <typename T>
 __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)p; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+__device__ __forceinline__ gptr<T> as_global(gptr<T> p) { return p; }
+#endif
 template <typename U, typename T>
 __device__ __forceinline__ gptr<U> gcast(gptr<T> p) { return (gptr<U>)p; }
 // (HIP's double2 / float4 are classes whose copy constructors take generic references: wide loads and stores

@@ -133,7 +133,25 @@ struct Ctrl {
   long long done_pub;
 };
 
-struct Dev {  // kernel argument block (by value)
+// Global address space.  A pointer LOADED from memory (every array of the argument block) is a generic pointer
+// to the compiler, and a load through it is a FLAT instruction: it counts in lgkmcnt as well as vmcnt, so every
+// wait for an LDS read (`s_waitcnt lgkmcnt(0)`) also drains the global loads and stores in flight.  The
+// kernels therefore read the block through `DevG`, the same layout with its pointers typed as global
+// (address space 1) in the DEVICE pass -- loads become global_load (vmcnt only, SGPR base + VGPR offset),
+// atomics global_atomic -- while the host fills in `Dev` with ordinary pointers.  (In the host pass of the
+// translation unit the alias is a plain pointer, so that kernel bodies type-check there too.)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+using gptr = T __attribute__((address_space(1)))*;
+#else
+template <typename T>
+using gptr = T*;
+#endif
+template <bool G, typename T>
+using dptr = typename std::conditional<G, gptr<T>, T*>::type;
+
+template <bool G>
+struct DevT {  // kernel argument block (by value)
   long long n, n_pad;
   int32_t p, m, P, nchunks;
   int32_t batch_tune, batch_draw;
@@ -143,70 +161,73 @@ struct Dev {  // kernel argument block (by value)
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;
-  const double* prior_leaf;  // [PGB_MAX_DEPTH] device copy
-  const double* XT;  // [p][n_pad]
-  const float* XT32; // [p][n_pad] float32 shadow of XT (null unless the matrix is larger than the Infinity Cache)
-  const double* y;   // [n_pad]
-  const double* off; // [K][n_pad] offset of the linear predictor (per-row families; 0 by default)
-  double* st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
-  double2* pack;     // [n_pad] {sum_trees, y - noi}
-  double* rs_mean;
-  double* rs_m2;
-  uint8_t* tree_lid;  // [m][n_pad]
-  uint8_t* lid;       // [NGEN][MAXP][n_pad]
-  uint16_t* cc;       // [CC_ROUNDS*MAXP*2][nchunks]
-  DTree* trees;       // [m]
-  DPart* parts;       // [2][P]
-  Job* jobs;          // [2][P]
-  Acc* acc;           // [2][P][ACC_SLOTS]
-  AccL* accl;         // [2][P][LL_SLOTS]   (non-Normal families)
-  JobL* jobl;         // [2][P]   (non-Normal families)
-  InitAcc* initacc;   // [2][IA_SLOTS]
-  Cmd* cmd;           // [2]
-  Ctrl* ctrl;         // [2]
-  unsigned long long* counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
-  int32_t* vi;        // [p]
-  long long* alpha;   // [2][p] integer split weights (pgb_alpha_init + counts * alpha_unit)
-  long long* cdfS;    // [2][p] their prefix sums, as used by the sampler
+  dptr<G, const double> prior_leaf;  // [PGB_MAX_DEPTH] device copy
+  dptr<G, const double> XT;  // [p][n_pad]
+  dptr<G, const float> XT32; // [p][n_pad] float32 shadow of XT (null unless the matrix is larger than the Infinity Cache)
+  dptr<G, const double> y;   // [n_pad]
+  dptr<G, const double> off; // [K][n_pad] offset of the linear predictor (per-row families; 0 by default)
+  dptr<G, double> st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)
+  dptr<G, double2> pack;     // [n_pad] {sum_trees, y - noi}
+  dptr<G, double> rs_mean;
+  dptr<G, double> rs_m2;
+  dptr<G, uint8_t> tree_lid;  // [m][n_pad]
+  dptr<G, uint8_t> lid;       // [NGEN][MAXP][n_pad]
+  dptr<G, uint16_t> cc;       // [CC_ROUNDS*MAXP*2][nchunks]
+  dptr<G, DTree> trees;       // [m]
+  dptr<G, DPart> parts;       // [2][P]
+  dptr<G, Job> jobs;          // [2][P]
+  dptr<G, Acc> acc;           // [2][P][ACC_SLOTS]
+  dptr<G, AccL> accl;         // [2][P][LL_SLOTS]   (non-Normal families)
+  dptr<G, JobL> jobl;         // [2][P]   (non-Normal families)
+  dptr<G, InitAcc> initacc;   // [2][IA_SLOTS]
+  dptr<G, Cmd> cmd;           // [2]
+  dptr<G, Ctrl> ctrl;         // [2]
+  dptr<G, unsigned long long> counters;  // particle_steps, tree_updates, rows_touched, rounds, sat, slots
+  dptr<G, int32_t> vi;        // [p]
+  dptr<G, long long> alpha;   // [2][p] integer split weights (pgb_alpha_init + counts * alpha_unit)
+  dptr<G, long long> cdfS;    // [2][p] their prefix sums, as used by the sampler
   long long alpha_unit;
   double max_prior;
-  const int32_t* rules;
-  const int32_t* col_nan;
+  dptr<G, const int32_t> rules;
+  dptr<G, const int32_t> col_nan;
   // ---- K-vector leaves (K > 1): output 0 uses the scalar fields, outputs 1..K-1 these arrays
-  double* packx;      // [KX][n_pad]            sum_trees of outputs 1.. (as of INIT, like pack.x)
-  double* pvx;        // [2][MAXP][MAXN][KX]    particle leaf values
-  long long* pqx;     // [2][MAXP][MAXN][KX]    particle node sums of sum_trees
-  double* tvx;        // [m][MAXN][KX]          accepted trees' leaf values
-  long long* accx;    // [2][MAXP][AX_SLOTS][AX_REC]  row-pass statistics: aL[k], aN[k] (copies, see AX_SLOTS)
-  long long* iax;     // [2][IA_SLOTS][2*KX]    INIT/FINAL statistics: A[k], QSTD[k]
-  double* lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
-  long long* jqx;     // [2][MAXP][KX]          per job: parent's node sums
-  double* jvx;        // [2][MAXP][KX]          per job: parent's leaf values
-  double* jzx;        // [2][MAXP][KX][2]       per job: leaf noise of the children, outputs 1..K-1 (drawn one slot ahead like Job::z0 / z1)
-  double* lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
+  dptr<G, double> packx;      // [KX][n_pad]            sum_trees of outputs 1.. (as of INIT, like pack.x)
+  dptr<G, double> pvx;        // [2][MAXP][MAXN][KX]    particle leaf values
+  dptr<G, long long> pqx;     // [2][MAXP][MAXN][KX]    particle node sums of sum_trees
+  dptr<G, double> tvx;        // [m][MAXN][KX]          accepted trees' leaf values
+  dptr<G, long long> accx;    // [2][MAXP][AX_SLOTS][AX_REC]  row-pass statistics: aL[k], aN[k] (copies, see AX_SLOTS)
+  dptr<G, long long> iax;     // [2][IA_SLOTS][2*KX]    INIT/FINAL statistics: A[k], QSTD[k]
+  dptr<G, double> lvx;        // [2][2][256][KX]        label->value tables: [par][0 new | 1 next]
+  dptr<G, long long> jqx;     // [2][MAXP][KX]          per job: parent's node sums
+  dptr<G, double> jvx;        // [2][MAXP][KX]          per job: parent's leaf values
+  dptr<G, double> jzx;        // [2][MAXP][KX][2]       per job: leaf noise of the children, outputs 1..K-1 (drawn one slot ahead like Job::z0 / z1)
+  dptr<G, double> lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
   // ---- linear response (Normal family, K = 1, continuous columns)
   int32_t response, has_off;  // has_off: an offset of the linear predictor is set (else the array is all 0)
   double lin_R, inv_R;
-  const int32_t* col_ex;  // [p] exponent bound of every column
-  LinP* plin;             // [2][MAXP][MAXN]  particle leaves
-  LinP* tlin;             // [m][MAXN]        accepted trees' leaves
-  LinP* lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
-  AccU* accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
+  dptr<G, const int32_t> col_ex;  // [p] exponent bound of every column
+  dptr<G, LinP> plin;             // [2][MAXP][MAXN]  particle leaves
+  dptr<G, LinP> tlin;             // [m][MAXN]        accepted trees' leaves
+  dptr<G, LinP> lvl;              // [2][2][256]      label -> LinP tables: [par][0 new | 1 next]
+  dptr<G, AccU> accu;             // [2][MAXP][ACC_PER]  row-pass sums (copies like acc)
   // ... K-vector leaves: one slope per output on the shared regressor; output 0 lives in LinP,
   // outputs 1..K-1 in arrays laid out like pvx / tvx / lvx / accx
-  double* psx;            // [2][MAXP][MAXN][KX]  particle leaf slopes
-  double* tsx;            // [m][MAXN][KX]        accepted trees' leaf slopes
-  double* lsx;            // [2][2][256][KX]      label -> slope tables: [par][0 new | 1 next]
-  long long* accux;       // [2][MAXP][AX_SLOTS][AX_REC]  row-pass sums of u st_k: left [k], right [KX + k]
+  dptr<G, double> psx;            // [2][MAXP][MAXN][KX]  particle leaf slopes
+  dptr<G, double> tsx;            // [m][MAXN][KX]        accepted trees' leaf slopes
+  dptr<G, double> lsx;            // [2][2][256][KX]      label -> slope tables: [par][0 new | 1 next]
+  dptr<G, long long> accux;       // [2][MAXP][AX_SLOTS][AX_REC]  row-pass sums of u st_k: left [k], right [KX + k]
   // callback family only (null otherwise): what k_loglik hands to the host instead of evaluating it --
   // per particle and row, the linear predictor and the side (0 left, 1 right, 2 dropped, 3 not in the leaf)
-  double* cb_mu;      // [MAXP][n_pad]
-  uint8_t* cb_side;   // [MAXP][n_pad]
+  dptr<G, double> cb_mu;      // [MAXP][n_pad]
+  dptr<G, uint8_t> cb_side;   // [MAXP][n_pad]
   // profiling only (null otherwise): [PROF_RING][PROF_BLOCKS][2] device-clock stamps of the row pass
-  long long* prof_stamps;
-  unsigned long long* host_flag;  // pinned host word: number of completed asteps
-  long long* trace;               // PGB_TRACE builds only: [TRACE_SLOTS][TRACE_W] wall_clock64 stamps
+  dptr<G, long long> prof_stamps;
+  dptr<G, unsigned long long> host_flag;  // pinned host word: number of completed asteps
+  dptr<G, long long> trace;               // PGB_TRACE builds only: [TRACE_SLOTS][TRACE_W] wall_clock64 stamps
 };
+typedef DevT<false> Dev;   // as the host fills it in and the kernels receive it
+typedef DevT<true> DevG;   // as the kernels read it (see above)
+static_assert(sizeof(Dev) == sizeof(DevG), "the two views of the argument block must coincide");
 
 #ifdef PGB_TRACE
 #define TRACE_SLOTS 4096

@@ -2,7 +2,7 @@
 // ------------------------------------------------------------------ k_begin
 __global__ void k_begin(const Dev* __restrict__ Sp, int par, int tune, int n_steps, double inv_sigma2, double lik_param2,
                         int set_sigma) {
-  const Dev& S = *Sp;
+  const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   Ctrl* c = &S.ctrl[par];
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     c->tune = tune;
@@ -31,7 +31,7 @@ struct ChildVals {
   long long aL, aR;
   double vL, vR;
 };
-__device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cnt, long long p_q_st,
+__device__ __forceinline__ ChildVals child_values(const DevG& S, int rule, int cnt, long long p_q_st,
                                                   double p_value, unsigned long long a_cnts, long long a_aL,
                                                   long long a_aN, double z0, double z1, double leaf_sd) {
   ChildVals c;
@@ -57,14 +57,14 @@ __device__ __forceinline__ ChildVals child_values(const Dev& S, int rule, int cn
 #define KXMAX (PGB_MAX_OUTPUTS - 1)
 // leaf_sd of extension output k (0-based), with the pending update of a FINAL pass resolved the
 // same way as for output 0
-__device__ __forceinline__ double leaf_sd_x(const Dev& S, const Ctrl& c, int ctrl_par, int acc_par, int k) {
+__device__ __forceinline__ double leaf_sd_x(const DevG& S, const Ctrl& c, int ctrl_par, int acc_par, int k) {
   if (!(c.pend_leafsd && c.pend_iter > 2)) return S.lsdx[ctrl_par * KXMAX + k];
   const int KX = S.K - 1;
   long long q = 0;
   for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + KX + k];
   return ((double)q * S.sc.inv_c1) / (double)S.n;
 }
-__device__ __forceinline__ long long root_A_x(const Dev& S, int acc_par, int k) {
+__device__ __forceinline__ long long root_A_x(const DevG& S, int acc_par, int k) {
   const int KX = S.K - 1;
   long long q = 0;
   for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + k];
@@ -80,7 +80,7 @@ struct ChildX {
 // z0 / z1: the Box-Muller pair addressed by (iter, round, particle, LEAF, sub = k + 1), drawn one slot ahead by
 // the control kernel that proposed the split (Dev::jzx) -- the consumers (the next control kernel and this
 // slot's likelihood pass, in EVERY workgroup's prologue) used to redo Philox + log + sqrt + sincos per output.
-__device__ __forceinline__ ChildX child_values_x(const Dev& S, int ok, int cL, int cR, long long aLk,
+__device__ __forceinline__ ChildX child_values_x(const DevG& S, int ok, int cL, int cR, long long aLk,
                                                  long long aNk, long long pq, double pv, double z0, double z1,
                                                  double lsd) {
   ChildX c;
