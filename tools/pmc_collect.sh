@@ -1,25 +1,29 @@
 #!/bin/bash
-# HBM traffic (cfg2) / VALU instruction counts (cfg4, cfg5) of the hot kernels, per launch, from separate
-# rocprofv3 --pmc passes (counters only: no trace domains), written to profiles/r03_pmc_<workload>.json,
-# the file bench.py reads `roofline.traffic` from.  Run on the GPU box from the repo root.
+# HBM traffic / VALU instruction counts of the hot kernels, per launch, from separate rocprofv3 --pmc passes
+# (counters only: no trace domains), written to gpurun_out/r03_pmc_<workload>.json -- copy it to profiles/,
+# where bench.py reads `roofline.traffic` / the instruction counts from.  Run on the GPU box from the repo root.
+# The run under the counters follows the HEADLINE protocol (100 tune=1 asteps of burn-in, then tune=0); the
+# averages are taken over the LAST 15 % of each kernel's dispatches, i.e. the steady-state tune=0 part.
+# FETCH_SIZE x2 / WRITE_SIZE x1: calibrated on known byte counts for every stream width the passes use
+# (tools/microbench/fetch_calib.*, profiles/r03_fetch_calibration.json).
 # usage: tools/pmc_collect.sh cfg2|cfg4|cfg5
 W=${1:-cfg2}; R=$PWD; cd /tmp; export TMPDIR=/tmp
-if [ $W = cfg2 ]; then A="--steps 10 --warmup 2 --burnin 30 --repeats 1 --no-workloads"; else A="--workload $W --steps 3 --warmup 1 --burnin 3 --repeats 1"; fi
-A="$A --no-extras --no-cpu-baseline --no-roofline --no-multichain"
+if [ $W = cfg2 ]; then A="--steps 20 --warmup 5 --burnin 100 --repeats 2"; else A="--workload $W --steps 10 --warmup 2 --burnin 100 --repeats 2"; fi
+A="$A --no-extras --no-cpu-baseline --no-roofline --no-multichain --no-workloads"
 DIRS=""
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
   rm -rf /tmp/pmc_${W}_$C
   rocprofv3 --pmc $C -d /tmp/pmc_${W}_$C --output-format csv -- python3 $R/bench.py $A > /dev/null 2> /tmp/pmc_${W}_$C.err || tail -3 /tmp/pmc_${W}_$C.err
   DIRS="$DIRS /tmp/pmc_${W}_$C"
 done
-python3 $R/tools/pmc_summary.py $DIRS > /tmp/pmc_${W}.json
+python3 $R/tools/pmc_summary.py --tail 0.15 $DIRS > /tmp/pmc_${W}.json
 python3 - <<PY
 import json
 raw = json.load(open("/tmp/pmc_${W}.json"))
-out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged per launch by tools/pmc_summary.py)",
+out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged over the last 15 % of each kernel's dispatches by tools/pmc_summary.py --tail 0.15)",
        "workload": "$W",
-       "note": "FETCH_SIZE on gfx950 reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): corrected x2; WRITE_SIZE taken as reported (calibrated exact on k_transpose in round 1); units KB per launch as the counters report them; SQ_INSTS_VALU counts wave-instructions",
-       "raw": raw}
+       "note": "FETCH_SIZE on gfx950 counts a 128-B line fetched from the fabric as 64 B: x2 (exact to 4 digits for 1 / 4 / 16 / 32 B-per-lane streams, profiles/r03_fetch_calibration.json); WRITE_SIZE exact; units KB per launch as the counters report them; SQ_INSTS_VALU counts wave-instructions",
+       "raw": {k: v for k, v in raw.items() if k.startswith("k_")}}
 for k, v in raw.items():
     short = k.split("<")[0]
     f, w = v.get("FETCH_SIZE_avg_per_launch"), v.get("WRITE_SIZE_avg_per_launch")
