@@ -18,6 +18,21 @@
  *     Calls are stream-synchronous at return unless stated otherwise.
  *   - numerics follow include/pgbart_spec.h: results are a pure function of
  *     (settings, data, seed) and are bit-identical across conforming backends.
+ *
+ * Limits (compile-time sizes of device records; every violation is reported by pgb_create /
+ * pgb_set_data as PGB_E_INVALID or PGB_E_UNSUPPORTED with a message, never silently clamped).
+ * The reference bounds none of these (tests/test_bart.py:231 takes any num_particles,
+ * :117,155 any shape=(K, n)); upstream's defaults and tests sit far inside all of them.
+ *   num_particles        2 .. 64   (PGB_MAX_PARTICLES: one particle per lane of a wave64; the
+ *                                   resampling scan `pgb_scan64` is defined on 64 lanes)
+ *   n_outputs (K)        1 .. 8    (PGB_MAX_OUTPUTS; K = 2, 3, 4 have unrolled kernel instances)
+ *   nodes per tree       <= 255    (leaf labels are bytes; label 255 = dropped row); a tree that
+ *                                   would grow past it stops splitting (P ~ 0 under the prior)
+ *   tree depth           <= 64     (prior_leaf[64]; upstream cuts its table where P(leaf) >= 0.9999,
+ *                                   depth ~ 97 at alpha = 0.95, beta = 2: entries beyond 64 are 1)
+ *   SubsetSplit columns  integer category codes 0 .. 51 (the split value is a 52-bit mask in a double)
+ *   response linear/mix  ContinuousSplit columns only
+ *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory)
  */
 #ifndef PGBART_H
 #define PGBART_H

@@ -27,6 +27,9 @@ struct pgb_handle {
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;     // per allocation: payload size ...
   std::vector<char> alloc_persist;     // ... and whether a checkpoint carries it
+  std::vector<char> alloc_owned;       // ... and whether it is a hipMalloc of its own (else a piece of `slab`)
+  void* slab;                          // small records share one allocation (see dalloc_bytes)
+  size_t slab_used;
   long long slot;  // next slot index (parity = slot & 1)
   int st_cur, alpha_cur;  // mirrors of Ctrl::st_cur / alpha_cur at the last idle point
   int have_data, have_y;
@@ -100,16 +103,45 @@ static int join_async(pgb_handle* h) {
                                "checkpoint (pgb_checkpoint_load) or create a new sampler");                 \
   } while (0)
 
+// Device allocations.  The small records every slot touches first (control words, commands, job records,
+// split statistics, counters, split weights ...) are carved out of ONE slab: a dozen separate hipMallocs put
+// each of them on a page of its own, and the first loads of every (latency-bound) control kernel then paid a
+// TLB miss each -- most of the ~1.7 us a fresh kernel waited for its first data.
+#define SLAB_BYTES ((size_t)2 << 20)
+#define SLAB_ITEM_MAX ((size_t)192 << 10)
+static int dalloc_bytes(pgb_handle* h, void** p, size_t bytes) {
+  static const bool use_slab = !(getenv("PGB_NO_SLAB") && atoi(getenv("PGB_NO_SLAB")));
+  void* q = nullptr;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (use_slab && need <= SLAB_ITEM_MAX) {
+    if (!h->slab) {
+      hipError_t e = hipMalloc(&h->slab, SLAB_BYTES);
+      if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+      h->slab_used = 0;
+    }
+    if (h->slab_used + need <= SLAB_BYTES) {
+      q = (char*)h->slab + h->slab_used;
+      h->slab_used += need;
+      h->alloc_owned.push_back(0);
+    }
+  }
+  if (!q) {
+    hipError_t e = hipMalloc(&q, bytes + 256);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+    h->alloc_owned.push_back(1);
+  }
+  h->allocs.push_back(q);
+  h->alloc_bytes.push_back(bytes);
+  h->alloc_persist.push_back(1);
+  *p = q;
+  return PGB_OK;
+}
 template <typename T>
 static int dalloc(pgb_handle* h, T** p, size_t count) {
   void* q = nullptr;
-  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
-  if (e != hipSuccess) return fail_hip(e, "hipMalloc");
-  h->allocs.push_back(q);
-  h->alloc_bytes.push_back(count * sizeof(T));
-  h->alloc_persist.push_back(1);
-  *p = (T*)q;
-  return PGB_OK;
+  const int rc = dalloc_bytes(h, &q, count * sizeof(T));
+  if (rc == PGB_OK) *p = (T*)q;
+  return rc;
 }
 // data, per-tree scratch and pointer tables are rebuilt by create/set_data: not part of a checkpoint
 static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
@@ -181,6 +213,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->s = *s;
   h->stream = (hipStream_t)stream;
   h->stream_out = nullptr;
+  h->slab = nullptr;
+  h->slab_used = 0;
   h->slot = 0;
   h->has_subset = 0;
   h->rows_grid = 1024;
@@ -459,7 +493,9 @@ extern "C" int pgb_destroy(pgb_handle* h) {
   if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
   if (h->flag) (void)hipHostFree((void*)h->flag);
   if (h->out_host) (void)hipHostFree((void*)h->out_host);
-  for (void* p : h->allocs) (void)hipFree(p);
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (h->alloc_owned[i]) (void)hipFree(h->allocs[i]);
+  if (h->slab) (void)hipFree(h->slab);
   delete h;
   return PGB_OK;
 }

@@ -557,3 +557,75 @@ def test_prediction_rejects_a_matrix_narrower_than_the_trees(hip):
     assert _sample_posterior(s, X, np.random.default_rng(0), size=2).shape == (2, 400, 1)
     with pytest.raises(_abi.PGBError, match="column"):
         _sample_posterior(s, X[:, :2], np.random.default_rng(0), size=2)
+
+
+def test_packed_tree_record_on_gpu_equals_the_array_export(hip, oracle):
+    """``pgb_export_trees_packed`` on the HIP backend: the record served from the mapped block of the last
+    ``pgb_step_host`` and the one fetched from the device (after ``pgb_step``) both equal the array export,
+    and equal the oracle's record byte for byte."""
+    import ctypes as C
+
+    from pymc_bart_amd import _abi
+    from pymc_bart_amd.trees import TreeArrays
+
+    c = make_case("cfg1_friedman")
+    st = PyBartSettings.from_data(c["X"], c["Y"], m=c["m"], num_particles=c["P"], seed=c["seed"])
+    rules, prior = np.zeros(c["X"].shape[1], np.int32), np.ones(c["X"].shape[1])
+    g = PySampler(st, c["X"], c["Y"], rules, prior, backend=hip)
+    o = PySampler(st, c["X"], c["Y"], rules, prior, backend=oracle)
+    for s_ in (g, o):
+        s_.set_likelihood([1.0])
+
+    def arrays(s_, which):
+        lib = s_.backend.lib
+        cc = _abi.TreeArraysC()
+        lib.check(lib.lib.pgb_export_trees(s_._h, which, C.byref(cc)), "size")
+        ta = TreeArrays.empty(cc.n_trees, cc.total_nodes, cc.n_outputs)
+        c2 = ta.as_c()
+        lib.check(lib.lib.pgb_export_trees(s_._h, which, C.byref(c2)), "fill")
+        return ta
+
+    for it in range(6):
+        fetch = it % 2 == 0           # host-output step (mapped block) / device-output step (fetched)
+        g.step(it < 3, fetch=fetch)
+        o.step(it < 3, fetch=fetch)
+        for which in (0, 1):
+            pg, po, ag = g.export_trees(which), o.export_trees(which), arrays(g, which)
+            assert pg.raw == po.raw
+            for f in ("tree_id", "node_off", "var", "split", "left", "right", "count", "value"):
+                assert np.array_equal(getattr(pg, f), getattr(ag, f)), (it, which, f)
+
+
+def test_failed_callback_poisons_the_gpu_handle_until_a_checkpoint_is_loaded(hip):
+    """include/pgbart.h: a log-likelihood callback that fails abandons the astep half-way; every later step /
+    export on that handle is refused (PGB_E_STATE) until an idle image is restored, after which the chain is the
+    one that never saw the failure."""
+    from pymc_bart_amd import _abi
+
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(3000, 3))
+    Y = X[:, 0] + rng.normal(0, 0.3, 3000)
+    st = PyBartSettings.from_data(X, Y, m=5, num_particles=6, seed=2, family="callback")
+    good = lambda y, mu: -0.5 * ((y - mu) / 0.3) ** 2  # noqa: E731
+    s = PySampler(st, X, Y, np.zeros(3, np.int32), np.ones(3), backend=hip)
+    t = PySampler(st, X, Y, np.zeros(3, np.int32), np.ones(3), backend=hip)
+    for q in (s, t):
+        q.set_loglik_callback(good)
+        q.step(True)
+    image = s.checkpoint()
+
+    def bad(y, mu):
+        raise FloatingPointError("logp overflowed")
+
+    s.set_loglik_callback(bad)
+    with pytest.raises(_abi.PGBError, match="logp overflowed"):
+        s.step(True)
+    s.set_loglik_callback(good)
+    for call in (lambda: s.step(True), lambda: s.step_async(True, 1), lambda: s.export_trees(0)):
+        with pytest.raises(_abi.PGBError, match="abandoned half-way"):
+            call()
+    s.restore(image)
+    for _ in range(3):
+        a, _ = s.step(True)
+        b, _ = t.step(True)
+        assert np.array_equal(a, b)
