@@ -541,14 +541,13 @@ def main():
         def extra_chains(count, first_chain):
             """More independent chains on this GPU, each on its own HIP stream."""
             out = []
-            for c in range(count):
-                with torch.cuda.stream(torch.cuda.Stream()):
-                    stc = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"],
-                                                   seed=seed + 1000 * (first_chain + c), family=w["family"],
-                                                   n_outputs=w.get("K", 1), response=args.response)
-                    sc = PySampler(stc, step._X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
-                    sc.set_likelihood([1.0] if w["family"] == "normal" else [])
-                    out.append(sc)
+            for c in range(count):  # (every sampler takes a stream of its own: TorchHipMemory.sampler_stream)
+                stc = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"],
+                                               seed=seed + 1000 * (first_chain + c), family=w["family"],
+                                               n_outputs=w.get("K", 1), response=args.response)
+                sc = PySampler(stc, step._X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
+                sc.set_likelihood([1.0] if w["family"] == "normal" else [])
+                out.append(sc)
             torch.cuda.synchronize()
             return out
 

@@ -171,6 +171,14 @@ int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi
 int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host_out, int32_t* vi_counts_host_out,
                   pgb_counters* counters_out);
 
+/* Optional: a second stream (a hipStream_t of the sampler's device, owned by the caller) on which the results of
+ * pgb_step_host leave the device -- the export kernel and the copy of sum_trees then run past the few idle slots
+ * still queued on the sampler's own stream instead of behind them.  NULL (the default): the sampler's stream.
+ * HIP multiplexes streams onto 4 hardware queues; give every sampler of a process the SAME output stream (an
+ * otherwise idle one) so that it does not take a queue away from a concurrently running chain.  Ignored by CPU
+ * backends.                                                                                                   */
+int pgb_set_output_stream(pgb_handle* h, void* stream);
+
 /* Asynchronous variant for throughput runs: pgb_step_async starts `n_steps` asteps and RETURNS
  * while they run (a worker thread owned by the handle feeds the device state machine; CPU backends
  * may run them before returning); pgb_sync waits for them, reports their error if any and fills

@@ -845,6 +845,12 @@ static int o_step(pgb_handle* h, int tune) {
   return PGB_OK;
 }
 
+int pgb_set_output_stream(pgb_handle* h, void* stream) { /* no streams on this backend */
+  (void)stream;
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  return PGB_OK;
+}
+
 int pgb_set_loglik_callback(pgb_handle* h, pgb_loglik_fn fn, void* ctx) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   if (h->s.family != PGB_FAMILY_CALLBACK) return fail(PGB_E_INVALID, "the sampler was not created with the callback family");

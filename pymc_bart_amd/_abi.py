@@ -64,6 +64,7 @@ SYMBOLS = (
     "pgb_set_offset",
     "pgb_set_likelihood",
     "pgb_set_loglik_callback",
+    "pgb_set_output_stream",
     "pgb_step",
     "pgb_step_host",
     "pgb_step_async",
@@ -175,6 +176,7 @@ class PGBLibrary:
         lib.pgb_set_offset.argtypes = [vp, vp]
         lib.pgb_set_likelihood.argtypes = [vp, vp, C.c_int32]
         lib.pgb_set_loglik_callback.argtypes = [vp, LOGLIK_FN, vp]
+        lib.pgb_set_output_stream.argtypes = [vp, vp]
         lib.pgb_step.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_host.argtypes = [vp, C.c_int32, vp, vp, C.POINTER(Counters)]
         lib.pgb_step_async.argtypes = [vp, C.c_int32, C.c_int32]

@@ -31,6 +31,48 @@ class TorchHipMemory:
     def stream_ptr(self) -> int:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    _queue_pad: dict = {}
+
+    @classmethod
+    def _prime_queues(cls, torch, device):
+        """HIP multiplexes the streams of a process onto 4 hardware queues: a stream that is used for the first
+        time gets a queue of its own while fewer than 4 exist and one of the least-referenced queues afterwards --
+        and two BUSY chains on one queue run at half speed (four concurrent chains on one GPU: 3.9 M instead of
+        5.7 M particle-steps/s; `tools/multichain_probe.py`, `profiles/r03_experiments.md`).  With 1-3 queues
+        taken when the chains arrive (the legacy default stream alone is enough) the fourth chain lands on another
+        chain's queue.  The first sampler of a process therefore makes the count even before its own stream is
+        used: it touches the default stream and three padding streams (kept alive, idle), after which every run
+        of four new chain streams is spread over the four queues.  The first padding stream doubles as the
+        output stream of every sampler (`pgb_set_output_stream`), so that one takes no queue of its own.
+        Best effort: streams the application itself has used are not known here."""
+        key = str(device)
+        if key not in cls._queue_pad:
+            pads = []
+            torch.zeros(1, device=device)
+            for _ in range(3):
+                st = torch.cuda.Stream(device)
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=device)
+                pads.append(st)
+            torch.cuda.synchronize(device)
+            cls._queue_pad[key] = pads
+        return cls._queue_pad[key]
+
+    def sampler_stream(self):
+        """The HIP stream a new sampler enqueues its slots on: the caller's current stream -- unless that is the
+        legacy default stream, which synchronises with every other stream of the device: then a stream of the
+        sampler's own, after :meth:`_prime_queues`.  Every entry point of the library is synchronous at return,
+        so the caller's own stream ordering is not involved.  Returns the torch stream (keep it alive)."""
+        self._prime_queues(self.torch, self.device)
+        cur = self.torch.cuda.current_stream(self.device)
+        if int(cur.cuda_stream) == 0:
+            return self.torch.cuda.Stream(self.device)
+        return cur
+
+    def output_stream(self):
+        """The stream on which the results of `pgb_step_host` leave the device (shared by all samplers)."""
+        return self._prime_queues(self.torch, self.device)[0]
+
     def from_host(self, arr: np.ndarray):
         t = self.torch.from_numpy(np.ascontiguousarray(arr))
         return t.to(self.device, non_blocking=False)

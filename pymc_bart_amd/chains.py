@@ -77,16 +77,13 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
     produces when run alone (``tests/test_parity_gpu.py``)."""
     import threading
 
-    import torch
-
     out: list = [None] * chains
     errs: list = []
 
     def work(c: int) -> None:
         try:
-            with torch.cuda.stream(torch.cuda.Stream()):
-                out[c] = sample_chain(op, tune, draws, chain=c, **kw)
-                torch.cuda.current_stream().synchronize()
+            # (each chain's sampler takes a stream of its own: TorchHipMemory.sampler_stream)
+            out[c] = sample_chain(op, tune, draws, chain=c, **kw)
         except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
             errs.append(e)
 

@@ -1,6 +1,7 @@
 // pgb_host.h -- part of pgbart_hip.hip (not a standalone header): host side: handles, the C ABI of include/pgbart.h, slot enqueueing.
 // ------------------------------------------------------------------ host side
 enum { PK_CTRL = 0, PK_ROWS = 1, PK_LL = 2, PK_COUNT = 3 };
+static std::atomic<int> g_live_handles{0};  // samplers alive in this process (see feed_until_flag)
 static thread_local char g_err[512];
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
@@ -210,6 +211,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     return PGB_E_DEVICE;
   }
   pgb_handle* h = new pgb_handle();
+  g_live_handles.fetch_add(1);
   h->s = *s;
   h->stream = (hipStream_t)stream;
   h->stream_out = nullptr;
@@ -390,7 +392,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     h->flag[0] = 0;  // asteps whose last tree has been accepted (its FINAL row pass may still be running)
     h->flag[1] = 0;  // asteps that are complete on the device (published by the first idle slot after them)
     h->flag[2] = 0;  // slots whose control kernel has started (the credit the host enqueues against)
-    HC(hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
+    // (h->stream_out: see pgb_set_output_stream)
     void* dp = nullptr;
     HC(hipHostGetDevicePointer(&dp, hp, 0));
     d.host_flag = (unsigned long long*)dp;
@@ -490,12 +492,12 @@ extern "C" int pgb_destroy(pgb_handle* h) {
   if (h->worker.joinable()) h->worker.join();
   for (int k = 0; k < PK_COUNT; ++k)
     for (hipEvent_t e : h->ev[k]) (void)hipEventDestroy(e);
-  if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
   if (h->flag) (void)hipHostFree((void*)h->flag);
   if (h->out_host) (void)hipHostFree((void*)h->out_host);
   for (size_t i = 0; i < h->allocs.size(); ++i)
     if (h->alloc_owned[i]) (void)hipFree(h->allocs[i]);
   if (h->slab) (void)hipFree(h->slab);
+  g_live_handles.fetch_sub(1);
   delete h;
   return PGB_OK;
 }
@@ -836,6 +838,7 @@ static int callback_host_phase(pgb_handle* h, int par) {
 // bundles: the throttle costs the device nothing and the host one read of pinned memory.
 #define FEED_AHEAD 24
 #define FEED_MIN 6
+#define FEED_RUN 8
 static int feed_until_flag(pgb_handle* h, int n_steps) {
   Dev& d = h->d;
   const long long start = h->slot;
@@ -869,12 +872,21 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
     expect_end = start + (long long)(e > 1.0 ? e : 1.0);
   }
   long long idle_polls = 0;
+  int refill = 0;
   while (*h->flag < (unsigned long long)h->steps_target) {
     const long long executed = (long long)h->flag[2];
     long long limit = executed + feed_ahead;
     if (limit > expect_end) limit = expect_end;
     if (limit < executed + feed_min) limit = executed + feed_min;
-    if (h->slot < limit) {
+    // far from the expected end the queue is topped up in runs of FEED_RUN slots (several chains share the
+    // runtime's launch path: slot-by-slot refills of four chains at once cost them 30 % of their aggregate);
+    // near it, slot by slot
+    if (refill == 0 && h->slot < limit) {
+      const bool far = limit == executed + feed_ahead;
+      if (!far || h->slot - executed <= feed_ahead - FEED_RUN) refill = far ? FEED_RUN : 1;
+    }
+    if (refill > 0 && h->slot < limit) {
+      refill -= 1;
       if ((rc = enqueue_slots(h, 1)) != PGB_OK) return rc;
       if (h->slot > cap) {
         h->poisoned = 1;
@@ -882,7 +894,11 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
       }
       idle_polls = 0;
     } else {
+      refill = 0;
       for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+      // several chains feed their own streams from their own threads (chains.sample_chains, bench.py's
+      // concurrent chains): a waiting feeder gives its core away instead of spinning against the others
+      if (g_live_handles.load(std::memory_order_relaxed) > 1) sched_yield();
       // a device that stops publishing progress (lost GPU, a kernel that faulted) ends the call, not the process
       if ((++idle_polls & 0xFFFF) == 0) {
         if ((long long)h->flag[2] != executed) {
@@ -965,6 +981,13 @@ static int fetch_counters(pgb_handle* h, pgb_counters* out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   counters_from(h, c);
   if (out) *out = h->ctr;
+  return PGB_OK;
+}
+
+extern "C" int pgb_set_output_stream(pgb_handle* h, void* stream) {
+  if (!h) return fail(PGB_E_INVALID, "null handle");
+  JOIN_ASYNC(h);
+  h->stream_out = (hipStream_t)stream;  // owned by the caller
   return PGB_OK;
 }
 

@@ -32,6 +32,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <sched.h>
 #include <thread>
 #include <type_traits>
 #include <vector>

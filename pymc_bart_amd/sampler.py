@@ -173,7 +173,13 @@ class PySampler:
         lib, mem = self.backend.lib, self.backend.mem
         self._h = C.c_void_p()
         cs = settings.as_c()
-        lib.check(lib.lib.pgb_create(C.byref(cs), mem.stream_ptr, C.byref(self._h)), "pgb_create")
+        # (device backends: a stream object to keep alive; the CPU oracle has none)
+        self._stream = mem.sampler_stream() if hasattr(mem, "sampler_stream") else None
+        stream_ptr = int(self._stream.cuda_stream) if self._stream is not None else mem.stream_ptr
+        lib.check(lib.lib.pgb_create(C.byref(cs), stream_ptr, C.byref(self._h)), "pgb_create")
+        if hasattr(mem, "output_stream"):
+            self._out_stream = mem.output_stream()
+            lib.check(lib.lib.pgb_set_output_stream(self._h, int(self._out_stream.cuda_stream)), "pgb_set_output_stream")
         X = np.ascontiguousarray(X, dtype=np.float64)
         self._rules = np.ascontiguousarray(rules, dtype=np.int32)
         prior = np.ascontiguousarray(split_prior, dtype=np.float64)
