@@ -229,6 +229,10 @@ class PySampler:
 
     # -- likelihood parameters at the current point -------------------------------
     def set_likelihood(self, params) -> None:
+        key = tuple(params) if isinstance(params, (list, tuple)) else None
+        if key is not None and key == getattr(self, "_lik_key", None):
+            return  # unchanged since the last call (sigma fixed, parameter-free families): nothing to send
+        self._lik_key = key
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(params, np.float64)))
         keep = np.zeros(1) if a.size == 0 else a  # a valid pointer even for parameter-free families
         lib = self.backend.lib
@@ -369,6 +373,7 @@ class PySampler:
         lib = self.backend.lib
         buf = np.frombuffer(blob, np.uint8)
         lib.check(lib.lib.pgb_checkpoint_load(self._h, buf.ctypes.data, buf.size), "pgb_checkpoint_load")
+        self._lik_key = None  # the image carries its own likelihood parameters
 
     def profile(self, enable: bool) -> tuple[float, int]:
         lib = self.backend.lib
