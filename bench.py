@@ -711,6 +711,10 @@ def main():
         cpu = cpu_baseline(wname, wkw, seed, args.cpu_budget, response=args.response)
         line["cpu_baseline"] = cpu
         line["speedup_vs_cpu_baseline"] = line["value"] / cpu["value"]
+        # (the CPU chain is younger -- 10 tune asteps of burn-in, not 100 -- and touches more rows per
+        #  particle-step; in rows touched per second the ratio is the fairer one: round-2 VERDICT, weak #8)
+        line["speedup_vs_cpu_rows_touched_per_s"] = (line["tree_updates_per_s"] * line["rows_touched_per_tree"]
+                                                     / cpu["rows_touched_per_s"])
         if "all_cores" in cpu:
             line["speedup_vs_cpu_all_cores"] = line["value"] / cpu["all_cores"]["value"]
 

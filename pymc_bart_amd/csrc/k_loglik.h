@@ -113,6 +113,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   __shared__ double s_lnv[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
   __shared__ double s_ly[DENSE && !YBIT ? BT / 64 : 1][DENSE && !YBIT ? LL_DENSE_MAX : 1];
   __shared__ uint8_t s_lfl[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
+  constexpr bool MKPASS = KT >= 2 && !LIN;  // K = 2, 3, 4 with constant leaves: the pass loop (see below)
+  __shared__ uint16_t s_lrow[MKPASS ? BT / 64 : 1][MKPASS ? LL_DENSE_MAX : 1];
   // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
   // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
   // SLOWER at cfg4, 184 k / 171 k vs 223 k particle-steps/s: with a quarter of the lanes active the
@@ -317,11 +319,108 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
     uint32_t root_ids = 0;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
-      yv[e] = gy[base + e];
-      nv[e] = noi[base + e];
-      if constexpr (KT == 1)
-        if (S.has_off) nv[e] = nv[e] + goff[base + e];  // (adding the default 0.0 would give the same bits)
+      if constexpr (!MKPASS) {  // (the pass loop of the K = 2, 3, 4 instances fetches a row's inputs where it evaluates it)
+        yv[e] = gy[base + e];
+        nv[e] = noi[base + e];
+        if constexpr (KT == 1)
+          if (S.has_off) nv[e] = nv[e] + goff[base + e];  // (adding the default 0.0 would give the same bits)
+      }
       if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+    }
+    if constexpr (MKPASS) {
+      // K = 2, 3, 4, constant leaves: ONE evaluation site, visited once per PASS.  Plain: pass e evaluates the
+      // lane's own row e where it is in the split leaf (4 passes).  Dense (a wave with <= LL_DENSE_MAX of its 256
+      // rows in the leaf, i.e. every round but the first few): the wave lists {row in chunk, side} of its
+      // matching rows (ballot + mbcnt rank) and pass k evaluates list entries 64 k .. 64 k + 63 -- 1-2 passes
+      // instead of 4, none at all for a wave without a matching row.  A row's inputs (y, K predictors) are
+      // fetched where it is evaluated (L1 hits: the chunk was just read by this workgroup).
+      const long long cbase = (long long)chunk * CH;
+      for (int g = g0; g < g1; ++g) {
+        const LJob& lj = s_job[g];
+        const uint32_t ids = lj.src < 0 ? root_ids : *gcast<const uint32_t>(glid + lj.src + base);
+        const uint32_t nid = *gcast<const uint32_t>(newl + (size_t)lj.p * S.n_pad + base);
+        const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
+        double vLr[KB], vRr[KB];
+        vLr[0] = lj.vL;
+        vRr[0] = lj.vR;
+#pragma unroll
+        for (int k = 1; k < KB; ++k) {
+          vLr[k] = lj.vLx[k - 1];
+          vRr[k] = lj.vRx[k - 1];
+        }
+        unsigned long long mk[RPT];
+        int M = 0;
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+          mk[e] = __ballot(((ids >> (8 * e)) & 255u) == lab);
+          M += __popcll(mk[e]);
+        }
+        const bool dense = M <= LL_DENSE_MAX;  // (wave-uniform)
+        if (dense && M > 0) {
+          int off = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            if (((ids >> (8 * e)) & 255u) == lab) {
+              const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u));
+              const uint32_t nl = (nid >> (8 * e)) & 255u;
+              const uint32_t side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
+              s_lrow[w][pos] = (uint16_t)((uint32_t)(tid * RPT + e) | (side << 10));
+            }
+            off += __popcll(mk[e]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const int npass = dense ? (M + 63) >> 6 : RPT;
+        long long v0 = 0, v1 = 0, v2 = 0;
+        for (int ps = 0; ps < npass; ++ps) {
+          bool act;
+          int r, side;
+          if (dense) {
+            const int k = lane + 64 * ps;
+            act = k < M;
+            const uint32_t ent = act ? (uint32_t)s_lrow[w][k] : 0u;
+            r = (int)(ent & 1023u);
+            side = (int)(ent >> 10);
+          } else {
+            r = tid * RPT + ps;
+            act = ((ids >> (8 * ps)) & 255u) == lab;
+            const uint32_t nl = (nid >> (8 * ps)) & 255u;
+            side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
+          }
+          if (act) {
+            const long long row = cbase + r;
+            const double yr = gy[row];
+            double mu[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+              const double vk = side == 0 ? vLr[k] : side == 1 ? vRr[k] : 0.0;
+              const double nk = noi[(size_t)k * S.n_pad + row];
+              mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + row] : nk) + vk;
+            }
+            const double llv = S.family == PGB_FAMILY_CATEGORICAL ? loglik_cat_fast<KB>(yr, mu) : pgb_loglik(S.family, K, yr, mu);
+            const long long q = quant_ll(llv, cl);
+            if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
+          }
+        }
+        if (dense) __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
+        const int slot = (g - g0) * 3;
+        const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
+        if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+      }
+      __syncthreads();
+      for (int t = tid; t < (g1 - g0) * 3; t += BT) {
+        const int gi = t / 3, i = t % 3;
+        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        if (s != 0) {
+          AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
+          atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
+        }
+      }
+      __syncthreads();
+      continue;
     }
     if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
       for (int g = g0; g < g1; ++g) {
