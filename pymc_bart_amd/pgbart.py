@@ -299,7 +299,7 @@ class PGBART(_Base):
                  random_seed=None, chain=0, backend=None, range_exp=None):
         self._binding = None
         duck = vars is not None and len(vars) == 1 and getattr(vars[0], "owner", None) is None
-        if _HAVE_PYMC and not duck and likelihood is None:  # pragma: no cover - needs a real PyMC model
+        if _HAVE_PYMC and not duck and likelihood is None:
             # reference call convention (tests/test_bart.py:231-235): PGBART([rv], num_particles=...) inside
             # a model context; family, observed response and shared variables come from the model
             from ._pymc_bridge import bind_model
@@ -423,7 +423,7 @@ class PGBART(_Base):
         model): a Normal model fits ``observed - offset``, the per-row families add it to the linear
         predictor.
         """
-        if self._binding is not None:  # pragma: no cover - PyMC model: parameters and offset at the shared values
+        if self._binding is not None:  # PyMC model: parameters and offset at the shared values
             params, model_offset = self._binding.current()
             if model_offset is not None:
                 offset = model_offset
