@@ -164,8 +164,9 @@ int pgb_step(pgb_handle* h, int32_t tune, double* sum_trees_dev_out, int32_t* vi
              pgb_counters* counters_out);
 
 /* The same astep with HOST outputs -- what PGBART.astep hands back to PyMC's trace (SURVEY.md 8a
- * a2: sum_trees (K,n) device->host per step): sum_trees_host_out receives K*n doubles (pinned
- * memory makes the copy a single DMA; pageable memory works), vi / counters as in pgb_step.  The
+ * a2: sum_trees (K,n) device->host per step): sum_trees_host_out receives K*n doubles (device-accessible
+ * pinned memory -- hipHostMalloc -- is written by the export kernel itself; pageable memory works through one
+ * more copy), vi / counters as in pgb_step.  The
  * trees this step re-sampled are fetched in the same device->host transaction, so a following
  * pgb_export_trees(h, 0, ...) is served from host memory without touching the device.           */
 int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host_out, int32_t* vi_counts_host_out,
