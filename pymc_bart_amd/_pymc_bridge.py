@@ -181,7 +181,7 @@ def bind_model(vars, model=None, initial_point=None, compile_kwargs=None):  # no
     [P] Written against PyMC >= 5 / PyTensor from memory of the public API (``modelcontext``,
     ``make_shared_replacements``, ``join_nonshared_inputs``, ``model.replace_rvs_by_values``), the
     calls upstream's PGBART made to compile its log-likelihood.  PyMC is not installable on the build
-    box; ``tests/test_bind_model_double.py`` executes this function end to end against a double of
+    box; ``tests/test_pymc_bind_model_double.py`` executes this function end to end against a double of
     exactly these calls (closures for graphs) -- it proves the glue, not the real API's shapes."""
     from pymc.model import modelcontext
     from pymc.pytensorf import inputvars, join_nonshared_inputs, make_shared_replacements
