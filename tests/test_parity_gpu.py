@@ -629,3 +629,29 @@ def test_failed_callback_poisons_the_gpu_handle_until_a_checkpoint_is_loaded(hip
         a, _ = s.step(True)
         b, _ = t.step(True)
         assert np.array_equal(a, b)
+
+
+def test_pageable_and_pinned_output_buffers_receive_the_same_sum_trees(hip):
+    """`pgb_step_host` writes sum_trees straight into device-accessible pinned memory (what PySampler hands in) and
+    goes through a densify + DMA for a pageable buffer; with and without a second output stream.  Same chain, same
+    bits, whichever way the results leave the device."""
+    import ctypes as C
+
+    c = make_case("cfg1_friedman")
+    st = PyBartSettings.from_data(c["X"], c["Y"], m=c["m"], num_particles=c["P"], seed=c["seed"])
+    rules, prior = np.zeros(c["X"].shape[1], np.int32), np.ones(c["X"].shape[1])
+    a = PySampler(st, c["X"], c["Y"], rules, prior, backend=hip)      # pinned buffers, shared output stream
+    b = PySampler(st, c["X"], c["Y"], rules, prior, backend=hip)      # pageable buffer, results on the sampler's stream
+    lib = hip.lib
+    lib.check(lib.lib.pgb_set_output_stream(b._h, None), "pgb_set_output_stream")
+    for s_ in (a, b):
+        s_.set_likelihood([1.0])
+    n = c["X"].shape[0]
+    vi = np.zeros(c["X"].shape[1], np.int32)
+    for it in range(8):
+        ra, via = a.step(it < 4)
+        rb = np.empty(n)                                               # ordinary (pageable) memory
+        lib.check(lib.lib.pgb_step_host(b._h, int(it < 4), rb.ctypes.data, vi.ctypes.data, C.byref(b.counters)),
+                  "pgb_step_host")
+        assert np.array_equal(ra, rb) and np.array_equal(via, vi)
+        assert a.export_trees(0).raw == b.export_trees(0).raw

@@ -73,14 +73,19 @@ def fake_pymc(monkeypatch, oracle):
     import pymc_bart_amd.pgbart as pgb
     import pymc_bart_amd.sampler as smp
 
+    # (the module is re-executed under the double and its ORIGINAL namespace put back afterwards: test modules
+    #  that imported PGBART at collection keep the very class object `pymc_bart_amd.pgbart.PGBART` names, which
+    #  pickling checks -- whatever order the test files run in)
+    saved = {m: dict(m.__dict__) for m in (pgb, pymc_bart_amd)}
     importlib.reload(pgb)
     importlib.reload(pymc_bart_amd)
     monkeypatch.setattr(smp, "_DEFAULT_BACKEND", oracle)
     yield pm, pgb
     for name in ("pymc", "pymc.step_methods", "pymc.step_methods.arraystep", "pymc.step_methods.compound"):
         sys.modules.pop(name, None)
-    importlib.reload(pgb)
-    importlib.reload(pymc_bart_amd)
+    for m, ns in saved.items():
+        m.__dict__.clear()
+        m.__dict__.update(ns)
 
 
 def _two_term_data(seed=3415, n=30):
