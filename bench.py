@@ -369,6 +369,11 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
         name: {"pct": 100.0 * k["ms"] / tot_ms, "avg_us": k["ms"] * 1e3 / k["launches"],
                "launches": k["launches"], "workgroups": k["workgroups"]}
         for name, k in kern.items()}}
+    if "k_ctrl" in out["roofline_kernels"]:
+        # the control kernel has no bandwidth or FLOP roofline: one workgroup per particle walks a chain of
+        # dependent loads and scalar decisions (profiles/r03_experiments.md section 5: ~1.6 us until its first data,
+        # ~3.8 us of dependent work); its floor is latency, and it is the other half of a cfg2 slot
+        out["roofline_kernels"]["k_ctrl"]["bound"] = "latency (serial control: one workgroup per particle)"
     pmc, pmc_src = load_pmc(wname) if default_cfg else ({}, None)
     ms_rows, launches = prof["ms_rows"], prof["launches"]
     tu, rt, parts = prof["tree_updates"], prof["rows_touched"], prof["partitions"]

@@ -839,7 +839,7 @@ static int callback_host_phase(pgb_handle* h, int par) {
 // enqueues against flag[2] like against a credit: up to FEED_AHEAD slots beyond the executed one while the
 // step is expected to need them (running mean - 1 sd of the slots such a call took), FEED_MIN beyond it
 // after that -- so a finished step leaves at most a few idle slots (~2.6 us each) behind it.  No events, no
-// bundles: the throttle costs the device nothing and the host one read of pinned memory.
+// barrier packets: the throttle costs the device nothing and the host one read of pinned memory.
 #define FEED_AHEAD 24
 #define FEED_MIN 6
 #define FEED_RUN 8
