@@ -1,0 +1,63 @@
+"""The posterior-sampling glue and the variable-importance helpers against vectors produced by RUNNING the
+reference's own code (`pymc_bart/utils.py:26-107` `_sample_posterior` / `_MultiChainSampler`, `:1330-1346`
+`generate_sequences` / `pearsonr2`; generator `tests/golden/make_utils_golden.py`, which executes the reference's
+definitions against a deterministic stand-in for the native `PosteriorSampler`).  Pins, exactly: which draws are
+selected from which chain for a given generator state, the order the chains are called in, how a list of samplers
+is stacked, and the `(*size, n_rows, n_outputs)` layout (`utils.py:71`)."""
+import json
+import os
+
+import numpy as np
+
+from pymc_bart_amd.importance import generate_sequences, pearsonr2
+from pymc_bart_amd.utils import _MultiChainSampler, _sample_posterior
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "utils_glue.json")))
+
+
+class FakeChain:
+    """The same stand-in the generator used (see its docstring): out[d, k, r] identifies chain, draw, output, row."""
+
+    def __init__(self, chain, n_draws, n_outputs):
+        self.chain, self.n_draws, self.n_outputs = chain, n_draws, n_outputs
+        self.calls = []
+
+    def sample_posterior(self, X, draw_indices, excluded):
+        X = np.asarray(X, dtype=np.float64)
+        idx = [int(i) for i in draw_indices]
+        self.calls.append(idx)
+        ex = 0.0 if not excluded else 0.5 * sum(int(e) + 1 for e in excluded)
+        out = np.empty((len(idx), self.n_outputs, X.shape[0]))
+        for a, d in enumerate(idx):
+            for k in range(self.n_outputs):
+                out[a, k] = 1000.0 * self.chain + 10.0 * d + k + ex + 0.001 * X.sum(axis=1)
+        return out
+
+
+def test_sample_posterior_and_multichain_dispatch_match_the_reference():
+    for c in GOLD["sample_posterior"]:
+        chains = [FakeChain(i, nd, c["K"]) for i, nd in enumerate(c["chains"])]
+        sampler = _MultiChainSampler(chains)
+        assert sampler.n_draws == c["n_draws"] and sampler.n_outputs == c["K"]
+        size = tuple(c["size"]) if isinstance(c["size"], list) else c["size"]
+        out = _sample_posterior(sampler, np.array(c["X"]), np.random.default_rng(c["seed"]), size=size,
+                                excluded=c["excluded"])
+        assert list(out.shape) == c["shape"]
+        assert np.array_equal(out.ravel(), np.array(c["out"]))            # same draws, same chains, same layout
+        # each chain was asked for the same local draw indices (the reference calls chains in ascending order,
+        # each at most once, and skips chains no requested draw falls into)
+        assert [ch.calls for ch in chains] == c["calls"]
+
+
+def test_a_list_of_samplers_is_stacked_along_the_outputs_axis():
+    s = GOLD["sampler_list"]
+    group = [_MultiChainSampler([FakeChain(0, 4, 1)]), _MultiChainSampler([FakeChain(7, 4, 2)])]
+    out = _sample_posterior(group, np.array(s["X"]), np.random.default_rng(s["seed"]), size=s["size"])
+    assert list(out.shape) == s["shape"] and np.array_equal(out.ravel(), np.array(s["out"]))
+
+
+def test_variable_importance_helpers_match_the_reference():
+    for g in GOLD["generate_sequences"]:
+        assert [list(t) for t in generate_sequences(g["n_vars"], g["i_var"], list(g["include"]))] == g["out"]
+    for g in GOLD["pearsonr2"]:
+        assert abs(pearsonr2(np.array(g["A"]), np.array(g["B"])) - g["out"]) <= 1e-14 * max(1.0, abs(g["out"]))
