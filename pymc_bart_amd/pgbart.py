@@ -363,6 +363,10 @@ class PGBART(_Base):
             batch=batch, seed=seed, response=self.response, y_obs=y_obs, range_exp=range_exp,
         )
         self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
+        self._backend_arg = backend  # (not pickled: a worker process builds on its own default backend)
+        self._base_seed = seed       # before any per-chain re-keying (set_rng / first astep in a PyMC worker)
+        self._keyed = random_seed is not None and not (_HAVE_PYMC and not duck)  # explicit seed, no PyMC: final
+        self._stepped = False
         self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
         if self.likelihood.family == "callback":
             self.sampler.set_loglik_callback(self.likelihood.logp)
@@ -388,11 +392,13 @@ class PGBART(_Base):
         (on that process's current GPU)."""
         d = dict(self.__dict__)
         d["_checkpoint"] = d.pop("sampler").checkpoint()
+        d.pop("_backend_arg", None)
         return d
 
     def __setstate__(self, d):
         blob = d.pop("_checkpoint")
         self.__dict__.update(d)
+        self._backend_arg = None
         _pick_device()
         self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
                                  self._split_prior, backend=None)
@@ -415,6 +421,43 @@ class PGBART(_Base):
     def stop_tuning(self):
         self.tune = False
 
+    # -- per-chain random streams ----------------------------------------------------
+    # PyMC builds ONE step method and hands a copy of it to every chain (fork or pickle): the copies share the
+    # seed they were built with, and the sampler's random numbers are addressed by (seed, iteration, ...) -- so
+    # without the two hooks below every chain of `pm.sample(chains=4)` would draw the SAME forests.
+    def set_rng(self, rng):
+        """[P] PyMC >= 5.17 gives every chain's copy of a step method its own generator (`step.set_rng(rng)`) before
+        the first draw: the chain's Philox key is derived from it (reproducible under `pm.sample(random_seed=...)`).
+        Once the chain has stepped the key stays (re-keying would restart the forest)."""
+        gen = np.random.default_rng(rng)
+        self.rng = gen
+        if not self._stepped:
+            self._rekey(int(gen.integers(0, 2**63 - 1)))
+            self._keyed = True
+
+    def _rekey(self, seed: int) -> None:
+        """The same sampler on another Philox key (before its first step: there is no state to lose)."""
+        self.settings.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids, self._split_prior,
+                                 backend=self._backend_arg)
+        if self.likelihood.family == "callback":
+            self.sampler.set_loglik_callback(self.likelihood.logp)
+        if self._offset is not None:
+            self._apply_offset(self._offset)
+
+    def _key_for_this_process(self) -> None:
+        """Older PyMC has no `set_rng`: it seeds NumPy's global generator per chain (`np.random.seed(chain_seed)`)
+        in the process that runs the chain.  At the first astep of a chain that nobody keyed, the key is therefore
+        mixed with one draw from that generator and with the worker's ordinal in its pool -- different in every
+        chain, reproducible under `pm.sample(random_seed=...)`."""
+        import multiprocessing as mp
+
+        ident = getattr(mp.current_process(), "_identity", ()) or (0,)
+        mix = np.random.SeedSequence([self._base_seed & 0xFFFFFFFF, self._base_seed >> 32,
+                                      int(np.random.randint(0, 2**31 - 1)), *[int(i) for i in ident]])
+        self._rekey(int(mix.generate_state(1, np.uint64)[0]))
+        self._keyed = True
+
     def astep(self, _q=None, point=None, offset=None):
         """Re-sample the next batch of trees; returns ``(sum_trees, [stats])``.
 
@@ -423,6 +466,10 @@ class PGBART(_Base):
         model): a Normal model fits ``observed - offset``, the per-row families add it to the linear
         predictor.
         """
+        if not self._stepped:
+            if not self._keyed:
+                self._key_for_this_process()
+            self._stepped = True
         if self._binding is not None:  # PyMC model: parameters and offset at the shared values
             params, model_offset = self._binding.current()
             if model_offset is not None:

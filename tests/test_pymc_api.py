@@ -327,3 +327,62 @@ def test_an_offset_that_is_zero_at_bind_time_is_still_followed(fake_pymc, oracle
             ref.stop_tuning()
         mu_ref, _ = ref.astep(None, offset=3.0 * z)
     assert np.array_equal(mu, mu_ref)
+
+
+class _Owner:
+    def __init__(self, op):
+        self.op = op
+
+
+class _ModelVar:  # a model variable (not duck-typed): has an owner whose op carries the BART attributes
+    def __init__(self, op):
+        self.owner = _Owner(op)
+        self.name = "mu"
+
+
+def test_every_chain_copy_of_a_step_method_gets_its_own_key(fake_pymc, oracle, monkeypatch):
+    """PyMC builds ONE step method and copies it into every chain.  The copies must not draw the same forests:
+    `set_rng` ([P] PyMC >= 5.17 calls it per chain) keys a copy reproducibly; without it, the first astep of a copy
+    keys itself from NumPy's global generator (which older PyMC seeds per chain) and the worker's ordinal."""
+    import multiprocessing as mp
+
+    _, pgb = fake_pymc
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(150, 2))
+    Y = X[:, 0] + rng.normal(0, 0.3, 150)
+
+    RV = _ModelVar
+    def build():
+        st = pgb.PGBART([RV(pgb.BARTOp(X, Y, m=5))], num_particles=5, likelihood=pgb.NormalLikelihood(1.0),
+                        random_seed=7, backend=oracle)
+        assert not st._keyed                       # under PyMC an explicit seed is the BASE of the chains' keys
+        return st
+
+    def run(st, k=4):
+        return np.array([st.astep(None)[0] for _ in range(k)])
+
+    # set_rng: same generator state -> same chain, different -> different; reproducible across copies
+    a, b, c = build(), build(), build()
+    a.set_rng(np.random.default_rng(100))
+    b.set_rng(np.random.default_rng(100))
+    c.set_rng(np.random.default_rng(101))
+    ra, rb, rc = run(a), run(b), run(c)
+    assert np.array_equal(ra, rb) and not np.array_equal(ra, rc)
+    key = a.settings.seed
+    a.set_rng(np.random.default_rng(5))            # after the first step the key stays (the forest is not restarted)
+    assert a.settings.seed == key
+    # no set_rng: two copies of ONE step method in two "worker processes" of an older PyMC
+    parent = build()
+    blob = pickle.dumps(parent)
+    outs = []
+    for ident, seed in (((1,), 555), ((2,), 555), ((1,), 556), ((1,), 555)):
+        monkeypatch.setattr(mp.current_process(), "_identity", ident, raising=False)
+        np.random.seed(seed)                       # what pm.sample does in the process that runs the chain
+        outs.append(run(pickle.loads(blob)))
+    assert not np.array_equal(outs[0], outs[1])    # other worker
+    assert not np.array_equal(outs[0], outs[2])    # other chain seed
+    assert np.array_equal(outs[0], outs[3])        # same worker ordinal, same chain seed: reproducible
+    # without PyMC semantics (duck-typed op, explicit seed) nothing is re-keyed: the chain is a function of the seed
+    d1 = pgb.PGBART([pgb.BARTOp(X, Y, m=5)], num_particles=5, random_seed=7, backend=oracle)
+    d2 = pgb.PGBART([pgb.BARTOp(X, Y, m=5)], num_particles=5, random_seed=7, backend=oracle)
+    assert d1._keyed and np.array_equal(run(d1), run(d2))
