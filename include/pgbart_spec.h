@@ -603,6 +603,14 @@ PGB_HD double pgb_softplus(double t) {
  *   STUDENT_T(sigma, nu): -((nu + 1) / 2) log(1 + ((y - mu) / sigma)^2 / nu)
  *   GAMMA_LOG(alpha):    -alpha (y e^-mu + mu - 1 - log y)   (relative to the saturated model)
  * (both without their mu-free normalising terms, hence <= 0). */
+/* The Bernoulli families on the SIGNED predictor s = mu for y = 1, -mu for y = 0 (the response only picks the
+ * sign): callers that evaluate one row for many particles flip the sign with the row's precomputed mask. */
+PGB_HD double pgb_loglik_bern_s(int family, double smu, const double* tn, const double* tp) {
+  double ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
+  if (!(ll > -2047.0)) ll = -2047.0;
+  if (ll > 0.0) ll = 0.0;
+  return ll;
+}
 PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double param2, const double* tn,
                            const double* tp) {
   double ll;
@@ -629,8 +637,7 @@ PGB_HD double pgb_loglik1q(int family, double y, double mu, double param, double
     const double u = (y - mu) / param;
     ll = (-0.5 * (param2 + 1.0)) * pgb_log(1.0 + (u * u) / param2);
   } else {
-    const double smu = y > 0.5 ? mu : -mu;
-    ll = family == PGB_FAMILY_BERNOULLI_PROBIT ? pgb_log_ndtr_t(smu, tn, tp) : -pgb_softplus(-smu);
+    return pgb_loglik_bern_s(family, y > 0.5 ? mu : -mu, tn, tp);
   }
   if (!(ll > -2047.0)) ll = -2047.0;
   if (ll > 0.0) ll = 0.0;

@@ -316,11 +316,13 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
     u += g1 - g0;
     const long long base = (long long)chunk * CH + tid * RPT;
     double yv[RPT], nv[RPT];
+    uint32_t ysgn[RPT];  // (Bernoulli families: sign mask of the predictor, once per row instead of once per evaluation)
     uint32_t root_ids = 0;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
       if constexpr (!MKPASS) {  // (the pass loop of the K = 2, 3, 4 instances fetches a row's inputs where it evaluates it)
         yv[e] = gy[base + e];
+        if constexpr (YBIT) ysgn[e] = yv[e] > 0.5 ? 0u : 0x80000000u;  // Bernoulli: the response only picks the sign
         nv[e] = noi[base + e];
         if constexpr (KT == 1)
           if (S.has_off) nv[e] = nv[e] + goff[base + e];  // (adding the default 0.0 would give the same bits)
@@ -546,7 +548,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               const uint32_t nl = (nid >> (8 * e)) & 255u;
               const uint32_t side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
               s_lnv[w][pos] = nv[e];
-              if constexpr (YBIT) s_lfl[w][pos] = (uint8_t)(side | (yv[e] > 0.5 ? 4u : 0u));
+              if constexpr (YBIT) s_lfl[w][pos] = (uint8_t)(side | (ysgn[e] >> 29));  // bit 2: y = 0 (flip the sign)
               else { s_lfl[w][pos] = (uint8_t)side; s_ly[w][pos] = yv[e]; }
             }
             off += __popcll(mk[e]);
@@ -558,11 +560,15 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
             const uint32_t fl = s_lfl[w][k];
             const int side = (int)(fl & 3u);
             // (Bernoulli: the evaluation only asks whether y > 0.5)
-            const double yk = YBIT ? ((fl & 4u) ? 1.0 : 0.0) : s_ly[w][k];
             const double mu = s_lnv[w][k] + (side == 0 ? vL : side == 1 ? vR : 0.0);
-            const long long q = quant_ll(pgb_loglik1q(FAM, yk, mu, cn.inv_sigma2, cn.lik_param2,
-                                                      PROBIT ? s_ln : pgb_ln_tn(),
-                                                      PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl);
+            double llk;
+            if constexpr (YBIT) {
+              llk = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)(fl & 4u) << 61)),
+                                      PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp());
+            } else {
+              llk = pgb_loglik1q(FAM, s_ly[w][k], mu, cn.inv_sigma2, cn.lik_param2, pgb_ln_tn(), pgb_ln_tp());
+            }
+            const long long q = quant_ll(llk, cl);
             vt += q;
             v0 += side == 0 ? q : 0;
             if (drops) v2 += side == 2 ? q : 0;
@@ -591,9 +597,15 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
             }
           }
           const double mu = nv[e] + vleaf;
-          const long long q = quant_ll(pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2,
-                                                    PROBIT ? s_ln : pgb_ln_tn(),
-                                                    PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()), cl);
+          double llr;
+          if constexpr (YBIT) {
+            llr = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)ysgn[e] << 32)),
+                                    PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp());
+          } else {
+            llr = pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, pgb_ln_tn(),
+                               pgb_ln_tp());
+          }
+          const long long q = quant_ll(llr, cl);
           vt += q;
           v0 += side == 0 ? q : 0;
           if (drops) v2 += side == 2 ? q : 0;

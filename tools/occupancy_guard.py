@@ -129,10 +129,13 @@ def check(rows: list[dict], budget: dict) -> list[str]:
         if r["wgs_per_cu"] < b["min_wgs_per_cu"]:
             bad.append(f"{r['kernel']}: {r['wgs_per_cu']} workgroups/CU (VGPR {r['vgpr']}+{r['agpr']} -> {r['vgpr_alloc']}, "
                        f"LDS {r['lds_bytes']} B; limited by {r['limited_by']}) < budget {b['min_wgs_per_cu']}")
-        if r["scratch_bytes"] > b.get("max_scratch_bytes", 0):
-            bad.append(f"{r['kernel']}: {r['scratch_bytes']} B of scratch > budget {b.get('max_scratch_bytes', 0)}")
-        if r["vgpr_spills"] > b.get("max_vgpr_spills", 0):  # (SGPR spills go to VGPR lanes: cheap, not budgeted)
-            bad.append(f"{r['kernel']}: {r['vgpr_spills']} VGPR spills > budget {b.get('max_vgpr_spills', 0)}")
+        # scratch / VGPR spills: an instance that had none must stay without; one that already spills (the generic
+        # K <= 8 and linear-response instances) may move by half its budget + a few registers before it is news
+        sb, vb = b.get("max_scratch_bytes", 0), b.get("max_vgpr_spills", 0)
+        if r["scratch_bytes"] > (sb * 3 // 2 + 32 if sb else 0):
+            bad.append(f"{r['kernel']}: {r['scratch_bytes']} B of scratch > budget {sb}")
+        if r["vgpr_spills"] > (vb * 3 // 2 + 4 if vb else 0):  # (SGPR spills go to VGPR lanes: cheap, not budgeted)
+            bad.append(f"{r['kernel']}: {r['vgpr_spills']} VGPR spills > budget {vb}")
     return bad
 
 
