@@ -587,8 +587,14 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           // ONE evaluation per row: the side only selects the leaf value and the accumulator
           // (separate calls per side would run one after the other on a divergent wave)
           const uint32_t nl = (nid >> (8 * e)) & 255u;
-          const int side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
-          double vleaf = side == 0 ? vL : side == 1 ? vR : 0.0;  // dropped: predicts 0
+          int side = nl == lab ? 0 : 1;
+          double vleaf = nl == lab ? vL : vR;
+          // (only a split on a column with missing values drops rows -- wave-uniform per particle: every other
+          //  split is decided by ONE compare and select per row instead of two)
+          if (drops && nl != lab && nl != nlab) {
+            side = 2;
+            vleaf = 0.0;  // dropped: predicts 0
+          }
           if constexpr (LIN) {
             const int sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
             if (sv >= 0) {
