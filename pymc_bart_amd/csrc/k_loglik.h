@@ -342,6 +342,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         const uint32_t ids = lj.src < 0 ? root_ids : *gcast<const uint32_t>(glid + lj.src + base);
         const uint32_t nid = *gcast<const uint32_t>(newl + (size_t)lj.p * S.n_pad + base);
         const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
+        const bool mk_drops = lj.check_nan != 0;
         double vLr[KB], vRr[KB];
         vLr[0] = lj.vL;
         vRr[0] = lj.vR;
@@ -398,7 +399,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
             double mu[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-              const double vk = side == 0 ? vLr[k] : side == 1 ? vRr[k] : 0.0;
+              // (side 2 -- a row dropped by a split on a column with missing values -- only where such a split is)
+              double vk = side == 0 ? vLr[k] : vRr[k];
+              if (mk_drops && side == 2) vk = 0.0;
               const double nk = noi[(size_t)k * S.n_pad + row];
               mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + row] : nk) + vk;
             }
