@@ -655,3 +655,17 @@ def test_pageable_and_pinned_output_buffers_receive_the_same_sum_trees(hip):
                   "pgb_step_host")
         assert np.array_equal(ra, rb) and np.array_equal(via, vi)
         assert a.export_trees(0).raw == b.export_trees(0).raw
+
+
+def test_soak_of_every_stepping_api_in_random_alternation(hip, oracle):
+    """`tools/soak_parity.py` for a few seconds inside the suite: host-output asteps, device-output steps, asynchronous
+    batches, tune flips, sigma changes, checkpoint -> fresh sampler -> restore and exports in random alternation on
+    one chain, HIP and oracle compared after every call (the round's run of it: 49 174 asteps, 1 820 restores, 0
+    mismatches -- profiles/r03_experiments.md)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_parity
+
+    calls, steps, kinds = soak_parity.run(6.0, 11, backs={"hip": hip, "oracle": oracle})
+    assert calls > 200 and steps > 200 and len(kinds) >= 6
