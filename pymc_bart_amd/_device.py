@@ -32,6 +32,7 @@ class TorchHipMemory:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     _queue_pad: dict = {}
+    _queue_lock = __import__("threading").Lock()
 
     @classmethod
     def _prime_queues(cls, torch, device):
@@ -46,6 +47,11 @@ class TorchHipMemory:
         output stream of every sampler (`pgb_set_output_stream`), so that one takes no queue of its own.
         Best effort: streams the application itself has used are not known here."""
         key = str(device)
+        with cls._queue_lock:  # (chains.sample_chains builds its samplers from several threads at once)
+            return cls._prime_locked(torch, device, key)
+
+    @classmethod
+    def _prime_locked(cls, torch, device, key):
         if key not in cls._queue_pad:
             pads = []
             torch.zeros(1, device=device)
