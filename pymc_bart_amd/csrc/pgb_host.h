@@ -60,8 +60,6 @@ struct pgb_handle {
   StepOutLayout out_layout;
   double* st_dense;          // [K][n] staging of sum_trees in HBM
   int out_valid;             // the block holds the trees of the last step (pgb_export_trees(0) reads it)
-  void* out_host_ptr;        // last sum_trees_host_out seen by pgb_step_host and its device address (null: pageable)
-  double* out_dev_ptr;
   int poisoned;              // a step was abandoned half-way (callback error, stuck state machine): the device
                              // state is undefined until pgb_checkpoint_load restores an idle image
   // pgb_step_async: a worker thread feeds the state machine while the caller goes on
@@ -235,8 +233,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->out_host = h->out_dev = nullptr;
   h->st_dense = nullptr;
   h->out_valid = 0;
-  h->out_host_ptr = nullptr;
-  h->out_dev_ptr = nullptr;
   h->poisoned = 0;
   h->job_running = 0;
   h->job_rc = PGB_OK;
@@ -1068,15 +1064,10 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   // kernel, a copy kernel and the gap between them.  Pageable memory: densify in HBM, then one DMA.
   double* direct = nullptr;
   if (sum_trees_host_out && !(getenv("PGB_NO_DIRECT_OUT") && atoi(getenv("PGB_NO_DIRECT_OUT")))) {
-    if ((void*)sum_trees_host_out == h->out_host_ptr) {
-      direct = h->out_dev_ptr;
-    } else {
-      void* dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, sum_trees_host_out, 0) == hipSuccess && dp) direct = (double*)dp;
-      else (void)hipGetLastError();  // not pinned: the DMA path
-      h->out_host_ptr = sum_trees_host_out;
-      h->out_dev_ptr = direct;
-    }
+    // (asked every time: the same address may be pinned in one call and ordinary memory in the next)
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, sum_trees_host_out, 0) == hipSuccess && dp) direct = (double*)dp;
+    else (void)hipGetLastError();  // not pinned: the DMA path
   }
   hipLaunchKernelGGL(k_export_step, dim3((unsigned)grid), dim3(BT), 0, so, (const Dev*)h->d_dev,
                      (int)(h->slot & 1), h->last_lower, nt, h->out_dev, h->out_layout,
