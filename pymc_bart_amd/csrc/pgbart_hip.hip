@@ -64,3 +64,4 @@
 #include "k_export.h"
 #include "pgb_host.h"
 #include "pgb_checkpoint.h"
+#include "pgb_probe.h"
