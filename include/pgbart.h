@@ -31,7 +31,8 @@
  *   tree depth           <= 64     (prior_leaf[64]; upstream cuts its table where P(leaf) >= 0.9999,
  *                                   depth ~ 97 at alpha = 0.95, beta = 2: entries beyond 64 are 1)
  *   SubsetSplit columns  integer category codes 0 .. 51 (the split value is a 52-bit mask in a double)
- *   response linear/mix  ContinuousSplit columns only
+ *   response linear/mix  any split rule (a leaf regresses on the column its parent split on, upstream's
+ *                        fast_linear_fit; on a SubsetSplit column that is the category code)
  *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory)
  */
 #ifndef PGBART_H

@@ -292,8 +292,6 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
       if (a > amax) amax = a; /* NaN compares false */
     }
     h->col_ex[j] = pgb_col_exponent(amax);
-    if (h->s.response != PGB_RESPONSE_CONSTANT && rules[j] != PGB_RULE_CONTINUOUS)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix needs ContinuousSplit columns");
   }
   build_cdf(h);
   h->have_data = 1;

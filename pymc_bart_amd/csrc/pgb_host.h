@@ -518,8 +518,6 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
       return fail(PGB_E_UNSUPPORTED, "unknown split rule");
     if (!(split_prior_host[j] > 0.0)) return fail(PGB_E_INVALID, "split_prior must be positive");
     if (split_prior_host[j] > mx) mx = split_prior_host[j];
-    if (d.response != PGB_RESPONSE_CONSTANT && rules_host[j] != PGB_RULE_CONTINUOUS)
-      return fail(PGB_E_UNSUPPORTED, "response linear/mix needs ContinuousSplit columns");
   }
   d.max_prior = mx;
   d.alpha_unit = pgb_alpha_unit(mx);
@@ -710,7 +708,10 @@ static int enqueue_slots(pgb_handle* h, int count) {
       LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
-      if (lin) {
+      if (lin && h->has_subset) {  // (a linear leaf regresses on whatever column its parent split on)
+        if (nrm) LAUNCH_K(PK_ROWS, (k_rows<true, true, true>), grows, ROWS_ARGS);
+        else LAUNCH_K(PK_ROWS, (k_rows<true, false, true>), grows, ROWS_ARGS);
+      } else if (lin) {
         if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, true>), grows, ROWS_ARGS);
         else LAUNCH_K(PK_ROWS, (k_rows<false, false, true>), grows, ROWS_ARGS);
       } else if (h->has_subset) {

@@ -155,6 +155,31 @@ def make_case(name: str):
         f = np.where(X[:, 0] < 0, 2 * X[:, 0] + 1, -1.5 * X[:, 0] + 1) + 0.5 * np.nan_to_num(X[:, 1])
         Y = f + rng.normal(0, 0.1, n)
         c.update(m=8, P=12, steps=30, response="linear" if name == "linear_response" else "mix")
+    elif name in ("linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules"):
+        # linear / mix leaves next to OneHot / Subset columns: a leaf regresses on whatever column its parent
+        # split on (upstream: fast_linear_fit on X[idx, selected_predictor], whatever the rule, bart.py:88-103)
+        n, p = 3000, 5
+        X = rng.uniform(-2, 2, size=(n, p))
+        X[:, 2] = rng.integers(0, 3, n)        # one-hot column
+        X[:, 3] = rng.integers(0, 9, n)        # subset column, 9 categories
+        X[:, 4] = 1.0                          # subset column with a single category (every split fails)
+        X[rng.random(n) < 0.1, 1] = np.nan
+        X[rng.random(n) < 0.1, 3] = np.nan
+        f = np.where(X[:, 0] < 0, 2 * X[:, 0] + 1, -1.5 * X[:, 0] + 1) + (X[:, 2] == 1) + 0.3 * np.nan_to_num(X[:, 3])
+        c.update(m=8, P=12, steps=30, rules=np.array([0, 0, 1, 2, 2], np.int32), prior=np.array([1.0, 1.0, 2.0, 2.0, 1.0]))
+        if name == "linear_mixed_rules":
+            Y = f + rng.normal(0, 0.2, n)
+            c.update(response="linear")
+        elif name == "mix_probit_mixed_rules":
+            from scipy.special import ndtr
+            Y = (rng.random(n) < ndtr(f - 1.0)).astype(float)
+            c.update(family="bernoulli_probit", response="mix")
+        else:
+            K = 3
+            F = np.stack([f, -f, 0.5 * (X[:, 2] == 2)])
+            pr = np.exp(F) / np.exp(F).sum(0)
+            Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+            c.update(family="categorical", K=K, response="linear", steps=20)
     elif name == "meanscale_k2_reference":  # reference tests/test_bart.py:107-123 (shape=(2, 250))
         n, p = 250, 3
         X = rng.normal(0, 1, size=(n, p))
@@ -212,7 +237,8 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
-         "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset"]
+         "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
+         "linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -281,9 +307,11 @@ def digest(res) -> dict:
     }
 
 
-def random_case(seed):
+def random_case(seed, large=False):
     """A random configuration for the fuzz parity test: sizes around the chunk / wave boundaries,
-    every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta."""
+    every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta.
+    `large`: hundreds of chunks per pass (work items beyond one per workgroup, particle groups of
+    more than one particle), few trees and steps so that the oracle still answers in seconds."""
     rng = np.random.default_rng(seed)
     fam = rng.choice(["normal", "normal", "normal", "bernoulli_probit", "bernoulli_logit", "categorical", "normal_meanscale",
                       "poisson_log", "negbin_log", "asymmetric_laplace", "student_t", "gamma_log"])
@@ -291,6 +319,10 @@ def random_case(seed):
     p = int(rng.integers(1, 9))
     m = int(rng.integers(1, 12))
     P = int(rng.choice([2, 3, 5, 10, 20, 40, 64]))
+    if large:
+        n = int(rng.choice([50_000, 131_072, 200_001, 400_000, 1_048_577]))
+        m = int(rng.integers(1, 5))
+        P = int(rng.choice([5, 20, 40, 64]))
     X = rng.normal(size=(n, p))
     rules = np.zeros(p, np.int32)
     for j in range(p):
@@ -321,8 +353,10 @@ def random_case(seed):
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
     response = "constant"
-    if not rules.any():  # linear / mix need continuous columns
+    if not rules.any():
         response = str(rng.choice(["constant", "linear", "mix"]))
+    elif rng.random() < 0.25:  # linear / mix leaves next to one-hot / subset columns
+        response = str(rng.choice(["linear", "mix"]))
     extra = {}
     if fam in ("poisson_log", "negbin_log"):
         extra["bart_Y"] = np.log(Y + 0.5)
@@ -339,6 +373,6 @@ def random_case(seed):
         extra["offset"] = rng.normal(0, 0.3, n)  # another additive term of the linear predictor
     elif fam in ("categorical", "normal_meanscale") and rng.random() < 0.3:
         extra["offset"] = rng.normal(0, 0.3, (K, n))  # ... of every linear predictor of a K-vector model
-    return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(4, 14)), batch=batch, rules=rules,
+    return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(2, 5) if large else rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

@@ -634,9 +634,20 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
     np.testing.assert_allclose(ps.sample_posterior(X, list(range(10)))[:, 0, :], res["mu"], rtol=0, atol=1e-9)
     assert res["vi_counts"].sum(axis=0)[0] > res["vi_counts"].sum(axis=0)[1]
-    # not every combination exists: categorical rules are rejected
-    with pytest.raises(_abi.PGBError, match="ContinuousSplit"):
-        PGBART([BARTOp(X, Y, m=2, response="linear", split_rules=["OneHotSplit", "ContinuousSplit"])], backend=oracle)
+    # categorical rules next to linear leaves: a leaf regresses on whatever column its parent split on, as
+    # upstream's fast_linear_fit does on X[idx, selected_predictor] (a one-hot left child has no spread: constant)
+    Xc = X.copy()
+    Xc[:, 0] = rng.integers(0, 5, 200)
+    Yc = 0.5 * X[:, 1] + 1.0 * Xc[:, 0] + rng.normal(0, 0.2, 200)
+    opc = BARTOp(Xc, Yc, m=5, response="linear", split_rules=["OneHotSplit", "ContinuousSplit"])
+    resc = sample_chain(opc, tune=40, draws=10, random_seed=2, backend=oracle)
+    basec, batchesc = resc["history"]
+    rules_c = np.array([_abi.RULE_ONEHOT, _abi.RULE_CONTINUOUS], np.int32)
+    psc = PosteriorSampler.from_history(batchesc, basec, 5, 1, rules=rules_c, backend=oracle)
+    np.testing.assert_allclose(psc.sample_posterior(Xc, list(range(10)))[:, 0, :], resc["mu"], rtol=0, atol=1e-9)
+    last = psc.pool
+    onehot_leaf = (last.svar == 0)
+    assert onehot_leaf.any()                           # leaves below a one-hot split keep that regressor
     # K-vector leaves carry one slope per output on the shared regressor (the reference's
     # test_shape[linear-response] case: shape=(2, n) observed through Normal(w[0], |w[1]|))
     st = PyBartSettings.from_data(X, Y, m=6, num_particles=8, family="normal_meanscale", n_outputs=2,

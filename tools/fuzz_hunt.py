@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Parity hunt on a GPU box: random configurations (tests/_cases.random_case) through the HIP library and
-the CPU oracle, bit-for-bit digests compared.  usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS]"""
+the CPU oracle, bit-for-bit digests compared.
+usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS] [large]   (large: n = 50k .. 1M, few trees)"""
 import os
 import sys
 import time
@@ -15,13 +16,14 @@ from pymc_bart_amd.sampler import default_backend  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+large = len(sys.argv) > 4 and sys.argv[4] == "large"
 hip, orc = default_backend(0), oracle_backend()
 t0, bad, done = time.time(), [], 0
 fam = {}
 for seed in range(first, first + count):
     if time.time() - t0 > budget:
         break
-    c = random_case(seed)
+    c = random_case(seed, large)
     g, o = digest(run_case(c, hip)), digest(run_case(c, orc))
     done += 1
     key = (c["family"], int(c["K"]), str(c.get("response", "constant")))
