@@ -73,6 +73,22 @@ __device__ __forceinline__ double loglik_cat_fast(double y, const double* mu) {
   return ll;
 }
 
+// The K-vector families are two -- softmax and Normal mean/scale (K = 2) -- and pgb_loglikq dispatches exactly
+// like this.  Naming them here keeps the one-predictor families (log Phi tables, softplus, the count models'
+// exp / log chains: ~10 KB of code per call site) out of the K >= 2 instances: k_loglik<4> was 92 KB, more than
+// the instruction cache two CUs share, and a fifth of its wave-cycles waited for instructions.
+// (The run-time-K instances, KT = 0, keep the spec's own dispatcher: they are the rarely used ones -- K = 5..8 and
+// K-vector linear leaves -- and their register allocation sits exactly at its occupancy edge.)
+template <int KT>
+__device__ __forceinline__ double loglik_mk(int family, int K, double y, const double* mu) {
+  if constexpr (KT == 0) {
+    return pgb_loglik(family, K, y, mu);
+  } else {
+    if (KT >= 3 || family == PGB_FAMILY_CATEGORICAL) return loglik_cat_fast<KT>(y, mu);
+    return pgb_loglik_meanscale(y, mu);
+  }
+}
+
 // pgb_quant of a per-row log-likelihood that has already been clamped to the contract's range
 // (|ll| <= 2047, never NaN: every pgb_loglik* routine ends with that clamp): |ll * cl| < 2^50, so none of
 // pgb_quant's NaN / saturation branches can fire and what is left of it is the rounding itself.  Same bits.
@@ -260,14 +276,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
                 mu_stump[k] = (noi0[(size_t)k * S.n_pad + row] + offk) + S.init_leaf;
                 mu_cur[k] = stk + offk;
               }
-            if constexpr (KT >= 2) {
-              const bool cat = S.family == PGB_FAMILY_CATEGORICAL;
-              ce[0] += quant_ll(cat ? loglik_cat_fast<KT>(yr, mu_stump) : pgb_loglik(S.family, Kn, yr, mu_stump), S.sc.cl);
-              ce[1] += quant_ll(cat ? loglik_cat_fast<KT>(yr, mu_cur) : pgb_loglik(S.family, Kn, yr, mu_cur), S.sc.cl);
-            } else {
-              ce[0] += quant_ll(pgb_loglik(S.family, Kn, yr, mu_stump), S.sc.cl);
-              ce[1] += quant_ll(pgb_loglik(S.family, Kn, yr, mu_cur), S.sc.cl);
-            }
+            ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_stump), S.sc.cl);
+            ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_cur), S.sc.cl);
           } else {
             const double offv = offr[e];
             ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noir[e] + offv) + init_leaf, cn.inv_sigma2, cn.lik_param2,
@@ -405,7 +415,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               const double nk = noi[(size_t)k * S.n_pad + row];
               mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + row] : nk) + vk;
             }
-            const double llv = S.family == PGB_FAMILY_CATEGORICAL ? loglik_cat_fast<KB>(yr, mu) : pgb_loglik(S.family, K, yr, mu);
+            const double llv = loglik_mk<KT>(S.family, K, yr, mu);
             const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
@@ -473,12 +483,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
                 const double nk = noi[(size_t)k * S.n_pad + base + e];
                 mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + base + e] : nk) + vk;
               }
-            double llv;
-            if constexpr (KT >= 2) {
-              llv = S.family == PGB_FAMILY_CATEGORICAL ? loglik_cat_fast<KT>(yv[e], mu) : pgb_loglik(S.family, K, yv[e], mu);
-            } else {
-              llv = pgb_loglik(S.family, K, yv[e], mu);
-            }
+            const double llv = loglik_mk<KT>(S.family, K, yv[e], mu);
             const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }

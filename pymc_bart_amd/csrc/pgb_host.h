@@ -283,6 +283,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->ll_kernel, BT, 0) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && per_cu > 0 && cus > 0) {
+      // (K = 2, 3, 4: the instances are compiled for PGB_LLK_WGS workgroups per CU and measured best there --
+      //  cfg5: 768 workgroups 27.2-27.9 us, 1024 28.1-31.2 us, 1280 30.5-31.0 us -- whatever else would fit)
+      if (d.K >= 2 && d.K <= 4 && d.response == PGB_RESPONSE_CONSTANT && per_cu > PGB_LLK_WGS) per_cu = PGB_LLK_WGS;
       long long g = (long long)per_cu * cus;
       if (g < 256) g = 256;
       if (g > 2048) g = 2048;
