@@ -191,7 +191,11 @@ PGB_HD double pgb_exp(double x) {
   double kf = x * 1.4426950408889634074; /* 1/ln2 */
   /* |kf| <= 1010 after the clamp: 32-bit conversions give the same integers as 64-bit ones and are
    * single instructions on the GPU (f64 <-> i64 is emulated there) */
-  kf = (kf >= 0.0) ? (double)(int32_t)(kf + 0.5) : (double)(int32_t)(kf - 0.5);
+  /* round half away from zero: one add of +-0.5 carrying kf's sign and ONE conversion (the two-sided form
+   * `kf >= 0 ? (int)(kf + 0.5) : (int)(kf - 0.5)` costs the GPU both conversions and two 64-bit selects;
+   * same integers, -0.0 included: both give 0) */
+  const int32_t k = (int32_t)(kf + __builtin_copysign(0.5, kf));
+  kf = (double)k;
   double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
   double p = 1.6059043836821613e-10;      /* 1/13! */
   p = PGB_FMA(p, r, 2.08767569878681e-09);       /* 1/12! */
@@ -207,7 +211,6 @@ PGB_HD double pgb_exp(double x) {
   p = PGB_FMA(p, r, 0.5);
   p = PGB_FMA(p, r, 1.0);
   p = PGB_FMA(p, r, 1.0);
-  int32_t k = (int32_t)kf;
   double scale = pgb_u2d((uint64_t)(uint32_t)(k + 1023) << 52);
   return p * scale;
 }
