@@ -23,8 +23,9 @@ from __future__ import annotations
 import numpy as np
 from scipy.special import expit, ndtr, ndtri
 
-from .pgbart import (BernoulliLikelihood, CallbackLikelihood, CategoricalLikelihood, NegativeBinomialLikelihood,
-                     NormalLikelihood, NormalMeanScaleLikelihood, PoissonLikelihood)
+from .pgbart import (AsymmetricLaplaceLikelihood, BernoulliLikelihood, CallbackLikelihood, CategoricalLikelihood,
+                     GammaLikelihood, NegativeBinomialLikelihood, NormalLikelihood, NormalMeanScaleLikelihood,
+                     PoissonLikelihood, StudentTLikelihood)
 
 _TOL = 1e-8
 
@@ -34,7 +35,8 @@ class Binding:
     parameters and the offset of the linear predictor, both read from ``probe`` at ``x = 0``."""
 
     #: kinds whose linear predictor may carry other additive terms of the model
-    OFFSET_KINDS = ("normal", "bernoulli_probit", "bernoulli_logit", "poisson", "negbin")
+    OFFSET_KINDS = ("normal", "bernoulli_probit", "bernoulli_logit", "poisson", "negbin", "student_t",
+                    "asymmetric_laplace", "gamma_scale", "gamma_rate")
 
     def __init__(self, likelihood, probe, shape, kind, has_offset=None):
         self.likelihood = likelihood
@@ -63,7 +65,28 @@ class Binding:
             return [], np.broadcast_to(np.log(p[0]), self.shape)
         if k == "negbin":
             return [_scalar(p[1], "alpha")], np.broadcast_to(np.log(p[0]), self.shape)
+        if k == "student_t":  # [P] dist params (nu, mu, sigma); the kernel family takes (sigma, nu)
+            return [_scalar(p[2], "sigma"), _scalar(p[0], "nu")], np.broadcast_to(np.asarray(p[1], float), self.shape)
+        if k == "asymmetric_laplace":  # [P] dist params (b, kappa, mu), see _ald_params
+            return _ald_params(p[0], p[1]), np.broadcast_to(np.asarray(p[2], float), self.shape)
+        if k in ("gamma_scale", "gamma_rate"):
+            return [_scalar(p[0], "alpha")], np.broadcast_to(np.log(_gamma_mean(p, k)), self.shape)
         return [], None  # categorical / mean-scale: no free parameters, no offsets
+
+
+def _ald_params(b, kappa):
+    """PyMC's AsymmetricLaplace(b, kappa, mu) has log-density -b kappa (y - mu) above mu and -(b / kappa) (mu - y)
+    below; the kernel family is -rho_q((y - mu) / s) = -(q / s)(y - mu) above, -((1 - q) / s)(mu - y) below.
+    Hence q = kappa^2 / (1 + kappa^2) (PyMC's own `q` argument: kappa = sqrt(q / (1 - q))) and
+    s = sqrt(q (1 - q)) / b.  Returned in the kernel's order (s, q)."""
+    kappa, b = _scalar(kappa, "kappa"), _scalar(b, "b")
+    q = kappa * kappa / (1.0 + kappa * kappa)
+    return [float(np.sqrt(q * (1.0 - q)) / b), float(q)]
+
+
+def _gamma_mean(p, kind):
+    a, second = np.asarray(p[0], float), np.asarray(p[1], float)
+    return a * second if kind == "gamma_scale" else a / second
 
 
 def _scalar(a, what):
@@ -125,10 +148,28 @@ def identify(probe, shape, seed=0) -> Binding:
         if _close(np.log(pr[0]) - np.log(p0[0]), xr) and _close(pr[1], p0[1]):
             return Binding(NegativeBinomialLikelihood(_scalar(p0[1], "alpha")), probe, shape, "negbin")
         raise NotImplementedError("NegativeBinomial likelihood outside mu = exp(BART + other terms), alpha free")
+    if name in ("studentt", "student_t", "studentt_rv", "t"):  # [P] (nu, mu, sigma)
+        if len(p0) == 3 and _close(np.asarray(pr[1]) - np.asarray(p0[1]), xr) and _close(pr[0], p0[0]) and _close(pr[2], p0[2]):
+            return Binding(StudentTLikelihood(_scalar(p0[0], "nu"), _scalar(p0[2], "sigma")), probe, shape, "student_t")
+        raise NotImplementedError("StudentT likelihood outside mu = BART + other terms with nu, sigma free of BART")
+    if name in ("asymmetriclaplace", "asymmetric_laplace", "asymmetriclaplace_rv"):  # [P] (b, kappa, mu)
+        if len(p0) == 3 and _close(np.asarray(pr[2]) - np.asarray(p0[2]), xr) and _close(pr[0], p0[0]) and _close(pr[1], p0[1]):
+            s_, q_ = _ald_params(p0[0], p0[1])
+            return Binding(AsymmetricLaplaceLikelihood(q=q_, b=s_), probe, shape, "asymmetric_laplace")
+        raise NotImplementedError("AsymmetricLaplace likelihood outside mu = BART + other terms with b, kappa free of BART")
+    if name in ("gamma", "gamma_rv"):
+        # shape alpha free of BART, mean = exp(BART + other terms); the second parameter is a scale in recent
+        # PyTensor (alpha, 1 / beta) and a rate in older releases (alpha, beta): whichever makes the mean log-linear
+        if len(p0) == 2 and _close(pr[0], p0[0]):
+            for kind in ("gamma_scale", "gamma_rate"):
+                m0, mr = _gamma_mean(p0, kind), _gamma_mean(pr, kind)
+                if np.all(m0 > 0) and np.all(mr > 0) and _close(np.log(mr) - np.log(m0), xr):
+                    return Binding(GammaLikelihood(_scalar(p0[0], "alpha")), probe, shape, kind)
+        raise NotImplementedError("Gamma likelihood outside alpha free of BART, mean = exp(BART + other terms)")
     raise NotImplementedError(
         f"observed distribution {name!r} is not in this sampler's closed likelihood family (Normal, "
-        "Bernoulli probit/logit, Categorical softmax, Normal mean/scale, Poisson, NegativeBinomial); "
-        "pass likelihood= explicitly if it is one of them in disguise")
+        "Bernoulli probit/logit, Categorical softmax, Normal mean/scale, Poisson, NegativeBinomial, StudentT, "
+        "AsymmetricLaplace, Gamma with a log link); pass likelihood= explicitly if it is one of them in disguise")
 
 
 class FullVectorLogp:

@@ -246,7 +246,20 @@ def _probe_factory(kind, n=40, K=1, offset=None, **par):
             return "negative_binomial", [np.exp(x + off), np.full(n, par.get("alpha", 2.0))]
         if kind == "hetero":
             return "normal", [x, np.exp(0.1 * x)]
-        return "gamma", [x]
+        if kind == "student_t":     # [P] StudentT: (nu, mu, sigma)
+            return "studentt", [np.full(n, par.get("nu", 4.0)), x + off, np.full(n, par.get("sigma", 0.6))]
+        if kind == "ald":           # [P] AsymmetricLaplace: (b, kappa, mu)
+            return "asymmetriclaplace", [np.full(n, par.get("b", 2.0)), np.full(n, par.get("kappa", 3.0)), x + off]
+        if kind == "gamma_scale":   # Gamma(alpha, scale = mean / alpha)
+            a = par.get("alpha", 3.0)
+            return "gamma", [np.full(n, a), np.exp(x + off) / a]
+        if kind == "gamma_rate":    # older PyTensor: Gamma(alpha, rate = alpha / mean)
+            a = par.get("alpha", 3.0)
+            return "gamma", [np.full(n, a), a / np.exp(x + off)]
+        if kind == "gamma_musigma":  # Gamma(mu = exp(BART), sigma fixed): alpha moves with BART -- not in the family
+            m = np.exp(x)
+            return "gamma", [m * m / 0.25, 0.25 / m]
+        return "weibull", [x]
 
     return probe
 
@@ -272,9 +285,46 @@ def test_likelihood_family_is_identified_numerically():
     assert b.likelihood.family == "poisson_log" and b.current()[1] is not None
     b = identify(_probe_factory("negbin", alpha=2.5), (n,))
     assert b.likelihood.family == "negbin_log" and b.current()[0] == [2.5]
-    for bad in ("cloglog", "hetero", "gamma"):
+    b = identify(_probe_factory("student_t", offset=off, nu=5.0, sigma=0.4), (n,))
+    params, o = b.current()
+    assert b.likelihood.family == "student_t" and params == [0.4, 5.0] and np.allclose(o, off)   # kernel order: sigma, nu
+    b = identify(_probe_factory("ald", offset=off, b=2.0, kappa=3.0), (n,))
+    params, o = b.current()
+    assert b.likelihood.family == "asymmetric_laplace" and np.allclose(o, off)
+    assert params[1] == pytest.approx(0.9) and params[0] == pytest.approx(np.sqrt(0.9 * 0.1) / 2.0)   # q = k^2 / (1 + k^2)
+    for kind in ("gamma_scale", "gamma_rate"):
+        b = identify(_probe_factory(kind, offset=off, alpha=3.0), (n,))
+        params, o = b.current()
+        assert b.likelihood.family == "gamma_log" and params == [3.0] and np.allclose(o, off)
+    for bad in ("cloglog", "hetero", "gamma_musigma", "weibull"):
         with pytest.raises(NotImplementedError):
             identify(_probe_factory(bad), (n,))
+
+
+def test_asymmetric_laplace_parameters_map_pymc_density_onto_the_kernel_family(oracle):
+    """[P] PyMC: logp = log(b / (kappa + 1/kappa)) - b kappa (y - mu) for y >= mu, - (b / kappa)(mu - y) below
+    (AsymmetricLaplace.logp).  With (s, q) from the bridge the kernel family must give the same DIFFERENCES in mu."""
+    import ctypes as C
+
+    from pymc_bart_amd import _abi
+    from pymc_bart_amd._pymc_bridge import _ald_params
+
+    f = oracle.lib.lib.pgbo_loglikq
+    f.restype, f.argtypes = None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]
+    rng = np.random.default_rng(12)
+    y, mu_a, mu_b = rng.normal(0, 2, 2000), rng.normal(0, 1, 2000), rng.normal(0, 1, 2000)
+
+    def pymc_logp(mu, b, kappa):
+        v = y - mu
+        return np.log(b / (kappa + 1 / kappa)) - np.where(v >= 0, b * kappa * v, -(b / kappa) * v)
+
+    for b_, kappa in ((2.0, 3.0), (0.7, 1.0), (5.0, 0.4)):
+        s_, q_ = _ald_params(b_, kappa)
+        la, lb = np.zeros(2000), np.zeros(2000)
+        f(_abi.FAMILIES["asymmetric_laplace"], y.ctypes.data, mu_a.ctypes.data, 2000, s_, q_, la.ctypes.data)
+        f(_abi.FAMILIES["asymmetric_laplace"], y.ctypes.data, mu_b.ctypes.data, 2000, s_, q_, lb.ctypes.data)
+        ok = (la > -2047) & (lb > -2047)
+        np.testing.assert_allclose((la - lb)[ok], (pymc_logp(mu_a, b_, kappa) - pymc_logp(mu_b, b_, kappa))[ok], rtol=1e-10, atol=1e-10)
 
 
 def test_an_offset_that_is_zero_at_bind_time_is_still_followed(fake_pymc, oracle):

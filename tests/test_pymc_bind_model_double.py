@@ -134,6 +134,9 @@ def _build_model(kind, n=200, seed=5):
     if kind == "normal":
         Y = f + 2.0 * z + rng.normal(0, 0.2, n)
         bart_Y = Y
+    elif kind == "studentt":  # heavy tails: StudentT(nu = 4, mu = BART + b z, sigma)
+        Y = f + 2.0 * z + 0.2 * rng.standard_t(4, n)
+        bart_Y = Y
     else:  # an observed distribution outside the closed family: Laplace noise, scale 0.2
         Y = f + 2.0 * z + rng.laplace(0, 0.2, n)
         bart_Y = Y
@@ -143,8 +146,11 @@ def _build_model(kind, n=200, seed=5):
     sig_rv, b_rv = Var("sigma_rv"), Var("b_rv")
     mean = Var("mean", fn=lambda env: env["mu"] + env["b"] * z, parents=(mu_rv, b_rv))
     sigma = Var("sigma_expr", fn=lambda env: np.full(n, float(env["sigma"])), parents=(sig_rv,))
-    dist = DistOp("normal" if kind == "normal" else "laplace")
-    y_rv = Var("y", owner=Owner(dist, [Var("rng"), Var("size"), mean, sigma]))
+    dist = DistOp({"normal": "normal", "studentt": "studentt"}.get(kind, "laplace"))
+    params = [mean, sigma]
+    if kind == "studentt":  # [P] StudentT's parameters: (nu, mu, sigma)
+        params = [Var("nu_expr", fn=lambda env: np.full(n, 4.0)), mean, sigma]
+    y_rv = Var("y", owner=Owner(dist, [Var("rng"), Var("size")] + params))
     y_val = Var("y_obs", data=Y)
     logp_el = Var("logp", fn=lambda env: -np.abs(Y - (env["mu"] + env["b"] * z)) / float(env["sigma"])
                   - np.log(2 * float(env["sigma"])))
@@ -211,3 +217,24 @@ def test_bind_model_falls_back_to_the_models_elementwise_logp(graph_api, oracle,
         step.likelihood.logp.set_base(point["mu"])                # (the bridge's callback scatters into the current value)
         point, _ = step.step(point)
     assert np.corrcoef(point["mu"], P["f"])[0, 1] > 0.7          # fitted through the model's own logp, offset included
+
+
+def test_bind_model_puts_a_student_t_model_on_the_device_family(graph_api, oracle, monkeypatch):
+    """StudentT(nu, BART + b z, sigma) is one of the kernel families: no callback, sigma and nu read from the
+    model every step in the kernel's order, the other term followed as an offset of the linear predictor."""
+    _, pgb = graph_api
+    model, P = _build_model("studentt")
+    _install_fake_pymc_graph_api(monkeypatch, model)
+    step = pgb.PGBART([P["mu_rv"]], num_particles=6, batch=(1.0, 1.0), model=model, backend=oracle, random_seed=5)
+    assert step._binding.kind == "student_t" and step.likelihood.family == "student_t"
+    point = model.initial_point()
+    point["b"] = np.array(2.0)
+    point["sigma"] = np.array(0.25)
+    for it in range(30):
+        if it == 15:
+            step.stop_tuning()
+        point, _ = step.step(point)
+    params, off = step._binding.current()
+    assert params == [0.25, 4.0] and np.allclose(off, 2.0 * P["z"])
+    assert np.corrcoef(point["mu"], P["f"])[0, 1] > 0.9          # BART explains f, the offset carries 2 z
+    assert abs(np.corrcoef(point["mu"], P["z"])[0, 1]) < 0.3
