@@ -35,7 +35,7 @@ class Binding:
     parameters and the offset of the linear predictor, both read from ``probe`` at ``x = 0``."""
 
     #: kinds whose linear predictor may carry other additive terms of the model
-    OFFSET_KINDS = ("normal", "bernoulli_probit", "bernoulli_logit", "poisson", "negbin", "student_t",
+    OFFSET_KINDS = ("normal", "bernoulli_probit", "bernoulli_logit", "poisson", "negbin", "negbin_np", "student_t",
                     "asymmetric_laplace", "gamma_scale", "gamma_rate")
 
     def __init__(self, likelihood, probe, shape, kind, has_offset=None):
@@ -65,6 +65,8 @@ class Binding:
             return [], np.broadcast_to(np.log(p[0]), self.shape)
         if k == "negbin":
             return [_scalar(p[1], "alpha")], np.broadcast_to(np.log(p[0]), self.shape)
+        if k == "negbin_np":  # (n, p) of the underlying nbinom variable: alpha = n, mean = n (1 - p) / p
+            return [_scalar(p[0], "alpha")], np.broadcast_to(np.log(_nbinom_mean(p)), self.shape)
         if k == "student_t":  # [P] dist params (nu, mu, sigma); the kernel family takes (sigma, nu)
             return [_scalar(p[2], "sigma"), _scalar(p[0], "nu")], np.broadcast_to(np.asarray(p[1], float), self.shape)
         if k == "asymmetric_laplace":  # [P] dist params (b, kappa, mu), see _ald_params
@@ -82,6 +84,11 @@ def _ald_params(b, kappa):
     kappa, b = _scalar(kappa, "kappa"), _scalar(b, "b")
     q = kappa * kappa / (1.0 + kappa * kappa)
     return [float(np.sqrt(q * (1.0 - q)) / b), float(q)]
+
+
+def _nbinom_mean(p):
+    n_, pr_ = np.asarray(p[0], float), np.asarray(p[1], float)
+    return n_ * (1.0 - pr_) / pr_
 
 
 def _gamma_mean(p, kind):
@@ -147,6 +154,11 @@ def identify(probe, shape, seed=0) -> Binding:
     if name in ("negative_binomial", "negativebinomial", "nbinom", "negative_binomial_rv"):
         if _close(np.log(pr[0]) - np.log(p0[0]), xr) and _close(pr[1], p0[1]):
             return Binding(NegativeBinomialLikelihood(_scalar(p0[1], "alpha")), probe, shape, "negbin")
+        # [P] PyMC hands its (mu, alpha) to the nbinom variable as n = alpha, p = alpha / (mu + alpha)
+        if (_close(pr[0], p0[0]) and np.all((np.asarray(p0[1]) > 0) & (np.asarray(p0[1]) < 1))
+                and np.all((np.asarray(pr[1]) > 0) & (np.asarray(pr[1]) < 1))
+                and _close(np.log(_nbinom_mean(pr)) - np.log(_nbinom_mean(p0)), xr)):
+            return Binding(NegativeBinomialLikelihood(_scalar(p0[0], "alpha")), probe, shape, "negbin_np")
         raise NotImplementedError("NegativeBinomial likelihood outside mu = exp(BART + other terms), alpha free")
     if name in ("studentt", "student_t", "studentt_rv", "t"):  # [P] (nu, mu, sigma)
         if len(p0) == 3 and _close(np.asarray(pr[1]) - np.asarray(p0[1]), xr) and _close(pr[0], p0[0]) and _close(pr[2], p0[2]):

@@ -244,6 +244,9 @@ def _probe_factory(kind, n=40, K=1, offset=None, **par):
             return "poisson", [np.exp(x + off)]
         if kind == "negbin":
             return "negative_binomial", [np.exp(x + off), np.full(n, par.get("alpha", 2.0))]
+        if kind == "negbin_np":     # [P] the nbinom variable's own parameters: n = alpha, p = alpha / (mu + alpha)
+            a = par.get("alpha", 2.0)
+            return "nbinom", [np.full(n, a), a / (np.exp(x + off) + a)]
         if kind == "hetero":
             return "normal", [x, np.exp(0.1 * x)]
         if kind == "student_t":     # [P] StudentT: (nu, mu, sigma)
@@ -285,6 +288,9 @@ def test_likelihood_family_is_identified_numerically():
     assert b.likelihood.family == "poisson_log" and b.current()[1] is not None
     b = identify(_probe_factory("negbin", alpha=2.5), (n,))
     assert b.likelihood.family == "negbin_log" and b.current()[0] == [2.5]
+    b = identify(_probe_factory("negbin_np", offset=off, alpha=1.5), (n,))
+    params, o = b.current()
+    assert b.likelihood.family == "negbin_log" and params == [1.5] and np.allclose(o, off)
     b = identify(_probe_factory("student_t", offset=off, nu=5.0, sigma=0.4), (n,))
     params, o = b.current()
     assert b.likelihood.family == "student_t" and params == [0.4, 5.0] and np.allclose(o, off)   # kernel order: sigma, nu
