@@ -30,7 +30,8 @@
  *                                   would grow past it stops splitting (P ~ 0 under the prior)
  *   tree depth           <= 64     (prior_leaf[64]; upstream cuts its table where P(leaf) >= 0.9999,
  *                                   depth ~ 97 at alpha = 0.95, beta = 2: entries beyond 64 are 1)
- *   SubsetSplit columns  integer category codes 0 .. 51 (the split value is a 52-bit mask in a double)
+ *   SubsetSplit columns  integer category codes 0 .. 51 or NaN (the split value is a 52-bit mask in a double);
+ *                        pgb_set_data checks every value and returns PGB_E_INVALID naming the column
  *   response linear/mix  any split rule (a leaf regresses on the column its parent split on, upstream's
  *                        fast_linear_fit; on a SubsetSplit column that is the category code)
  *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory)

@@ -292,6 +292,16 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
       if (a > amax) amax = a; /* NaN compares false */
     }
     h->col_ex[j] = pgb_col_exponent(amax);
+    if (rules[j] == PGB_RULE_SUBSET) /* category codes outside 0 .. 51 are refused, not clamped */
+      for (int64_t i = 0; i < n; ++i) {
+        double x = h->X[(size_t)j * n + i];
+        if (x == x && !(x >= 0.0 && x <= (double)(PGB_SUBSET_BITS - 1) && x == (double)(int)x)) {
+          static __thread char msg[128];
+          snprintf(msg, sizeof msg, "SubsetSplit column %d: categories must be integer codes in [0, %d) (NaN = missing)",
+                   j, PGB_SUBSET_BITS);
+          return fail(PGB_E_INVALID, msg);
+        }
+      }
   }
   build_cdf(h);
   h->have_data = 1;

@@ -55,6 +55,19 @@ __global__ __launch_bounds__(BT) void k_colmax(const double* __restrict__ XT, lo
   }
   if (threadIdx.x == 0) amax[blockIdx.x] = sm[0];
 }
+// SubsetSplit columns hold integer category codes 0 .. PGB_SUBSET_BITS - 1 (NaN = missing); anything else would be
+// clamped by pgb_subset_code, so pgb_set_data refuses it: one workgroup per column, *bad = 1 + the first such column
+__global__ __launch_bounds__(BT) void k_subset_check(const double* __restrict__ XT, long long n, long long n_pad,
+                                                     const int32_t* __restrict__ rules, int* __restrict__ bad) {
+  if (rules[blockIdx.x] != PGB_RULE_SUBSET) return;
+  const double* c = XT + (size_t)blockIdx.x * n_pad;
+  bool b = false;
+  for (long long i = threadIdx.x; i < n; i += BT) {
+    const double v = c[i];
+    if (v == v && !(v >= 0.0 && v <= (double)(PGB_SUBSET_BITS - 1) && v == (double)(int)v)) b = true;
+  }
+  if (b) atomicMax(bad, (int)blockIdx.x + 1);
+}
 __global__ void k_fill_f64(double* a, long long n, double v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;

@@ -533,6 +533,25 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   dim3 grid((unsigned)(d.n_pad / 32), (unsigned)((d.p + 31) / 32));
   hipLaunchKernelGGL(k_transpose, grid, dim3(BT), 0, sm, X_dev, (long long)ldx, (double*)d.XT, d.n,
                      d.n_pad, d.p, (int32_t*)d.col_nan);
+  if (h->has_subset) {  // category codes outside 0 .. 51 are refused, not clamped (include/pgbart.h, Limits)
+    int* bad_dev = nullptr;
+    int bad = 0;
+    HIPCHK(hipMalloc((void**)&bad_dev, sizeof(int)));
+    hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), sm);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_subset_check, dim3((unsigned)d.p), dim3(BT), 0, sm, d.XT, d.n, d.n_pad, (const int32_t*)d.rules, bad_dev);
+      e = hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, sm);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(sm);
+    (void)hipFree(bad_dev);
+    HIPCHK(e);
+    if (bad) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "SubsetSplit column %d: categories must be integer codes in [0, %d) (NaN = missing)", bad - 1,
+               PGB_SUBSET_BITS);
+      return fail(PGB_E_INVALID, msg);
+    }
+  }
   // A design matrix that does not fit the 256 MiB Infinity Cache streams from HBM in every row pass: the
   // row pass (single output, K = 2..4) then reads a float32 shadow of the split column (k_rows<..., F32>); smaller
   // matrices stay on the float64 path (cache-resident, latency-bound: the shadow only adds conversions).

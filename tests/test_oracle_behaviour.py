@@ -471,6 +471,31 @@ def test_subset_rule_recovers_a_set_valued_effect(oracle):
                backend=oracle)
 
 
+def _subset_codes_are_checked_by_the_library(backend):
+    """At the ABI itself (PySampler, no PGBART in front): a SubsetSplit column must hold integer codes 0 .. 51 or
+    NaN -- 52, a fraction or a negative code would be CLAMPED by the split rule, so pgb_set_data refuses them."""
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(300, 3))
+    X[:, 1] = rng.integers(0, 52, 300)
+    X[::7, 1] = np.nan
+    Y = rng.normal(size=300)
+    rules = np.array([0, 2, 0], np.int32)
+    st = PyBartSettings.from_data(X, Y, m=3, num_particles=4)
+    PySampler(st, X, Y, rules, np.ones(3), backend=backend).step(True)       # 0 .. 51 and NaN are fine
+    for bad in (52.0, 3.5, -1.0, np.inf):
+        Xb = X.copy()
+        Xb[5, 1] = bad
+        with pytest.raises(_abi.PGBError, match="SubsetSplit column 1"):
+            PySampler(st, Xb, Y, rules, np.ones(3), backend=backend)
+    Xc = X.copy()
+    Xc[5, 0] = 99.5                                                           # other rules take any value
+    PySampler(st, Xc, Y, rules, np.ones(3), backend=backend).step(True)
+
+
+def test_subset_codes_are_checked_by_the_library(oracle):
+    _subset_codes_are_checked_by_the_library(oracle)
+
+
 def test_variable_importance_ranks_the_informative_covariates(oracle):
     # SURVEY.md 8f f4 / reference utils.py:868-1090: "VI" follows the inclusion counts, "backward"
     # the greedy elimination by squared correlation with the full prediction

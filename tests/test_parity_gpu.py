@@ -559,6 +559,12 @@ def test_prediction_rejects_a_matrix_narrower_than_the_trees(hip):
         _sample_posterior(s, X[:, :2], np.random.default_rng(0), size=2)
 
 
+def test_subset_codes_are_checked_by_the_library_on_gpu(hip):
+    from test_oracle_behaviour import _subset_codes_are_checked_by_the_library
+
+    _subset_codes_are_checked_by_the_library(hip)
+
+
 def test_packed_tree_record_on_gpu_equals_the_array_export(hip, oracle):
     """``pgb_export_trees_packed`` on the HIP backend: the record served from the mapped block of the last
     ``pgb_step_host`` and the one fetched from the device (after ``pgb_step``) both equal the array export,
