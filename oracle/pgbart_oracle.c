@@ -810,8 +810,13 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
     for (int k = 0; k < T->n_nodes; ++k)
       if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += h->alpha_unit;
     if (h->iter > 2) {
-      h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
-      for (int o = 1; o < K; ++o) h->leaf_sdx[o - 1] = ((double)qstdx[o - 1] * h->sc.inv_c1) / (double)n;
+      /* [U] leaf_sd = RunningSd.update(new tree's predictions).  Deviation 12: a running sd of exactly 0 -- every
+       * tree accepted so far predicts the same constant, e.g. the untouched stump won the first three updates -- is
+       * not adopted: leaf values are mean(sum_trees)/m + N(0,1) leaf_sd, so leaf_sd = 0 would never let a leaf move
+       * again and the chain would sit on the initial constant for ever (seen at 2 of 70 keys with 6 particles). */
+      if (qstd > 0) h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
+      for (int o = 1; o < K; ++o)
+        if (qstdx[o - 1] > 0) h->leaf_sdx[o - 1] = ((double)qstdx[o - 1] * h->sc.inv_c1) / (double)n;
     }
   } else {
     for (int k = 0; k < T->n_nodes; ++k)

@@ -62,6 +62,7 @@ __device__ __forceinline__ double leaf_sd_x(const DevG& S, const Ctrl& c, int ct
   const int KX = S.K - 1;
   long long q = 0;
   for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + KX + k];
+  if (q <= 0) return S.lsdx[ctrl_par * KXMAX + k];  // (a running sd of exactly 0 is not adopted: deviation 12)
   return ((double)q * S.sc.inv_c1) / (double)S.n;
 }
 __device__ __forceinline__ long long root_A_x(const DevG& S, int acc_par, int k) {

@@ -471,6 +471,44 @@ def test_subset_rule_recovers_a_set_valued_effect(oracle):
                backend=oracle)
 
 
+def test_a_chain_whose_first_updates_keep_the_stump_does_not_die(oracle):
+    """Deviation 12.  leaf_sd is tuned to the running sd of the accepted trees' predictions from the third
+    tree update on ([U] RunningSd); if the untouched stump wins the first three updates that sd is exactly 0,
+    and a leaf value is mean(sum_trees) / m + N(0, 1) leaf_sd: with leaf_sd = 0 no leaf ever moves again.
+    This key did exactly that (found as a 1-in-35 flake of the step-method test; 62 of 150 keys at m = 2, P = 3)."""
+    rng = np.random.default_rng(5)
+    n = 200
+    X = rng.normal(size=(n, 2))
+    z = rng.normal(size=n)
+    f = np.where(X[:, 0] > 0, 1.0, -1.0)
+    Y = f + 2.0 * z + rng.normal(0, 0.2, n)
+    st = PyBartSettings.from_data(X, Y, m=8, num_particles=6, seed=3330035369473741674, batch=(1.0, 1.0))
+    s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+    s.set_likelihood([0.2])
+    for _ in range(10):
+        mu, _ = s.step(True)
+    assert s.state()["leaf_sd"][0] > 0.0 and mu.std() > 0.5 and np.corrcoef(mu, Y)[0, 1] > 0.3
+    dead = 0
+    Xs, Ys = X[:120], Y[:120]
+    for seed in range(60):                      # tiny forests, few particles: the stump wins often
+        st = PyBartSettings.from_data(Xs, Ys, m=2, num_particles=3, seed=seed)
+        s = PySampler(st, Xs, Ys, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+        s.set_likelihood([1.0])
+        for _ in range(6):
+            s.step(True)
+        dead += s.state()["leaf_sd"][0] == 0.0
+    assert dead == 0
+    # K-vector leaves: no output's leaf_sd may collapse either
+    Yc = (rng.random(n) < 0.5).astype(float) + (X[:, 0] > 0)
+    for seed in range(20):
+        st = PyBartSettings.from_data(X, Yc, m=2, num_particles=3, seed=seed, family="categorical", n_outputs=3)
+        s = PySampler(st, X, Yc, np.zeros(2, np.int32), np.ones(2), backend=oracle)
+        s.set_likelihood([])
+        for _ in range(6):
+            s.step(True)
+        assert np.all(s.state()["leaf_sd"] > 0.0), seed
+
+
 def _subset_codes_are_checked_by_the_library(backend):
     """At the ABI itself (PySampler, no PGBART in front): a SubsetSplit column must hold integer codes 0 .. 51 or
     NaN -- 52, a fraction or a negative code would be CLAMPED by the split rule, so pgb_set_data refuses them."""

@@ -238,3 +238,44 @@ def test_bind_model_puts_a_student_t_model_on_the_device_family(graph_api, oracl
     assert params == [0.25, 4.0] and np.allclose(off, 2.0 * P["z"])
     assert np.corrcoef(point["mu"], P["f"])[0, 1] > 0.9          # BART explains f, the offset carries 2 z
     assert abs(np.corrcoef(point["mu"], P["z"])[0, 1]) < 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["normal", "studentt"])
+def test_step_method_bound_to_a_model_gives_the_same_chain_on_gpu_and_oracle(graph_api, hip, oracle, monkeypatch, kind):
+    """Row f3 on the GPU, against something other than itself: the step method built the reference way
+    (``PGBART([mu_rv], ...)`` inside a model; family, sigma / nu and the other additive term read from the model
+    every step) driven through ``step(point)`` with another sampler moving ``b`` and ``sigma`` in between -- the
+    HIP backend and the oracle must produce the same points, statistics and tree history, bit for bit."""
+    _, pgb = graph_api
+
+    def run(backend):
+        np.random.seed(20261002)   # older PyMC seeds NumPy's global generator per chain; the step method keys itself from it
+        model, P = _build_model(kind)
+        _install_fake_pymc_graph_api(monkeypatch, model)
+        step = pgb.PGBART([P["mu_rv"]], num_particles=8, batch=(0.5, 0.5), model=model, backend=backend, random_seed=9)
+        point = model.initial_point()
+        rng = np.random.default_rng(1)
+        out = []
+        for it in range(24):
+            if it == 12:
+                step.stop_tuning()
+            point, stats = step.step(point)
+            res = P["Y"] - point["mu"]
+            point["b"] = np.array(float(res @ P["z"] / (P["z"] @ P["z"])) + rng.normal(0, 0.01))       # "NUTS" moves b
+            r2 = res - float(point["b"]) * P["z"]
+            point["sigma"] = np.array(float(np.sqrt((1.0 + 0.5 * r2 @ r2) / rng.gamma(1.0 + 0.5 * len(r2)))))
+            out.append((point["mu"].copy(), bytes(np.ascontiguousarray(stats[0]["variable_inclusion"]).tobytes()),
+                        float(point["b"]), float(point["sigma"])))
+        base, batches = P["op"].all_trees[0]
+        return step, out, base, list(batches)
+
+    sg, og, bg, tg = run(hip)
+    so, oo, bo, to = run(oracle)
+    assert sg.sampler.backend.lib.backend_name == "hip-gfx950" and sg._binding.kind == so._binding.kind
+    for (mg, vg, b_g, s_g), (mo, vo, b_o, s_o) in zip(og, oo):
+        assert np.array_equal(mg, mo) and vg == vo and b_g == b_o and s_g == s_o
+    assert len(tg) == len(to) == 12
+    for a, b in zip([bg] + tg, [bo] + to):
+        for f in ("var", "split", "value", "count", "left", "right"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
