@@ -471,6 +471,65 @@ def test_subset_rule_recovers_a_set_valued_effect(oracle):
                backend=oracle)
 
 
+@pytest.mark.parametrize("alpha,beta,P", [(0.95, 2.0, 10), (0.5, 1.0, 5), (0.95, 1.0, 20), (0.95, 2.0, 2)])
+def test_flat_likelihood_reproduces_the_tree_prior(oracle, alpha, beta, P):
+    """An oracle-INDEPENDENT check of the particle machinery (proposal, weights, resampling, final pick, batch
+    cursor): with a likelihood that cannot tell trees apart (sigma = 1e6) the chain's trees must be draws from the
+    prior of Chipman et al. (reference bart.py:108-113): a node at depth d splits with probability
+    alpha (1 + d)^-beta.  Expected number of leaves of that Galton-Watson tree: L_d = (1 - p_d) + 2 p_d L_{d+1}."""
+    L = 1.0
+    for d in range(60, -1, -1):
+        p_d = alpha * (1 + d) ** -beta
+        L = (1 - p_d) + 2 * p_d * L
+    rng = np.random.default_rng(0)
+    n, p, m = 4000, 3, 40
+    X, Y = rng.normal(size=(n, p)), rng.normal(size=n)
+    st = PyBartSettings.from_data(X, Y, m=m, num_particles=P, seed=7, batch=(1.0, 1.0), alpha=alpha, beta=beta)
+    s = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=oracle)
+    s.set_likelihood([1e6])
+    leaves, stumps = [], []
+    for it in range(120):
+        s.step(False)
+        if it >= 20 and it % 4 == 0:
+            t = s.export_trees(1)
+            off = np.append(np.asarray(t.node_off), t.total_nodes)
+            for k in range(m):
+                v = np.asarray(t.var)[off[k]:off[k + 1]]
+                leaves.append(int((v < 0).sum()))
+                stumps.append(len(v) == 1)
+    se = np.std(leaves) / np.sqrt(len(leaves) / 4.0)           # (draws 4 steps apart are still correlated)
+    assert abs(np.mean(leaves) - L) < 4 * se + 0.02, (np.mean(leaves), L)
+    assert abs(np.mean(stumps) - (1 - alpha)) < 0.04, np.mean(stumps)
+
+
+def test_flat_likelihood_reproduces_the_split_prior_and_uniform_split_rows(oracle):
+    """Same device, one level down: under a flat likelihood the split VARIABLE of the root follows `split_prior`
+    (reference bart.py:96-99) and its split VALUE is the value of a uniformly chosen row, i.e. its rank among the
+    column's values is uniform."""
+    rng = np.random.default_rng(1)
+    n, m = 3000, 40
+    X, Y = rng.normal(size=(n, 4)), rng.normal(size=n)
+    prior = np.array([3.0, 1.0, 1.0, 0.5])
+    st = PyBartSettings.from_data(X, Y, m=m, num_particles=8, seed=11, batch=(1.0, 1.0))
+    s = PySampler(st, X, Y, np.zeros(4, np.int32), prior, backend=oracle)
+    s.set_likelihood([1e6])
+    ranks = np.sort(X, axis=0)
+    var_counts, quantiles = np.zeros(4), []
+    for it in range(140):
+        s.step(False)
+        if it >= 20 and it % 4 == 0:
+            t = s.export_trees(1)
+            for k in np.asarray(t.node_off)[:m]:
+                j = int(np.asarray(t.var)[k])
+                if j >= 0:
+                    var_counts[j] += 1
+                    quantiles.append(np.searchsorted(ranks[:, j], np.asarray(t.split)[k]) / n)
+    freq = var_counts / var_counts.sum()
+    assert np.max(np.abs(freq - prior / prior.sum())) < 0.04, freq
+    q = np.asarray(quantiles)
+    assert abs(q.mean() - 0.5) < 0.03 and abs(np.mean(q < 0.25) - 0.25) < 0.04 and abs(np.mean(q > 0.75) - 0.25) < 0.04
+
+
 def test_a_chain_whose_first_updates_keep_the_stump_does_not_die(oracle):
     """Deviation 12.  leaf_sd is tuned to the running sd of the accepted trees' predictions from the third
     tree update on ([U] RunningSd); if the untouched stump wins the first three updates that sd is exactly 0,
