@@ -180,6 +180,28 @@ def make_case(name: str):
             pr = np.exp(F) / np.exp(F).sum(0)
             Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
             c.update(family="categorical", K=K, response="linear", steps=20)
+    elif name.startswith("stump_first_"):
+        # deviation 12 on the per-row families: tiny forest, three particles, and a key under which the untouched
+        # stump wins the first tree updates -- the running sd of the accepted predictions is exactly 0 when leaf_sd
+        # is first tuned, in k_ctrl AND in the likelihood pass's own copy of that rule (a 429-of-11 674 fuzz
+        # divergence in round 3 when only one of the two had it)
+        r77 = np.random.default_rng(77)
+        n, p = 600, 3
+        X = r77.normal(size=(n, p))
+        f = 1.2 * X[:, 0]
+        Yb = (r77.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+        Yc = np.clip(np.round(f + r77.normal(0, 0.5, n) + 1), 0, 2)
+        Yp = r77.poisson(np.exp(f)).astype(float)
+        c.update(m=2, P=3, steps=14, batch=(0.5, 0.5))
+        if name == "stump_first_probit":
+            Y = Yb
+            c.update(family="bernoulli_probit", seed=0)
+        elif name == "stump_first_categorical":
+            Y = Yc
+            c.update(family="categorical", K=3, seed=3)
+        else:
+            Y = Yp
+            c.update(family="poisson_log", seed=0, bart_Y=np.log(Yp + 0.5))
     elif name == "meanscale_k2_reference":  # reference tests/test_bart.py:107-123 (shape=(2, 250))
         n, p = 250, 3
         X = rng.normal(0, 1, size=(n, p))
@@ -238,7 +260,8 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
          "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
-         "linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules"]
+         "linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules",
+         "stump_first_probit", "stump_first_categorical", "stump_first_poisson"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
