@@ -878,6 +878,16 @@ PGB_HD double pgb_leaf_pred(double value, double slope, double xbar, double x) {
   return value + slope * (x - xbar);
 }
 
+/* leaf_sd after the tree update number `iter` (1-based) whose accepted tree added `qstd` = sum over the rows of
+ * quant(running sd of the accepted trees' predictions) to the tuning statistics ([U] RunningSd.update; adopted from
+ * the third update on).  A running sd of EXACTLY 0 -- every accepted prediction so far is the same constant, e.g.
+ * the untouched stump won the first updates -- is not adopted: leaf values are mean(sum_trees)/m + N(0,1) leaf_sd,
+ * so leaf_sd = 0 would never let a leaf move again (DESIGN.md deviation 12).  ONE definition for the oracle, the
+ * control kernel, the likelihood pass (which re-derives leaf values), the K-vector outputs and pgb_get_state. */
+PGB_HD double pgb_tuned_leaf_sd(double current, int64_t iter, int64_t qstd, double inv_c1, int64_t n) {
+  return (iter > 2 && qstd > 0) ? ((double)qstd * inv_c1) / (double)n : current;
+}
+
 /* Leaf value: mean of sum_trees over the leaf rows / m + noise (upstream
  * draw_leaf_value); empty leaf -> 0. */
 PGB_HD double pgb_leaf_value(int64_t cnt, int64_t q_st, double inv_c1, double m, double z,

@@ -809,15 +809,11 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
     if (h->iter > s->m) build_cdf(h); /* [U] ssv rebuilt before this tree's counts are added */
     for (int k = 0; k < T->n_nodes; ++k)
       if (T->nd[k].var >= 0) h->alpha_vec[T->nd[k].var] += h->alpha_unit;
-    if (h->iter > 2) {
-      /* [U] leaf_sd = RunningSd.update(new tree's predictions).  Deviation 12: a running sd of exactly 0 -- every
-       * tree accepted so far predicts the same constant, e.g. the untouched stump won the first three updates -- is
-       * not adopted: leaf values are mean(sum_trees)/m + N(0,1) leaf_sd, so leaf_sd = 0 would never let a leaf move
-       * again and the chain would sit on the initial constant for ever (seen at 2 of 70 keys with 6 particles). */
-      if (qstd > 0) h->leaf_sd = ((double)qstd * h->sc.inv_c1) / (double)n;
-      for (int o = 1; o < K; ++o)
-        if (qstdx[o - 1] > 0) h->leaf_sdx[o - 1] = ((double)qstdx[o - 1] * h->sc.inv_c1) / (double)n;
-    }
+    /* [U] leaf_sd = RunningSd.update(new tree's predictions) from the third update on; a running sd of exactly
+     * 0 is not adopted (deviation 12, pgb_tuned_leaf_sd) */
+    h->leaf_sd = pgb_tuned_leaf_sd(h->leaf_sd, h->iter, qstd, h->sc.inv_c1, n);
+    for (int o = 1; o < K; ++o)
+      h->leaf_sdx[o - 1] = pgb_tuned_leaf_sd(h->leaf_sdx[o - 1], h->iter, qstdx[o - 1], h->sc.inv_c1, n);
   } else {
     for (int k = 0; k < T->n_nodes; ++k)
       if (T->nd[k].var >= 0) h->vi[T->nd[k].var] += 1;

@@ -356,8 +356,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
 
   // pending leaf_sd from the FINAL pass of the previous slot ([U] RunningSd -> leaf_sd)
   double leaf_sd = c.leaf_sd;
-  // (a running sd of exactly 0 is not adopted: DESIGN.md deviation 12)
-  if (c.pend_leafsd && c.pend_iter > 2 && ia.QSTD > 0) leaf_sd = ((double)ia.QSTD * S.sc.inv_c1) / (double)S.n;
+  if (c.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(c.leaf_sd, c.pend_iter, ia.QSTD, S.sc.inv_c1, S.n);
 
   if (b == 0 && tid == 0 && c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
   if (tid < ACC_SLOTS) {

@@ -159,8 +159,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       qstd += src[k].QSTD;
       rootA += src[k].A;
     }
-    // (a running sd of exactly 0 is not adopted: DESIGN.md deviation 12 -- the same rule as in k_ctrl)
-    if (cn.pend_leafsd && cn.pend_iter > 2 && qstd > 0) leaf_sd = ((double)qstd * S.sc.inv_c1) / (double)S.n;
+    if (cn.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(cn.leaf_sd, cn.pend_iter, qstd, S.sc.inv_c1, S.n);
   }
   const Job* jobs = S.jobs + (size_t)par * MAXP;
   if (tid < 64) {

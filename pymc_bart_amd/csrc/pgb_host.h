@@ -1266,7 +1266,7 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
   double leaf_sd = c.leaf_sd;
   long long qstd = 0;
   for (int k = 0; k < IA_SLOTS; ++k) qstd += ia[k].QSTD;
-  if (c.pend_leafsd && c.pend_iter > 2 && qstd > 0) leaf_sd = ((double)qstd * d.sc.inv_c1) / (double)d.n;
+  if (c.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(c.leaf_sd, c.pend_iter, qstd, d.sc.inv_c1, d.n);
   if (leaf_sd_out) {
     leaf_sd_out[0] = leaf_sd;
     const int KX = d.K - 1;
@@ -1278,10 +1278,10 @@ extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_o
       HIPCHK(hipMemcpy(lsdx, d.lsdx, sizeof lsdx, hipMemcpyDeviceToHost));
       for (int k = 0; k < KX; ++k) {
         double v = lsdx[(h->slot & 1) * KXMAX + k];
-        if (c.pend_leafsd && c.pend_iter > 2) {
+        if (c.pend_leafsd) {
           long long q = 0;
           for (int sl = 0; sl < IA_SLOTS; ++sl) q += ix[(size_t)sl * 2 * KX + KX + k];
-          if (q > 0) v = ((double)q * d.sc.inv_c1) / (double)d.n;
+          v = pgb_tuned_leaf_sd(v, c.pend_iter, q, d.sc.inv_c1, d.n);
         }
         leaf_sd_out[k + 1] = v;
       }

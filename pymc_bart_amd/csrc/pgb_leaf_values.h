@@ -58,12 +58,12 @@ __device__ __forceinline__ ChildVals child_values(const DevG& S, int rule, int c
 // leaf_sd of extension output k (0-based), with the pending update of a FINAL pass resolved the
 // same way as for output 0
 __device__ __forceinline__ double leaf_sd_x(const DevG& S, const Ctrl& c, int ctrl_par, int acc_par, int k) {
-  if (!(c.pend_leafsd && c.pend_iter > 2)) return S.lsdx[ctrl_par * KXMAX + k];
+  const double cur = S.lsdx[ctrl_par * KXMAX + k];
+  if (!(c.pend_leafsd && c.pend_iter > 2)) return cur;
   const int KX = S.K - 1;
   long long q = 0;
   for (int sl = 0; sl < IA_SLOTS; ++sl) q += S.iax[((size_t)acc_par * IA_SLOTS + sl) * 2 * KX + KX + k];
-  if (q <= 0) return S.lsdx[ctrl_par * KXMAX + k];  // (a running sd of exactly 0 is not adopted: deviation 12)
-  return ((double)q * S.sc.inv_c1) / (double)S.n;
+  return pgb_tuned_leaf_sd(cur, c.pend_iter, q, S.sc.inv_c1, S.n);
 }
 __device__ __forceinline__ long long root_A_x(const DevG& S, int acc_par, int k) {
   const int KX = S.K - 1;
