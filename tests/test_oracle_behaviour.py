@@ -215,6 +215,42 @@ def test_tuning_updates_split_prior_and_leaf_sd(oracle):
     assert np.array_equal(s.split_weights(), frozen) and vi.sum() >= 0
 
 
+def test_leaf_sd_is_the_running_sd_of_the_accepted_trees_recomputed_in_numpy(oracle):
+    """[U] RunningSd (Welford per row over the predictions of every accepted tree, count from 1, mean and m2 from 0),
+    leaf_sd = mean over the rows of sqrt(m2 / count) from the third tree update on -- recomputed here from the
+    exported trees alone and compared with what the sampler tuned itself to."""
+    rng = np.random.default_rng(18)
+    n, m = 150, 4
+    X = rng.normal(size=(n, 3))
+    Y = 2 * X[:, 1] + rng.normal(0, 0.3, n)
+    st = PyBartSettings.from_data(X, Y, m=m, num_particles=8, seed=5, batch=(1.0, 1.0))
+    s = PySampler(st, X, Y, np.zeros(3, np.int32), np.ones(3), backend=oracle)
+    s.set_likelihood([0.3])
+    rules = np.zeros(3, np.int32)
+    count, mean, m2, want = 0, np.zeros(n), np.zeros(n), st.init_leaf_sd
+    w_before = s.split_weights()
+    for _ in range(7):
+        s.step(True)
+        step_trees = s.export_trees(0)                       # the m trees this step accepted, in update order
+        assert step_trees.n_trees == m
+        # [U] alpha_vec[j] += 1 for every split on column j in an accepted tree (while tuning)
+        used = np.asarray(step_trees.var)
+        w_after = s.split_weights()
+        assert np.array_equal(w_after - w_before, np.bincount(used[used >= 0], minlength=3))
+        w_before = w_after
+        for k in range(m):
+            nv = predict_numpy(step_trees, np.array([[k]]), X, rules)[0, 0]
+            count += 1
+            delta = nv - mean
+            mean = mean + delta / count
+            m2 = m2 + delta * (nv - mean)
+            sd = float(np.mean(np.sqrt(m2 / count)))
+            if count > 2 and sd > 0:
+                want = sd
+        assert s.state()["leaf_sd"][0] == pytest.approx(want, rel=1e-9, abs=1e-9)
+    assert want != st.init_leaf_sd
+
+
 def test_error_paths(oracle):
     X = np.zeros((10, 2))
     Y = np.zeros(10)
