@@ -371,7 +371,11 @@ def random_case(seed, large=False):
     elif fam == "gamma_log":
         Y = rng.gamma(2.0, np.exp(np.clip(f, -3, 3)) / 2.0) + 1e-6
     elif fam == "categorical":
-        K = int(rng.integers(2, 8)); Y = rng.integers(0, K, n).astype(float)
+        # classes that DEPEND on the covariates (Gumbel-max over logits that fan out with f): with a pure-noise
+        # response the stump wins nearly every update and the K-vector growth paths are hardly exercised
+        K = int(rng.integers(2, 8))
+        logits = np.stack([f * (k - 0.5 * (K - 1)) for k in range(K)]) + rng.gumbel(size=(K, n))
+        Y = np.argmax(logits, axis=0).astype(float)
     else:
         K = 2; Y = f + rng.normal(0, 1, n) * (0.5 + (np.nan_to_num(X[:, 0]) > 0))
     batch = (float(rng.choice([0.1, 0.34, 1.0])), float(rng.choice([0.1, 0.5])))
