@@ -251,6 +251,76 @@ def test_leaf_sd_is_the_running_sd_of_the_accepted_trees_recomputed_in_numpy(ora
     assert want != st.init_leaf_sd
 
 
+def _scale_equivariance(backend, n=700):
+    """Y -> c Y with sigma -> c sigma leaves every likelihood ratio where it was, so a Normal-family chain must come
+    out scaled: the same splits, every sum_trees times c -- EXACTLY for a power of two (the fixed-point range
+    follows the data), to rounding otherwise.  Nothing in the sampler may depend on the units of the response."""
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(n, 4))
+    X[rng.random(n) < 0.1, 2] = np.nan
+    Y = np.sin(X[:, 0]) + 0.5 * X[:, 1] + rng.normal(0, 0.3, n)
+
+    def run(c):
+        st = PyBartSettings.from_data(X, Y * c, m=12, num_particles=8, seed=21, batch=(0.5, 0.5))
+        s = PySampler(st, X, Y * c, np.zeros(4, np.int32), np.ones(4), backend=backend)
+        s.set_likelihood([0.3 * c])
+        mus = np.array([s.step(it < 15)[0] for it in range(30)])
+        return st, mus, s.export_trees(1), s.state()["leaf_sd"][0]
+
+    st1, m1, t1, sd1 = run(1.0)
+    assert np.std(m1[-1]) > 0.3
+    for c in (4.0, 0.125, 3.0):
+        stc, mc, tc, sdc = run(c)
+        assert np.array_equal(t1.var, tc.var) and np.array_equal(t1.split, tc.split) and np.array_equal(t1.count, tc.count)
+        if c != 3.0:
+            assert stc.range_exp != st1.range_exp                   # the fixed-point range moved with the data ...
+            assert np.array_equal(mc, m1 * c) and sdc == sd1 * c    # ... and the chain is the same chain, exactly
+            assert np.array_equal(np.asarray(tc.value), np.asarray(t1.value) * c)
+        else:
+            np.testing.assert_allclose(mc, m1 * c, rtol=0, atol=1e-12 * np.abs(mc).max())
+
+
+def _monotone_invariance(backend, n=900):
+    """Trees with ContinuousSplit see a column only through the ORDER of its values: x -> g(x), g strictly
+    increasing, must leave every partition, every weight and so the whole chain where it was -- bit for bit, with
+    each split value mapped through g (constant leaves; NaNs stay NaN; a whole-number column with heavy ties in it).
+    On the GPU this also crosses the float32 shadow of the split columns when that path is forced on."""
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(n, 4))
+    X[rng.random(n) < 0.1, 2] = np.nan
+    X[:, 3] = np.round(X[:, 3])
+    Y = np.sin(X[:, 0]) + 0.5 * X[:, 1] + 0.3 * X[:, 3] + rng.normal(0, 0.3, n)
+
+    def g(x):
+        return np.sinh(x) * 8.0 - 3.0
+
+    Xg = g(X)
+    for j in range(4):                                            # g merged no two values in floating point
+        assert len(np.unique(X[~np.isnan(X[:, j]), j])) == len(np.unique(Xg[~np.isnan(Xg[:, j]), j]))
+
+    def run(Xv, family, Yv):
+        st = PyBartSettings.from_data(Xv, Yv, m=12, num_particles=8, seed=21, batch=(0.5, 0.5), family=family)
+        s = PySampler(st, Xv, Yv, np.zeros(4, np.int32), np.ones(4), backend=backend)
+        s.set_likelihood([0.3] if family == "normal" else [])
+        return np.array([s.step(it < 15)[0] for it in range(30)]), s.export_trees(1)
+
+    for family, Yv in (("normal", Y), ("bernoulli_probit", (Y > Y.mean()).astype(float))):
+        m1, t1 = run(X, family, Yv)
+        m2, t2 = run(Xg, family, Yv)
+        assert np.std(m1[-1]) > 0.2
+        assert np.array_equal(m1, m2) and np.array_equal(t1.var, t2.var) and np.array_equal(t1.count, t2.count)
+        inner = np.asarray(t1.var) >= 0
+        assert np.array_equal(g(np.asarray(t1.split)[inner]), np.asarray(t2.split)[inner])
+
+
+def test_chain_is_invariant_under_monotone_transforms_of_the_covariates(oracle):
+    _monotone_invariance(oracle)
+
+
+def test_normal_chain_is_equivariant_under_rescaling_of_the_response(oracle):
+    _scale_equivariance(oracle)
+
+
 def test_error_paths(oracle):
     X = np.zeros((10, 2))
     Y = np.zeros(10)

@@ -559,6 +559,22 @@ def test_prediction_rejects_a_matrix_narrower_than_the_trees(hip):
         _sample_posterior(s, X[:, :2], np.random.default_rng(0), size=2)
 
 
+def test_normal_chain_is_equivariant_under_rescaling_of_the_response_on_gpu(hip):
+    """A property of the HIP backend by itself (no oracle involved), at a size with many chunks per pass."""
+    from test_oracle_behaviour import _scale_equivariance
+
+    _scale_equivariance(hip, n=40_000)
+
+
+@pytest.mark.parametrize("x32", ["default", "float32 shadow forced"])
+def test_chain_is_invariant_under_monotone_transforms_of_the_covariates_on_gpu(hip, monkeypatch, x32):
+    from test_oracle_behaviour import _monotone_invariance
+
+    if x32 != "default":
+        monkeypatch.setenv("PGB_X32_MIN_MB", "0")
+    _monotone_invariance(hip, n=30_000)
+
+
 def test_subset_codes_are_checked_by_the_library_on_gpu(hip):
     from test_oracle_behaviour import _subset_codes_are_checked_by_the_library
 
