@@ -356,7 +356,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
 
   // pending leaf_sd from the FINAL pass of the previous slot ([U] RunningSd -> leaf_sd)
   double leaf_sd = c.leaf_sd;
-  if (c.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(c.leaf_sd, c.pend_iter, ia.QSTD, S.sc.inv_c1, S.n);
+  // (the "third update on" test is repeated out here on purpose: with pend_iter tested only inside the call the
+  //  compiler re-ordered the first loads of this kernel and every launch took 0.3 us longer -- 6.45 -> 6.75 us,
+  //  A/B of five statement shapes on one box, profiles/r03_experiments.md section 14)
+  if (c.pend_leafsd && c.pend_iter > 2) leaf_sd = pgb_tuned_leaf_sd(c.leaf_sd, c.pend_iter, ia.QSTD, S.sc.inv_c1, S.n);
 
   if (b == 0 && tid == 0 && c.phase != PH_IDLE) atomicAdd(&S.counters[5], 1ull);  // slots that did work
   if (tid < ACC_SLOTS) {

@@ -159,7 +159,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       qstd += src[k].QSTD;
       rootA += src[k].A;
     }
-    if (cn.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(cn.leaf_sd, cn.pend_iter, qstd, S.sc.inv_c1, S.n);
+    if (cn.pend_leafsd && cn.pend_iter > 2) leaf_sd = pgb_tuned_leaf_sd(cn.leaf_sd, cn.pend_iter, qstd, S.sc.inv_c1, S.n);
   }
   const Job* jobs = S.jobs + (size_t)par * MAXP;
   if (tid < 64) {

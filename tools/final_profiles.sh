@@ -17,4 +17,5 @@ for w in cfg2 cfg4 cfg5; do
   cp /tmp/ktrace_bench.json $O/r03_bench_${w}_under_rocprof.json
   tools/pmc_busy.sh gpurun_out/fin/r03_${w}_issue_wait.txt $A --no-roofline > /dev/null 2>&1
 done
+python tools/latency_guard.py > $O/r03_latency_guard.txt 2>&1; echo "latency guard rc=$?" >> $O/r03_latency_guard.txt; tail -3 $O/r03_latency_guard.txt
 ls -la $O
