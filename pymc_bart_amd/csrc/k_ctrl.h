@@ -282,8 +282,11 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
 template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
-void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias,
+void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias,
             const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all) {
+  // nwg repeats gridDim.x as an explicit argument (it takes the padding after `par`): explicit arguments arrive
+  // preloaded in SGPRs, gridDim.x is a HIDDEN one and cost a scalar load with its wait in front of the first batch
+  // of global loads of every launch
   // ctrls / ias / jobs_all / acc_all / parts_all repeat S.ctrl / S.initacc / S.jobs / S.acc / S.parts as
   // kernel arguments (preloaded into SGPRs): their first loads do not wait for the argument block S
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);  // device-resident: kernel arguments live in host-coherent memory, HBM is closer
@@ -305,9 +308,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, Ctrl* __restrict__ ctrls, const
   // in idle / first slots (the records exist).
   Job j_pre;
   Acc a_pre;
-  // (only the lanes that can be particles: the grid has P - 1 or P workgroups, so lanes 1 .. gridDim.x cover
+  // (only the lanes that can be particles: the grid has P - 1 or P workgroups, so lanes 1 .. nwg (= gridDim.x) cover
   //  particles 1 .. P - 1 -- at P = 40 the other 23 lanes made 37 % of this batch for nothing)
-  if (threadIdx.x >= 1 && threadIdx.x <= gridDim.x) {
+  if (threadIdx.x >= 1 && threadIdx.x <= (unsigned)nwg) {
     j_pre = jobs_all[(size_t)(par ^ 1) * MAXP + threadIdx.x];
     a_pre = load_acc(&acc_all[((size_t)(par ^ 1) * MAXP + threadIdx.x) * ACC_PER]);
   }

@@ -708,11 +708,11 @@ static int enqueue_slots(pgb_handle* h, int count) {
   const bool lin = d.response != PGB_RESPONSE_CONSTANT;
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-#define CTRL_ARGS dd, par, d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
-    if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS);
-    else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS);
-    else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS);
-    else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), dim3((unsigned)d.P), CTRL_ARGS);  // + the workgroup that builds the label tables ahead
+#define CTRL_ARGS(nwg) dd, par, (int)(nwg), d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
+    if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS(gctrl.x));
+    else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS(gctrl.x));
+    else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS(gctrl.x));
+    else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), dim3((unsigned)d.P), CTRL_ARGS(d.P));  // + the workgroup that builds the label tables ahead
 #undef CTRL_ARGS
 #define ROWS_ARGS dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
