@@ -575,6 +575,40 @@ def test_chain_is_invariant_under_monotone_transforms_of_the_covariates_on_gpu(h
     _monotone_invariance(hip, n=30_000)
 
 
+def test_thirty_million_rows_stay_consistent(hip):
+    """Size edge (include/pgbart.h: n < 2^31 - 1024; memory sized for 288 GB): n = 30 M rows -- 29 297 chunks per
+    pass, label rings of 15 GB, element offsets beyond 2^32 -- with the properties that need no oracle: every row
+    is in exactly one leaf of every tree, sum_trees is the sum of the stored trees' predictions (checked on a
+    sample of rows through the prediction kernel), the chain is finite and has moved."""
+    rng = np.random.default_rng(30)
+    n, p, m = 30_000_000, 4, 5
+    X = rng.standard_normal((n, p))
+    X[::1000, 2] = np.nan
+    Y = np.sin(X[:, 0]) + 0.5 * (X[:, 1] > 0) + 0.1 * rng.standard_normal(n)
+    st = PyBartSettings.from_data(X, Y, m=m, num_particles=10, seed=7, batch=(1.0, 1.0))
+    s = PySampler(st, X, Y, np.zeros(p, np.int32), np.ones(p), backend=hip)
+    s.set_likelihood([0.1])
+    for _ in range(3):
+        mu, _ = s.step(True)
+    assert mu.shape == (n,) and np.all(np.isfinite(mu)) and mu.std() > 0.05
+    forest = s.export_trees(1)
+    off = np.asarray(forest.node_off)
+    count, var, left, right = (np.asarray(getattr(forest, f)) for f in ("count", "var", "left", "right"))
+    for k in range(m):
+        assert count[off[k]] == n                                            # the root holds every row
+        nodes = np.arange(off[k], off[k + 1])
+        inner = nodes[var[nodes] >= 0]
+        kids = count[off[k] + left[inner]] + count[off[k] + right[inner]]
+        assert np.all(kids <= count[inner]) and np.all(count[inner] - kids <= np.isnan(X[:, 2]).sum())   # only NaN rows drop out
+    rows = rng.integers(0, n, 50_000)
+    rows[:3] = [0, n - 1, 2 ** 24 + 1]
+    ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 1, np.zeros(p, np.int32), backend=hip)
+    pred = ps.sample_posterior(X[rows], [0])[0, 0]
+    ok = ~np.isnan(X[rows, 2])                                                # (a dropped row is predicted by its parent's mixture)
+    np.testing.assert_allclose(pred[ok], mu[rows][ok], rtol=0, atol=1e-9)
+    assert s.counters.saturations == 0
+
+
 def test_subset_codes_are_checked_by_the_library_on_gpu(hip):
     from test_oracle_behaviour import _subset_codes_are_checked_by_the_library
 
