@@ -34,7 +34,10 @@
  *                        pgb_set_data checks every value and returns PGB_E_INVALID naming the column
  *   response linear/mix  any split rule (a leaf regresses on the column its parent split on, upstream's
  *                        fast_linear_fit; on a SubsetSplit column that is the category code)
- *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory)
+ *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory: per row the device holds 8 p bytes
+ *                        of the design matrix (+ 4 p for its float32 shadow when it exceeds the Infinity Cache),
+ *                        m bytes of tree labels, 512 bytes of particle labels (8 generations x 64 slots) and
+ *                        ~ 64 K bytes of running statistics -- 30 M rows x 4 columns x 5 trees: 17 GB, in the suite)
  */
 #ifndef PGBART_H
 #define PGBART_H
