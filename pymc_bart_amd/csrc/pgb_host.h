@@ -493,6 +493,12 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
 extern "C" int pgb_destroy(pgb_handle* h) {
   if (!h) return PGB_OK;
   if (h->worker.joinable()) h->worker.join();
+  // pgb_step_host returns while up to FEED_MIN idle slots are still queued on the sampler's stream (they write
+  // the pinned flag words and the control records): nothing below may be freed under them, and torch's
+  // streams are non-blocking, so no implicit ordering can be relied on
+  (void)hipStreamSynchronize(h->stream);
+  if (h->stream_out) (void)hipStreamSynchronize(h->stream_out);
+  (void)hipGetLastError();
   for (int k = 0; k < PK_COUNT; ++k)
     for (hipEvent_t e : h->ev[k]) (void)hipEventDestroy(e);
   if (h->flag) (void)hipHostFree((void*)h->flag);
@@ -859,6 +865,10 @@ static int callback_host_phase(pgb_handle* h, int par) {
 // step is expected to need them (running mean - 1 sd of the slots such a call took), FEED_MIN beyond it
 // after that -- so a finished step leaves at most a few idle slots (~2.6 us each) behind it.  No events, no
 // barrier packets: the throttle costs the device nothing and the host one read of pinned memory.
+static double watchdog_seconds() {
+  static const double v = getenv("PGB_WATCHDOG_S") ? atof(getenv("PGB_WATCHDOG_S")) : 20.0;
+  return v > 0.1 ? v : 0.1;
+}
 #define FEED_AHEAD 24
 #define FEED_MIN 6
 #define FEED_RUN 8
@@ -896,6 +906,11 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
   }
   long long idle_polls = 0;
   int refill = 0;
+  // lost-device watchdog by the WALL clock (a poll count means different times on different hosts, and a false
+  // trip poisons the chain): PGB_WATCHDOG_S seconds without a single slot starting; the deadline moves whenever
+  // the device publishes progress
+  long long seen = (long long)h->flag[2];
+  auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
   while (*h->flag < (unsigned long long)h->steps_target) {
     const long long executed = (long long)h->flag[2];
     long long limit = executed + feed_ahead;
@@ -923,10 +938,12 @@ static int feed_until_flag(pgb_handle* h, int n_steps) {
       // concurrent chains): a waiting feeder gives its core away instead of spinning against the others
       if (g_live_handles.load(std::memory_order_relaxed) > 1) sched_yield();
       // a device that stops publishing progress (lost GPU, a kernel that faulted) ends the call, not the process
-      if ((++idle_polls & 0xFFFF) == 0) {
-        if ((long long)h->flag[2] != executed) {
-          idle_polls = 0;
-        } else if (idle_polls >= (1ll << 26)) {  // ~10 s of polling without a single slot starting
+      if ((++idle_polls & 0x3FFF) == 0) {
+        const auto now = std::chrono::steady_clock::now();
+        if ((long long)h->flag[2] != seen) {
+          seen = (long long)h->flag[2];
+          deadline = now + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
+        } else if (now > deadline) {
           hipError_t e = hipStreamQuery(h->stream);
           h->poisoned = 1;
           if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "device stopped making progress");
@@ -1067,7 +1084,17 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   const bool early = h->s.family != PGB_FAMILY_CALLBACK && !h->prof && h->stream_out != nullptr;
   if (early) {
     int extra = 0;
+    long long polls = 0;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
     while (h->flag[1] < (unsigned long long)h->steps_target) {
+      // (a device that faults between "last tree accepted" and the first idle slot would otherwise hold this
+      //  loop for ever, with the GIL released)
+      if ((++polls & 0x3FFF) == 0 && std::chrono::steady_clock::now() > deadline) {
+        hipError_t e = hipStreamQuery(h->stream);
+        h->poisoned = 1;
+        if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "device stopped before the step-complete word");
+        return fail(PGB_E_STATE, "the step-complete word never fired");
+      }
       // every enqueued slot has started and none of them was an idle one behind the finishing slot: one more
       if ((long long)h->flag[2] >= h->slot) {
         if (h->flag[1] >= (unsigned long long)h->steps_target) break;

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <sched.h>
 #include <thread>

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Build an experiment variant of the HIP library next to the product build:
-  python tools/build_variant.py NAME [-DFOO=1 ...]   ->  pymc_bart_amd/csrc/libpgbart_hip_NAME.so
+  python tools/build_variant.py NAME [-DFOO=1 ...]   ->  build/variants/libpgbart_hip_NAME.so
 (same flags as __graft_entry__.build plus the given ones).  Run a bench against it with
-PGBART_HIP_LIB=<that path>; variants are git-ignored (*.so) but travel to the GPU box."""
+PGBART_HIP_LIB=<that path>; variants are git-ignored (build/) but travel to the GPU box."""
 import os
 import subprocess
 import sys
@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 name, extra = sys.argv[1], sys.argv[2:]
-out = os.path.join(g.CSRC, f"libpgbart_hip_{name}.so")
+vdir = os.path.join(ROOT, "build", "variants")  # (csrc/ holds the product library only)
+os.makedirs(vdir, exist_ok=True)
+out = os.path.join(vdir, f"libpgbart_hip_{name}.so")
 subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *g.HIPCC_FLAGS, *extra, g.HIP_SRC, "-o", out])
 print(out)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Slot anatomy from the in-kernel device-clock stamps (-DPGB_TRACE build of the HIP library).
 
-Builds pymc_bart_amd/csrc/libpgbart_hip_trace.so (same flags as __graft_entry__.build plus
+Builds build/variants/libpgbart_hip_trace.so (same flags as __graft_entry__.build plus
 -DPGB_TRACE) when run with --build (no GPU needed), and on a GPU box runs cfg2 for a few asteps
 and prints, per stage stamp, the median offset from the entry of k_ctrl (workgroup 1), for plain
 SMC rounds and for the slots that start a tree.  Stamps (k_ctrl.h / k_rows.h):
@@ -25,12 +25,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-TRACE_SO = os.path.join(ROOT, "pymc_bart_amd", "csrc", "libpgbart_hip_trace.so")
+TRACE_SO = os.path.join(ROOT, "build", "variants", "libpgbart_hip_trace.so")
 
 
 def build(extra=(), out=TRACE_SO):
     import __graft_entry__ as g
 
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *g.HIPCC_FLAGS, "-DPGB_TRACE", *extra, g.HIP_SRC, "-o", out]
     subprocess.check_call(cmd)
     print("built", out)
