@@ -21,10 +21,13 @@ over the m trees), switch to tune=0, W untimed warm-up asteps, then blocks of EX
 bracketed by barrier + synchronize, until at least ``--min-seconds`` of GPU time have been timed (or
 ``--repeats`` blocks when given); ``value`` is the median block (min / max alongside).  Further legs at
 N=1: ``resident_path``, ``tune1``, the per-kernel profile behind ``roofline`` / ``roofline_kernels``, 4
-chains on the one GPU, the CPU baseline (1 core and 8 chains on 8 cores) -- and the other single-GPU
-configurations of BASELINE.json, cfg4 (Bernoulli-probit, n=1M) and cfg5 (K=4 softmax, n=250k), each with
-its own value, dominant-kernel roofline, row-pass HBM roofline from measured bytes and a short CPU
-baseline, under ``workloads``.
+chains on the one GPU -- and the other single-GPU configurations of BASELINE.json, cfg4 (Bernoulli-probit,
+n=1M) and cfg5 (K=4 softmax, n=250k), each with its own value, dominant-kernel roofline and row-pass HBM
+roofline from measured bytes, under ``workloads``.  ALL GPU legs run first, back to back (the GPU is held
+for ~30 s contiguously); the CPU baselines (cfg2: 1 core and 8 chains on 8 cores; cfg4 / cfg5: a bounded
+sample) follow, each with a GPU rate at the SAME chain age beside it (``matched_age``).  The line ENDS with
+a compact ``summary`` object that repeats every headline figure (a log tail keeps it); the prose that
+explains the fields is profiles/BENCH_NOTES.md.
 """
 
 from __future__ import annotations
@@ -46,7 +49,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # fp64 VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, a wave64 fp64 instruction occupies its SIMD for 4
 # cycles (78.6 TFLOP/s fp64 vector = 16 lanes x 2 flop per SIMD and clock)
 VALU_F64_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # G wave-instructions / s
-ROUND = "r03"
+ROUND = "r04"
+NOTES = "profiles/BENCH_NOTES.md"
 
 METRIC = {
     "cfg2": "particle-steps/sec (n=100k, p=50, m=200, 40 particles)",
@@ -62,8 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed blocks of --steps asteps; value = median.  0 (default): as many as --min-seconds needs")
-    ap.add_argument("--min-seconds", type=float, default=2.5,
-                    help="GPU time the headline's timed blocks cover at least (round-2 VERDICT: >= 2 s)")
+    ap.add_argument("--min-seconds", type=float, default=5.0,
+                    help="GPU time the headline's timed blocks cover at least (also of each workload leg)")
     ap.add_argument("--burnin", type=int, default=100,
                     help="tune=1 asteps before anything is timed (100 = 10 sweeps at the default batch)")
     ap.add_argument("--n", type=int, default=100_000)
@@ -174,7 +178,7 @@ def cpu_baseline(wname, wkw, seed, budget_s, response="constant"):
 
     so_path, flags = build_oracle_native()
     cores = min(8, os.cpu_count() or 1)
-    burn = 10 if wname == "cfg2" else 0  # one tune=1 sweep first (a fraction of the GPU burn-in: CPU time)
+    burn = CPU_BURN_CFG2 if wname == "cfg2" else 0  # (the GPU rate at this chain age: cpu_baseline.matched_age)
     ctx = mp.get_context("spawn")
     with ctx.Pool(1) as pool:
         one = pool.map(_cpu_worker, [(wname, wkw, seed, budget_s, burn, response, so_path)])[0]
@@ -185,10 +189,9 @@ def cpu_baseline(wname, wkw, seed, budget_s, response="constant"):
                                           for c in range(cores)])
     out = {
         "value": one["particle_steps"] / one["dt"], "unit": "particle-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{one['steps']} tune=0 asteps ({one['tree_updates']} tree updates, {one['dt']:.1f} s) of the "
-                  f"same {wname} data after {burn} tune=1 + 1 tune=0 warm-up asteps; restated CPU baseline "
-                  "(oracle/), not the reference binary (bartrs is not installable here); one chain on one "
-                  "core, as upstream runs a chain (chains are processes)",
+        "sample": f"{one['steps']} tune=0 asteps ({one['tree_updates']} tree updates, {one['dt']:.1f} s) of the same "
+                  f"{wname} data after {burn} tune=1 + 1 tune=0 warm-up asteps; oracle/ (C restatement), 1 chain on 1 core",
+        "burnin_asteps_tune1": burn,
         "compiler": flags,
         "tree_updates_per_s": one["tree_updates"] / one["dt"],
         "rows_touched_per_particle_step": one["rows_touched"] / max(one["particle_steps"], 1),
@@ -218,8 +221,8 @@ def cpu_baseline_short(w, wname, seed, budget_s):
     return {
         "value": r["particle_steps"] / r["dt"], "unit": "particle-steps/s", "cores": 1, "kind": "port",
         "sample": f"{r['tree_updates']} tune=0 tree updates ({r['dt']:.1f} s, one tree per step) of the same {wname} "
-                  f"data from the start of a chain, after 1 warm-up tree update; restated CPU baseline (oracle/), "
-                  f"one chain on one core; sampler construction ({r['create_s']:.1f} s) not timed",
+                  f"data from the start of a chain after 1 warm-up tree update; oracle/ (C restatement), 1 chain on 1 core",
+        "tree_updates": r["tree_updates"],
         "compiler": flags,
         "rows_touched_per_particle_step": r["rows_touched"] / max(r["particle_steps"], 1),
         "rows_touched_per_s": r["rows_touched"] / r["dt"],
@@ -348,7 +351,7 @@ def kernel_profile(s, tune, steps):
 def load_pmc(wname):
     """Per-launch counter averages of the hot kernels from the separate ``rocprofv3 --pmc`` passes
     (``tools/pmc_collect.sh``; the newest round's file that exists)."""
-    for rnd in (ROUND, "r02"):
+    for rnd in (ROUND, "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wname}.json")
         if os.path.exists(path):
             with open(path) as fh:
@@ -373,7 +376,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
         # the control kernel has no bandwidth or FLOP roofline: one workgroup per particle walks a chain of
         # dependent loads and scalar decisions (profiles/r03_experiments.md section 5: ~1.6 us until its first data,
         # ~3.8 us of dependent work); its floor is latency, and it is the other half of a cfg2 slot
-        out["roofline_kernels"]["k_ctrl"]["bound"] = "latency (serial control: one workgroup per particle)"
+        out["roofline_kernels"]["k_ctrl"]["bound"] = "latency"
     pmc, pmc_src = load_pmc(wname) if default_cfg else ({}, None)
     ms_rows, launches = prof["ms_rows"], prof["launches"]
     tu, rt, parts = prof["tree_updates"], prof["rows_touched"], prof["partitions"]
@@ -398,19 +401,14 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
             "bound": "hbm", "kernel": "k_rows" if K_out == 1 else "k_rows_mk", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": (pmc_src + ": " + pmc.get("command", "")) if pmc else None,
+            "traffic_source": pmc_src,
             "launches": launches, "avg_launch_us": avg_us,
             "avg_kernel_us_device_clock": (prof["clk_ms"] * 1e3 / prof["clk_launches"]) if prof["clk_launches"] else None,
             "frac_device_clock": (alg / (prof["clk_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof["clk_ms"] > 0 else None,
             "algorithmic_bytes_per_launch": alg / max(launches, 1),
             "implementation_bytes_per_launch_model": impl / max(launches, 1),
             "implementation_GBps_model": impl / (ms_rows * 1e-3) / 1e9,
-            "note": "achieved = ALGORITHMIC bytes (sum over tree updates of 48 n + 40 rows_touched for K=1, "
-                    "SURVEY.md 8d: the traffic of the reference's index-list layout) / total time of the row pass "
-                    "from HIP events attached to each dispatch; a work rate.  `traffic` = HBM bytes per launch "
-                    "from the PMC passes; implementation_* = byte model of what this layout streams per launch "
-                    "(labels 1 B in + 1 B out and the split column of every ACTIVE particle, 16 B per row and "
-                    "particle group), most of it served by L2 / Infinity Cache at cfg2.",
+            "note": NOTES + "#roofline-of-the-row-pass",
         }
         if traffic:
             rows["measured_hbm_GBps"] = traffic / (avg_us * 1e-6) / 1e9
@@ -428,17 +426,13 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
             "frac": (ginst / VALU_F64_PEAK_GINST) if ginst else None,
             "avg_launch_us": kl["ms"] * 1e3 / kl["launches"], "launches": kl["launches"],
             "valu_wave_insts_per_launch": insts, "insts_source": pmc_src,
-            "note": "the per-row log-likelihood pass is the dominant kernel of this workload and is bound by "
-                    "fp64 VALU issue (peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 "
-                    "instruction); instructions per launch from the SQ_INSTS_VALU pass under profiles/",
+            "note": NOTES + "#roofline-of-the-likelihood-pass",
         }
         if rows is not None:
             if rows.get("measured_hbm_GBps"):
                 rows["model_achieved"], rows["model_frac"] = rows["achieved"], rows["frac"]
                 rows["achieved"], rows["frac"] = rows["measured_hbm_GBps"], rows["measured_hbm_frac"]
-                rows["note"] = ("achieved = MEASURED HBM bytes per launch (`traffic`: FETCH_SIZE x2 + WRITE_SIZE from the "
-                                "PMC passes) / the live average launch duration from HIP events; model_* keep the "
-                                "SURVEY 8d index-list byte model, which exceeds what this layout moves. " + rows["note"])
+                rows["note"] = NOTES + "#row-pass-graded-on-measured-bytes"
             out["roofline_rows"] = rows
     elif rows is not None:
         out["roofline"] = rows
@@ -449,6 +443,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    t_start = time.perf_counter()
 
     import torch
 
@@ -507,13 +502,13 @@ def main():
     tune = bool(args.tune)
     default_cfg = (args.workload != "cfg2") or (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40)
 
-    def make_chain(wn, kw, sd, be):
+    def make_chain(wn, kw, sd, be, batch=(0.1, 0.1), wl=None):
         """One chain of workload ``wn`` as the step method itself: its sampler is the resident path."""
         from pymc_bart_amd.pgbart import (PGBART, BARTOp, BernoulliLikelihood, CategoricalLikelihood,
                                           NormalLikelihood)
         import warnings
 
-        wl = getattr(workloads, wn)(**kw)
+        wl = getattr(workloads, wn)(**kw) if wl is None else wl
         lik = {"normal": lambda: NormalLikelihood(1.0),  # sigma fixed at 1 (SURVEY.md 8d)
                "bernoulli_probit": lambda: BernoulliLikelihood("probit"),
                "categorical": lambda: CategoricalLikelihood(wl.get("K", 1))}[wl["family"]]()
@@ -521,7 +516,7 @@ def main():
             warnings.simplefilter("ignore")  # response=linear is flagged experimental, as upstream
             op = BARTOp(wl["X"], wl["Y"], m=wl["m"], response=args.response)
         st = PGBART([op], num_particles=wl["num_particles"], likelihood=lik, observed=wl["Y"], random_seed=sd,
-                    backend=be)
+                    backend=be, batch=batch)
         return wl, st
 
     if dry:
@@ -652,8 +647,7 @@ def main():
                 "value": u_r["particle_steps"] / el_r, "unit": "particle-steps/s", "ms_per_step": el_r * 1e3 / args.steps,
                 "value_min": r_min, "value_max": r_max, "repeats": 5,
                 "astep_fraction_of_resident": line["value"] / (u_r["particle_steps"] / el_r),
-                "note": "pgb_step_async + pgb_sync: the same asteps without sum_trees on the host, tree export and "
-                        "stats -- the rate of the device state machine alone",
+                "note": NOTES + "#resident-path",
             }
 
     # ---- roofline of the dominant kernel + per-kernel shares: a further block with events attached
@@ -698,30 +692,76 @@ def main():
                                      "note": "4 independent chains on one GPU, one HIP stream each"}
         del ss4
 
-    # ---- the other single-GPU configurations of BASELINE.json, under the same clock (round-2 VERDICT #1)
+    # ---- the other single-GPU configurations of BASELINE.json, under the same clock: GPU legs only here,
+    #      back to back with the headline's; their CPU samples follow after every GPU leg of the run
+    pending_cpu = []
     if solo and args.workload == "cfg2" and default_cfg and not args.no_extras and not args.no_workloads and not tune:
         del samplers, s
         step.sampler = None
         line["workloads"] = {}
         for wn in ("cfg4", "cfg5"):
-            line["workloads"][wn] = workload_leg(wn, make_chain, be, args, torch)
-        line["config"]["also_measured"] = {
-            wn: {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                 "roofline_kernel": d.get("roofline", {}).get("kernel"), "roofline_frac": d.get("roofline", {}).get("frac"),
-                 "rows_hbm_frac": d.get("roofline_rows", {}).get("frac"),
-                 "cpu_baseline_value": d.get("cpu_baseline", {}).get("value")}
-            for wn, d in line["workloads"].items()}
+            d, wl = workload_leg(wn, make_chain, be, args, torch)
+            line["workloads"][wn] = d
+            pending_cpu.append((wn, d, wl))
+    # ---- GPU rate at the chain age of the CPU sample (10 tune asteps of burn-in instead of 100: the CPU leg
+    #      cannot afford 100) so that the ratio compares like with like
+    matched = None
+    if rank == 0 and world == 1 and solo and not args.no_cpu_baseline and default_cfg and wname == "cfg2":
+        _, stm = make_chain(wname, wkw, seed, be)
+        sm = stm.sampler
+        run_all([sm], True, CPU_BURN_CFG2)
+        run_all([sm], False, 1)
+        (el_m, u_m), _, _ = median_block(resident_blocks([sm], False, args.steps, 3, barrier))
+        matched = {"gpu_value": u_m["particle_steps"] / el_m, "path": "resident", "burnin_asteps_tune1": CPU_BURN_CFG2,
+                   "rows_touched_per_particle_step": u_m["rows_touched"] / max(u_m["particle_steps"], 1)}
+        del sm
+        stm.sampler = None
+    gpu_done_s = time.perf_counter() - t_start
 
+    # ---- CPU baselines, after every GPU leg
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         cpu = cpu_baseline(wname, wkw, seed, args.cpu_budget, response=args.response)
         line["cpu_baseline"] = cpu
         line["speedup_vs_cpu_baseline"] = line["value"] / cpu["value"]
-        # (the CPU chain is younger -- 10 tune asteps of burn-in, not 100 -- and touches more rows per
-        #  particle-step; in rows touched per second the ratio is the fairer one: round-2 VERDICT, weak #8)
         line["speedup_vs_cpu_rows_touched_per_s"] = (line["tree_updates_per_s"] * line["rows_touched_per_tree"]
                                                      / cpu["rows_touched_per_s"])
+        if matched:
+            matched["speedup_vs_cpu_baseline"] = matched["gpu_value"] / cpu["value"]
+            line["cpu_baseline"]["matched_age"] = matched
         if "all_cores" in cpu:
             line["speedup_vs_cpu_all_cores"] = line["value"] / cpu["all_cores"]["value"]
+        for wn, d, wl in pending_cpu:
+            d["cpu_baseline"] = cpu_baseline_short(wl, wn, 3415, min(args.cpu_budget, 8.0))
+            d["speedup_vs_cpu_baseline"] = d["value"] / d["cpu_baseline"]["value"]
+            if d.get("chain_start"):
+                d["cpu_baseline"]["matched_age"] = dict(
+                    d.pop("chain_start"), speedup_vs_cpu_baseline=None)
+                ma = d["cpu_baseline"]["matched_age"]
+                ma["speedup_vs_cpu_baseline"] = ma["gpu_value"] / d["cpu_baseline"]["value"]
+    line["gpu_legs_seconds"] = gpu_done_s
+
+    # ---- the last object of the line: every headline figure again, compact (a kept log tail holds it)
+    def brief(d):
+        rf, rr = d.get("roofline") or {}, d.get("roofline_rows") or {}
+        kk = d.get("roofline_kernels") or {}
+        b = {"value": _r(d.get("value")), "ms": _r(d.get("ms_per_step")),
+             "resident": _r((d.get("resident_path") or {}).get("value")),
+             "kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": _r(rf.get("frac")),
+             "rows_hbm_frac": _r(rr.get("frac") if rr else (rf.get("measured_hbm_frac") if rf.get("bound") == "hbm" else None)),
+             "us": {k: _r(v["avg_us"]) for k, v in kk.items()},
+             "cpu": _r((d.get("cpu_baseline") or {}).get("value")),
+             "x_cpu": _r(d.get("speedup_vs_cpu_baseline")),
+             "x_cpu_same_age": _r(((d.get("cpu_baseline") or {}).get("matched_age") or {}).get("speedup_vs_cpu_baseline"))}
+        return {k: v for k, v in b.items() if v is not None}
+
+    summ = {"cfg2" if default_cfg and wname == "cfg2" else wname: brief(line)}
+    if "all_cores" in (line.get("cpu_baseline") or {}):
+        summ[next(iter(summ))]["cpu8"] = _r(line["cpu_baseline"]["all_cores"]["value"])
+    if "concurrent_chains" in line:
+        summ[next(iter(summ))]["chains4"] = _r(line["concurrent_chains"]["value"])
+    for wn, d in (line.get("workloads") or {}).items():
+        summ[wn] = brief(d)
+    line["summary"] = summ
 
     if rank == 0:
         print(json.dumps(line))
@@ -731,10 +771,24 @@ def main():
         dist.destroy_process_group()
 
 
+def _r(x, sig=4):
+    """Round to ``sig`` significant digits (the compact summary)."""
+    if x is None:
+        return None
+    x = float(x)
+    if x == 0.0 or not np.isfinite(x):
+        return x
+    return float(f"{x:.{sig}g}")
+
+
+CPU_BURN_CFG2 = 10  # tune=1 asteps before the cfg2 CPU sample (50 s per 100 on one core): see matched_age
+
+
 def workload_leg(wn, make_chain, be, args, torch):
-    """One further BASELINE configuration on the one GPU, same protocol as the headline: burn-in with tune=1,
-    warm-up, blocks of PGBART.astep until >= 1.5 s are timed, the resident path, the per-kernel profile, a
-    bounded CPU sample."""
+    """GPU legs of one further BASELINE configuration, same protocol as the headline: burn-in with tune=1,
+    warm-up, blocks of PGBART.astep until >= --min-seconds are timed, the resident path, the per-kernel profile,
+    and the rate at the START of a chain (one tree per step: what the bounded CPU sample of this workload
+    runs).  Returns (leg, workload data); the CPU sample itself is taken after every GPU leg of the run."""
     def sync():
         torch.cuda.synchronize()
 
@@ -747,7 +801,7 @@ def workload_leg(wn, make_chain, be, args, torch):
     st.tune = False
     for _ in range(2):
         st.astep(None)
-    blocks = astep_blocks(st, steps, 0, sync, min_seconds=1.5, max_blocks=60)
+    blocks = astep_blocks(st, steps, 0, sync, min_seconds=args.min_seconds, max_blocks=200)
     (el, u), vmin, vmax = median_block(blocks)
     st._batches.clear()
     d = {
@@ -768,11 +822,19 @@ def workload_leg(wn, make_chain, be, args, torch):
     if not args.no_roofline:
         d.update(rooflines(wn, w, w["X"].shape, kernel_profile(s, False, steps)))
     del s
-    st.sampler = None  # free the chain's HBM before the next workload
+    st.sampler = None  # free the chain's HBM before the next chain
     if not args.no_cpu_baseline:
-        d["cpu_baseline"] = cpu_baseline_short(w, wn, 3415, min(args.cpu_budget, 8.0))
-        d["speedup_vs_cpu_baseline"] = d["value"] / d["cpu_baseline"]["value"]
-    return d
+        # the chain age of the CPU sample: a fresh chain, one tree per step, one warm-up tree update
+        _, st1 = make_chain(wn, dict(seed=3415), 3415, be, batch=(1, 1), wl=w)
+        s1 = st1.sampler
+        run_all([s1], False, 1)
+        (el_c, u_c), _, _ = median_block(resident_blocks([s1], False, 8, 3, sync))
+        d["chain_start"] = {"gpu_value": u_c["particle_steps"] / el_c, "path": "resident, one tree per step",
+                            "tree_updates": 24,
+                            "rows_touched_per_particle_step": u_c["rows_touched"] / max(u_c["particle_steps"], 1)}
+        del s1
+        st1.sampler = None
+    return d, w
 
 
 if __name__ == "__main__":

@@ -30,6 +30,10 @@ def main():
     Y = X[:, 0] - 2 * X[:, 2] + rng.normal(0, 0.3, 2000)
     res = sample_chain(BARTOp(X, Y, m=6), tune=10, draws=8, random_seed=3415, chain=rank, backend=be)
     got = gather_chains(res, dist, dst=0, force_collective=True)
+    # keep_draws=False: only sigma travels densely (the dense tensor has a zero-width mu block)
+    res_nd = sample_chain(BARTOp(X, Y, m=6), tune=10, draws=8, random_seed=3415, chain=rank, backend=be,
+                          keep_draws=False)
+    got_nd = gather_chains(res_nd, dist, dst=0, force_collective=True)
     ones = torch.ones(4, device="cuda")
     dist.all_reduce(ones)
     out = {"backend": dist.get_backend(), "world": world, "allreduce": float(ones[0].item())}
@@ -39,6 +43,11 @@ def main():
         out["sigma_equal"] = bool(np.array_equal(got[0]["sigma"], res["sigma"]))
         out["vi_equal"] = bool(np.array_equal(got[0]["vi_counts"], res["vi_counts"]))
         out["n_batches"] = len(got[0]["history"][1])
+        out["nodraws_mu_none"] = got_nd[0]["mu"] is None
+        out["nodraws_sigma_equal"] = bool(np.array_equal(got_nd[0]["sigma"], res_nd["sigma"])
+                                          and np.array_equal(res_nd["sigma"], res["sigma"]))
+        out["nodraws_vi_equal"] = bool(np.array_equal(got_nd[0]["vi_counts"], res_nd["vi_counts"]))
+        out["nodraws_n_batches"] = len(got_nd[0]["history"][1])
         print("RCCL_CHILD " + json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -32,6 +32,27 @@ def test_dry_run_two_ranks_over_gloo():
     assert d["gather_ms"] >= 0 and d["steps"] == 4
 
 
+def test_dry_run_eight_ranks_over_gloo():
+    """The shape of the driver's 8-GPU run before it meets eight GPUs (round-3 VERDICT #5): launcher, 8-way
+    all_reduce / all_gather, one line, clean exit in under a minute."""
+    import time
+
+    t0 = time.perf_counter()
+    r = _run("--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1", "--burnin", "2", "--repeats", "3")
+    took = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_reported_by_collective"] == 8
+    assert d["config"]["chains"] == 8 and d["config"]["parallelism"] == "chains8" and d["scaling"] == "weak"
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in d["per_rank_ms_per_step"])
+    assert d["value"] is None and d["data"] == "dry-run"
+    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 64
+    assert list(d)[-1] == "summary"  # the compact copy of the figures ends the line
+    assert took < 60, took
+
+
 def test_multi_gpu_request_without_gpus_fails_loudly():
     import torch
 

@@ -52,3 +52,5 @@ def test_gather_chains_collective_branch_on_cuda_over_rccl():
     d = json.loads(out[0][len("RCCL_CHILD "):])
     assert d["backend"] == "nccl" and d["world"] == 1 and d["allreduce"] == 1.0
     assert d["chains"] == 1 and d["mu_equal"] and d["sigma_equal"] and d["vi_equal"] and d["n_batches"] == 8
+    # keep_draws=False through the same collectives (round-3 VERDICT #5)
+    assert d["nodraws_mu_none"] and d["nodraws_sigma_equal"] and d["nodraws_vi_equal"] and d["nodraws_n_batches"] == 8
