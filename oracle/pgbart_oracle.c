@@ -310,6 +310,11 @@ int pgb_set_data(pgb_handle* h, const double* X, int64_t ldx, const int32_t* rul
 
 int pgb_set_response(pgb_handle* h, const double* y) {
   if (!h || !y) return fail(PGB_E_INVALID, "null argument");
+  for (int64_t i = 0; i < h->s.n; ++i)
+    if (!(y[i] - y[i] == 0.0)) {
+      h->have_y = 0;
+      return fail(PGB_E_INVALID, "the response has non-finite values");
+    }
   memcpy(h->y, y, sizeof(double) * h->s.n);
   h->have_y = 1;
   return PGB_OK;
@@ -319,8 +324,16 @@ int pgb_set_offset(pgb_handle* h, const double* off) {
   if (!h) return fail(PGB_E_INVALID, "null handle");
   if (h->s.family == PGB_FAMILY_NORMAL)
     return fail(PGB_E_UNSUPPORTED, "offsets are for the per-row families (a Normal model fits observed - offset)");
-  if (off) memcpy(h->off, off, sizeof(double) * h->s.n * h->s.n_outputs);
-  else memset(h->off, 0, sizeof(double) * h->s.n * h->s.n_outputs);
+  if (off) {
+    for (int64_t i = 0; i < h->s.n * h->s.n_outputs; ++i)
+      if (!(off[i] - off[i] == 0.0)) {  /* (a linear predictor must be finite; the offset is zeroed) */
+        memset(h->off, 0, sizeof(double) * h->s.n * h->s.n_outputs);
+        return fail(PGB_E_INVALID, "the offset has non-finite values");
+      }
+    memcpy(h->off, off, sizeof(double) * h->s.n * h->s.n_outputs);
+  } else {
+    memset(h->off, 0, sizeof(double) * h->s.n * h->s.n_outputs);
+  }
   return PGB_OK;
 }
 
@@ -1240,8 +1253,15 @@ void pgbo_log_ndtr(const double* x, int64_t n, double* out) {
  *      nothing about it; these expose them to scipy / NumPy) */
 void pgbo_loglikq(int family, const double* y, const double* mu, int64_t n, double param, double param2,
                   double* out) {
-  for (int64_t i = 0; i < n; ++i)
-    out[i] = pgb_loglik1q(family, y[i], mu[i], param, param2, pgb_ln_tn(), pgb_ln_tp());
+  const pgb_lltabs tb = pgb_lltabs_default();
+  for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik1q(family, y[i], mu[i], param, param2, &tb);
+}
+/* the table-driven exp / log of the per-row likelihoods (pgb_exp_t, pgb_log_t) */
+void pgbo_math_t(const double* x, int64_t n, double* e, double* l) {
+  for (int64_t i = 0; i < n; ++i) {
+    e[i] = pgb_exp_t(x[i], pgb_tab_exp());
+    l[i] = pgb_log_t(x[i], pgb_tab_log());
+  }
 }
 void pgbo_loglik_multi(int family, int K, const double* y, const double* mu /* [n][K] */, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik(family, K, y[i], mu + i * K);

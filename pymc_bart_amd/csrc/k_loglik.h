@@ -31,61 +31,19 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
 #define PGB_LLK_WGS 3  // workgroups per CU the K = 2, 3, 4 instances are compiled for (experiment knob)
 #endif
 
-// Categorical-softmax with K known at compile time: pgb_loglik_cat's arithmetic with K - 1
-// exponentials instead of K.  The largest predictor contributes exp(0), which pgb_exp returns as
-// exactly 1.0, so the K - 1 other differences are gathered (selects), exponentiated, and put back
-// in output order for the same serial sum: the same bits.  Falls back to the spec routine when no
-// difference is exactly 0 (a NaN predictor).
-template <int KC>
-__device__ __forceinline__ double loglik_cat_fast(double y, const double* mu) {
-  double mx = mu[0];
-#pragma unroll
-  for (int k = 1; k < KC; ++k)
-    if (mu[k] > mx) mx = mu[k];
-  double dd[KC];
-  int imax = -1;
-#pragma unroll
-  for (int k = KC - 1; k >= 0; --k) {
-    dd[k] = mu[k] - mx;
-    if (dd[k] == 0.0) imax = k;  // the first maximum
-  }
-  if (imax < 0) return pgb_loglik_cat(KC, y, mu);
-  double ee[KC - 1];
-#pragma unroll
-  for (int j = 0; j < KC - 1; ++j) ee[j] = pgb_exp(j >= imax ? dd[j + 1] : dd[j]);
-  double sum = 0.0;
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    double ek = 1.0;
-    if (k != imax) ek = k > imax ? ee[k > 0 ? k - 1 : 0] : ee[k < KC - 1 ? k : 0];
-    sum += ek;
-  }
-  int c = (int)y;
-  if (c < 0) c = 0;
-  if (c > KC - 1) c = KC - 1;
-  double muc = mu[0];
-#pragma unroll
-  for (int k = 1; k < KC; ++k)
-    if (c == k) muc = mu[k];
-  double ll = (muc - mx) - pgb_log(sum);
-  if (!(ll > -2047.0)) ll = -2047.0;
-  if (ll > 0.0) ll = 0.0;
-  return ll;
-}
-
-// The K-vector families are two -- softmax and Normal mean/scale (K = 2) -- and pgb_loglikq dispatches exactly
-// like this.  Naming them here keeps the one-predictor families (log Phi tables, softplus, the count models'
-// exp / log chains: ~10 KB of code per call site) out of the K >= 2 instances: k_loglik<4> was 92 KB, more than
-// the instruction cache two CUs share, and a fifth of its wave-cycles waited for instructions.
-// (The run-time-K instances, KT = 0, keep the spec's own dispatcher: they are the rarely used ones -- K = 5..8 and
-// K-vector linear leaves -- and their register allocation sits exactly at its occupancy edge.)
+// The K-vector families are two -- softmax and Normal mean/scale (K = 2) -- and pgb_loglikq_t dispatches exactly
+// like this.  Naming them here keeps the one-predictor families out of the K >= 2 instances (round 3: k_loglik<4>
+// was 92 KB with them, more than the instruction cache two CUs share).  With K known at compile time the softmax
+// is K table-driven exponentials and one logarithm, fully unrolled (pgb_loglik_cat_t; round 4 -- the K - 1
+// exponentials of the previous form cost more in selects than the exponential they saved).
+// (The run-time-K instances, KT = 0, keep the spec's own dispatcher: K = 5..8 and K-vector linear leaves.)
 template <int KT>
-__device__ __forceinline__ double loglik_mk(int family, int K, double y, const double* mu) {
+__device__ __forceinline__ double loglik_mk(int family, int K, double y, const double* mu, const pgb_lltabs* tb) {
   if constexpr (KT == 0) {
-    return pgb_loglik(family, K, y, mu);
+    return pgb_loglikq_t(family, K, y, mu, 0.0, 1.0, tb);
   } else {
-    if (KT >= 3 || family == PGB_FAMILY_CATEGORICAL) return loglik_cat_fast<KT>(y, mu);
-    return pgb_loglik_meanscale(y, mu);
+    if (KT >= 3 || family == PGB_FAMILY_CATEGORICAL) return pgb_loglik_cat_t(KT, y, mu, tb);
+    return pgb_loglik_meanscale_t(y, mu, tb);
   }
 }
 
@@ -114,10 +72,20 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
-  // log Phi tables in LDS (single-output Bernoulli path): a per-lane row through the vector L1
-  // costs a cache-line access per distinct row and instruction; LDS serves them at bank speed
+  // the tables of the per-row likelihood math in LDS (a per-lane table row through the vector L1 costs a
+  // cache-line access per distinct row and instruction; LDS serves them at bank speed): log Phi for the probit
+  // instance (10.4 KB, coefficient-major: lanes reading coefficient k of different rows hit different banks),
+  // exp / log (2.3 KB) for every instance whose family uses them
   constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
-  __shared__ double s_ln[PROBIT ? (PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9 : 1];
+  constexpr bool EXPLOG = !(KT == 1 && (FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_ASYMLAPLACE ||
+                                        FAM == PGB_FAMILY_CALLBACK));
+  __shared__ double s_lphi[PROBIT ? PGB_LPHI_SIZE : 1];
+  __shared__ double s_expt[EXPLOG ? PGB_EXPT_SIZE : 1];
+  __shared__ __attribute__((aligned(16))) double s_logt[EXPLOG ? PGB_LOGT_SIZE : 2];
+  pgb_lltabs tb;
+  tb.lphi = PROBIT ? s_lphi : pgb_tab_lphi();
+  tb.expt = EXPLOG ? s_expt : pgb_tab_exp();
+  tb.logt = EXPLOG ? s_logt : pgb_tab_log();
   // wave-private lists of the dense path (see LL_DENSE_MAX); Bernoulli responses travel as a flag bit
   // (the evaluation is inlined a second time: the families whose instance would cross an occupancy edge with
   //  it -- Poisson, NegativeBinomial, Gamma: two exp / log chains each -- keep the plain path;
@@ -128,7 +96,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   constexpr bool YBIT = FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_BERNOULLI_LOGIT;
   __shared__ double s_lnv[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
   __shared__ double s_ly[DENSE && !YBIT ? BT / 64 : 1][DENSE && !YBIT ? LL_DENSE_MAX : 1];
-  __shared__ uint8_t s_lfl[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
+  __shared__ uint16_t s_lfl[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
   constexpr bool MKPASS = KT >= 2 && !LIN;  // K = 2, 3, 4 with constant leaves: the pass loop (see below)
   __shared__ uint16_t s_lrow[MKPASS ? BT / 64 : 1][MKPASS ? LL_DENSE_MAX : 1];
   // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
@@ -138,12 +106,16 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   const Cmd* cmd = &S.cmd[par];
   if (!(cmd->kind & CMD_PARTITION)) return;
   if constexpr (PROBIT) {
-    const double* gtn = pgb_ln_tn();
-    const double* gtp = pgb_ln_tp();
-    for (int i = threadIdx.x; i < PGB_LN_TN_ROWS * 9; i += BT) s_ln[i] = gtn[i];
-    for (int i = threadIdx.x; i < PGB_LN_TP_ROWS * 9; i += BT) s_ln[PGB_LN_TN_ROWS * 9 + i] = gtp[i];
-    // (the barrier after the job list below also publishes the tables)
+    const double* g = pgb_tab_lphi();
+    for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) s_lphi[i] = g[i];
   }
+  if constexpr (EXPLOG) {
+    const double* ge = pgb_tab_exp();
+    const double* gl = pgb_tab_log();
+    for (int i = threadIdx.x; i < PGB_EXPT_SIZE; i += BT) s_expt[i] = ge[i];
+    for (int i = threadIdx.x; i < PGB_LOGT_SIZE; i += BT) s_logt[i] = gl[i];
+  }
+  // (the barrier after the job list below also publishes the tables)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const Ctrl cn = S.ctrl[par ^ 1];  // the state this slot's k_ctrl produced
   const int round = cn.round - 1;   // round of the proposals of this slot
@@ -276,16 +248,13 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
                 mu_stump[k] = (noi0[(size_t)k * S.n_pad + row] + offk) + S.init_leaf;
                 mu_cur[k] = stk + offk;
               }
-            ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_stump), S.sc.cl);
-            ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_cur), S.sc.cl);
+            ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
+            ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
           } else {
             const double offv = offr[e];
-            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noir[e] + offv) + init_leaf, cn.inv_sigma2, cn.lik_param2,
-                                           PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
+            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noir[e] + offv) + init_leaf, cn.inv_sigma2, cn.lik_param2, &tb),
                               S.sc.cl);
-            ce[1] += quant_ll(pgb_loglik1q(fam, yr, str_[e] + offv, cn.inv_sigma2, cn.lik_param2,
-                                           PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp()),
-                              S.sc.cl);
+            ce[1] += quant_ll(pgb_loglik1q(fam, yr, str_[e] + offv, cn.inv_sigma2, cn.lik_param2, &tb), S.sc.cl);
           }
         }
       }
@@ -415,7 +384,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               const double nk = noi[(size_t)k * S.n_pad + row];
               mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + row] : nk) + vk;
             }
-            const double llv = loglik_mk<KT>(S.family, K, yr, mu);
+            const double llv = loglik_mk<KT>(S.family, K, yr, mu, &tb);
             const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
@@ -483,7 +452,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
                 const double nk = noi[(size_t)k * S.n_pad + base + e];
                 mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + base + e] : nk) + vk;
               }
-            const double llv = loglik_mk<KT>(S.family, K, yv[e], mu);
+            const double llv = loglik_mk<KT>(S.family, K, yv[e], mu, &tb);
             const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
@@ -515,7 +484,6 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         ids_n = ln.src < 0 ? root_ids : *gcast<const uint32_t>(glid + ln.src + base);
         nid_n = *gcast<const uint32_t>(newl + (size_t)ln.p * S.n_pad + base);
       }
-      long long v0 = 0, v1 = 0, v2 = 0;  // llL, llR, llN
       // (the particle's fields in registers: read through the LDS record they cost three LDS reads per ROW)
       const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
       const double vL = lj.vL, vR = lj.vR;
@@ -537,98 +505,105 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         *(uint32_t*)(S.cb_side + (size_t)lj.p * S.n_pad + base) = sides;
         continue;
       }
-      long long vt = 0;  // all rows of the split leaf: the right child is what the other two leave
-      if constexpr (DENSE) {
-        unsigned long long mk[RPT];
-        int M = 0;
-#pragma unroll
-        for (int e = 0; e < RPT; ++e) {
-          mk[e] = __ballot(((ids >> (8 * e)) & 255u) == lab);
-          M += __popcll(mk[e]);
-        }
-        if (M <= LL_DENSE_MAX) {  // (wave-uniform)
-          int off = 0;
-#pragma unroll
-          for (int e = 0; e < RPT; ++e) {
-            if (((ids >> (8 * e)) & 255u) == lab) {
-              const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u));
-              const uint32_t nl = (nid >> (8 * e)) & 255u;
-              const uint32_t side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
-              s_lnv[w][pos] = nv[e];
-              if constexpr (YBIT) s_lfl[w][pos] = (uint8_t)(side | (ysgn[e] >> 29));  // bit 2: y = 0 (flip the sign)
-              else { s_lfl[w][pos] = (uint8_t)side; s_ly[w][pos] = yv[e]; }
-            }
-            off += __popcll(mk[e]);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          for (int k = lane; k < M; k += 64) {
-            const uint32_t fl = s_lfl[w][k];
-            const int side = (int)(fl & 3u);
-            // (Bernoulli: the evaluation only asks whether y > 0.5)
-            const double mu = s_lnv[w][k] + (side == 0 ? vL : side == 1 ? vR : 0.0);
-            double llk;
-            if constexpr (YBIT) {
-              llk = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)(fl & 4u) << 61)),
-                                      PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp());
-            } else {
-              llk = pgb_loglik1q(FAM, s_ly[w][k], mu, cn.inv_sigma2, cn.lik_param2, pgb_ln_tn(), pgb_ln_tp());
-            }
-            const long long q = quant_ll(llk, cl);
-            vt += q;
-            v0 += side == 0 ? q : 0;
-            if (drops) v2 += side == 2 ? q : 0;
-          }
-          __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
-          v1 = vt - v0 - v2;
-          const int slot = (g - g0) * 3;
-          const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
-          if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
-          continue;
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < RPT; ++e) {
-        if (((ids >> (8 * e)) & 255u) == lab) {
-          // ONE evaluation per row: the side only selects the leaf value and the accumulator
-          // (separate calls per side would run one after the other on a divergent wave)
-          const uint32_t nl = (nid >> (8 * e)) & 255u;
-          int side = nl == lab ? 0 : 1;
-          double vleaf = nl == lab ? vL : vR;
-          // (only a split on a column with missing values drops rows -- wave-uniform per particle: every other
-          //  split is decided by ONE compare and select per row instead of two)
-          if (drops && nl != lab && nl != nlab) {
-            side = 2;
-            vleaf = 0.0;  // dropped: predicts 0
+      // One evaluation per row, two (three) running sums per lane: vt over every row of the split leaf, v0 over
+      // the rows that stayed left (v2: dropped by a missing split value); the right child is what they leave.
+      // Only a split on a column with missing values drops rows -- uniform per particle -- so the loop body is
+      // compiled twice: without drops the side is ONE compare, the leaf value one select, and there is no third
+      // sum (6 vector instructions fewer per evaluated row: profiles/r04_experiments.md).
+      auto eval_rows = [&](auto drops_c) {
+        constexpr bool DROPS = decltype(drops_c)::value;
+        long long vt = 0, v0 = 0, v2 = 0;
+        auto eval_one = [&](double nvr, uint32_t nl, double yr, uint32_t sgn_hi, int e_lin) {
+          const bool left = nl == lab;
+          double vleaf = left ? vL : vR;
+          bool dropped = false;
+          if constexpr (DROPS) {
+            dropped = !left && nl != nlab;
+            if (dropped) vleaf = 0.0;  // dropped: predicts 0
           }
           if constexpr (LIN) {
+            const int side = left ? 0 : dropped ? 2 : 1;
             const int sv = side == 0 ? lj.svarL : side == 1 ? lj.svarR : -1;
             if (sv >= 0) {
-              const double xv = S.XT[lj.xoff + base + e];
+              const double xv = S.XT[lj.xoff + base + e_lin];
               vleaf = pgb_leaf_pred(vleaf, side == 0 ? lj.slopeL : lj.slopeR, side == 0 ? lj.xbarL : lj.xbarR, xv);
             }
           }
-          const double mu = nv[e] + vleaf;
+          const double mu = nvr + vleaf;
           double llr;
-          if constexpr (YBIT) {
-            llr = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)ysgn[e] << 32)),
-                                    PROBIT ? s_ln : pgb_ln_tn(), PROBIT ? s_ln + PGB_LN_TN_ROWS * 9 : pgb_ln_tp());
+          if constexpr (YBIT) {  // (Bernoulli: the response only flips the sign of the predictor)
+            llr = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)sgn_hi << 32)), &tb);
           } else {
-            llr = pgb_loglik1q(FAM >= 0 ? FAM : S.family, yv[e], mu, cn.inv_sigma2, cn.lik_param2, pgb_ln_tn(),
-                               pgb_ln_tp());
+            llr = pgb_loglik1q(FAM >= 0 ? FAM : S.family, yr, mu, cn.inv_sigma2, cn.lik_param2, &tb);
           }
           const long long q = quant_ll(llr, cl);
           vt += q;
-          v0 += side == 0 ? q : 0;
-          if (drops) v2 += side == 2 ? q : 0;
+          v0 += left ? q : 0;
+          if constexpr (DROPS) v2 += dropped ? q : 0;
+        };
+        bool dense_done = false;
+        if constexpr (DENSE) {
+          unsigned long long mk[RPT];
+          int M = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            mk[e] = __ballot(((ids >> (8 * e)) & 255u) == lab);
+            M += __popcll(mk[e]);
+          }
+          if (M <= LL_DENSE_MAX) {  // (wave-uniform)
+            int off = 0;
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              if (((ids >> (8 * e)) & 255u) == lab) {
+                const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[e] >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mk[e], 0u));
+                const uint32_t nl = (nid >> (8 * e)) & 255u;
+                s_lnv[w][pos] = nv[e];
+                // the row's new label travels with it; Bernoulli: bit 8 = "y = 0" (flip the sign)
+                if constexpr (YBIT) s_lfl[w][pos] = (uint16_t)(nl | (ysgn[e] >> 23));
+                else { s_lfl[w][pos] = (uint16_t)nl; s_ly[w][pos] = yv[e]; }
+              }
+              off += __popcll(mk[e]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = lane; k < M; k += 64) {
+              const uint32_t fl = s_lfl[w][k];
+              eval_one(s_lnv[w][k], fl & 255u, YBIT ? 0.0 : s_ly[w][k], (fl & 256u) << 23, 0);
+            }
+            __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
+            dense_done = true;
+          }
         }
+        if (!dense_done) {
+          if constexpr (DENSE) {
+#pragma unroll
+            for (int e = 0; e < RPT; ++e)
+              if (((ids >> (8 * e)) & 255u) == lab) eval_one(nv[e], (nid >> (8 * e)) & 255u, yv[e], YBIT ? ysgn[e] : 0u, e);
+          } else {  // (one evaluation site: these instances are bound by their registers, not by a loop counter)
+#pragma unroll 1
+            for (int e = 0; e < RPT; ++e)
+              if (((ids >> (8 * e)) & 255u) == lab) eval_one(nv[e], (nid >> (8 * e)) & 255u, yv[e], 0u, e);
+          }
+        }
+        const int slot = (g - g0) * 3;
+        if constexpr (DROPS) {
+          const long long tot = wave_sum4(v0, vt - v0 - v2, v2, 0);  // lane l: total of value l & 3
+          if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+        } else {
+          const long long tot = wave_sum2(v0, vt - v0);  // lane l: total of value l & 1
+          if (lane < 3) s_red[(slot + lane) * 4 + w] = lane < 2 ? tot : 0;
+        }
+      };
+      // (the families with two exp / log chains per evaluation -- Poisson, NegativeBinomial, Gamma -- and the
+      //  run-time-family instance keep ONE copy of the loop: a second one costs them their occupancy)
+      if constexpr (DENSE) {
+        if (drops) eval_rows(std::true_type{});
+        else eval_rows(std::false_type{});
+      } else {
+        eval_rows(std::true_type{});
       }
-      v1 = vt - v0 - v2;
-      const int slot = (g - g0) * 3;
-      const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
-      if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
     }
     if constexpr (FAM == PGB_FAMILY_CALLBACK) continue;  // nothing to reduce: the host sums
     __syncthreads();

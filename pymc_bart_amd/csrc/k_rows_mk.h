@@ -3,10 +3,6 @@
 // K-vector leaves (K > 1, Categorical-softmax): the same slot logic as k_rows with sum_trees, leaf
 // values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
 // the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
-__device__ __forceinline__ double loglik_any(const DevG& S, double y, const double* mu) {
-  return pgb_loglik(S.family, S.K, y, mu);
-}
-
 // KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay
 // in registers), 0: any K <= PGB_MAX_OUTPUTS.
 // LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory

@@ -68,6 +68,18 @@ __global__ __launch_bounds__(BT) void k_subset_check(const double* __restrict__ 
   }
   if (b) atomicMax(bad, (int)blockIdx.x + 1);
 }
+// any non-finite value in `rows` rows of n values, `stride` apart?  -> *flag = 1 (the host's mapped word).
+// The linear predictor of a row must be finite: the likelihood tables are addressed by its bits (pgb_lphi_t).
+__global__ __launch_bounds__(BT) void k_nonfinite(const double* __restrict__ a, long long n, long long stride, int rows,
+                                                  unsigned long long* __restrict__ flag) {
+  bool b = false;
+  for (int r = 0; r < rows; ++r)
+    for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < n; i += (long long)gridDim.x * BT) {
+      const double v = a[(size_t)r * stride + i];
+      if (!(v - v == 0.0)) b = true;
+    }
+  if (__ballot(b) && (threadIdx.x & 63) == 0) *flag = 1ull;
+}
 __global__ void k_fill_f64(double* a, long long n, double v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;

@@ -104,6 +104,34 @@ __device__ __forceinline__ long long wave_sum4(long long v0, long long v1, long 
   return k;
 }
 
+// The same for TWO values (the per-row families reduce {all rows, left rows} per particle): the first exchange
+// halves the live values, five more finish -- 30 vector instructions.  Returns, in every lane, the wave total of
+// value number (lane & 1).
+__device__ __forceinline__ long long wave_sum2(long long v0, long long v1) {
+  const int lane = (int)(threadIdx.x & 63);
+  const bool b0 = (lane & 1) != 0;
+  long long k = b0 ? v1 : v0;
+  const long long s = b0 ? v0 : v1;
+  k += dpp_mov64<0xB1>(s);  // quad_perm [1,0,3,2]: lane l now carries value (l & 1) of its pair
+  k += dpp_mov64<0x4E>(k);  // quad_perm [2,3,0,1]
+  {
+    const int lo = dpp_xor4((int)k), hi = dpp_xor4((int)(k >> 32));
+    k += ((long long)hi << 32) | (unsigned)lo;
+  }
+  k += dpp_mov64<0x128>(k);  // row_ror:8
+  {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    k = (long long)(((unsigned long long)h[0] << 32) | l[0]) + (long long)(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    k = (long long)(((unsigned long long)h[0] << 32) | l[0]) + (long long)(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  return k;
+}
+
 // sum of the ACC_SLOTS copies of a particle's split statistics
 __device__ __forceinline__ Acc load_acc(const Acc* __restrict__ base) {
   Acc a = base[0];

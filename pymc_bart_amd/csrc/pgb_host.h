@@ -395,6 +395,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     h->flag[0] = 0;  // asteps whose last tree has been accepted (its FINAL row pass may still be running)
     h->flag[1] = 0;  // asteps that are complete on the device (published by the first idle slot after them)
     h->flag[2] = 0;  // slots whose control kernel has started (the credit the host enqueues against)
+    h->flag[4] = 0;  // set by k_nonfinite (pgb_set_response / pgb_set_offset)
     // (h->stream_out: see pgb_set_output_stream)
     void* dp = nullptr;
     HC(hipHostGetDevicePointer(&dp, hp, 0));
@@ -612,7 +613,14 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
   HIPCHK(hipMemcpyAsync((void*)h->d.y, y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (h->s.family == PGB_FAMILY_CALLBACK)
     HIPCHK(hipMemcpyAsync(h->y_host.data(), y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  h->flag[4] = 0;
+  hipLaunchKernelGGL(k_nonfinite, dim3(256), dim3(BT), 0, h->stream, (const double*)h->d.y, (long long)h->d.n,
+                     (long long)h->d.n_pad, 1, h->d.host_flag + 4);
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->flag[4]) {
+    h->have_y = 0;
+    return fail(PGB_E_INVALID, "the response has non-finite values");
+  }
   h->have_y = 1;
   return PGB_OK;
 }
@@ -638,7 +646,16 @@ extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
     h->d.has_off = offset_dev ? 1 : 0;
     HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
   }
+  h->flag[4] = 0;
+  if (offset_dev)
+    hipLaunchKernelGGL(k_nonfinite, dim3(256), dim3(BT), 0, h->stream, (const double*)h->d.off, (long long)h->d.n,
+                       (long long)h->d.n_pad, (int)h->d.K, h->d.host_flag + 4);
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->flag[4]) {  // (a linear predictor must be finite; the offset is zeroed so that the chain stays usable)
+    HIPCHK(hipMemsetAsync((void*)h->d.off, 0, (size_t)h->d.K * h->d.n_pad * sizeof(double), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return fail(PGB_E_INVALID, "the offset has non-finite values");
+  }
   return PGB_OK;
 }
 

@@ -33,27 +33,36 @@ enum {
   PROBE_LEAF = 9,  // pgb_leaf_value, pgb_leaf_sse
   PROBE_LIN = 10,  // pgb_lin_fit, pgb_lin_sse
   PROBE_GO_LEFT = 11,
+  PROBE_MATH_T = 12,   // pgb_exp_t, pgb_log_t (the table-driven forms of the per-row likelihoods), tables in LDS
+  PROBE_MULTI_LDS = 13,  // pgb_loglikq_t with every table in LDS (the form k_loglik<K> runs)
 };
 
 __global__ __launch_bounds__(256) void k_probe(ProbeArgs A) {
-  __shared__ double s_ln[(PGB_LN_TN_ROWS + PGB_LN_TP_ROWS) * 9];
-  if (A.what == PROBE_BERN_LDS) {
-    const double* gtn = pgb_ln_tn();
-    const double* gtp = pgb_ln_tp();
-    for (int i = threadIdx.x; i < PGB_LN_TN_ROWS * 9; i += blockDim.x) s_ln[i] = gtn[i];
-    for (int i = threadIdx.x; i < PGB_LN_TP_ROWS * 9; i += blockDim.x) s_ln[PGB_LN_TN_ROWS * 9 + i] = gtp[i];
+  // every table of the per-row likelihood math staged in LDS, as the likelihood pass does
+  __shared__ double s_lphi[PGB_LPHI_SIZE];
+  __shared__ double s_expt[PGB_EXPT_SIZE];
+  __shared__ __attribute__((aligned(16))) double s_logt[PGB_LOGT_SIZE];
+  pgb_lltabs lds;
+  lds.lphi = s_lphi;
+  lds.expt = s_expt;
+  lds.logt = s_logt;
+  const pgb_lltabs glob = pgb_lltabs_default();
+  if (A.what == PROBE_BERN_LDS || A.what == PROBE_MATH_T || A.what == PROBE_MULTI_LDS) {
+    for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += blockDim.x) s_lphi[i] = glob.lphi[i];
+    for (int i = threadIdx.x; i < PGB_EXPT_SIZE; i += blockDim.x) s_expt[i] = glob.expt[i];
+    for (int i = threadIdx.x; i < PGB_LOGT_SIZE; i += blockDim.x) s_logt[i] = glob.logt[i];
     __syncthreads();
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (long long)gridDim.x * blockDim.x) {
     switch (A.what) {
       case PROBE_LOGLIKQ:
-        A.o0[i] = pgb_loglik1q(A.family, A.a[i], A.b[i], A.p0, A.p1, pgb_ln_tn(), pgb_ln_tp());
+        A.o0[i] = pgb_loglik1q(A.family, A.a[i], A.b[i], A.p0, A.p1, &glob);
         break;
       case PROBE_BERN_LDS: {
         // the response as a sign mask, exactly as the likelihood pass flips the predictor
         const unsigned long long ysgn = A.a[i] > 0.5 ? 0ull : 0x8000000000000000ull;
         const double smu = pgb_u2d(pgb_d2u(A.b[i]) ^ ysgn);
-        A.o0[i] = pgb_loglik_bern_s(A.family, smu, s_ln, s_ln + PGB_LN_TN_ROWS * 9);
+        A.o0[i] = pgb_loglik_bern_s(A.family, smu, &lds);
         break;
       }
       case PROBE_MULTI: {
@@ -62,6 +71,16 @@ __global__ __launch_bounds__(256) void k_probe(ProbeArgs A) {
         A.o0[i] = pgb_loglik(A.family, A.K, A.a[i], mu);
         break;
       }
+      case PROBE_MULTI_LDS: {
+        double mu[PGB_MAX_OUTPUTS];
+        for (int k = 0; k < A.K; ++k) mu[k] = A.b[i * A.K + k];
+        A.o0[i] = pgb_loglikq_t(A.family, A.K, A.a[i], mu, A.p0, A.p1, &lds);
+        break;
+      }
+      case PROBE_MATH_T:
+        A.o0[i] = pgb_exp_t(A.a[i], s_expt);
+        A.o1[i] = pgb_log_t(A.a[i], s_logt);
+        break;
       case PROBE_LOG_NDTR:
         A.o0[i] = pgb_log_ndtr(A.a[i]);
         break;
@@ -178,6 +197,27 @@ int pgbh_loglik_multi(int family, int K, const double* y, const double* mu /* [n
   A.a = st.in(y, n); A.b = st.in(mu, n * K); A.o0 = st.out<double>(n);
   int rc = probe::run(A, st);
   if (rc == PGB_OK) st.back(out, A.o0, n);
+  return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");
+}
+int pgbh_loglik_multi_lds(int family, int K, const double* y, const double* mu /* [n][K] */, int64_t n, double param,
+                          double param2, double* out) {
+  if (K < 1 || K > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "probe: K");
+  probe::Stage st;
+  ProbeArgs A{};
+  A.what = PROBE_MULTI_LDS; A.family = family; A.K = K; A.n = n; A.p0 = param; A.p1 = param2;
+  A.a = st.in(y, n); A.b = st.in(mu, n * K); A.o0 = st.out<double>(n);
+  int rc = probe::run(A, st);
+  if (rc == PGB_OK) st.back(out, A.o0, n);
+  return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");
+}
+int pgbh_math_t(const double* x, int64_t n, double* e, double* l) {
+  probe::Stage st;
+  ProbeArgs A{};
+  A.what = PROBE_MATH_T; A.n = n;
+  A.a = st.in(x, n);
+  A.o0 = st.out<double>(n); A.o1 = st.out<double>(n);
+  int rc = probe::run(A, st);
+  if (rc == PGB_OK) { st.back(e, A.o0, n); st.back(l, A.o1, n); }
   return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");
 }
 int pgbh_log_ndtr(const double* x, int64_t n, double* out) {

@@ -53,7 +53,7 @@ def build_oracle(force: bool = False) -> str:
     stale = (not os.path.exists(ORACLE_SO)) or any(
         os.path.getmtime(f) > os.path.getmtime(ORACLE_SO)
         for f in (src, os.path.join(ROOT, "include", "pgbart.h"), os.path.join(ROOT, "include", "pgbart_pack.h"),
-                  os.path.join(ROOT, "include", "pgbart_spec.h"))
+                  os.path.join(ROOT, "include", "pgbart_spec.h"), os.path.join(ROOT, "include", "pgbart_lltab.h"))
     )
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])

@@ -156,36 +156,102 @@ def test_weight_pick_follows_inverse_cdf(oracle):
     assert [f(lw.ctypes.data, 1, 5, u, None) for u in (0.01, 0.5, 0.99)] == [2, 2, 2]
 
 
-def test_log_ndtr_against_scipy(oracle):
-    # pgb_log_ndtr: table-driven scaled-tail form (tools/fit_log_ndtr.py); the likelihood sums
-    # are fixed point, so the bar is absolute error (1 ulp of log Phi(-38) = -726 is 1.1e-13)
+def test_log_ndtr_against_scipy_and_mpmath(oracle):
+    """pgb_lphi_t (include/pgbart_spec.h, tables by tools/fit_ll_tables.py): log Phi for the probit likelihood from
+    ONE table entry and a degree-8 Horner chain.  The likelihood sums are fixed point, so the bar is ABSOLUTE error:
+    < 2e-14 for s >= -9 (1 ulp of log Phi(-9) = -43.6 is 7e-15), < 4 ulp of the result below, down to the lower
+    bound of a per-row log-likelihood, -2047, which the table returns exactly from s = -63.875 on."""
+    import mpmath as mp
     from scipy.special import log_ndtr
 
     f = _lib(oracle).pgbo_log_ndtr
     f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = None
+
+    def ev(x):
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.empty_like(x)
+        f(x.ctypes.data, x.size, out.ctypes.data)
+        return out
+
     rng = np.random.default_rng(1)
-    x = np.concatenate([np.linspace(-38, 38, 100001), rng.normal(0, 2, 50000),
+    x = np.concatenate([np.linspace(-63.87, 40, 300001), rng.normal(0, 2, 100000), rng.uniform(-0.2, 0.2, 50000),
                         [0.0, -0.0, 1e-300, -1e-300, 2.0 * 15 / 1 - 1e-9, 30.0, -30.0]])
-    out = np.empty_like(x)
-    f(x.ctypes.data, x.size, out.ctypes.data)
-    ref = log_ndtr(x)
-    assert np.max(np.abs(out - ref)) < 4e-13
-    body = np.abs(x) < 5
-    assert np.max(np.abs(out[body] - ref[body])) < 1e-14  # 3 ulp of 15
-    assert np.all(out <= 0.0) and np.all(np.diff(out[:100001]) >= -1e-15)  # a log-probability, monotone
-    # far tails stay finite and follow -x^2/2 - log(|x| sqrt(2 pi))
-    far = np.array([-1e3, -1e5, -1e8, 1e3, 1e8])
-    o2 = np.empty_like(far)
-    f(far.ctypes.data, far.size, o2.ctypes.data)
-    assert np.allclose(o2[:3], log_ndtr(far[:3]), rtol=1e-14) and np.all(o2[3:] == 0.0)
-    nan = np.array([np.nan])
-    f(nan.ctypes.data, 1, nan.ctypes.data)
-    assert np.isnan(nan[0])
+    out, ref = ev(x), log_ndtr(x)
+    err = np.abs(out - ref)
+    body = x >= -9
+    assert err[body].max() < 2e-14
+    assert (err[~body] / np.spacing(np.abs(ref[~body]))).max() <= 4.0
+    assert out.max() < 1e-16 and out.min() >= -2047.0       # a log-probability up to the fit error at 0
+    lin = out[:300001]
+    assert np.all(np.diff(lin) >= -4 * np.spacing(np.abs(lin[1:])) - 2e-14)   # monotone up to the error bound
+    # independent of SciPy: mpmath at 40 digits on a subsample
+    mp.mp.dps = 40
+    xs = np.concatenate([rng.uniform(-63.8, 9, 1500), rng.normal(0, 1.5, 1500)])
+    for v, g in zip(xs, ev(xs)):
+        r = mp.log(mp.erfc(-mp.mpf(float(v)) / mp.sqrt(2)) / 2)
+        e = abs(float(mp.mpf(float(g)) - r))
+        assert e < (2e-14 if v >= -9 else 4 * np.spacing(abs(float(r)))), (v, e)
+    # the lower bound is reached exactly, the upper tail is exactly 0, infinities give the limits
+    far = np.array([-63.875, -63.9, -64.0, -100.0, -1e300, -np.inf, 63.9, 64.0, 1e300, np.inf])
+    assert np.array_equal(ev(far), [-2047.0] * 6 + [0.0] * 4)
+    assert ev([-63.874])[0] > -2047.0
+    # the same table through the likelihood entry point: no clamp needed, y only picks the sign
+    g = _lib(oracle).pgbo_loglik
+    g.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    g.restype = None
+    mu = rng.normal(0, 3, 20000)
+    y = (rng.uniform(size=mu.size) < 0.5).astype(np.float64)
+    ll = np.empty_like(mu)
+    g(1, y.ctypes.data, mu.ctypes.data, mu.size, ll.ctypes.data)
+    assert np.array_equal(ll, ev(np.where(y > 0.5, mu, -mu)))
+
+
+def test_table_driven_exp_and_log_of_the_likelihood_pass(oracle):
+    """pgb_exp_t / pgb_log_t: exp as 2^k T[j] e^r (32-entry table, degree-6 polynomial), log as k ln2 + log c +
+    log1p(z / c - 1) (128-entry table, no division).  exp: < 1 ulp against mpmath; log: <= 2 ulp against NumPy
+    everywhere (full relative accuracy around 1), absolute error < 2e-16 max(1, |log x|)."""
+    import mpmath as mp
+
+    f = _lib(oracle).pgbo_math_t
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    f.restype = None
+
+    def ev(x):
+        x = np.ascontiguousarray(x, np.float64)
+        e, l = np.empty_like(x), np.empty_like(x)
+        f(x.ctypes.data, x.size, e.ctypes.data, l.ctypes.data)
+        return e, l
+
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-40, 40, 200000), rng.normal(0, 1, 100000)])
+    e, _ = ev(x)
+    ref = np.exp(x)
+    assert (np.abs(e - ref) / ref).max() < 1.2 * 2.2204e-16   # NumPy's exp is itself good to ~0.5 ulp
+    mp.mp.dps = 40
+    xs = rng.uniform(-700, 700, 2000)
+    for v, g in zip(xs, ev(xs)[0]):
+        r = mp.exp(mp.mpf(float(v)))
+        assert abs(float((mp.mpf(float(g)) - r) / r)) < 2.2204e-16, v
+    edge = np.array([0.0, -0.0, 709.7, -745.1, -800.0, 800.0, 1e5, -1e5])
+    ee = ev(edge)[0]
+    assert ee[0] == 1.0 and ee[1] == 1.0 and np.isclose(ee[2], np.exp(709.7), rtol=1e-13)
+    assert ee[3] == 5e-324 and ee[4] == 0.0 and ee[5] == np.inf and ee[6] == np.inf and ee[7] == 0.0
+    assert np.isnan(ev([np.nan])[0][0])
+    y = np.concatenate([np.exp(rng.uniform(-700, 700, 200000)), rng.uniform(0.5, 2, 300000),
+                        1 + rng.normal(0, 1e-3, 100000), 1 + rng.normal(0, 1e-6, 100000), rng.uniform(1, 9, 100000)])
+    _, l = ev(y)
+    ref = np.log(y)
+    assert (np.abs(l - ref) / np.spacing(np.abs(ref) + 1e-300)).max() <= 2.0
+    sp = np.array([1.0, 2.0, 0.5, 4e-320, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf, 0.0, -1.0])
+    ls = ev(sp)[1]
+    assert ls[0] == 0.0 and ls[1] == np.log(2.0) and ls[2] == -np.log(2.0)
+    assert np.allclose(ls[3:6], np.log(sp[3:6]), rtol=1e-15) and ls[6] == np.inf and ls[7] == -1e300 and ls[8] == -1e300
+    assert np.isnan(ev([np.nan])[1][0])
 
 
 def test_log_ndtr_local_variable_forms_agree_bit_for_bit():
-    """`pgb_log_ndtr_t` (include/pgbart_spec.h) builds its local variable u = 16 t - 1 from the mantissa bits below
+    """`pgb_lphi_t` (include/pgbart_spec.h) builds its local variable u = 16 t - 1 from the mantissa bits below
     the 3 interval bits as fma(2, 1 + 8 t, -3); the textbook form is (m - (1 + sub/8)) * 16 - 1 with m the mantissa
     in [1, 2).  Every intermediate of either form is exactly representable, so they must agree to the last bit --
     checked here on 2 million random bit patterns and the interval edges (NumPy: 2 * m8 is exact, so 2 * m8 - 3 is
