@@ -485,7 +485,7 @@ PGB_HD double pgb_clamp_ll_host(double ll, double hi) {
 /* log(1 + e^t) */
 PGB_HD double pgb_softplus_t(double t, const pgb_lltabs* tb) {
   if (t > 36.0) return t;
-  return pgb_log_pos_t(1.0 + pgb_exp_t(t, tb->expt), tb->logt);
+  return pgb_log_t(1.0 + pgb_exp_t(t, tb->expt), tb->logt); /* (the guarded form: a NaN stays a NaN) */
 }
 
 /* Per-row log-likelihood of the closed families with one linear predictor mu (K = 1).

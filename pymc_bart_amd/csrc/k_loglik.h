@@ -12,7 +12,7 @@ struct LJobLin {  // linear response: the children's linear parts
 struct LJobNone {};
 template <bool MK, bool LIN>
 struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant leaves: none of the linear fields in LDS)
-  long long src, xoff;
+  long long src, xoff, dst;  // byte offsets: the particle's labels before the split, its split column, its new labels
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
   double vLx[MK ? KXMAX : 1], vRx[MK ? KXMAX : 1];  // K-vector leaves: outputs 1..K-1
@@ -159,6 +159,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       lj.vR = cv.vR;
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
+      lj.dst = (long long)((size_t)tid * S.n_pad);
       if constexpr (LIN) {
         lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
         lj.svarL = lj.svarR = -1;
@@ -316,12 +317,25 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       // instead of 4, none at all for a wave without a matching row.  A row's inputs (y, K predictors) are
       // fetched where it is evaluated (L1 hits: the chunk was just read by this workgroup).
       const long long cbase = (long long)chunk * CH;
+      // the chunk's streams as wave-uniform bases (scalar registers) + a 32-bit row offset: the loads of a row's
+      // inputs then cost one shared offset instead of a 64-bit address computation each
+      const gptr<const double> gy_c = gy + cbase;
+      gptr<const double> noi_c[KB], off_c[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        noi_c[k] = noi + (size_t)k * S.n_pad + cbase;
+        off_c[k] = goff + (size_t)k * S.n_pad + cbase;
+      }
+      const bool has_off = S.has_off != 0;
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
-        const uint32_t ids = lj.src < 0 ? root_ids : *gcast<const uint32_t>(glid + lj.src + base);
-        const uint32_t nid = *gcast<const uint32_t>(newl + (size_t)lj.p * S.n_pad + base);
-        const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
-        const bool mk_drops = lj.check_nan != 0;
+        // (the record is the same in every lane: its offsets and labels go to scalar registers, the label words
+        //  are fetched at scalar base + 32-bit row offset)
+        const long long src_u = uni(lj.src), dst_u = uni(lj.dst);
+        const uint32_t base32 = (uint32_t)base;  // (n < 2^31)
+        const uint32_t ids = src_u < 0 ? root_ids : gload_u32_off(glid + src_u, base32);
+        const uint32_t nid = gload_u32_off(newl + dst_u, base32);
+        const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
         double vLr[KB], vRr[KB];
         vLr[0] = lj.vL;
         vRr[0] = lj.vR;
@@ -356,43 +370,57 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const int npass = dense ? (M + 63) >> 6 : RPT;
-        long long v0 = 0, v1 = 0, v2 = 0;
-        for (int ps = 0; ps < npass; ++ps) {
-          bool act;
-          int r, side;
-          if (dense) {
-            const int k = lane + 64 * ps;
-            act = k < M;
-            const uint32_t ent = act ? (uint32_t)s_lrow[w][k] : 0u;
-            r = (int)(ent & 1023u);
-            side = (int)(ent >> 10);
-          } else {
-            r = tid * RPT + ps;
-            act = ((ids >> (8 * ps)) & 255u) == lab;
-            const uint32_t nl = (nid >> (8 * ps)) & 255u;
-            side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
-          }
-          if (act) {
-            const long long row = cbase + r;
-            const double yr = gy[row];
-            double mu[KB];
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-              // (side 2 -- a row dropped by a split on a column with missing values -- only where such a split is)
-              double vk = side == 0 ? vLr[k] : vRr[k];
-              if (mk_drops && side == 2) vk = 0.0;
-              const double nk = noi[(size_t)k * S.n_pad + row];
-              mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + row] : nk) + vk;
+        // (only a split on a column with missing values drops rows -- uniform per particle: the pass loop is
+        //  compiled with and without the third side, see the single-output loop below)
+        auto passes = [&](auto drops_c) {
+          constexpr bool DROPS = decltype(drops_c)::value;
+          long long vt = 0, v0 = 0, v2 = 0;
+          for (int ps = 0; ps < npass; ++ps) {
+            bool act;
+            uint32_t r, side;
+            if (dense) {
+              const int k = lane + 64 * ps;
+              act = k < M;
+              const uint32_t ent = act ? (uint32_t)s_lrow[w][k] : 0u;
+              r = ent & 1023u;
+              side = ent >> 10;
+            } else {
+              r = (uint32_t)(tid * RPT + ps);
+              act = ((ids >> (8 * ps)) & 255u) == lab;
+              const uint32_t nl = (nid >> (8 * ps)) & 255u;
+              side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
             }
-            const double llv = loglik_mk<KT>(S.family, K, yr, mu, &tb);
-            const long long q = quant_ll(llv, cl);
-            if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
+            if (act) {
+              const uint32_t ro = r * 8u;  // (r < 1024)
+              const double yr = gload_d_off(gy_c, ro);
+              double mu[KB];
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                double vk = side == 0 ? vLr[k] : vRr[k];
+                if constexpr (DROPS)
+                  if (side == 2) vk = 0.0;
+                const double nk = gload_d_off(noi_c[k], ro);
+                mu[k] = (has_off ? nk + gload_d_off(off_c[k], ro) : nk) + vk;
+              }
+              const double llv = loglik_mk<KT>(S.family, K, yr, mu, &tb);
+              const long long q = quant_ll(llv, cl);
+              vt += q;
+              v0 += side == 0 ? q : 0;
+              if constexpr (DROPS) v2 += side == 2 ? q : 0;
+            }
           }
-        }
+          const int slot = (g - g0) * 3;
+          if constexpr (DROPS) {
+            const long long tot = wave_sum4(v0, vt - v0 - v2, v2, 0);  // lane l: total of value l & 3
+            if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+          } else {
+            const long long tot = wave_sum2(v0, vt - v0);  // lane l: total of value l & 1
+            if (lane < 3) s_red[(slot + lane) * 4 + w] = lane < 2 ? tot : 0;
+          }
+        };
+        if (uni(lj.check_nan) != 0) passes(std::true_type{});
+        else passes(std::false_type{});
         if (dense) __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
-        const int slot = (g - g0) * 3;
-        const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
-        if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
       }
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
@@ -474,20 +502,27 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       continue;
     }
     // the label words of the next particle are requested before this one is evaluated
-    uint32_t ids_n = s_job[g0].src < 0 ? root_ids : *gcast<const uint32_t>(glid + s_job[g0].src + base);
-    uint32_t nid_n = *gcast<const uint32_t>(newl + (size_t)s_job[g0].p * S.n_pad + base);
+    const uint32_t base32 = (uint32_t)base;  // (n < 2^31)
+    // (a job record is the same in every lane: offsets and labels go to scalar registers -- uni -- and the label
+    //  words are fetched at scalar base + 32-bit row offset; per-lane 64-bit address arithmetic on these was a
+    //  quarter of the pass's per-particle instructions)
+    auto label_words = [&](const LJob& q, uint32_t& ids_o, uint32_t& nid_o) {
+      const long long src_u = uni(q.src), dst_u = uni(q.dst);
+      ids_o = src_u < 0 ? root_ids : gload_u32_off(glid + src_u, base32);
+      nid_o = gload_u32_off(newl + dst_u, base32);
+    };
+    uint32_t ids_n, nid_n;
+    label_words(s_job[g0], ids_n, nid_n);
     for (int g = g0; g < g1; ++g) {
       const LJob& lj = s_job[g];
       const uint32_t ids = ids_n, nid = nid_n;
       if (g + 1 < g1) {
-        const LJob& ln = s_job[g + 1];
-        ids_n = ln.src < 0 ? root_ids : *gcast<const uint32_t>(glid + ln.src + base);
-        nid_n = *gcast<const uint32_t>(newl + (size_t)ln.p * S.n_pad + base);
+        label_words(s_job[g + 1], ids_n, nid_n);
       }
       // (the particle's fields in registers: read through the LDS record they cost three LDS reads per ROW)
-      const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
+      const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
       const double vL = lj.vL, vR = lj.vR;
-      const bool drops = lj.check_nan != 0;  // only a column with missing values drops rows
+      const bool drops = uni(lj.check_nan) != 0;  // only a column with missing values drops rows
       if constexpr (FAM == PGB_FAMILY_CALLBACK) {
         // the host evaluates this family (pgb_set_loglik_callback): hand it every row's side and the
         // linear predictor of the rows of the split leaf

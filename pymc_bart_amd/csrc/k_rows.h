@@ -216,8 +216,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           const double r = normal ? yv - noi : 0.0;  // Bernoulli families: no residual algebra
           unsigned sat1 = 0;
           qa[e] = pgb_quant(st, c1, &sat1);
-          qb[e] = pgb_quant(r, c1, &sat1);
-          qc[e] = pgb_quant(r * r, c2, &sat1);
+          qb[e] = normal ? pgb_quant(r, c1, &sat1) : 0;  // (per-row families: r is 0)
+          qc[e] = normal ? pgb_quant(r * r, c2, &sat1) : 0;
           strow[e] = st;
           rrow[e] = r;
           if (writer) {  // saturation is counted where the values are produced, once
@@ -316,6 +316,49 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           }
         };
         const int slot = (g - g0) * NRED;
+        if constexpr (!NORMAL && !LIN) {
+          // Per-row families: a split only needs the children's row counts and the left child's sum of sum_trees
+          // (the weights come from the likelihood pass).  The counts are wave votes -- s_bcnt1 of the compare
+          // masks, scalar instructions -- and ONE value per lane goes through the cross-lane reduction (24 vector
+          // instructions; the four-value butterfly and the packed 64-bit counters cost 42 + ~4 per row).
+          const bool cn = rj.check_nan != 0;  // (wave-uniform) the split column has missing values
+          long long sa = 0, sn = 0;
+          int cL = 0, cR = 0, cN = 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            const bool m = ((ids >> (8 * e)) & 255u) == r_label;
+            bool miss = false;
+            if (cn) miss = m && (F32 ? (xf[e] != xf[e]) : (x[e] != x[e]));  // (NaN stays NaN in float32)
+            bool l = false, r = false;
+            if (m && !miss) {
+              l = left_of(e);
+              r = !l;
+            }
+            cL += __popcll(__ballot(l));
+            cR += __popcll(__ballot(r));
+            if (r) out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
+            if (l) sa += qa[e];
+            if (cn) {
+              cN += __popcll(__ballot(miss));
+              if (miss) {
+                out |= 255u << (8 * e);  // PGB_ORPHAN
+                sn += qa[e];
+              }
+            }
+          }
+          *gcast<uint32_t>(dp) = out;
+          if (!cn) {
+            const long long tot = wave_sum_dpp(sa);  // lane 63
+            if (lane == 63) s_red[(slot + 1) * 4 + w] = tot;
+          } else {
+            const long long tot = wave_sum2(sa, sn);  // lane l: total of value l & 1
+            if (lane == 0) s_red[(slot + 1) * 4 + w] = tot;
+            if (lane == 1) s_red[(slot + 4) * 4 + w] = tot;
+          }
+          if (lane == 0)
+            s_red[(slot + 0) * 4 + w] = (long long)cL | ((long long)cR << 20) | ((long long)cN << 40);
+          continue;
+        }
         if (!rj.check_nan) {  // common case: the split column has no missing values
           long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
@@ -388,6 +431,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         const int gi = t / NRED, i = t % NRED;
         const RJob& rj = s_job[g0 + gi];
         if (!rj.active || (i >= 4 && i < 7 && !rj.check_nan)) continue;
+        if constexpr (!NORMAL && !LIN)
+          if (i == 2 || i == 3 || i == 5 || i == 6) continue;  // (no residual algebra: nothing was reduced)
         const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
         if constexpr (LIN) {
           if (i >= 7) {

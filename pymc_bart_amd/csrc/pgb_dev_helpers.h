@@ -27,6 +27,26 @@ __device__ __forceinline__ void gstore_d2(gptr<double> p, double a, double b) {
   *(gptr<pgb_v2f64>)p = v;
 }
 
+// a double at a wave-uniform base + a 32-bit BYTE offset: `global_load_dwordx2 v, v_off, s[base:base+1]` -- no
+// 64-bit address computation per load (base[i] with a 32-bit i cannot be selected that way: 8 i may overflow)
+__device__ __forceinline__ double gload_d_off(gptr<const double> base, uint32_t byte_off) {
+  return *(gptr<const double>)((gptr<const char>)base + byte_off);
+}
+
+// a 32-bit word at a wave-uniform base + a 32-bit byte offset (see gload_d_off)
+__device__ __forceinline__ uint32_t gload_u32_off(gptr<const uint8_t> base, uint32_t byte_off) {
+  return *(gptr<const uint32_t>)(base + byte_off);
+}
+// Values every lane of the wave holds alike (a record read from LDS by all lanes), moved to scalar registers: what
+// is computed from them -- 64-bit offsets, base addresses -- then runs on the scalar unit instead of once per lane.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ long long uni(long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long wave_sum(long long v) {
 #pragma unroll

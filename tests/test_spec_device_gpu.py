@@ -108,6 +108,16 @@ def test_elementary_functions_device_equals_host(hip, oracle):
     assert np.max(np.abs(dev[0][fin] / np.exp(x[fin]) - 1.0)) < 1e-15
     pos = np.isfinite(x) & (x > 1e-300)
     assert np.max(np.abs(dev[1][pos] - np.log(x[pos])) / (1.0 + np.abs(np.log(x[pos])))) < 2e-15
+    # the table-driven exp / log of the per-row likelihoods, tables staged in LDS as the likelihood pass does
+    sig = (C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+    devt, hostt = [np.zeros(n) for _ in range(2)], [np.zeros(n) for _ in range(2)]
+    assert _fn(dl, "pgbh_math_t", *sig)(x.ctypes.data, n, *[a.ctypes.data for a in devt]) == 0
+    _fn(ol, "pgbo_math_t", *sig, restype=None)(x.ctypes.data, n, *[a.ctypes.data for a in hostt])
+    big = np.abs(x) < 4e7   # (pgb_exp_t reads its integer part from 32 bits: defined up to |x| < 4.6e7)
+    _same_bits(devt[0][big], hostt[0][big], "pgb_exp_t")
+    _same_bits(devt[1], hostt[1], "pgb_log_t")
+    assert np.max(np.abs(devt[0][fin] / np.exp(x[fin]) - 1.0)) < 3e-16
+    assert np.max(np.abs(devt[1][pos] - np.log(x[pos])) / np.spacing(np.abs(np.log(x[pos])) + 1e-300)) <= 2.0
     # log Phi
     sig = (C.c_void_p, C.c_int64, C.c_void_p)
     d, h = np.zeros(n), np.zeros(n)
@@ -158,7 +168,8 @@ def test_per_row_loglikelihood_device_equals_host(hip, oracle, family):
         _fn(ol, "pgbo_loglikq", *sig, restype=None)(_abi.FAMILIES[family], y.ctypes.data, mu.ctypes.data, n, param,
                                                     param2, h.ctypes.data)
         _same_bits(d, h, f"pgb_loglik1q[{family}, {param}, {param2}]")
-        assert np.all((d <= 0.0) & (d >= -2047.0))
+        ok = np.isfinite(mu)  # (a predictor is finite: the boundary refuses non-finite responses / offsets)
+        assert np.all((d[ok] <= 1e-16) & (d[ok] >= -2047.0))  # (log Phi from its table: 0 up to the fit error)
         if family.startswith("bernoulli"):
             # the form the likelihood pass runs: sign mask on the predictor, log-Phi tables staged in LDS
             s = np.zeros(n)
@@ -182,6 +193,12 @@ def test_multi_output_loglikelihood_device_equals_host(hip, oracle):
             assert _fn(dl, "pgbh_loglik_multi", *sig)(_abi.FAMILIES[fam], K, y.ctypes.data, mu.ctypes.data, n, d.ctypes.data) == 0
             _fn(ol, "pgbo_loglik_multi", *sig, restype=None)(_abi.FAMILIES[fam], K, y.ctypes.data, mu.ctypes.data, n, h.ctypes.data)
             _same_bits(d, h, f"pgb_loglik[{fam}, K={K}]")
+            # the form k_loglik<K> runs: every table in LDS
+            dl_ = np.zeros(n)
+            assert _fn(dl, "pgbh_loglik_multi_lds", C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                       C.c_double, C.c_void_p)(_abi.FAMILIES[fam], K, y.ctypes.data, mu.ctypes.data, n, 0.0, 1.0,
+                                               dl_.ctypes.data) == 0
+            _same_bits(dl_, h, f"pgb_loglikq_t[{fam}, K={K}] with LDS tables")
 
 
 def test_random_stream_and_fixed_point_device_equals_host(hip, oracle):
