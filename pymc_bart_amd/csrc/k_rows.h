@@ -318,45 +318,38 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         const int slot = (g - g0) * NRED;
         if constexpr (!NORMAL && !LIN) {
           // Per-row families: a split only needs the children's row counts and the left child's sum of sum_trees
-          // (the weights come from the likelihood pass).  The counts are wave votes -- s_bcnt1 of the compare
-          // masks, scalar instructions -- and ONE value per lane goes through the cross-lane reduction (24 vector
-          // instructions; the four-value butterfly and the packed 64-bit counters cost 42 + ~4 per row).
+          // (the weights come from the likelihood pass): TWO values per lane through the cross-lane reduction
+          // (wave_sum2: 30 vector instructions; the four-value butterfly costs 42 and carried two zeros).
+          // (Measured and dropped, round 4: the counts as wave votes -- s_bcnt1 of the compare masks -- with a
+          //  one-value reduction: 20.8 -> 22.9 us at cfg4; the votes serialise on the scalar unit.)
+          long long v0 = 0, v1 = 0, v4 = 0;  // cnts(L | R<<20 | N<<40), aL, aN
           const bool cn = rj.check_nan != 0;  // (wave-uniform) the split column has missing values
-          long long sa = 0, sn = 0;
-          int cL = 0, cR = 0, cN = 0;
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
-            const bool m = ((ids >> (8 * e)) & 255u) == r_label;
-            bool miss = false;
-            if (cn) miss = m && (F32 ? (xf[e] != xf[e]) : (x[e] != x[e]));  // (NaN stays NaN in float32)
-            bool l = false, r = false;
-            if (m && !miss) {
-              l = left_of(e);
-              r = !l;
-            }
-            cL += __popcll(__ballot(l));
-            cR += __popcll(__ballot(r));
-            if (r) out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
-            if (l) sa += qa[e];
-            if (cn) {
-              cN += __popcll(__ballot(miss));
-              if (miss) {
+            if (((ids >> (8 * e)) & 255u) == r_label) {
+              const bool missing = cn && (F32 ? (xf[e] != xf[e]) : (x[e] != x[e]));  // (NaN stays NaN in float32)
+              if (missing) {
                 out |= 255u << (8 * e);  // PGB_ORPHAN
-                sn += qa[e];
+                v0 += 1ll << 40;
+                v4 += qa[e];
+              } else if (left_of(e)) {
+                v0 += 1;
+                v1 += qa[e];
+              } else {
+                out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
+                v0 += 1ll << 20;
               }
             }
           }
           *gcast<uint32_t>(dp) = out;
           if (!cn) {
-            const long long tot = wave_sum_dpp(sa);  // lane 63
-            if (lane == 63) s_red[(slot + 1) * 4 + w] = tot;
+            const long long tot = wave_sum2(v0, v1);  // lane l: total of value l & 1
+            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
           } else {
-            const long long tot = wave_sum2(sa, sn);  // lane l: total of value l & 1
-            if (lane == 0) s_red[(slot + 1) * 4 + w] = tot;
-            if (lane == 1) s_red[(slot + 4) * 4 + w] = tot;
+            const long long tot = wave_sum4(v0, v1, v4, 0);  // lane l: total of value l & 3
+            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
+            if (lane == 2) s_red[(slot + 4) * 4 + w] = tot;
           }
-          if (lane == 0)
-            s_red[(slot + 0) * 4 + w] = (long long)cL | ((long long)cR << 20) | ((long long)cN << 40);
           continue;
         }
         if (!rj.check_nan) {  // common case: the split column has no missing values
