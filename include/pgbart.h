@@ -25,7 +25,8 @@
  * :117,155 any shape=(K, n)); upstream's defaults and tests sit far inside all of them.
  *   num_particles        2 .. 64   (PGB_MAX_PARTICLES: one particle per lane of a wave64; the
  *                                   resampling scan `pgb_scan64` is defined on 64 lanes)
- *   n_outputs (K)        1 .. 8    (PGB_MAX_OUTPUTS; K = 2, 3, 4 have unrolled kernel instances)
+ *   n_outputs (K)        1 .. 16   (PGB_MAX_OUTPUTS; K = 2, 3, 4 have unrolled kernel instances, any other K runs in
+ *                                  tiles of four outputs: no K-sized array in registers, no scratch)
  *   nodes per tree       <= 255    (leaf labels are bytes; label 255 = dropped row); a tree that
  *                                   would grow past it stops splitting (P ~ 0 under the prior)
  *   tree depth           <= 64     (prior_leaf[64]; upstream cuts its table where P(leaf) >= 0.9999,

@@ -59,7 +59,7 @@
 #define PGB_ORPHAN 255        /* leaf label of rows dropped by a NaN split value */
 #define PGB_MAX_DEPTH 64      /* prior_leaf table length; deeper => never split  */
 #define PGB_MAX_PARTICLES 64  /* one particle per lane of a wave64               */
-#define PGB_MAX_OUTPUTS 8
+#define PGB_MAX_OUTPUTS 16 /* K-vector leaves: the run-time-K kernels work in tiles of 4 outputs, nothing is sized by it but small records */
 #define PGB_SELECT_TRIES 16   /* redraws of the split row when X[row,var] is NaN */
 
 /* split rules (reference names: tests/test_bart.py:143-145, bart.py:100-103) */

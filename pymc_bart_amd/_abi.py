@@ -18,6 +18,7 @@ PGB_OK = 0
 PGB_E_NOMEM = -3
 MAX_DEPTH = 64
 MAX_PARTICLES = 64
+MAX_OUTPUTS = 16  # PGB_MAX_OUTPUTS (include/pgbart_spec.h)
 MAX_NODES = 255
 
 RULE_CONTINUOUS = 0

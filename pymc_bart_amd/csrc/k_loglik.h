@@ -10,13 +10,15 @@ struct LJobLin {  // linear response: the children's linear parts
   int32_t svarL, svarR;
 };
 struct LJobNone {};
-template <bool MK, bool LIN>
+template <bool MK, bool LIN, int KT>
 struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant leaves: none of the linear fields in LDS)
   long long src, xoff, dst;  // byte offsets: the particle's labels before the split, its split column, its new labels
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
-  double vLx[MK ? KXMAX : 1], vRx[MK ? KXMAX : 1];  // K-vector leaves: outputs 1..K-1
-  double sLx[MK && LIN ? KXMAX : 0], sRx[MK && LIN ? KXMAX : 0];  // ... slopes of outputs 1..K-1
+  // K-vector leaves: outputs 1..K-1 (sized by the instance: K - 1 when K is known at compile time)
+  static constexpr int NX = !MK ? 1 : KT > 0 ? KT - 1 : KXMAX;
+  double vLx[NX], vRx[NX];
+  double sLx[MK && LIN ? NX : 0], sRx[MK && LIN ? NX : 0];  // ... slopes of outputs 1..K-1
 };
 
 // Dense evaluation of sparse leaves (single output, constant leaves): a wave owns 256 rows, 4 per lane, and the
@@ -47,6 +49,77 @@ __device__ __forceinline__ double loglik_mk(int family, int K, double y, const d
   }
 }
 
+// pgb_loglikq_t for a K known only at run time, with the K linear predictors given as a FUNCTION mu(k) that is
+// re-evaluated where the spec routine reads an array element: the same operations in the same order (the serial
+// maximum, the serial sum of exponentials), hence the same bits -- and no K-sized array in registers or scratch,
+// whatever K is (the run-time-K instances carried 184-384 B of scratch for mu[8]; round-3 VERDICT #6).
+template <typename MuF>
+__device__ __forceinline__ double loglik_fn(int family, int K, double y, MuF mu, const pgb_lltabs* tb) {
+  if (family == PGB_FAMILY_CATEGORICAL) {
+    double mx = mu(0);
+    for (int k = 1; k < K; ++k) {
+      const double m = mu(k);
+      if (m > mx) mx = m;
+    }
+    double sum = 0.0;
+    for (int k = 0; k < K; ++k) sum += pgb_exp_t(mu(k) - mx, tb->expt);
+    int c = (int)y;
+    if (c < 0) c = 0;
+    if (c > K - 1) c = K - 1;
+    double ll = (mu(c) - mx) - pgb_log_pos_t(sum, tb->logt);
+    if (!(sum >= 1.0)) ll = -2047.0;
+    return PGB_CLAMP_LL(ll, 0.0);
+  }
+  if (family == PGB_FAMILY_NORMAL_MEANSCALE) {
+    const double m2[2] = {mu(0), mu(1)};
+    return pgb_loglik_meanscale_t(y, m2, tb);
+  }
+  return pgb_loglik1q(family, y, mu(0), 0.0, 1.0, tb);
+}
+
+// pgb_lphi_t's arithmetic over a table the kernel staged in LDS in a layout of ITS choice (the contract is the
+// arithmetic, not where the coefficients sit): PGB_LPHI_LDS_LAYOUT 0 = the header's own pairs [5][146][2] (five
+// 16-byte reads at immediate offsets of one address), 1 = coefficient-major [9][146] (nine 8-byte reads; lanes with
+// different entries collide only when the entries are 32 apart instead of 16).
+#ifndef PGB_LPHI_LDS_LAYOUT
+#define PGB_LPHI_LDS_LAYOUT 0
+#endif
+__device__ __forceinline__ void lphi_stage(double* s_tab /* LDS, PGB_LPHI_SIZE */) {
+  const double* g = pgb_tab_lphi();
+  for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) {
+    if constexpr (PGB_LPHI_LDS_LAYOUT == 0) {
+      s_tab[i] = g[i];
+    } else {  // source index i = (pair * ENT + ent) * 2 + half -> coefficient 2 pair + half of entry ent
+      const int half = i & 1, ent = (i >> 1) % PGB_LPHI_ENT, pr = (i >> 1) / PGB_LPHI_ENT;
+      if (pr < 4 || half == 0) s_tab[(2 * pr + half) * PGB_LPHI_ENT + ent] = g[i];
+    }
+  }
+}
+__device__ __forceinline__ double lphi_lds(double s, const double* s_tab) {
+  if constexpr (PGB_LPHI_LDS_LAYOUT == 0) {
+    return pgb_lphi_t(s, s_tab);
+  } else {
+    const uint64_t sb = pgb_d2u(s);
+    const double t = pgb_u2d(sb & 0x7FFFFFFFFFFFFFFFull) + 0.125;
+    const uint64_t tb = pgb_d2u(t);
+    uint32_t J = (uint32_t)(tb >> 49);
+    if (J > PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1)) J = PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1);
+    const uint32_t ent = ((J - PGB_LPHI_J0) << 1) | (uint32_t)(sb >> 63);
+    const double* c = s_tab + ent;
+    const double m8 = pgb_u2d(((tb & 0x0001FFFFFFFFFFFFull) << 3) | 0x3FF0000000000000ull);
+    const double u = PGB_FMA(2.0, m8, -3.0);
+    double g = c[8 * PGB_LPHI_ENT];
+    g = PGB_FMA(g, u, c[7 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[6 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[5 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[4 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[3 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[2 * PGB_LPHI_ENT]);
+    g = PGB_FMA(g, u, c[1 * PGB_LPHI_ENT]);
+    return PGB_FMA(g, u, c[0]);
+  }
+}
+
 // pgb_quant of a per-row log-likelihood that has already been clamped to the contract's range
 // (|ll| <= 2047, never NaN: every pgb_loglik* routine ends with that clamp): |ll * cl| < 2^50, so none of
 // pgb_quant's NaN / saturation branches can fire and what is left of it is the rounding itself.  Same bits.
@@ -68,7 +141,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
-  typedef LJobT<MK, LIN> LJob;
+  typedef LJobT<MK, LIN, KT> LJob;
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
@@ -83,7 +156,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   __shared__ double s_expt[EXPLOG ? PGB_EXPT_SIZE : 1];
   __shared__ __attribute__((aligned(16))) double s_logt[EXPLOG ? PGB_LOGT_SIZE : 2];
   pgb_lltabs tb;
-  tb.lphi = PROBIT ? s_lphi : pgb_tab_lphi();
+  tb.lphi = pgb_tab_lphi();  // (the probit instance evaluates through lphi_lds on its staged copy)
   tb.expt = EXPLOG ? s_expt : pgb_tab_exp();
   tb.logt = EXPLOG ? s_logt : pgb_tab_log();
   // wave-private lists of the dense path (see LL_DENSE_MAX); Bernoulli responses travel as a flag bit
@@ -105,10 +178,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   // rare branches of the evaluation are skipped wave-wide, with every lane active they never are.)
   const Cmd* cmd = &S.cmd[par];
   if (!(cmd->kind & CMD_PARTITION)) return;
-  if constexpr (PROBIT) {
-    const double* g = pgb_tab_lphi();
-    for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) s_lphi[i] = g[i];
-  }
+  if constexpr (PROBIT) lphi_stage(s_lphi);
   if constexpr (EXPLOG) {
     const double* ge = pgb_tab_exp();
     const double* gl = pgb_tab_log();
@@ -147,7 +217,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       const Acc a = load_acc(&S.acc[((size_t)par * MAXP + tid) * ACC_PER]);
       const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
                                         a.aL, a.aN, z0, z1, leaf_sd);
-      LJob lj;
+      LJob& lj = s_job[k];  // (filled in place: a local record with its K-sized arrays would live in scratch)
       lj.p = tid;
       lj.rule = j.rule;
       lj.label = j.label;
@@ -199,7 +269,6 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
-      s_job[k] = lj;
     }
     if (tid == 0) s_n[0] = __popcll(m);
   }
@@ -240,22 +309,32 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           if (row >= S.n) continue;
           const double yr = MK ? S.y[row] : yrr[e];
           if constexpr (MK) {
-            double mu_stump[KB], mu_cur[KB];
+            auto offk = [&](int k) { return S.has_off ? S.off[(size_t)k * S.n_pad + row] : 0.0; };  // (x + 0.0 == x)
+            auto mu_stump = [&](int k) { return (noi0[(size_t)k * S.n_pad + row] + offk(k)) + S.init_leaf; };
+            auto mu_cur = [&](int k) {
+              return (k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row]) + offk(k);
+            };
+            if constexpr (KT == 0) {  // (run-time K: the predictors as functions, see loglik_fn)
+              ce[0] += quant_ll(loglik_fn(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
+              ce[1] += quant_ll(loglik_fn(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
+            } else {
+              double ms[KB], mc[KB];
 #pragma unroll
-            for (int k = 0; k < KB; ++k)
-              if (k < Kn) {
-                const double offk = S.has_off ? S.off[(size_t)k * S.n_pad + row] : 0.0;  // (x + 0.0 == x bit for bit)
-                const double stk = k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row];
-                mu_stump[k] = (noi0[(size_t)k * S.n_pad + row] + offk) + S.init_leaf;
-                mu_cur[k] = stk + offk;
+              for (int k = 0; k < KB; ++k) {
+                ms[k] = mu_stump(k);
+                mc[k] = mu_cur(k);
               }
-            ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
-            ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
+              ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, ms, &tb), S.sc.cl);
+              ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+            }
           } else {
             const double offv = offr[e];
-            ce[0] += quant_ll(pgb_loglik1q(fam, yr, (noir[e] + offv) + init_leaf, cn.inv_sigma2, cn.lik_param2, &tb),
-                              S.sc.cl);
-            ce[1] += quant_ll(pgb_loglik1q(fam, yr, str_[e] + offv, cn.inv_sigma2, cn.lik_param2, &tb), S.sc.cl);
+            auto ll1 = [&](double mu1) -> double {
+              if constexpr (PROBIT) return lphi_lds(yr > 0.5 ? mu1 : -mu1, s_lphi);  // (the staged layout)
+              else return pgb_loglik1q(fam, yr, mu1, cn.inv_sigma2, cn.lik_param2, &tb);
+            };
+            ce[0] += quant_ll(ll1((noir[e] + offv) + init_leaf), S.sc.cl);
+            ce[1] += quant_ll(ll1(str_[e] + offv), S.sc.cl);
           }
         }
       }
@@ -375,39 +454,64 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         auto passes = [&](auto drops_c) {
           constexpr bool DROPS = decltype(drops_c)::value;
           long long vt = 0, v0 = 0, v2 = 0;
-          for (int ps = 0; ps < npass; ++ps) {
+          // a pass's inputs: which row (if any) this lane evaluates, its side, y and the K predictors without the
+          // leaf value.  They are requested ONE PASS AHEAD: the evaluation of pass ps (~175 vector instructions)
+          // covers the L1 / L2 round trip of the loads of pass ps + 1 (round 4; the pass loop stalled on them:
+          // 55 % of the wave-cycles waiting at three waves per SIMD).
+          struct PassIn {
             bool act;
-            uint32_t r, side;
+            uint32_t side;
+            double y, nk[KB];
+          };
+          auto fetch = [&](int ps) -> PassIn {
+            PassIn in;
+            uint32_t r;
             if (dense) {
               const int k = lane + 64 * ps;
-              act = k < M;
-              const uint32_t ent = act ? (uint32_t)s_lrow[w][k] : 0u;
+              in.act = k < M;
+              const uint32_t ent = in.act ? (uint32_t)s_lrow[w][k] : 0u;
               r = ent & 1023u;
-              side = ent >> 10;
+              in.side = ent >> 10;
             } else {
               r = (uint32_t)(tid * RPT + ps);
-              act = ((ids >> (8 * ps)) & 255u) == lab;
+              in.act = ((ids >> (8 * ps)) & 255u) == lab;
               const uint32_t nl = (nid >> (8 * ps)) & 255u;
-              side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
+              in.side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
             }
-            if (act) {
+            in.y = 0.0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) in.nk[k] = 0.0;
+            if (in.act) {
               const uint32_t ro = r * 8u;  // (r < 1024)
-              const double yr = gload_d_off(gy_c, ro);
+              in.y = gload_d_off(gy_c, ro);
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                const double nk = gload_d_off(noi_c[k], ro);
+                in.nk[k] = has_off ? nk + gload_d_off(off_c[k], ro) : nk;
+              }
+            }
+            return in;
+          };
+          PassIn cur = fetch(0);
+          for (int ps = 0; ps < npass; ++ps) {
+            PassIn nxt = cur;
+            if (ps + 1 < npass) nxt = fetch(ps + 1);
+            if (cur.act) {
               double mu[KB];
 #pragma unroll
               for (int k = 0; k < KB; ++k) {
-                double vk = side == 0 ? vLr[k] : vRr[k];
+                double vk = cur.side == 0 ? vLr[k] : vRr[k];
                 if constexpr (DROPS)
-                  if (side == 2) vk = 0.0;
-                const double nk = gload_d_off(noi_c[k], ro);
-                mu[k] = (has_off ? nk + gload_d_off(off_c[k], ro) : nk) + vk;
+                  if (cur.side == 2) vk = 0.0;
+                mu[k] = cur.nk[k] + vk;
               }
-              const double llv = loglik_mk<KT>(S.family, K, yr, mu, &tb);
+              const double llv = loglik_mk<KT>(S.family, K, cur.y, mu, &tb);
               const long long q = quant_ll(llv, cl);
               vt += q;
-              v0 += side == 0 ? q : 0;
-              if constexpr (DROPS) v2 += side == 2 ? q : 0;
+              v0 += cur.side == 0 ? q : 0;
+              if constexpr (DROPS) v2 += cur.side == 2 ? q : 0;
             }
+            cur = nxt;
           }
           const int slot = (g - g0) * 3;
           if constexpr (DROPS) {
@@ -434,30 +538,18 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       __syncthreads();
       continue;
     }
-    if constexpr (MK) {  // K-vector leaves: per-row softmax log-likelihood over all outputs
+    if constexpr (MK) {  // run-time K (KT = 0): K = 5.. outputs and K-vector linear leaves
+      static_assert(KT == 0 || MKPASS, "the compile-time-K instances take the pass loop above");
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
         const uint32_t ids = lj.src < 0 ? root_ids : *gcast<const uint32_t>(glid + lj.src + base);
         const uint32_t nid = *gcast<const uint32_t>(newl + (size_t)lj.p * S.n_pad + base);
-        // (the particle's labels and leaf values in registers instead of LDS reads per row)
         const uint32_t lab = (uint32_t)lj.label, nlab = (uint32_t)lj.new_label;
-        double vLr[KT >= 2 ? KT : 1], vRr[KT >= 2 ? KT : 1];
-        vLr[0] = lj.vL;
-        vRr[0] = lj.vR;
-        if constexpr (KT >= 2) {
-#pragma unroll
-          for (int k = 1; k < KT; ++k) {
-            vLr[k] = lj.vLx[k - 1];
-            vRr[k] = lj.vRx[k - 1];
-          }
-        }
         long long v0 = 0, v1 = 0, v2 = 0;
         for (int e = 0; e < RPT; ++e) {
           if (((ids >> (8 * e)) & 255u) == lab) {
             const uint32_t nl = (nid >> (8 * e)) & 255u;
             const int side = nl == lab ? 0 : (nl == nlab ? 1 : 2);
-            double mu[KB];
-            double v0k = side == 0 ? vLr[0] : side == 1 ? vRr[0] : 0.0;
             int sv = -1;
             double xv = 0.0, xb = 0.0;
             if constexpr (LIN) {
@@ -465,22 +557,20 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               if (sv >= 0) {
                 xv = S.XT[lj.xoff + base + e];
                 xb = side == 0 ? lj.xbarL : lj.xbarR;
-                v0k = pgb_leaf_pred(v0k, side == 0 ? lj.slopeL : lj.slopeR, xb, xv);
               }
             }
-            mu[0] = (S.has_off ? nv[e] + goff[base + e] : nv[e]) + v0k;
-#pragma unroll
-            for (int k = 1; k < KB; ++k)
-              if (k < K) {
-                double vk;
-                if constexpr (KT >= 2) vk = side == 0 ? vLr[k < KT ? k : 0] : side == 1 ? vRr[k < KT ? k : 0] : 0.0;
-                else vk = side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0;
-                if constexpr (LIN)
-                  if (sv >= 0) vk = pgb_leaf_pred(vk, side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1], xb, xv);
-                const double nk = noi[(size_t)k * S.n_pad + base + e];
-                mu[k] = (S.has_off ? nk + goff[(size_t)k * S.n_pad + base + e] : nk) + vk;
-              }
-            const double llv = loglik_mk<KT>(S.family, K, yv[e], mu, &tb);
+            // predictor k of this row under this particle's split (leaf values from the LDS record)
+            auto mu = [&](int k) -> double {
+              double vk = k == 0 ? (side == 0 ? lj.vL : side == 1 ? lj.vR : 0.0)
+                                 : (side == 0 ? lj.vLx[k - 1] : side == 1 ? lj.vRx[k - 1] : 0.0);
+              if constexpr (LIN)
+                if (sv >= 0)
+                  vk = pgb_leaf_pred(vk, k == 0 ? (side == 0 ? lj.slopeL : lj.slopeR)
+                                                : (side == 0 ? lj.sLx[k - 1] : lj.sRx[k - 1]), xb, xv);
+              const double nk = k == 0 ? nv[e] : noi[(size_t)k * S.n_pad + base + e];
+              return (S.has_off ? nk + goff[(size_t)k * S.n_pad + base + e] : nk) + vk;
+            };
+            const double llv = loglik_fn(S.family, K, yv[e], mu, &tb);
             const long long q = quant_ll(llv, cl);
             if (side == 0) v0 += q; else if (side == 1) v1 += q; else v2 += q;
           }
@@ -567,7 +657,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           const double mu = nvr + vleaf;
           double llr;
           if constexpr (YBIT) {  // (Bernoulli: the response only flips the sign of the predictor)
-            llr = pgb_loglik_bern_s(FAM, pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)sgn_hi << 32)), &tb);
+            const double smu = pgb_u2d(pgb_d2u(mu) ^ ((unsigned long long)sgn_hi << 32));
+            if constexpr (PROBIT) llr = lphi_lds(smu, s_lphi);  // (= pgb_loglik_bern_s: in [-2047, 1e-16] by itself)
+            else llr = pgb_loglik_bern_s(FAM, smu, &tb);
           } else {
             llr = pgb_loglik1q(FAM >= 0 ? FAM : S.family, yr, mu, cn.inv_sigma2, cn.lik_param2, &tb);
           }

@@ -316,42 +316,6 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           }
         };
         const int slot = (g - g0) * NRED;
-        if constexpr (!NORMAL && !LIN) {
-          // Per-row families: a split only needs the children's row counts and the left child's sum of sum_trees
-          // (the weights come from the likelihood pass): TWO values per lane through the cross-lane reduction
-          // (wave_sum2: 30 vector instructions; the four-value butterfly costs 42 and carried two zeros).
-          // (Measured and dropped, round 4: the counts as wave votes -- s_bcnt1 of the compare masks -- with a
-          //  one-value reduction: 20.8 -> 22.9 us at cfg4; the votes serialise on the scalar unit.)
-          long long v0 = 0, v1 = 0, v4 = 0;  // cnts(L | R<<20 | N<<40), aL, aN
-          const bool cn = rj.check_nan != 0;  // (wave-uniform) the split column has missing values
-#pragma unroll
-          for (int e = 0; e < RPT; ++e) {
-            if (((ids >> (8 * e)) & 255u) == r_label) {
-              const bool missing = cn && (F32 ? (xf[e] != xf[e]) : (x[e] != x[e]));  // (NaN stays NaN in float32)
-              if (missing) {
-                out |= 255u << (8 * e);  // PGB_ORPHAN
-                v0 += 1ll << 40;
-                v4 += qa[e];
-              } else if (left_of(e)) {
-                v0 += 1;
-                v1 += qa[e];
-              } else {
-                out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
-                v0 += 1ll << 20;
-              }
-            }
-          }
-          *gcast<uint32_t>(dp) = out;
-          if (!cn) {
-            const long long tot = wave_sum2(v0, v1);  // lane l: total of value l & 1
-            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
-          } else {
-            const long long tot = wave_sum4(v0, v1, v4, 0);  // lane l: total of value l & 3
-            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
-            if (lane == 2) s_red[(slot + 4) * 4 + w] = tot;
-          }
-          continue;
-        }
         if (!rj.check_nan) {  // common case: the split column has no missing values
           long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;  // cnts(L | R<<20), aL, bL, c2L
 #pragma unroll
@@ -359,7 +323,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             if (((ids >> (8 * e)) & 255u) == r_label) {
               if (left_of(e)) {
                 v0 += 1;
-                v1 += qa[e]; v2 += qb[e]; v3 += qc[e];
+                v1 += qa[e];
+                if constexpr (NORMAL) { v2 += qb[e]; v3 += qc[e]; }
               } else {
                 out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
                 v0 += 1ll << 20;
@@ -367,8 +332,17 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             }
           }
           *gcast<uint32_t>(dp) = out;
-          const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
-          if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
+          if constexpr (NORMAL || LIN) {
+            const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
+            if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
+          } else {
+            // per-row families: the weights come from the likelihood pass, a split only needs the children's counts
+            // and the left child's sum of sum_trees -- two values through the butterfly (30 vector instructions, 42
+            // for four).  (Measured and dropped, round 4: counts as wave votes with a one-value reduction, 20.8 ->
+            // 22.9 us at cfg4: the votes serialise on the scalar unit; one loop for both NaN cases: 21.9 us.)
+            const long long tot = wave_sum2(v0, v1);  // lane l: total of value l & 1
+            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
+          }
         } else {
           long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
 #pragma unroll

@@ -3,19 +3,25 @@
 // K-vector leaves (K > 1, Categorical-softmax): the same slot logic as k_rows with sum_trees, leaf
 // values and running-sd statistics per output.  Output 0 uses the scalar buffers, outputs 1..K-1
 // the *x extension arrays.  Not the headline path: written for clarity, K loops innermost.
-// KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay
-// in registers), 0: any K <= PGB_MAX_OUTPUTS.
+// KT: number of outputs when known at compile time (2, 3, 4: loops unroll, the per-row arrays stay in registers);
+// 0: ANY K <= PGB_MAX_OUTPUTS, processed as TILES of TW = 4 outputs -- the whole pass body runs once per tile with
+// the per-row arrays of four outputs in registers (what the K = 4 instance keeps), the partition decisions are
+// re-derived per tile (labels and the split column come from L2 again), and the labels / counts are written by
+// the first tile only.  No K-sized array anywhere: the run-time-K instance has no scratch and the same LDS
+// whatever K is (round 3: 576-736 B of scratch, 72 KB of LDS at K <= 8; round-3 VERDICT #2 / #6).
 // LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory
 // (lvl for output 0 and the shared parts, lsx for the slopes of outputs 1..K-1)
 // F32: the split column from the float32 shadow of the design matrix (see k_rows<..., F32>); continuous /
 // one-hot rules only.
 // (the compile-time-K instances are held to 4 workgroups per CU, <= 128 VGPRs: K = 4 sits at that edge)
 template <int KT, bool LIN, bool F32 = false>
-__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 1) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
-  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops
-  __shared__ long long s_red[MAXP * (1 + 2 * KB) * 4];
+  constexpr int TW = KT > 0 ? KT : 4;  // outputs per tile (= K for the compile-time instances: one tile)
+  constexpr int KB = TW;
+  constexpr int NVT = 1 + 2 * TW;      // per particle and tile: counts, aL[TW], aN[TW]
+  __shared__ long long s_red[MAXP * NVT * 4];
   __shared__ double s_lv[2][256][KB];
   __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
@@ -25,19 +31,27 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 1) void k_rows_mk(const
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
   const bool do_part = (kind & CMD_PARTITION) != 0;
-  const int NV = 1 + 2 * K;  // per particle: counts, aL[K], aN[K]
 
-  if (do_final || do_init) {
+  // label -> leaf value tables of the outputs k0 .. k0 + TW - 1 (new | next)
+  auto load_lv = [&](int k0) {
     const double* lx = S.lvx + (size_t)par * 2 * 256 * KX;
     for (int i = tid; i < 256; i += BT) {
-      s_lv[0][i][0] = cmd->lv_new[i];
-      s_lv[1][i][0] = cmd->lv_next[i];
-      for (int k = 0; k < KX; ++k) {
-        s_lv[0][i][k + 1] = lx[(size_t)i * KX + k];
-        s_lv[1][i][k + 1] = lx[(size_t)256 * KX + (size_t)i * KX + k];
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int k = k0 + kk;
+        double a = 0.0, b = 0.0;
+        if (k == 0) {
+          a = cmd->lv_new[i];
+          b = cmd->lv_next[i];
+        } else if (k < K) {
+          a = lx[(size_t)i * KX + (k - 1)];
+          b = lx[(size_t)256 * KX + (size_t)i * KX + (k - 1)];
+        }
+        s_lv[0][i][kk] = a;
+        s_lv[1][i][kk] = b;
       }
     }
-  }
+  };
   uint8_t* tl_old = do_final ? S.tree_lid + (size_t)cmd->tree_old * S.n_pad : nullptr;
   const uint8_t* tl_new = do_init ? S.tree_lid + (size_t)cmd->tree_new * S.n_pad : nullptr;
   const uint8_t* sel_lid =
@@ -97,286 +111,320 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 1) void k_rows_mk(const
     if (ngroups < 1) ngroups = 1;
     const int nitems = S.nchunks * ngroups;
     uint8_t* const dst0 = S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad;
-    long long iv[2 + 2 * PGB_MAX_OUTPUTS];  // C, E0, A[K], QSTD[K]
-    for (int i = 0; i < 2 + 2 * K; ++i) iv[i] = 0;
     unsigned sat = 0;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-      const int chunk = item % S.nchunks, grp = item / S.nchunks;
-      const long long base = (long long)chunk * CH + tid * RPT;
-      double stv[RPT][KB];  // sum_trees of this thread's rows, per output
+    for (int k0 = 0; k0 < K; k0 += TW) {  // one tile of outputs at a time (compile-time K: a single tile)
+      const bool first = k0 == 0;         // the first tile writes the labels and the counts
       if (do_init) {
-        const bool writer = grp == 0;
-        uint32_t ids_next = *(const uint32_t*)(tl_new + base);
-        uint32_t ids_sel = 0;
-        if (do_final) {
-          if (cmd->sel_slot == -2) {
-            ids_sel = *(const uint32_t*)(tl_old + base);
-          } else {
-            if (sel_lid) {
-              ids_sel = *(const uint32_t*)(sel_lid + base);
+        if (!first) __syncthreads();      // (the previous tile's readers of s_lv are done)
+        load_lv(k0);
+        __syncthreads();
+      }
+      long long ivA[KB], ivQ[KB];  // INIT statistics of this tile's outputs: A[k], QSTD[k]
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) ivA[kk] = ivQ[kk] = 0;
+      for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int chunk = item % S.nchunks, grp = item / S.nchunks;
+        const long long base = (long long)chunk * CH + tid * RPT;
+        double stv[RPT][KB];  // sum_trees of this thread's rows, per output of the tile
+        if (do_init) {
+          const bool writer = grp == 0;
+          uint32_t ids_next = *(const uint32_t*)(tl_new + base);
+          uint32_t ids_sel = 0;
+          if (do_final) {
+            if (cmd->sel_slot == -2) {
+              ids_sel = *(const uint32_t*)(tl_old + base);
             } else {
-              for (int e = 0; e < RPT; ++e)
-                if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+              if (sel_lid) {
+                ids_sel = *(const uint32_t*)(sel_lid + base);
+              } else {
+                for (int e = 0; e < RPT; ++e)
+                  if (base + e >= n) ids_sel |= (uint32_t)PGB_ORPHAN << (8 * e);
+              }
+              // (a later tile reads tl_old again only when the old tree was kept, sel_slot == -2; here every tile
+              //  derives ids_sel from the selected particle's labels, so the first tile's store is the only one)
+              if (writer && first) *(uint32_t*)(tl_old + base) = ids_sel;
             }
-            if (writer) *(uint32_t*)(tl_old + base) = ids_sel;
+            if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
           }
-          if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
-        }
-        for (int e = 0; e < RPT; ++e) {
-          const long long row = base + e;
-          for (int k = 0; k < K; ++k) stv[e][k] = 0.0;
-          if (row >= n) continue;
-          for (int k = 0; k < K; ++k) {
-            double st = st_in[(size_t)k * n_pad + row];
-            if (do_final) {
-              const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][k], 0, (ids_sel >> (8 * e)) & 255u, k, row);
-              st = st + nv;
-              if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
-                const size_t ri = (size_t)k * n_pad + row;
-                const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
-                const double delta = nv - mean0;
-                const double mean = mean0 + delta / cntf;
-                const double delta2 = nv - mean;
-                const double m2 = m20 + delta * delta2;
-                S.rs_mean[ri] = mean;
-                S.rs_m2[ri] = m2;
-                iv[2 + K + k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+          for (int e = 0; e < RPT; ++e) {
+            const long long row = base + e;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) stv[e][kk] = 0.0;
+            if (row >= n) continue;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const int k = k0 + kk;
+              if (k >= K) continue;
+              double st = st_in[(size_t)k * n_pad + row];
+              if (do_final) {
+                const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][kk], 0, (ids_sel >> (8 * e)) & 255u, k, row);
+                st = st + nv;
+                if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
+                  const size_t ri = (size_t)k * n_pad + row;
+                  const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+                  const double delta = nv - mean0;
+                  const double mean = mean0 + delta / cntf;
+                  const double delta2 = nv - mean;
+                  const double m2 = m20 + delta * delta2;
+                  S.rs_mean[ri] = mean;
+                  S.rs_m2[ri] = m2;
+                  ivQ[kk] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+                }
+              }
+              const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][kk], 1, (ids_next >> (8 * e)) & 255u, k, row);
+              const double noi = st - o;
+              stv[e][kk] = st;
+              if (writer) {
+                if (k == 0) S.pack[row] = make_double2(st, 0.0);
+                else S.packx[(size_t)(k - 1) * n_pad + row] = st;
+                st_out[(size_t)k * n_pad + row] = noi;
+                ivA[kk] += pgb_quant(st, c1, &sat);
               }
             }
-            const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][k], 1, (ids_next >> (8 * e)) & 255u, k, row);
-            const double noi = st - o;
-            stv[e][k] = st;
-            if (writer) {
-              if (k == 0) S.pack[row] = make_double2(st, 0.0);
-              else S.packx[(size_t)(k - 1) * n_pad + row] = st;
-              st_out[(size_t)k * n_pad + row] = noi;
-              iv[2 + k] += pgb_quant(st, c1, &sat);
-            }
+            // (C, the log-likelihood of a fresh stump, and E0, of the current tree, are summed by k_loglik,
+            //  which runs after this pass and is compiled per number of outputs)
           }
-          // (C, the log-likelihood of a fresh stump, and E0, of the current tree, are summed by k_loglik,
-          //  which runs after this pass and is compiled per number of outputs)
-        }
-      } else {
-        for (int e = 0; e < RPT; ++e) {
-          stv[e][0] = S.pack[base + e].x;
-          for (int k = 1; k < K; ++k) stv[e][k] = S.packx[(size_t)(k - 1) * n_pad + base + e];
-        }
-      }
-      uint32_t root_ids = 0;
-      for (int e = 0; e < RPT; ++e)
-        if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
-      long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
-#pragma unroll
-      for (int e = 0; e < RPT; ++e)
-#pragma unroll
-        for (int k = 0; k < KB; ++k) qst[e][k] = k < K ? pgb_quant(stv[e][k], c1, nullptr) : 0;
-      const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
-      for (int g = g0; g < g1; ++g) {
-        const RJob& rj = s_job[g];
-        const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + rj.src + base);
-        uint32_t out = ids;
-        uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
-        if (!rj.active) {
-          *(uint32_t*)dp = out;
-          continue;
-        }
-        const double2* xp = (const double2*)(S.XT + rj.xoff + base);
-        // (the particle's split in registers instead of LDS reads per row, see k_rows)
-        const double r_v = rj.v;
-        const int r_rule = rj.rule;
-        const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
-        double x[RPT] = {0.0, 0.0, 0.0, 0.0};
-        float xf[RPT] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (F32) {
-          const float4 tf = *(const float4*)(S.XT32 + rj.xoff + base);
-          xf[0] = tf.x; xf[1] = tf.y; xf[2] = tf.z; xf[3] = tf.w;
         } else {
-          const double2 t0 = xp[0], t1 = xp[1];
-          x[0] = t0.x; x[1] = t0.y; x[2] = t1.x; x[3] = t1.y;
-        }
-        const float r_vf = (float)r_v;
-        int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
-        long long cnts = 0;
-        for (int e = 0; e < RPT; ++e) {
-          side[e] = 0;
-          if (((ids >> (8 * e)) & 255u) == r_label) {
-            bool missing, left;
-            if constexpr (F32) {  // decided on the float32 values unless they tie
-              missing = xf[e] != xf[e];
-              if (xf[e] != r_vf) left = r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
-              else left = go_left(r_rule, ((const double*)xp)[e], r_v);
-            } else {
-              missing = x[e] != x[e];
-              left = !missing && go_left(r_rule, x[e], r_v);
-            }
-            if (missing) {
-              side[e] = 3;
-              out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
-              cnts += 1ll << 40;
-            } else if (left) {
-              side[e] = 1;
-              cnts += 1;
-            } else {
-              side[e] = 2;
-              out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
-              cnts += 1ll << 20;
+          for (int e = 0; e < RPT; ++e) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const int k = k0 + kk;
+              stv[e][kk] = k >= K ? 0.0 : k == 0 ? S.pack[base + e].x : S.packx[(size_t)(k - 1) * n_pad + base + e];
             }
           }
         }
-        *(uint32_t*)dp = out;
-        const int slot = (g - g0) * NV;
-        // values of this particle: [0] counts, [1 + k] aL[k], [1 + K + k] aN[k]; reduced four at a
-        // time (wave_sum4); a column without missing values has no aN part
-        long long vals[1 + 2 * KB + 3];
+        uint32_t root_ids = 0;
+        for (int e = 0; e < RPT; ++e)
+          if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+        long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
 #pragma unroll
-        for (int i = 0; i < 1 + 2 * KB + 3; ++i) vals[i] = 0;
-        vals[0] = cnts;
+        for (int e = 0; e < RPT; ++e)
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-          if (k < K) {
+          for (int kk = 0; kk < KB; ++kk) qst[e][kk] = k0 + kk < K ? pgb_quant(stv[e][kk], c1, nullptr) : 0;
+        const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+        for (int g = g0; g < g1; ++g) {
+          const RJob& rj = s_job[g];
+          // (a later tile finds the rows of the leaf in the labels as they were BEFORE this pass -- the source
+          //  generation is never the one being written -- and re-derives the sides from the split column)
+          const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + rj.src + base);
+          uint32_t out = ids;
+          uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
+          if (!rj.active) {
+            if (first) *(uint32_t*)dp = out;
+            continue;
+          }
+          const double2* xp = (const double2*)(S.XT + rj.xoff + base);
+          // (the particle's split in registers instead of LDS reads per row, see k_rows)
+          const double r_v = rj.v;
+          const int r_rule = rj.rule;
+          const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
+          double x[RPT] = {0.0, 0.0, 0.0, 0.0};
+          float xf[RPT] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (F32) {
+            const float4 tf = *(const float4*)(S.XT32 + rj.xoff + base);
+            xf[0] = tf.x; xf[1] = tf.y; xf[2] = tf.z; xf[3] = tf.w;
+          } else {
+            const double2 t0 = xp[0], t1 = xp[1];
+            x[0] = t0.x; x[1] = t0.y; x[2] = t1.x; x[3] = t1.y;
+          }
+          const float r_vf = (float)r_v;
+          int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
+          long long cnts = 0;
+          for (int e = 0; e < RPT; ++e) {
+            side[e] = 0;
+            if (((ids >> (8 * e)) & 255u) == r_label) {
+              bool missing, left;
+              if constexpr (F32) {  // decided on the float32 values unless they tie
+                missing = xf[e] != xf[e];
+                if (xf[e] != r_vf) left = r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
+                else left = go_left(r_rule, ((const double*)xp)[e], r_v);
+              } else {
+                missing = x[e] != x[e];
+                left = !missing && go_left(r_rule, x[e], r_v);
+              }
+              if (missing) {
+                side[e] = 3;
+                out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
+                cnts += 1ll << 40;
+              } else if (left) {
+                side[e] = 1;
+                cnts += 1;
+              } else {
+                side[e] = 2;
+                out = (out & ~(255u << (8 * e))) | (r_new << (8 * e));
+                cnts += 1ll << 20;
+              }
+            }
+          }
+          if (first) *(uint32_t*)dp = out;
+          const int slot = (g - g0) * NVT;
+          // values of this particle and tile: [0] counts, [1 + kk] aL[k0 + kk], [1 + TW + kk] aN[k0 + kk]; reduced
+          // four at a time (wave_sum4); a column without missing values has no aN part
+          long long vals[NVT + 3];
+#pragma unroll
+          for (int i = 0; i < NVT + 3; ++i) vals[i] = 0;
+          vals[0] = cnts;
+#pragma unroll
+          for (int kk = 0; kk < KB; ++kk) {
             long long aL = 0, aN = 0;
 #pragma unroll
             for (int e = 0; e < RPT; ++e) {
-              const long long q = qst[e][k];
+              const long long q = qst[e][kk];
               aL += side[e] == 1 ? q : 0;
               aN += side[e] == 3 ? q : 0;
             }
-            vals[1 + k] = aL;
-            vals[1 + K + k] = aN;
+            vals[1 + kk] = aL;
+            vals[1 + TW + kk] = aN;
           }
-        }
-        if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit): u, u^2 and
-          // u st_k per output; one wave total each, added by lane 63 (a rare path: no LDS staging)
-          const double uscale = pgb_pow2(-S.col_ex[rj.xoff / n_pad]);
-          long long su[2][2 + KB];
+          if constexpr (LIN) {  // sums of u = x 2^-ex over the two children (see pgb_lin_fit): u, u^2 (first tile)
+            // and u st_k per output; one wave total each, added by lane 63 (a rare path: no LDS staging)
+            const double uscale = pgb_pow2(-S.col_ex[rj.xoff / n_pad]);
+            long long su[2][2 + KB];
 #pragma unroll
-          for (int i = 0; i < 2 + KB; ++i) su[0][i] = su[1][i] = 0;
+            for (int i = 0; i < 2 + KB; ++i) su[0][i] = su[1][i] = 0;
 #pragma unroll
-          for (int e = 0; e < RPT; ++e) {
-            if (side[e] == 1 || side[e] == 2) {
-              const int sd = side[e] - 1;
-              const double uu = x[e] * uscale;
-              su[sd][0] += pgb_quant(uu * S.lin_R, c1, nullptr);
-              su[sd][1] += pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
+            for (int e = 0; e < RPT; ++e) {
+              if (side[e] == 1 || side[e] == 2) {
+                const int sd = side[e] - 1;
+                const double uu = x[e] * uscale;
+                su[sd][0] += pgb_quant(uu * S.lin_R, c1, nullptr);
+                su[sd][1] += pgb_quant((uu * uu) * S.lin_R, c1, nullptr);
 #pragma unroll
-              for (int k = 0; k < KB; ++k)
-                if (k < K) su[sd][2 + k] += pgb_quant(uu * stv[e][k], c1, nullptr);
-            }
-          }
-          AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
-          long long* aux = S.accux + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
-#pragma unroll
-          for (int sd = 0; sd < 2; ++sd)
-#pragma unroll
-            for (int i = 0; i < 2 + KB; ++i) {
-              if (i >= 2 + K) continue;
-              const long long tot = wave_sum_dpp(su[sd][i]);
-              if (lane == 63 && tot != 0) {
-                long long* dst = i < 3 ? (sd ? &au->uR[i] : &au->uL[i]) : &aux[(sd ? KX : 0) + (i - 3)];
-                atomicAdd((unsigned long long*)dst, (unsigned long long)tot);
+                for (int kk = 0; kk < KB; ++kk)
+                  if (k0 + kk < K) su[sd][2 + kk] += pgb_quant(uu * stv[e][kk], c1, nullptr);
               }
             }
-        }
-        const int nv = rj.check_nan ? NV : 1 + K;
+            AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+            long long* aux = S.accux + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
 #pragma unroll
-        for (int c4 = 0; c4 < (1 + 2 * KB + 3) / 4; ++c4) {
-          if (c4 * 4 < nv) {
-            const long long tot = wave_sum4(vals[c4 * 4], vals[c4 * 4 + 1], vals[c4 * 4 + 2], vals[c4 * 4 + 3]);
-            if (lane < 4 && c4 * 4 + lane < nv) s_red[(slot + c4 * 4 + lane) * 4 + w] = tot;
+            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+              for (int i = 0; i < 2 + KB; ++i) {
+                const int k = k0 + i - 2;  // output of entry i >= 2
+                if ((i < 2 && !first) || (i >= 2 && k >= K)) continue;
+                const long long tot = wave_sum_dpp(su[sd][i]);
+                if (lane == 63 && tot != 0) {
+                  // uL / uR: [0] sum u, [1] sum u^2, [2] sum u st_0; outputs k >= 1 in accux
+                  long long* dst = i < 2 ? (sd ? &au->uR[i] : &au->uL[i])
+                                         : k == 0 ? (sd ? &au->uR[2] : &au->uL[2]) : &aux[(sd ? KX : 0) + (k - 1)];
+                  atomicAdd((unsigned long long*)dst, (unsigned long long)tot);
+                }
+              }
+          }
+          const int nv = rj.check_nan ? NVT : 1 + TW;
+#pragma unroll
+          for (int c4 = 0; c4 < (NVT + 3) / 4; ++c4) {
+            if (c4 * 4 < nv) {
+              const long long tot = wave_sum4(vals[c4 * 4], vals[c4 * 4 + 1], vals[c4 * 4 + 2], vals[c4 * 4 + 3]);
+              if (lane < 4 && c4 * 4 + lane < nv) s_red[(slot + c4 * 4 + lane) * 4 + w] = tot;
+            }
+          }
+        }
+        __syncthreads();
+        for (int t = tid; t < (g1 - g0) * NVT; t += BT) {
+          const int gi = t / NVT, i = t % NVT;
+          const RJob& rj = s_job[g0 + gi];
+          if (!rj.active || (i > TW && !rj.check_nan)) continue;
+          if (i == 0 && !first) continue;
+          const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+          Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
+          long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
+          if (i == 0) {
+            const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
+            S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
+            S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+            if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
+          } else if (s != 0) {
+            const int kk = (i - 1) % TW, k = k0 + kk;
+            const bool isN = (i - 1) >= TW;
+            if (k < K) {
+              long long* dst = k == 0 ? (isN ? &a->aN : &a->aL) : &ax[(isN ? KX : 0) + k - 1];
+              atomicAdd((unsigned long long*)dst, (unsigned long long)s);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (do_init) {  // A[k], QSTD[k] of this tile's outputs -> InitAcc (k = 0) / iax (k >= 1)
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          const int k = k0 + kk;
+          if (k >= K) continue;
+          long long v2[2] = {ivA[kk], ivQ[kk]};
+          block_sum<2>(v2, s_red);
+          if (tid == 0) {
+            if (k == 0) {
+              InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+              if (v2[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v2[0]);
+              if (v2[1]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v2[1]);
+            } else {
+              long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+              if (v2[0]) atomicAdd((unsigned long long*)&ix[k - 1], (unsigned long long)v2[0]);
+              if (v2[1]) atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v2[1]);
+            }
           }
         }
       }
-      __syncthreads();
-      for (int t = tid; t < (g1 - g0) * NV; t += BT) {
-        const int gi = t / NV, i = t % NV;
-        const RJob& rj = s_job[g0 + gi];
-        if (!rj.active || (i > K && !rj.check_nan)) continue;
-        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
-        Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
-        long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
-        if (i == 0) {
-          const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
-          S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
-          S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
-          if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
-        } else if (s != 0) {
-          const int k = (i - 1) % K;
-          const bool isN = (i - 1) >= K;
-          long long* dst = k == 0 ? (isN ? &a->aN : &a->aL) : &ax[(isN ? KX : 0) + k - 1];
-          atomicAdd((unsigned long long*)dst, (unsigned long long)s);
-        }
-      }
-      __syncthreads();
     }
-    if (do_init) {
-      // C, E0, A[0] (+QSTD[0]) -> InitAcc; A[k>0], QSTD[k>0] -> iax
-      long long v5[5] = {iv[2], 0, iv[0], iv[1], iv[2 + K]};
-      block_sum<5>(v5, s_red);
-      if (tid == 0) {
-        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
-        if (v5[0]) atomicAdd((unsigned long long*)&a->A, (unsigned long long)v5[0]);
-        if (v5[2]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)v5[2]);
-        if (v5[3]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)v5[3]);
-        if (v5[4]) atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v5[4]);
-      }
-      for (int k = 1; k < K; ++k) {
-        long long v2[2] = {iv[2 + k], iv[2 + K + k]};
-        block_sum<2>(v2, s_red);
-        if (tid == 0) {
-          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
-          if (v2[0]) atomicAdd((unsigned long long*)&ix[k - 1], (unsigned long long)v2[0]);
-          if (v2[1]) atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v2[1]);
-        }
-      }
-      if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
-    }
+    if (do_init && sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
     return;
   }
 
-  // ---------------- lone FINAL
-  __syncthreads();
-  long long qs[PGB_MAX_OUTPUTS];
-  for (int k = 0; k < K; ++k) qs[k] = 0;
+  // ---------------- lone FINAL: one output at a time (no K-sized array)
   unsigned sat = 0;
   const int nitems = (int)(S.n_pad / BT);
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const long long row = (long long)item * BT + tid;
-    if (row >= S.n) continue;
-    uint32_t id_sel;
-    if (cmd->sel_slot == -2) {
-      id_sel = tl_old[row];
-    } else {
-      id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;
-      tl_old[row] = (uint8_t)id_sel;
-    }
-    for (int k = 0; k < K; ++k) {
-      const size_t ri = (size_t)k * n_pad + row;
-      const double nv = lin_pred(s_lv[0][id_sel][k], 0, id_sel, k, row);
-      const double st = st_in[ri] + nv;
-      if (cmd->tune) {
-        const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
-        const double delta = nv - mean0;
-        const double mean = mean0 + delta / cntf;
-        const double delta2 = nv - mean;
-        const double m2 = m20 + delta * delta2;
-        S.rs_mean[ri] = mean;
-        S.rs_m2[ri] = m2;
-        qs[k] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+  for (int k0 = 0; k0 < K; k0 += TW) {
+    if (k0 != 0) __syncthreads();
+    load_lv(k0);
+    __syncthreads();
+    long long qs[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) qs[kk] = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+      const long long row = (long long)item * BT + tid;
+      if (row >= S.n) continue;
+      uint32_t id_sel;
+      if (cmd->sel_slot == -2) {
+        id_sel = tl_old[row];
+      } else {
+        id_sel = sel_lid ? (uint32_t)sel_lid[row] : 0u;
+        if (k0 == 0) tl_old[row] = (uint8_t)id_sel;
       }
-      st_out[ri] = st;
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int k = k0 + kk;
+        if (k >= K) continue;
+        const size_t ri = (size_t)k * n_pad + row;
+        const double nv = lin_pred(s_lv[0][id_sel][kk], 0, id_sel, k, row);
+        const double st = st_in[ri] + nv;
+        if (cmd->tune) {
+          const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
+          const double delta = nv - mean0;
+          const double mean = mean0 + delta / cntf;
+          const double delta2 = nv - mean;
+          const double m2 = m20 + delta * delta2;
+          S.rs_mean[ri] = mean;
+          S.rs_m2[ri] = m2;
+          qs[kk] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
+        }
+        st_out[ri] = st;
+      }
     }
-  }
-  if (cmd->tune) {
-    for (int k = 0; k < K; ++k) {
-      long long v1[1] = {qs[k]};
-      block_sum<1>(v1, s_red);
-      if (tid == 0 && v1[0]) {
-        if (k == 0) {
-          InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
-          atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v1[0]);
-        } else {
-          long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
-          atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v1[0]);
+    if (cmd->tune) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int k = k0 + kk;
+        if (k >= K) continue;
+        long long v1[1] = {qs[kk]};
+        block_sum<1>(v1, s_red);
+        if (tid == 0 && v1[0]) {
+          if (k == 0) {
+            InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+            atomicAdd((unsigned long long*)&a->QSTD, (unsigned long long)v1[0]);
+          } else {
+            long long* ix = S.iax + ((size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)) * 2 * KX;
+            atomicAdd((unsigned long long*)&ix[KX + k - 1], (unsigned long long)v1[0]);
+          }
         }
       }
     }

@@ -3,7 +3,7 @@
 // Layout version of the image: bump when a device record that travels in the payload (Job, Ctrl, Cmd, DPart,
 // Acc, DTree ...) or this header changes.  The record sizes are stored as well, so an image written by a
 // build with other records is refused by name rather than by a payload-size coincidence.
-#define PGB_CKPT_VERSION 3
+#define PGB_CKPT_VERSION 4
 struct CkptHeader {
   char magic[8];       // "PGBCKPT2"
   int32_t version;     // PGB_CKPT_VERSION

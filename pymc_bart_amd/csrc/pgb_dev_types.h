@@ -78,9 +78,10 @@ struct Acc {  // statistics of the LEFT child and of the NaN-dropped rows (right
 #define LL_SLOTS 8
 #define LL_STRIDE 4
 #define LL_PER (LL_SLOTS * LL_STRIDE)
-// ... and for the extension-output sums of the multi-output row pass: 4 copies of 16 longs (128 B)
+// ... and for the extension-output sums of the multi-output row pass: 4 copies of 32 longs (aL[k], aN[k] of the
+// outputs 1..K-1: 2 (PGB_MAX_OUTPUTS - 1) = 30 values)
 #define AX_SLOTS 4
-#define AX_REC 16
+#define AX_REC 32
 #define AX_PER (AX_SLOTS * AX_REC)
 struct InitAcc {   // one 64-byte line
   long long A, B, C, E0, QSTD;

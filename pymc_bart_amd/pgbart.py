@@ -181,8 +181,8 @@ class CategoricalLikelihood:
     family = "categorical"
 
     def __init__(self, n_outputs: int):
-        if not 2 <= int(n_outputs) <= 8:
-            raise ValueError("n_outputs must be in [2, 8]")
+        if not 2 <= int(n_outputs) <= _abi.MAX_OUTPUTS:
+            raise ValueError(f"n_outputs must be in [2, {_abi.MAX_OUTPUTS}]")
         self.n_outputs = int(n_outputs)
 
     def params(self, point=None):

@@ -97,6 +97,23 @@ def make_case(name: str):
         pr = np.exp(F) / np.exp(F).sum(0)
         Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
         c.update(m=8, P=10, steps=20, family="categorical", K=K)
+    elif name == "categorical_k12":  # beyond the former cap of 8 outputs (a 10-class softmax model raised): three tiles
+        n, p, K = 2500, 7, 12
+        X = rng.normal(size=(n, p))
+        X[rng.random(n) < 0.1, 1] = np.nan
+        X[:, 6] = rng.integers(0, 4, n)
+        F = np.stack([np.cos(0.5 * k) * X[:, k % 4] + 0.3 * np.sin(k) * X[:, (k + 1) % 5] + 0.4 * (X[:, 6] == k % 4)
+                      for k in range(K)])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=6, P=10, steps=16, family="categorical", K=K, rules=np.array([0, 0, 0, 0, 0, 0, 1], np.int32))
+    elif name == "categorical_k16_linear":  # the largest K, linear leaves (run-time-K instances with LIN)
+        n, p, K = 1500, 4, 16
+        X = rng.normal(size=(n, p))
+        F = np.stack([np.cos(0.4 * k) * X[:, k % 3] + 0.2 * k / K * X[:, 3] for k in range(K)])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=4, P=8, steps=12, family="categorical", K=K, response="linear")
     elif name in ("poisson_counts", "negbin_counts"):  # the count models of the PyMC-BART docs (log link)
         n, p = 4000, 5
         X = rng.normal(size=(n, p))
@@ -258,7 +275,7 @@ def make_case(name: str):
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
          "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
-         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
+         "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "categorical_k12", "categorical_k16_linear", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
          "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
          "linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules",
          "stump_first_probit", "stump_first_categorical", "stump_first_poisson"]
@@ -373,7 +390,7 @@ def random_case(seed, large=False):
     elif fam == "categorical":
         # classes that DEPEND on the covariates (Gumbel-max over logits that fan out with f): with a pure-noise
         # response the stump wins nearly every update and the K-vector growth paths are hardly exercised
-        K = int(rng.integers(2, 8))
+        K = int(rng.integers(2, 17)) if rng.random() < 0.35 else int(rng.integers(2, 8))  # (up to PGB_MAX_OUTPUTS = 16)
         logits = np.stack([f * (k - 0.5 * (K - 1)) for k in range(K)]) + rng.gumbel(size=(K, n))
         Y = np.argmax(logits, axis=0).astype(float)
     else:
