@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains run concurrently on each GPU (own stream each); the headline "
                          "is quoted at 1, as north_star shards one chain per GPU")
+    ap.add_argument("--outputs", type=int, default=4, help="cfg5 only: number of outputs K (4 = BASELINE's cfg5)")
     ap.add_argument("--response", default="constant", choices=["constant", "linear", "mix"])
     ap.add_argument("--no-multichain", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -496,11 +497,12 @@ def main():
         wname, wkw = "cfg4", dict(seed=3415, n=args.n if args.n != 100_000 else 1_000_000,
                                   p=args.p if args.p != 50 else 100, m=args.m, num_particles=args.particles)
     elif args.workload == "cfg5":
-        wname, wkw = "cfg5", dict(seed=3415, num_particles=args.particles)
+        wname, wkw = "cfg5", dict(seed=3415, num_particles=args.particles, K=args.outputs)
     else:
         wname, wkw = "cfg2", dict(seed=3415, n=args.n, p=args.p, m=args.m, num_particles=args.particles)
     tune = bool(args.tune)
-    default_cfg = (args.workload != "cfg2") or (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40)
+    default_cfg = ((args.workload != "cfg2") or (args.n, args.p, args.m, args.particles) == (100_000, 50, 200, 40)) \
+        and (args.workload != "cfg5" or args.outputs == 4)
 
     def make_chain(wn, kw, sd, be, batch=(0.1, 0.1), wl=None):
         """One chain of workload ``wn`` as the step method itself: its sampler is the resident path."""

@@ -61,12 +61,16 @@ __device__ __forceinline__ double loglik_fn(int family, int K, double y, MuF mu,
       const double m = mu(k);
       if (m > mx) mx = m;
     }
-    double sum = 0.0;
-    for (int k = 0; k < K; ++k) sum += pgb_exp_t(mu(k) - mx, tb->expt);
     int c = (int)y;
     if (c < 0) c = 0;
     if (c > K - 1) c = K - 1;
-    double ll = (mu(c) - mx) - pgb_log_pos_t(sum, tb->logt);
+    double sum = 0.0, muc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double m = mu(k);
+      if (k == c) muc = m;  // (the observed class's predictor, picked up on the way: the same value)
+      sum += pgb_exp_t(m - mx, tb->expt);
+    }
+    double ll = (muc - mx) - pgb_log_pos_t(sum, tb->logt);
     if (!(sum >= 1.0)) ll = -2047.0;
     return PGB_CLAMP_LL(ll, 0.0);
   }
@@ -75,6 +79,37 @@ __device__ __forceinline__ double loglik_fn(int family, int K, double y, MuF mu,
     return pgb_loglik_meanscale_t(y, m2, tb);
   }
   return pgb_loglik1q(family, y, mu(0), 0.0, 1.0, tb);
+}
+
+// pgb_loglikq_t for a run-time K <= KBND with the predictors in a REGISTER array of compile-time size KBND: every
+// loop is unrolled to KBND and guarded by the wave-uniform `k < K` (a scalar branch skips the exponentials of the
+// outputs a model does not have), the observed class's predictor is picked by compares instead of a dynamic index.
+// Same operations in the same order as pgb_loglik_cat_t.  What the array buys over loglik_fn: the K loads behind it
+// are issued together (and a pass ahead), where the one-at-a-time loops paid 2 K serialised memory round trips per
+// evaluated row -- the run-time-K pass was 3.5 x slower PER OUTPUT than the unrolled K = 4 instance.
+template <int KBND>
+__device__ __forceinline__ double loglik_arr(int family, int K, double y, const double (&mu)[KBND], const pgb_lltabs* tb) {
+  if (family == PGB_FAMILY_NORMAL_MEANSCALE) {
+    const double m2[2] = {mu[0], mu[KBND > 1 ? 1 : 0]};
+    return pgb_loglik_meanscale_t(y, m2, tb);
+  }
+  double mx = mu[0];
+#pragma unroll
+  for (int k = 1; k < KBND; ++k)
+    if (k < K && mu[k] > mx) mx = mu[k];
+  int c = (int)y;
+  if (c < 0) c = 0;
+  if (c > K - 1) c = K - 1;
+  double sum = 0.0, muc = 0.0;
+#pragma unroll
+  for (int k = 0; k < KBND; ++k)
+    if (k < K) {
+      if (k == c) muc = mu[k];
+      sum += pgb_exp_t(mu[k] - mx, tb->expt);
+    }
+  double ll = (muc - mx) - pgb_log_pos_t(sum, tb->logt);
+  if (!(sum >= 1.0)) ll = -2047.0;
+  return PGB_CLAMP_LL(ll, 0.0);
 }
 
 // pgb_lphi_t's arithmetic over a table the kernel staged in LDS in a layout of ITS choice (the contract is the
@@ -136,11 +171,11 @@ template <int KT, int FAM, bool LIN>
 // (compiled for 3 workgroups per CU, i.e. <= 168 VGPRs: the K = 4 instance sits right at that edge, and one
 //  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5;
 //  the probit instance -- cfg4's dominant kernel -- for 5: <= 96 VGPRs, where a 97th costs it a fifth)
-__global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : (KT >= 2 && !LIN) ? PGB_LLK_WGS : 3)
+__global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : (KT >= 2 && !LIN) ? PGB_LLK_WGS : KT == 0 ? 2 : 3)
 void k_loglik(const Dev* __restrict__ Sp, int par) {
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   constexpr bool MK = KT != 1;
-  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;
+  constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops (run-time K: guarded by k < K)
   typedef LJobT<MK, LIN, KT> LJob;
   __shared__ long long s_red[MAXP * 3 * 4];
   __shared__ LJob s_job[MAXP];
@@ -170,7 +205,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   __shared__ double s_lnv[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
   __shared__ double s_ly[DENSE && !YBIT ? BT / 64 : 1][DENSE && !YBIT ? LL_DENSE_MAX : 1];
   __shared__ uint16_t s_lfl[DENSE ? BT / 64 : 1][DENSE ? LL_DENSE_MAX : 1];
-  constexpr bool MKPASS = KT >= 2 && !LIN;  // K = 2, 3, 4 with constant leaves: the pass loop (see below)
+  constexpr bool MKPASS = MK && !LIN;  // K-vector constant leaves: the pass loop (see below); KT = 0: any K
   __shared__ uint16_t s_lrow[MKPASS ? BT / 64 : 1][MKPASS ? LL_DENSE_MAX : 1];
   // (Measured and dropped: listing each wave's matching rows with ballot + mbcnt and evaluating the
   // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
@@ -314,18 +349,26 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
             auto mu_cur = [&](int k) {
               return (k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row]) + offk(k);
             };
-            if constexpr (KT == 0) {  // (run-time K: the predictors as functions, see loglik_fn)
+            if constexpr (LIN && KT == 0) {  // (the rare instance keeps the predictors as functions, see loglik_fn)
               ce[0] += quant_ll(loglik_fn(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
               ce[1] += quant_ll(loglik_fn(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
             } else {
               double ms[KB], mc[KB];
 #pragma unroll
               for (int k = 0; k < KB; ++k) {
-                ms[k] = mu_stump(k);
-                mc[k] = mu_cur(k);
+                ms[k] = mc[k] = 0.0;
+                if (k < Kn) {  // (wave-uniform; the loads behind the predictors go out together)
+                  ms[k] = mu_stump(k);
+                  mc[k] = mu_cur(k);
+                }
               }
-              ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, ms, &tb), S.sc.cl);
-              ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              if constexpr (KT > 0) {
+                ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, ms, &tb), S.sc.cl);
+                ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              } else {
+                ce[0] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, ms, &tb), S.sc.cl);
+                ce[1] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              }
             }
           } else {
             const double offv = offr[e];
@@ -402,8 +445,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       gptr<const double> noi_c[KB], off_c[KB];
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
-        noi_c[k] = noi + (size_t)k * S.n_pad + cbase;
-        off_c[k] = goff + (size_t)k * S.n_pad + cbase;
+        const int kc = k < K ? k : 0;  // (outputs the model does not have: never read)
+        noi_c[k] = noi + (size_t)kc * S.n_pad + cbase;
+        off_c[k] = goff + (size_t)kc * S.n_pad + cbase;
       }
       const bool has_off = S.has_off != 0;
       for (int g = g0; g < g1; ++g) {
@@ -415,11 +459,13 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         const uint32_t ids = src_u < 0 ? root_ids : gload_u32_off(glid + src_u, base32);
         const uint32_t nid = gload_u32_off(newl + dst_u, base32);
         const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
-        double vLr[KB], vRr[KB];
+        // (compile-time K: the particle's leaf values in registers; run-time K: read from its LDS record where used)
+        constexpr int KV = KT > 0 ? KT : 1;
+        double vLr[KV], vRr[KV];
         vLr[0] = lj.vL;
         vRr[0] = lj.vR;
 #pragma unroll
-        for (int k = 1; k < KB; ++k) {
+        for (int k = 1; k < KV; ++k) {
           vLr[k] = lj.vLx[k - 1];
           vRr[k] = lj.vRx[k - 1];
         }
@@ -460,7 +506,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           // 55 % of the wave-cycles waiting at three waves per SIMD).
           struct PassIn {
             bool act;
-            uint32_t side;
+            uint32_t side, ro;  // (ro: the row's byte offset in its chunk -- what the run-time-K evaluation reads with)
             double y, nk[KB];
           };
           auto fetch = [&](int ps) -> PassIn {
@@ -479,16 +525,17 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               in.side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
             }
             in.y = 0.0;
+            in.ro = r * 8u;  // (r < 1024)
 #pragma unroll
             for (int k = 0; k < KB; ++k) in.nk[k] = 0.0;
             if (in.act) {
-              const uint32_t ro = r * 8u;  // (r < 1024)
-              in.y = gload_d_off(gy_c, ro);
+              in.y = gload_d_off(gy_c, in.ro);
 #pragma unroll
-              for (int k = 0; k < KB; ++k) {
-                const double nk = gload_d_off(noi_c[k], ro);
-                in.nk[k] = has_off ? nk + gload_d_off(off_c[k], ro) : nk;
-              }
+              for (int k = 0; k < KB; ++k)
+                if (k < K) {  // (wave-uniform)
+                  const double nk = gload_d_off(noi_c[k], in.ro);
+                  in.nk[k] = has_off ? nk + gload_d_off(off_c[k], in.ro) : nk;
+                }
             }
             return in;
           };
@@ -500,12 +547,20 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               double mu[KB];
 #pragma unroll
               for (int k = 0; k < KB; ++k) {
-                double vk = cur.side == 0 ? vLr[k] : vRr[k];
-                if constexpr (DROPS)
-                  if (cur.side == 2) vk = 0.0;
-                mu[k] = cur.nk[k] + vk;
+                mu[k] = 0.0;
+                if (k < K) {
+                  double vk;
+                  if constexpr (KT > 0) vk = cur.side == 0 ? vLr[k] : vRr[k];
+                  else vk = k == 0 ? (cur.side == 0 ? vLr[0] : vRr[0])
+                                   : (cur.side == 0 ? uni(lj.vLx[k > 0 ? k - 1 : 0]) : uni(lj.vRx[k > 0 ? k - 1 : 0]));
+                  if constexpr (DROPS)
+                    if (cur.side == 2) vk = 0.0;
+                  mu[k] = cur.nk[k] + vk;
+                }
               }
-              const double llv = loglik_mk<KT>(S.family, K, cur.y, mu, &tb);
+              double llv;
+              if constexpr (KT > 0) llv = loglik_mk<KT>(S.family, K, cur.y, mu, &tb);
+              else llv = loglik_arr<KB>(S.family, K, cur.y, mu, &tb);
               const long long q = quant_ll(llv, cl);
               vt += q;
               v0 += cur.side == 0 ? q : 0;

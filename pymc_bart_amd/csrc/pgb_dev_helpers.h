@@ -47,6 +47,12 @@ __device__ __forceinline__ long long uni(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+__device__ __forceinline__ double uni(double v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane(__double2loint(v));
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ long long wave_sum(long long v) {
 #pragma unroll

@@ -61,7 +61,10 @@ def cfg5(seed: int = 3415, n: int = 250_000, p: int = 200, K: int = 4, m: int = 
     """Multi-output (shape=(K, n)) BART with a Categorical-softmax likelihood, all ContinuousSplit."""
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, p))
-    F = np.stack([X[:, 0], -X[:, 0] + 0.5 * X[:, 1], 1.5 * X[:, 2] * X[:, 3], np.zeros(n)])[:K]
+    rows = [X[:, 0], -X[:, 0] + 0.5 * X[:, 1], 1.5 * X[:, 2] * X[:, 3], np.zeros(n)]
+    # (K > 4 -- the run-time-K kernels: further logits on the first covariates; K <= 4 is BASELINE's cfg5 unchanged)
+    rows += [0.7 * math.cos(k) * X[:, k % 6] + 0.5 * math.sin(k) * X[:, (k + 2) % 7] for k in range(4, K)]
+    F = np.stack(rows)[:K]
     pr = np.exp(F - F.max(axis=0))
     pr /= pr.sum(axis=0)
     Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(axis=0).clip(0, K - 1).astype(np.float64)
