@@ -424,12 +424,12 @@ typedef double pgb_d2v __attribute__((ext_vector_type(2)));
   } while (0)
 #endif
 
-/* log Phi(s) (standard normal CDF) for the probit likelihood: ONE table entry, one degree-8 Horner chain, for
- * either sign and any magnitude -- no division, no exp, no log, no branch, no clamp.
- *   t = |s| + 1/8 >= 1/8: the dyadic interval of t (exponent -3..5 and top three mantissa bits -> row 0..71) and
- *   the local variable u in [-1, 1) (the remaining 49 mantissa bits: u = 2 (1 + 8 frac) - 3, exact) come from the
- *   bits of t; per row and sign the table holds log Phi(+-(t - 1/8)) itself as a polynomial in u.  Everything
- *   from t = 64 on shares the clamp row 72: exactly -2047 for s < 0 -- the lower bound of a per-row
+/* log Phi(s) (standard normal CDF) for the probit likelihood: ONE table entry, one Horner chain (degree
+ * PGB_LPHI_DEG = 7), for either sign and any magnitude -- no division, no exp, no log, no branch, no clamp.
+ *   t = |s| + 1/8 >= 1/8: the dyadic interval of t (exponent -3..5 and the top PGB_LPHI_SUBBITS = 4 mantissa bits
+ *   -> row 0..143) and the local variable u in [-1, 1) (the remaining mantissa bits: u = 2 (1 + 16 frac) - 3,
+ *   exact) come from the bits of t; per row and sign the table holds log Phi(+-(t - 1/8)) itself as a polynomial
+ *   in u.  Everything from t = 64 on shares the last row, the clamp row: exactly -2047 for s < 0 -- the lower bound of a per-row
  *   log-likelihood; log Phi(-63.875) = -2045.08, so every other row stays above it -- and 0 for s > 0
  *   (log Phi(9) = -1.1e-19).  +-inf therefore give the limits 0 / -2047.
  *   The rounding of t is an argument perturbation of at most 2^-54 |t|: <= 1 ulp of the result.
@@ -438,33 +438,25 @@ typedef double pgb_d2v __attribute__((ext_vector_type(2)));
  * The argument must not be NaN: the linear predictor of a row is a sum of finite leaf values and the offsets /
  * responses the boundary checked (pgb_set_offset, pgb_set_response refuse non-finite values); a NaN would read
  * the clamp row of ITS sign bit, which compilers do not agree on.
- * gfx950: 17 vector instructions + five table reads (before round 4: ~50 and nine). */
-#define PGB_LPHI_J0 (1020u << 3) /* (biased exponent of 1/8) << 3 */
+ * gfx950: 29 vector instructions with the sign flip, quantisation and two running sums + four 16-byte table reads
+ * (before round 4: 66 and nine 8-byte reads). */
+#define PGB_LPHI_J0 (1020u << PGB_LPHI_SUBBITS) /* (biased exponent of 1/8) << SUBBITS */
 PGB_HD double pgb_lphi_t(double s, const double* T) {
   const uint64_t sb = pgb_d2u(s);
   const double t = pgb_u2d(sb & 0x7FFFFFFFFFFFFFFFull) + 0.125;
   const uint64_t tb = pgb_d2u(t);
-  uint32_t J = (uint32_t)(tb >> 49); /* (biased exponent << 3) | top three mantissa bits; t > 0 */
+  uint32_t J = (uint32_t)(tb >> (52 - PGB_LPHI_SUBBITS)); /* (biased exponent << SUBBITS) | top mantissa bits; t > 0 */
   if (J > PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1)) J = PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1);
   const uint32_t ent = ((J - PGB_LPHI_J0) << 1) | (uint32_t)(sb >> 63);
   const double* c = T + 2 * ent;
-  const double m8 = pgb_u2d(((tb & 0x0001FFFFFFFFFFFFull) << 3) | 0x3FF0000000000000ull); /* 1 + 8 frac */
-  const double u = PGB_FMA(2.0, m8, -3.0);
-  double c0, c1, c2, c3, c4, c5, c6, c7, g, pad;
-  PGB_LD2(c + 4 * 2 * PGB_LPHI_ENT, g, pad); /* (c8, 0): every read 16 bytes from the one address */
-  (void)pad;
-  PGB_LD2(c + 3 * 2 * PGB_LPHI_ENT, c6, c7);
-  PGB_LD2(c + 2 * 2 * PGB_LPHI_ENT, c4, c5);
-  PGB_LD2(c + 1 * 2 * PGB_LPHI_ENT, c2, c3);
-  PGB_LD2(c, c0, c1);
-  g = PGB_FMA(g, u, c7);
-  g = PGB_FMA(g, u, c6);
-  g = PGB_FMA(g, u, c5);
-  g = PGB_FMA(g, u, c4);
-  g = PGB_FMA(g, u, c3);
-  g = PGB_FMA(g, u, c2);
-  g = PGB_FMA(g, u, c1);
-  return PGB_FMA(g, u, c0);
+  /* the mantissa bits below the row bits, moved up under the exponent of 1.0: 1 + 2^SUBBITS frac in [1, 2) */
+  const double mm = pgb_u2d(((tb & ((1ull << (52 - PGB_LPHI_SUBBITS)) - 1ull)) << PGB_LPHI_SUBBITS) | 0x3FF0000000000000ull);
+  const double u = PGB_FMA(2.0, mm, -3.0);
+  double cf[2 * PGB_LPHI_PAIRS];
+  for (int p = PGB_LPHI_PAIRS - 1; p >= 0; --p) PGB_LD2(c + p * 2 * PGB_LPHI_ENT, cf[2 * p], cf[2 * p + 1]);
+  double g = cf[PGB_LPHI_DEG];
+  for (int k = PGB_LPHI_DEG - 1; k >= 0; --k) g = PGB_FMA(g, u, cf[k]);
+  return g;
 }
 PGB_HD double pgb_log_ndtr(double x) { return pgb_lphi_t(x, pgb_tab_lphi()); }
 

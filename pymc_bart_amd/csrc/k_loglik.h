@@ -112,48 +112,15 @@ __device__ __forceinline__ double loglik_arr(int family, int K, double y, const 
   return PGB_CLAMP_LL(ll, 0.0);
 }
 
-// pgb_lphi_t's arithmetic over a table the kernel staged in LDS in a layout of ITS choice (the contract is the
-// arithmetic, not where the coefficients sit): PGB_LPHI_LDS_LAYOUT 0 = the header's own pairs [5][146][2] (five
-// 16-byte reads at immediate offsets of one address), 1 = coefficient-major [9][146] (nine 8-byte reads; lanes with
-// different entries collide only when the entries are 32 apart instead of 16).
-#ifndef PGB_LPHI_LDS_LAYOUT
-#define PGB_LPHI_LDS_LAYOUT 0
-#endif
+// The probit instance evaluates pgb_lphi_t on a copy of its table staged in LDS (the header's own layout: coefficient
+// pairs [PAIRS][entries][2], one 16-byte read per pair at an immediate offset of ONE address).
+// (Measured and dropped, round 4: the coefficient-major layout [9][entries] with nine 8-byte reads -- lanes with
+//  different entries then collide only when the entries are 32 apart instead of 16 -- 24.6 -> 32.3 us at cfg4.)
 __device__ __forceinline__ void lphi_stage(double* s_tab /* LDS, PGB_LPHI_SIZE */) {
   const double* g = pgb_tab_lphi();
-  for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) {
-    if constexpr (PGB_LPHI_LDS_LAYOUT == 0) {
-      s_tab[i] = g[i];
-    } else {  // source index i = (pair * ENT + ent) * 2 + half -> coefficient 2 pair + half of entry ent
-      const int half = i & 1, ent = (i >> 1) % PGB_LPHI_ENT, pr = (i >> 1) / PGB_LPHI_ENT;
-      if (pr < 4 || half == 0) s_tab[(2 * pr + half) * PGB_LPHI_ENT + ent] = g[i];
-    }
-  }
+  for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) s_tab[i] = g[i];
 }
-__device__ __forceinline__ double lphi_lds(double s, const double* s_tab) {
-  if constexpr (PGB_LPHI_LDS_LAYOUT == 0) {
-    return pgb_lphi_t(s, s_tab);
-  } else {
-    const uint64_t sb = pgb_d2u(s);
-    const double t = pgb_u2d(sb & 0x7FFFFFFFFFFFFFFFull) + 0.125;
-    const uint64_t tb = pgb_d2u(t);
-    uint32_t J = (uint32_t)(tb >> 49);
-    if (J > PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1)) J = PGB_LPHI_J0 + (PGB_LPHI_ROWS - 1);
-    const uint32_t ent = ((J - PGB_LPHI_J0) << 1) | (uint32_t)(sb >> 63);
-    const double* c = s_tab + ent;
-    const double m8 = pgb_u2d(((tb & 0x0001FFFFFFFFFFFFull) << 3) | 0x3FF0000000000000ull);
-    const double u = PGB_FMA(2.0, m8, -3.0);
-    double g = c[8 * PGB_LPHI_ENT];
-    g = PGB_FMA(g, u, c[7 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[6 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[5 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[4 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[3 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[2 * PGB_LPHI_ENT]);
-    g = PGB_FMA(g, u, c[1 * PGB_LPHI_ENT]);
-    return PGB_FMA(g, u, c[0]);
-  }
-}
+__device__ __forceinline__ double lphi_lds(double s, const double* s_tab) { return pgb_lphi_t(s, s_tab); }
 
 // pgb_quant of a per-row log-likelihood that has already been clamped to the contract's range
 // (|ll| <= 2047, never NaN: every pgb_loglik* routine ends with that clamp): |ll * cl| < 2^50, so none of
@@ -177,7 +144,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops (run-time K: guarded by k < K)
   typedef LJobT<MK, LIN, KT> LJob;
-  __shared__ long long s_red[MAXP * 3 * 4];
+  // per (particle of the span, side): the four waves ADD their totals (LDS atomics; the reducer thread reads the sum
+  // and leaves a zero) -- a quarter of the storage of one cell per wave, which is what fits a fifth workgroup of the
+  // probit instance into the CU next to its 18.6 KB table
+  __shared__ long long s_red[MAXP * 3 < 8 ? 8 : MAXP * 3];
   __shared__ LJob s_job[MAXP];
   __shared__ int s_n[2];
   // the tables of the per-row likelihood math in LDS (a per-lane table row through the vector L1 costs a
@@ -187,7 +157,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   constexpr bool PROBIT = KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT;
   constexpr bool EXPLOG = !(KT == 1 && (FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_ASYMLAPLACE ||
                                         FAM == PGB_FAMILY_CALLBACK));
-  __shared__ double s_lphi[PROBIT ? PGB_LPHI_SIZE : 1];
+  __shared__ __attribute__((aligned(16))) double s_lphi[PROBIT ? PGB_LPHI_SIZE : 2];
   __shared__ double s_expt[EXPLOG ? PGB_EXPT_SIZE : 1];
   __shared__ __attribute__((aligned(16))) double s_logt[EXPLOG ? PGB_LOGT_SIZE : 2];
   pgb_lltabs tb;
@@ -391,6 +361,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   }
   const int nact = s_n[0];
   if (nact == 0) return;
+  for (int i = tid; i < MAXP * 3; i += BT) s_red[i] = 0;  // (the waves add into it; block_sum above used it as scratch)
+  __syncthreads();
   // (arrays of the argument block as GLOBAL pointers -- see as_global: a flat load also counts in lgkmcnt, so
   //  the first LDS table read of an evaluation waited for the label words requested for the NEXT particle)
   const gptr<const double> gy = as_global(S.y), goff = as_global(S.off);
@@ -571,10 +543,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           const int slot = (g - g0) * 3;
           if constexpr (DROPS) {
             const long long tot = wave_sum4(v0, vt - v0 - v2, v2, 0);  // lane l: total of value l & 3
-            if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+            if (lane < 3 && tot != 0) atomicAdd((unsigned long long*)&s_red[slot + lane], (unsigned long long)tot);
           } else {
             const long long tot = wave_sum2(v0, vt - v0);  // lane l: total of value l & 1
-            if (lane < 3) s_red[(slot + lane) * 4 + w] = lane < 2 ? tot : 0;
+            if (lane < 2 && tot != 0) atomicAdd((unsigned long long*)&s_red[slot + lane], (unsigned long long)tot);
           }
         };
         if (uni(lj.check_nan) != 0) passes(std::true_type{});
@@ -584,7 +556,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
         const int gi = t / 3, i = t % 3;
-        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        const long long s = s_red[t];
+        s_red[t] = 0;
         if (s != 0) {
           AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
           atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
@@ -632,12 +605,13 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         }
         const int slot = (g - g0) * 3;
         const long long tot = wave_sum4(v0, v1, v2, 0);  // lane l: total of value l & 3
-        if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+        if (lane < 3 && tot != 0) atomicAdd((unsigned long long*)&s_red[slot + lane], (unsigned long long)tot);
       }
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
         const int gi = t / 3, i = t % 3;
-        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        const long long s = s_red[t];
+        s_red[t] = 0;
         if (s != 0) {
           AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
           atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
@@ -772,10 +746,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         const int slot = (g - g0) * 3;
         if constexpr (DROPS) {
           const long long tot = wave_sum4(v0, vt - v0 - v2, v2, 0);  // lane l: total of value l & 3
-          if (lane < 3) s_red[(slot + lane) * 4 + w] = tot;
+          if (lane < 3 && tot != 0) atomicAdd((unsigned long long*)&s_red[slot + lane], (unsigned long long)tot);
         } else {
           const long long tot = wave_sum2(v0, vt - v0);  // lane l: total of value l & 1
-          if (lane < 3) s_red[(slot + lane) * 4 + w] = lane < 2 ? tot : 0;
+          if (lane < 2 && tot != 0) atomicAdd((unsigned long long*)&s_red[slot + lane], (unsigned long long)tot);
         }
       };
       // (the families with two exp / log chains per evaluation -- Poisson, NegativeBinomial, Gamma -- and the
@@ -791,7 +765,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
     __syncthreads();
     for (int t = tid; t < (g1 - g0) * 3; t += BT) {
       const int gi = t / 3, i = t % 3;
-      const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+      const long long s = s_red[t];
+      s_red[t] = 0;
       if (s != 0) {
         AccL* a = &S.accl[((size_t)par * MAXP + s_job[g0 + gi].p) * LL_PER + (chunk & (LL_SLOTS - 1)) * LL_STRIDE];
         atomicAdd((unsigned long long*)(i == 0 ? &a->llL : i == 1 ? &a->llR : &a->llN), (unsigned long long)s);
