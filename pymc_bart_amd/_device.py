@@ -45,7 +45,12 @@ class TorchHipMemory:
         used: it touches the default stream and three padding streams (kept alive, idle), after which every run
         of four new chain streams is spread over the four queues.  The first padding stream doubles as the
         output stream of every sampler (`pgb_set_output_stream`), so that one takes no queue of its own.
-        Best effort: streams the application itself has used are not known here."""
+        Best effort: streams the application itself has used are not known here.  Limit: torch hands its streams
+        out round-robin from a pool of 32 per device and priority, so in a process that creates samplers for a long
+        time the ~30th LIVE sampler shares its hipStream_t with the padding / output stream or with another live
+        sampler.  Results stay correct (every entry point of the library is synchronous at return, and a step's
+        export is ordered behind its slots on whatever stream it is given); what stops holding is the balancing
+        over the four hardware queues and the early export past the idle slots."""
         key = str(device)
         with cls._queue_lock:  # (chains.sample_chains builds its samplers from several threads at once)
             return cls._prime_locked(torch, device, key)

@@ -367,9 +367,13 @@ class PGBART(_Base):
         self._base_seed = seed       # before any per-chain re-keying (set_rng / first astep in a PyMC worker)
         self._keyed = random_seed is not None and not (_HAVE_PYMC and not duck)  # explicit seed, no PyMC: final
         self._stepped = False
-        self.sampler = PySampler(self.settings, X, y_obs, rule_ids, split_prior, backend=backend)
-        if self.likelihood.family == "callback":
-            self.sampler.set_loglik_callback(self.likelihood.logp)
+        # The native sampler (design matrix uploaded and transposed in HBM) is built when the Philox key is FINAL:
+        # at once for a keyed step method; under PyMC -- where every chain's copy takes its own key through
+        # set_rng or at its first astep -- on first use, so that re-keying never builds a second sampler and
+        # uploads X again (several GB at the sizes this backend is for; round-3 ADVICE).
+        self._sampler = None
+        if self._keyed:
+            self._sampler = self._build_sampler()
         # the op is a mailbox: utils.py:125 reads op.n_outputs, which the step method sets
         op.n_outputs = n_outputs
         op._rule_ids = rule_ids
@@ -385,13 +389,34 @@ class PGBART(_Base):
             # them before astep(q) runs): likelihood parameters bound to those variables are read there
             super().__init__([self._var], dict(shared or {}))
 
+    def _build_sampler(self):
+        smp = PySampler(self.settings, self._X, self._y_obs, self._rule_ids, self._split_prior,
+                        backend=self._backend_arg)
+        if self.likelihood.family == "callback":
+            smp.set_loglik_callback(self.likelihood.logp)
+        return smp
+
+    @property
+    def sampler(self):
+        if self._sampler is None:
+            self._sampler = self._build_sampler()
+            if getattr(self, "_offset", None) is not None:
+                self._apply_offset(self._offset)
+        return self._sampler
+
+    @sampler.setter
+    def sampler(self, value):
+        self._sampler = value
+
     # -- pickling: PyMC sends the step method to its worker processes ----------
     def __getstate__(self):
         """Everything but the native handle; the chain itself travels as a checkpoint image, so
         a step method pickled mid-run resumes bit-identically in the process that unpickles it
         (on that process's current GPU)."""
         d = dict(self.__dict__)
-        d["_checkpoint"] = d.pop("sampler").checkpoint()
+        smp = self.sampler  # (builds it if nobody has yet)
+        d.pop("_sampler", None)
+        d["_checkpoint"] = smp.checkpoint()
         d.pop("_backend_arg", None)
         return d
 
@@ -438,12 +463,9 @@ class PGBART(_Base):
     def _rekey(self, seed: int) -> None:
         """The same sampler on another Philox key (before its first step: there is no state to lose)."""
         self.settings.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids, self._split_prior,
-                                 backend=self._backend_arg)
-        if self.likelihood.family == "callback":
-            self.sampler.set_loglik_callback(self.likelihood.logp)
-        if self._offset is not None:
-            self._apply_offset(self._offset)
+        if self._sampler is not None:  # somebody looked at the sampler before the key was final: rebuild it
+            self._sampler = None
+            _ = self.sampler
 
     def _key_for_this_process(self) -> None:
         """Older PyMC has no `set_rng`: it seeds NumPy's global generator per chain (`np.random.seed(chain_seed)`)
@@ -453,8 +475,14 @@ class PGBART(_Base):
         import multiprocessing as mp
 
         ident = getattr(mp.current_process(), "_identity", ()) or (0,)
-        mix = np.random.SeedSequence([self._base_seed & 0xFFFFFFFF, self._base_seed >> 32,
-                                      int(np.random.randint(0, 2**31 - 1)), *[int(i) for i in ident]])
+        # The global generator's STATE is read, not advanced (round-3 ADVICE: drawing from it changed what the
+        # user's own code draws next): two chains that one worker runs one after the other differ only in the
+        # seed pm.sample gave that generator, so it has to enter the key -- next to the explicit random_seed of
+        # the step method, which is always mixed in.
+        st = np.random.get_state()
+        glob = [int(x) for x in np.asarray(st[1][:4], np.uint64)] + [int(st[2])]
+        mix = np.random.SeedSequence([self._base_seed & 0xFFFFFFFF, self._base_seed >> 32, *glob,
+                                      *[int(i) for i in ident]])
         self._rekey(int(mix.generate_state(1, np.uint64)[0]))
         self._keyed = True
 

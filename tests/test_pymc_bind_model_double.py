@@ -230,8 +230,8 @@ def test_bind_model_puts_a_student_t_model_on_the_device_family(graph_api, oracl
     point = model.initial_point()
     point["b"] = np.array(2.0)
     point["sigma"] = np.array(0.25)
-    for it in range(30):
-        if it == 15:
+    for it in range(60):  # (one key, one chain: long enough that the fit does not hang on the draw of the key)
+        if it == 30:
             step.stop_tuning()
         point, _ = step.step(point)
     params, off = step._binding.current()
