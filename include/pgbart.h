@@ -23,8 +23,11 @@
  * pgb_set_data as PGB_E_INVALID or PGB_E_UNSUPPORTED with a message, never silently clamped).
  * The reference bounds none of these (tests/test_bart.py:231 takes any num_particles,
  * :117,155 any shape=(K, n)); upstream's defaults and tests sit far inside all of them.
- *   num_particles        2 .. 64   (PGB_MAX_PARTICLES: one particle per lane of a wave64; the
- *                                   resampling scan `pgb_scan64` is defined on 64 lanes)
+ *   num_particles        2 .. pgb_max_particles(): 64 in libpgbart_hip.so (one particle per lane of a wave64), 128
+ *                                   in libpgbart_hip_p128.so (the same source built with -DPGB_MAX_PARTICLES=128: two
+ *                                   particles per lane of the control kernel, cumulative weights as two chained
+ *                                   64-entry scans -- pgb_weights_scan); a chain of <= 64 particles is bit-identical
+ *                                   on either build.  The Python binding picks the build by num_particles.
  *   n_outputs (K)        1 .. 16   (PGB_MAX_OUTPUTS; K = 2, 3, 4 have unrolled kernel instances, any other K runs in
  *                                  tiles of four outputs: no K-sized array in registers, no scratch)
  *   nodes per tree       <= 255    (leaf labels are bytes; label 255 = dropped row); a tree that
@@ -37,7 +40,7 @@
  *                        fast_linear_fit; on a SubsetSplit column that is the category code)
  *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory: per row the device holds 8 p bytes
  *                        of the design matrix (+ 4 p for its float32 shadow when it exceeds the Infinity Cache),
- *                        m bytes of tree labels, 512 bytes of particle labels (8 generations x 64 slots) and
+ *                        m bytes of tree labels, 8 x pgb_max_particles() bytes of particle labels (8 generations) and
  *                        ~ 64 K bytes of running statistics -- 30 M rows x 4 columns x 5 trees: 17 GB, in the suite)
  */
 #ifndef PGBART_H
@@ -118,6 +121,8 @@ typedef struct {
 
 const char* pgb_last_error(void);
 const char* pgb_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
+int32_t pgb_max_particles(void);    /* PGB_MAX_PARTICLES of this build (64 or 128): the largest num_particles pgb_create
+                                       accepts.  Replaces nothing in the reference (tests/test_bart.py:231 takes any int) */
 
 /* Create a sampler.  `stream` is a hipStream_t (NULL = default stream); ignored by
  * CPU backends.  Replaces PGBART.__init__ / PySampler construction.            */

@@ -58,7 +58,13 @@
 #define PGB_MAX_LEAVES 128
 #define PGB_ORPHAN 255        /* leaf label of rows dropped by a NaN split value */
 #define PGB_MAX_DEPTH 64      /* prior_leaf table length; deeper => never split  */
-#define PGB_MAX_PARTICLES 64  /* one particle per lane of a wave64               */
+/* particles: one per lane of a wave64, or -- library built with -DPGB_MAX_PARTICLES=128 -- two per lane (the
+ * control kernel finishes lanes' particles q and q + 64 one after the other, the cumulative weights are two
+ * 64-entry scans chained by the first block's total: pgb_weights_scan).  A chain of <= 64 particles draws the same
+ * numbers from either build. */
+#ifndef PGB_MAX_PARTICLES
+#define PGB_MAX_PARTICLES 64
+#endif
 #define PGB_MAX_OUTPUTS 16 /* K-vector leaves: the run-time-K kernels work in tiles of 4 outputs, nothing is sized by it but small records */
 #define PGB_SELECT_TRIES 16   /* redraws of the split row when X[row,var] is NaN */
 
@@ -675,16 +681,22 @@ PGB_HD void pgb_scan64(double* x) {
   for (int i = 32; i < 64; ++i) x[i] = x[i] + x[31];
 }
 
-/* [U] normalize + inverse_cdf: particles occupy entries [first, first+cnt) of a 64-entry
- * array of log-weights.  w_i = exp(lw_i - max) + 1e-12, W = pgb_scan64(w), total = W[last].
+/* [U] normalize + inverse_cdf: particles occupy entries [first, first+cnt) of a PGB_MAX_PARTICLES-entry
+ * array of log-weights.  w_i = exp(lw_i - max) + 1e-12; W = the inclusive scan of w in BLOCKS of 64 entries, each
+ * block in the order of pgb_scan64, every later block shifted by the (shifted) total of the block before it -- the
+ * tree of additions a GPU evaluates with one DPP scan per block and one add; total = W[last].
  * pgb_pick returns the first i in [first, last) with !(u * total > W[i]), else last. */
 PGB_HD void pgb_weights_scan(const double* lw, int first, int cnt, double* W) {
   double mx = lw[first];
   for (int i = first + 1; i < first + cnt; ++i)
     if (lw[i] > mx) mx = lw[i];
-  for (int i = 0; i < 64; ++i) W[i] = 0.0;
+  for (int i = 0; i < PGB_MAX_PARTICLES; ++i) W[i] = 0.0;
   for (int i = first; i < first + cnt; ++i) W[i] = pgb_exp(lw[i] - mx) + 1e-12;
-  pgb_scan64(W);
+  for (int b = 0; b < PGB_MAX_PARTICLES; b += 64) {
+    pgb_scan64(W + b);
+    if (b > 0)
+      for (int i = b; i < b + 64; ++i) W[i] = W[i] + W[b - 1];
+  }
 }
 PGB_HD int pgb_pick(const double* W, int first, int cnt, double u) {
   const int last = first + cnt - 1;

@@ -61,6 +61,7 @@ static int fail(int code, const char* msg) {
 }
 const char* pgb_last_error(void) { return g_err; }
 const char* pgb_backend_name(void) { return "oracle-cpu"; }
+int32_t pgb_max_particles(void) { return PGB_MAX_PARTICLES; }
 
 typedef struct {
   int32_t var; /* -1 leaf */
@@ -176,7 +177,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (!s || !out) return fail(PGB_E_INVALID, "null argument");
   if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
-    return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
+    return fail(PGB_E_INVALID, "num_particles must be in [2, PGB_MAX_PARTICLES]");
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
       return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
@@ -731,7 +732,7 @@ static double o_logw(const pgb_handle* h, const otree* T) {
  * Cumulative weights and the inverse-CDF walk are pgb_weights_scan / pgb_pick (numeric contract). */
 static void o_resample(pgb_handle* h, uint32_t round) {
   int P = h->s.num_particles, Lc = P - 1;
-  double lw[64], W[64];
+  double lw[PGB_MAX_PARTICLES], W[PGB_MAX_PARTICLES];
   for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
   pgb_weights_scan(lw, 1, Lc, W);
   pgb_u2 u = pgb_draw2(h->s.seed, (uint32_t)h->iter, round, 0, PGB_RNG_RESAMPLE, 0);
@@ -749,7 +750,7 @@ static void o_tree_end(pgb_handle* h, int tree_id, int tune) {
   const pgb_settings* s = &h->s;
   int64_t n = s->n;
   int P = s->num_particles;
-  double lw[64], W[64];
+  double lw[PGB_MAX_PARTICLES], W[PGB_MAX_PARTICLES];
   lw[0] = s->family == PGB_FAMILY_NORMAL ? h->sse0 * (-0.5 * h->inv_sigma2) : (double)h->ll0 * h->sc.inv_cl;
   for (int q = 1; q < P; ++q) lw[q] = o_logw(h, &h->part[q]);
   pgb_weights_scan(lw, 0, P, W);
@@ -1236,9 +1237,9 @@ int64_t pgbo_sizeof_counters(void) { return (int64_t)sizeof(pgb_counters); }
 int64_t pgbo_sizeof_tree_arrays(void) { return (int64_t)sizeof(pgb_tree_arrays); }
 void pgbo_scan64(double* x) { pgb_scan64(x); }
 int pgbo_pick(const double* lw, int first, int cnt, double u, double* W_out) {
-  double W[64];
+  double W[PGB_MAX_PARTICLES];
   pgb_weights_scan(lw, first, cnt, W);
-  if (W_out) memcpy(W_out, W, sizeof W);
+  if (W_out) memcpy(W_out, W, 64 * sizeof(double)); /* (the test hook hands in 64 entries) */
   return pgb_pick(W, first, cnt, u);
 }
 void pgbo_loglik(int family, const double* y, const double* mu, int64_t n, double* out) {

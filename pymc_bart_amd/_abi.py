@@ -17,7 +17,7 @@ import numpy as np
 PGB_OK = 0
 PGB_E_NOMEM = -3
 MAX_DEPTH = 64
-MAX_PARTICLES = 64
+MAX_PARTICLES = 128  # of the p128 build of the library; the default build takes 64 (PGBLibrary.max_particles)
 MAX_OUTPUTS = 16  # PGB_MAX_OUTPUTS (include/pgbart_spec.h)
 MAX_NODES = 255
 
@@ -58,6 +58,7 @@ FAMILIES = {
 SYMBOLS = (
     "pgb_last_error",
     "pgb_backend_name",
+    "pgb_max_particles",
     "pgb_create",
     "pgb_destroy",
     "pgb_set_data",
@@ -201,10 +202,15 @@ class PGBLibrary:
             fn = getattr(lib, name)
             if name not in ("pgb_last_error", "pgb_backend_name"):
                 fn.restype = C.c_int
+        lib.pgb_max_particles.argtypes = []
 
     @property
     def backend_name(self) -> str:
         return self.lib.pgb_backend_name().decode()
+
+    @property
+    def max_particles(self) -> int:
+        return int(self.lib.pgb_max_particles())
 
     def check(self, rc: int, what: str) -> None:
         if rc != PGB_OK:
@@ -212,23 +218,28 @@ class PGBLibrary:
             raise PGBError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
-_HIP_LIB: PGBLibrary | None = None
+_HIP_LIB: dict = {}
 
 
-def hip_library_path() -> str:
-    """The in-tree gfx950 build; ``PGBART_HIP_LIB`` names another build of the same library (profiling /
-    experiment builds -- it must still be the HIP backend, see :func:`load_hip_library`)."""
+def hip_library_path(max_particles: int = 64) -> str:
+    """The in-tree gfx950 build -- ``libpgbart_hip.so`` (up to 64 particles, one per lane) or, for more,
+    ``libpgbart_hip_p128.so`` (the same source with ``-DPGB_MAX_PARTICLES=128``).  ``PGBART_HIP_LIB`` names another
+    build of the 64-particle library (profiling / experiment builds -- it must still be the HIP backend, see
+    :func:`load_hip_library`)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    if max_particles > 64:
+        return os.path.join(here, "libpgbart_hip_p128.so")
     override = os.environ.get("PGBART_HIP_LIB")
     if override:
         return override
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpgbart_hip.so")
+    return os.path.join(here, "libpgbart_hip.so")
 
 
-def load_hip_library() -> PGBLibrary:
-    """Load the gfx950 HIP build.  Fails loudly when it has not been built."""
-    global _HIP_LIB
-    if _HIP_LIB is None:
-        path = hip_library_path()
+def load_hip_library(max_particles: int = 64) -> PGBLibrary:
+    """Load the gfx950 HIP build that takes ``max_particles`` particles.  Fails loudly when it has not been built."""
+    key = 128 if max_particles > 64 else 64
+    if key not in _HIP_LIB:
+        path = hip_library_path(key)
         if not os.path.exists(path):
             raise PGBError(
                 f"{path} is missing: the HIP extension has not been built. Run "
@@ -242,5 +253,7 @@ def load_hip_library() -> PGBLibrary:
         lib = PGBLibrary(path)
         if lib.backend_name != "hip-gfx950":
             raise PGBError(f"{path} is not the HIP backend (it reports {lib.backend_name!r})")
-        _HIP_LIB = lib
-    return _HIP_LIB
+        if lib.max_particles < key:
+            raise PGBError(f"{path} takes {lib.max_particles} particles, {key} wanted")
+        _HIP_LIB[key] = lib
+    return _HIP_LIB[key]

@@ -18,29 +18,56 @@ struct Fin {  // result of finishing the pending split of an old particle (kept 
 // [U] normalize + inverse-CDF pick on ONE wave, one particle per lane: lanes [first, first+cnt)
 // hold log-weights.  Cumulative weights are the fixed-order wave scan the numeric contract
 // defines (pgb_scan64 / pgb_weights_scan / pgb_pick in include/pgbart_spec.h).
-__device__ __forceinline__ int wave_pick(double lw, int first, int cnt, double u) {
+// NH = PGB_MAX_PARTICLES / 64 particles per lane: lane l holds the log-weights of particles l, l + 64, ...; the
+// cumulative weights are one DPP scan per block of 64, each later block shifted by the total of the block before.
+template <int NH>
+__device__ __forceinline__ int wave_pick(const double (&lw)[NH], int first, int cnt, double u) {
   const int lane = threadIdx.x & 63;
-  const bool act = lane >= first && lane < first + cnt;
-  const double mx = wave_max_d(act ? lw : -1.0e308);
-  double W = act ? pgb_exp(lw - mx) + 1e-12 : 0.0;
+  bool act[NH];
+  double m = -1.0e308;
+#pragma unroll
+  for (int hq = 0; hq < NH; ++hq) {
+    const int q = lane + 64 * hq;
+    act[hq] = q >= first && q < first + cnt;
+    if (act[hq] && lw[hq] > m) m = lw[hq];  // (a maximum: any order)
+  }
+  const double mx = wave_max_d(m);
+  double W[NH];
 #define PGB_SCAN_STEP(ctrl, rm)                                                       \
   {                                                                                   \
-    const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(W), ctrl, rm, 0xf, 0); \
-    const int th = __builtin_amdgcn_update_dpp(0, __double2hiint(W), ctrl, rm, 0xf, 0); \
-    W = W + __hiloint2double(th, tl);                                                 \
+    const int tl = __builtin_amdgcn_update_dpp(0, __double2loint(Wh), ctrl, rm, 0xf, 0); \
+    const int th = __builtin_amdgcn_update_dpp(0, __double2hiint(Wh), ctrl, rm, 0xf, 0); \
+    Wh = Wh + __hiloint2double(th, tl);                                               \
   }
-  PGB_SCAN_STEP(0x111, 0xf)  // row_shr:1
-  PGB_SCAN_STEP(0x112, 0xf)  // row_shr:2
-  PGB_SCAN_STEP(0x114, 0xf)  // row_shr:4
-  PGB_SCAN_STEP(0x118, 0xf)  // row_shr:8
-  PGB_SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
-  PGB_SCAN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+  double carry = 0.0;
+#pragma unroll
+  for (int hq = 0; hq < NH; ++hq) {
+    double Wh = act[hq] ? pgb_exp(lw[hq] - mx) + 1e-12 : 0.0;
+    PGB_SCAN_STEP(0x111, 0xf)  // row_shr:1
+    PGB_SCAN_STEP(0x112, 0xf)  // row_shr:2
+    PGB_SCAN_STEP(0x114, 0xf)  // row_shr:4
+    PGB_SCAN_STEP(0x118, 0xf)  // row_shr:8
+    PGB_SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    PGB_SCAN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+    if (hq > 0) Wh = Wh + carry;  // (pgb_weights_scan: a later block is shifted by the total before it)
+    if (hq + 1 < NH) carry = readlane_d(Wh, 63);
+    W[hq] = Wh;
+  }
 #undef PGB_SCAN_STEP
   const int last = first + cnt - 1;
-  const double thr = u * readlane_d(W, last);
-  const bool hit = act && (lane < last) && !(thr > W);
-  const unsigned long long m = __ballot(hit);
-  return m ? (int)__ffsll((long long)m) - 1 : last;
+  double tot = 0.0;
+#pragma unroll
+  for (int hq = 0; hq < NH; ++hq)
+    if ((last >> 6) == hq) tot = readlane_d(W[hq], last & 63);  // (wave-uniform)
+  const double thr = u * tot;
+#pragma unroll
+  for (int hq = 0; hq < NH; ++hq) {
+    const int q = lane + 64 * hq;
+    const bool hit = act[hq] && (q < last) && !(thr > W[hq]);
+    const unsigned long long mk = __ballot(hit);
+    if (mk) return 64 * hq + (int)__ffsll((long long)mk) - 1;
+  }
+  return last;
 }
 
 // [U] SampleSplittingVariable.rvs on one wave, from stored prefix sums (pgb_sample_var)
@@ -306,13 +333,18 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
   // The previous round's job record and split statistics of old particle q = lane (wave 0) are
   // requested FIRST, together with the control word: their addresses depend on `par` alone.  Harmless
   // in idle / first slots (the records exist).
-  Job j_pre;
-  Acc a_pre;
-  // (only the lanes that can be particles: the grid has P - 1 or P workgroups, so lanes 1 .. nwg (= gridDim.x) cover
-  //  particles 1 .. P - 1 -- at P = 40 the other 23 lanes made 37 % of this batch for nothing)
-  if (threadIdx.x >= 1 && threadIdx.x <= (unsigned)nwg) {
-    j_pre = jobs_all[(size_t)(par ^ 1) * MAXP + threadIdx.x];
-    a_pre = load_acc(&acc_all[((size_t)(par ^ 1) * MAXP + threadIdx.x) * ACC_PER]);
+  constexpr int NH = MAXP / 64;  // particles per lane of wave 0: q = lane, lane + 64, ...
+  Job j_pre[NH];
+  Acc a_pre[NH];
+  // (only the lanes that can be particles: the grid has P - 1 or P workgroups, so particles 1 .. nwg (= gridDim.x)
+  //  cover particles 1 .. P - 1 -- at P = 40 the other 23 lanes made 37 % of this batch for nothing)
+#pragma unroll
+  for (int hq = 0; hq < NH; ++hq) {
+    const unsigned qq = threadIdx.x + 64u * hq;
+    if (threadIdx.x < 64u && qq >= 1 && qq <= (unsigned)nwg) {
+      j_pre[hq] = jobs_all[(size_t)(par ^ 1) * MAXP + qq];
+      a_pre[hq] = load_acc(&acc_all[((size_t)(par ^ 1) * MAXP + qq) * ACC_PER]);
+    }
   }
   if (threadIdx.x >= BT - 64) s_prior[threadIdx.x - (BT - 64)] = S.prior_leaf[threadIdx.x - (BT - 64)];
   const Ctrl c = load_uniform(&ctrls[par]);
@@ -489,7 +521,16 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
     // -------- wave 0: finish round r-1 for every old particle (lane q <-> old particle q),
     //          then decide stop / ancestor / final choice
     if (tid < 64) {
-      const int q = tid;
+      double lwv[NH];     // log-weights of this lane's particles
+      DNode popv[NH];     // the node each of them pops next (stored after the pick, see below)
+      bool ispv[NH];
+      bool pend_any = false;
+      int n_popped = 0, n_active = 0;
+      long long rt_lane = 0;
+      const double u_res = c.u_res;
+#pragma unroll
+      for (int hq = 0; hq < NH; ++hq) {
+      const int q = tid + 64 * hq;
       const bool isp = q >= 1 && q < P;
       // this lane's record is built directly in LDS (a register copy with a final struct store
       // defeats scalar replacement and ends up in scratch); slot 0 is unused in this phase
@@ -507,8 +548,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       lk.svarL = lk.svarR = -1;
       lk.linL = lk.linR = false;
       if (isp) {
-        j = j_pre;
-        a = a_pre;
+        j = j_pre[hq];
+        a = a_pre[hq];
         // requested as soon as the job header is here; consumed at the end of this phase
         if (j.h_next_pop < j.h_n_nodes) popn = OT[q].nd[j.h_next_pop];
         if (!normal) {
@@ -524,7 +565,6 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       // ahead (same addresses: (iter, r - 1, q, LEAF) and (iter, r - 1, 0, RESAMPLE)) and arrive with the
       // job record / control word
       const double z0 = isp ? j.z0 : 0.0, z1 = isp ? j.z1 : 0.0;
-      const double u_res = c.u_res;
       if (isp) {
         if (r1) {  // round-0 jobs were written before the root statistics existed
           j.p_q_st = ia.A;
@@ -628,35 +668,46 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
         lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
                     : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
       }
+      lwv[hq] = lw;
+      popv[hq] = popn;
+      ispv[hq] = isp;
+      pend_any = pend_any || pending;
+      if (b == 0) {  // (see below)
+        n_popped += __popcll(__ballot(isp && j.popped));
+        n_active += __popcll(__ballot(isp && j.active));
+        rt_lane += isp && j.active ? (long long)j.cnt : 0ll;
+      }
+      }  // (particles of this lane)
       TR(2);
       if (b == 0) {
         // particle steps / partitions / rows touched of the round the previous slot proposed, counted here
         // from its job records: 39 workgroups adding to one line at the end of a kernel serialise (~12 ns
         // each) and the kernel does not end before the last one is acknowledged
-        const unsigned long long mp = __ballot(isp && j.popped), ma = __ballot(isp && j.active);
-        const long long rt = wave_sum_dpp(isp && j.active ? (long long)j.cnt : 0ll);
+        const long long rt = wave_sum_dpp(rt_lane);
         if (tid == 63) {
-          if (mp) atomicAdd(&S.counters[0], (unsigned long long)__popcll(mp));
-          if (ma) {
-            atomicAdd(&S.counters[6], (unsigned long long)__popcll(ma));
+          if (n_popped) atomicAdd(&S.counters[0], (unsigned long long)n_popped);
+          if (n_active) {
+            atomicAdd(&S.counters[6], (unsigned long long)n_active);
             atomicAdd(&S.counters[2], (unsigned long long)rt);
           }
         }
       }
-      stop = __ballot(pending) == 0ull;
+      stop = __ballot(pend_any) == 0ull;
       int pick;
       if (!stop) {
         // [U] systematic resampling of particles 1..P-1: ancestor of new particle p
         const double ui = (u_res + (double)(p - 1)) / (double)Lc;
-        pick = wave_pick(lw, 1, Lc, ui);
+        pick = wave_pick<NH>(lwv, 1, Lc, ui);
       } else {
         // [U] get_particle_tree: final choice among all P particles (lane 0 = reference particle)
-        if (q == 0) lw = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
-        pick = wave_pick(lw, 0, P, c.u_fin);  // (iter, 0, 0, FINAL), drawn one slot ahead
+        if (tid == 0) lwv[0] = normal ? sse0 * (-0.5 * c.inv_sigma2) : sse0;
+        pick = wave_pick<NH>(lwv, 0, P, c.u_fin);  // (iter, 0, 0, FINAL), drawn one slot ahead
       }
       // (stored only now: the load was requested when the job header arrived and its round trip runs
       //  under the weights, the scan and the pick instead of ending the finish stage)
-      if (isp) s_pop[q] = popn;
+#pragma unroll
+      for (int hq = 0; hq < NH; ++hq)
+        if (ispv[hq]) s_pop[tid + 64 * hq] = popv[hq];
       pick0 = pick;
       if (tid == 0) {
         s_i[0] = stop ? 1 : 0;
@@ -669,7 +720,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       // them meanwhile -- output k on wave 1 + k % 3, old particle q on lane q -- instead of wave 0
       // doing K - 1 of those chains one after the other.  Same routine, same inputs.
       if (tid >= 64) {
-        const int wv = tid >> 6, q = tid & 63;
+        const int wv = tid >> 6;
+#pragma unroll
+        for (int hq = 0; hq < NH; ++hq) {
+        const int q = (tid & 63) + 64 * hq;
         if (q >= 1 && q < P && JP[q].active) {
           unsigned long long cnts = 0;
 #pragma unroll
@@ -685,6 +739,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
                                           load_accx(S.accx, par ^ 1, q, KX + k), pq, pv, zz[0], zz[1],
                                           leaf_sd_x(S, c, par, par ^ 1, k));
           }
+        }
         }
       }
     }

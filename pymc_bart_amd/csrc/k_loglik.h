@@ -210,20 +210,24 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   }
   const Job* jobs = S.jobs + (size_t)par * MAXP;
   if (tid < 64) {
+    int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
+#pragma unroll
+    for (int hq = 0; hq < MAXP / 64; ++hq) {
+    const int q = tid + 64 * hq;
     Job j;
     j.active = 0;
-    if (tid >= 1 && tid < S.P) j = jobs[tid];
+    if (q >= 1 && q < S.P) j = jobs[q];
     const bool has = j.active != 0;
     const unsigned long long m = __ballot(has);
     // the leaf noise of particle `tid` in this round: drawn by the control kernel of this slot, in the job
     const double z0 = has ? j.z0 : 0.0, z1 = has ? j.z1 : 0.0;
     if (has) {
-      const int k = __popcll(m & ((1ull << tid) - 1ull));
-      const Acc a = load_acc(&S.acc[((size_t)par * MAXP + tid) * ACC_PER]);
+      const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
+      const Acc a = load_acc(&S.acc[((size_t)par * MAXP + q) * ACC_PER]);
       const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
                                         a.aL, a.aN, z0, z1, leaf_sd);
       LJob& lj = s_job[k];  // (filled in place: a local record with its K-sized arrays would live in scratch)
-      lj.p = tid;
+      lj.p = q;
       lj.rule = j.rule;
       lj.label = j.label;
       lj.new_label = j.new_label;
@@ -234,7 +238,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       lj.vR = cv.vR;
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
-      lj.dst = (long long)((size_t)tid * S.n_pad);
+      lj.dst = (long long)((size_t)q * S.n_pad);
       if constexpr (LIN) {
         lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
         lj.svarL = lj.svarR = -1;
@@ -244,8 +248,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       lk.linL = lk.linR = false;
       if constexpr (LIN) {
         if (cv.ok == 1) {
-          lk = lin_children(S, &S.accu[((size_t)par * MAXP + tid) * ACC_PER], j.var, cv.cL, cv.cR,
-                            cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)tid);
+          lk = lin_children(S, &S.accu[((size_t)par * MAXP + q) * ACC_PER], j.var, cv.cL, cv.cR,
+                            cv.aL, cv.aR, it, (uint32_t)round, (uint32_t)q);
           lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
@@ -253,18 +257,18 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       if constexpr (MK)
       for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
         const int KX = (KT > 0 ? KT : S.K) - 1;
-        const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + tid) * KX + kx];
-        const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + tid) * KX + kx];
-        const double* zz = S.jzx + (((size_t)par * MAXP + tid) * KX + kx) * 2;  // drawn by this slot's control kernel
-        ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, tid, kx),
-                                   load_accx(S.accx, par, tid, KX + kx), pq, pv, zz[0], zz[1],
+        const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + q) * KX + kx];
+        const double pv = round == 0 ? S.init_leaf : S.jvx[((size_t)par * MAXP + q) * KX + kx];
+        const double* zz = S.jzx + (((size_t)par * MAXP + q) * KX + kx) * 2;  // drawn by this slot's control kernel
+        ChildX cx = child_values_x(S, cv.ok, cv.cL, cv.cR, load_accx(S.accx, par, q, kx),
+                                   load_accx(S.accx, par, q, KX + kx), pq, pv, zz[0], zz[1],
                                    leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
         if constexpr (LIN) {
           if (cv.ok == 1)
-            lin_children_x(S, lk, cx, j.var, cv.cL, cv.cR, load_accx(S.accux, par, tid, kx),
-                           load_accx(S.accux, par, tid, KX + kx));
+            lin_children_x(S, lk, cx, j.var, cv.cL, cv.cR, load_accx(S.accux, par, q, kx),
+                           load_accx(S.accux, par, q, KX + kx));
           lj.sLx[kx] = cx.sL;
           lj.sRx[kx] = cx.sR;
         }
@@ -275,7 +279,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
     }
-    if (tid == 0) s_n[0] = __popcll(m);
+    nlist += __popcll(m);
+    }
+    if (tid == 0) s_n[0] = nlist;
   }
   __syncthreads();
   if constexpr (FAM != PGB_FAMILY_CALLBACK) {

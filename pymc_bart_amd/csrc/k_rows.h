@@ -89,16 +89,20 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     // list of particles with work in this pass (split or forced label refresh); their job
     // fields are cached in LDS once per workgroup
     if (tid < 64) {
+      int nlist = 0;  // (wave 0 lists the particles with work: lanes' particles tid, tid + 64, ... one block after the other)
+#pragma unroll
+      for (int hq = 0; hq < MAXP / 64; ++hq) {
+      const int q = tid + 64 * hq;
       Job j;
       j.active = 0;
       j.copy = 0;
-      if (tid >= 1 && tid < S.P) j = jobs[tid];  // one round trip: the whole job
+      if (q >= 1 && q < S.P) j = jobs[q];  // one round trip: the whole job
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
       if (has) {
-        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
-        rj.p = tid;
+        rj.p = q;
         rj.active = j.active;
         rj.check_nan = j.check_nan;
         rj.rule = j.rule;
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         if constexpr (LIN) rj.uscale = j.active ? pgb_pow2(-S.col_ex[j.var]) : 1.0;
         s_job[k] = rj;
       }
-      if (tid == 0) s_n[0] = __popcll(m);
+      nlist += __popcll(m);
+      }
+      if (tid == 0) s_n[0] = nlist;
     }
     __syncthreads();
     TRR(13, 0);

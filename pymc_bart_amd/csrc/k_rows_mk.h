@@ -77,16 +77,20 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
   if (do_part) {
     const Job* jobs = S.jobs + (size_t)par * MAXP;
     if (tid < 64) {
+      int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
+#pragma unroll
+      for (int hq = 0; hq < MAXP / 64; ++hq) {
+      const int q = tid + 64 * hq;
       Job j;
       j.active = 0;
       j.copy = 0;
-      if (tid >= 1 && tid < S.P) j = jobs[tid];
+      if (q >= 1 && q < S.P) j = jobs[q];
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
       if (has) {
-        const int k = __popcll(m & ((1ull << tid) - 1ull));
+        const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
-        rj.p = tid;
+        rj.p = q;
         rj.active = j.active;
         rj.check_nan = j.check_nan;
         rj.rule = j.rule;
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
         rj.xoff = (long long)((size_t)j.var * S.n_pad);
         s_job[k] = rj;
       }
-      if (tid == 0) s_n[0] = __popcll(m);
+      nlist += __popcll(m);
+      }
+      if (tid == 0) s_n[0] = nlist;
     }
     __syncthreads();
     const int nact = s_n[0];

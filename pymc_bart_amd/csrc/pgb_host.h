@@ -149,6 +149,7 @@ static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
 
 extern "C" const char* pgb_last_error(void) { return g_err; }
 extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
+extern "C" int32_t pgb_max_particles(void) { return PGB_MAX_PARTICLES; }
 
 // The instance of k_loglik a sampler launches, chosen once: per number of outputs (loops unrolled for
 // K = 2, 3, 4), per family for single-output constant leaves (one family's code per instance).
@@ -181,7 +182,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
   if (s->n >= (1ll << 31) - CH) return fail(PGB_E_UNSUPPORTED, "n too large");
   if (s->num_particles < 2 || s->num_particles > PGB_MAX_PARTICLES)
-    return fail(PGB_E_INVALID, "num_particles must be in [2, 64]");
+    return fail(PGB_E_INVALID, PGB_MAX_PARTICLES == 64
+                                   ? "num_particles must be in [2, 64] (libpgbart_hip_p128.so takes up to 128)"
+                                   : "num_particles must be in [2, 128]");
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
       return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");

@@ -170,6 +170,9 @@ class PySampler:
                  rules: np.ndarray, split_prior: np.ndarray, backend: Backend | None = None):
         self.backend = backend if backend is not None else default_backend()
         self.settings = settings
+        if settings.num_particles > self.backend.lib.max_particles and self.backend.lib.backend_name == "hip-gfx950":
+            # more than one particle per lane: the build of the same library that puts two on a lane (include/pgbart.h)
+            self.backend = Backend(lib=_abi.load_hip_library(settings.num_particles), mem=self.backend.mem)
         lib, mem = self.backend.lib, self.backend.mem
         self._h = C.c_void_p()
         cs = settings.as_c()

@@ -48,6 +48,17 @@ def make_case(name: str):
         X = rng.normal(size=(n, p))
         Y = np.sin(3 * X[:, 0]) * 4 + rng.normal(0, 0.3, n)
         c.update(m=6, P=64, steps=12)
+    elif name == "particles_128":  # beyond one particle per lane: the 128-particle build of the library (two per lane)
+        n, p = 2600, 5
+        X = rng.normal(size=(n, p))
+        X[rng.random(n) < 0.08, 2] = np.nan
+        Y = np.sin(3 * X[:, 0]) * 3 + X[:, 1] * np.nan_to_num(X[:, 2]) + rng.normal(0, 0.3, n)
+        c.update(m=5, P=128, steps=12)
+    elif name == "particles_100_probit":  # an odd count above 64, a per-row family
+        n, p = 1800, 4
+        X = rng.normal(size=(n, p))
+        Y = (rng.random(n) < 1 / (1 + np.exp(-2 * X[:, 0] + X[:, 1]))).astype(float)
+        c.update(m=4, P=100, steps=10, family="bernoulli_probit")
     elif name == "duplicates":
         n, p = 4096, 3
         X = rng.integers(0, 3, (n, p)).astype(float)  # heavy ties, no jitter at this level
@@ -273,7 +284,7 @@ def make_case(name: str):
 
 
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
-         "max_particles", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
+         "max_particles", "particles_128", "particles_100_probit", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "categorical_k12", "categorical_k16_linear", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
          "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
@@ -358,11 +369,11 @@ def random_case(seed, large=False):
     n = int(rng.choice([3, 17, 255, 256, 257, 1023, 1024, 1025, 2049, 5000, 20000]))
     p = int(rng.integers(1, 9))
     m = int(rng.integers(1, 12))
-    P = int(rng.choice([2, 3, 5, 10, 20, 40, 64]))
+    P = int(rng.choice([2, 3, 5, 10, 20, 40, 64, 65, 97, 128]))  # (> 64: the two-particles-per-lane build)
     if large:
         n = int(rng.choice([50_000, 131_072, 200_001, 400_000, 1_048_577]))
         m = int(rng.integers(1, 5))
-        P = int(rng.choice([5, 20, 40, 64]))
+        P = int(rng.choice([5, 20, 40, 64, 128]))
     X = rng.normal(size=(n, p))
     rules = np.zeros(p, np.int32)
     for j in range(p):

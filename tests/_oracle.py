@@ -68,7 +68,7 @@ def build_oracle_native() -> tuple[str, str]:
     out = os.path.join(ORACLE_DIR, "libpgbart_oracle_native.so")
     flags = "gcc -O3 -march=native -std=gnu11 -ffp-contract=off"
     try:
-        subprocess.check_call(flags.split() + ["-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+        subprocess.check_call(flags.split() + ["-fPIC", "-shared", "-DPGB_MAX_PARTICLES=128", "-I" + os.path.join(ROOT, "include"), src,
                                                "-o", out, "-lm"], stderr=subprocess.DEVNULL)
         return out, flags
     except (subprocess.CalledProcessError, OSError):

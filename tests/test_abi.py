@@ -71,9 +71,18 @@ def test_library_override_must_still_be_the_hip_backend(oracle, monkeypatch):
     at anything that is not the gfx950 backend -- the CPU checker, say -- is refused: the product has
     no CPU path, by override or otherwise."""
     monkeypatch.setenv("PGBART_HIP_LIB", oracle.lib.path)
-    monkeypatch.setattr(_abi, "_HIP_LIB", None)
+    monkeypatch.setattr(_abi, "_HIP_LIB", {})
     with pytest.raises(_abi.PGBError, match="not the HIP backend"):
         _abi.load_hip_library()
-    assert _abi._HIP_LIB is None  # a refused library is not kept
+    assert not _abi._HIP_LIB  # a refused library is not kept
     monkeypatch.delenv("PGBART_HIP_LIB")
     assert _abi.load_hip_library().backend_name == "hip-gfx950"
+
+
+def test_both_builds_of_the_hip_library_export_the_abi_and_state_their_particle_limit():
+    """libpgbart_hip.so: one particle per lane (64); libpgbart_hip_p128.so: the same source with two per lane."""
+    for want in (64, 128):
+        lib = _abi.load_hip_library(want)
+        assert lib.backend_name == "hip-gfx950" and lib.max_particles == want
+        for sym in _abi.SYMBOLS:
+            assert hasattr(lib.lib, sym), (want, sym)
