@@ -137,14 +137,17 @@ int pgb_destroy(pgb_handle* h);
 int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
                  const double* split_prior_host);
 
-/* Observed response of the likelihood, n doubles (class index for categorical). */
+/* Observed response of the likelihood, n doubles (class index for categorical).  Every value must be finite:
+ * PGB_E_INVALID otherwise (the linear predictor of a row is a sum of finite leaf values and of what this call and
+ * pgb_set_offset hand in; the per-row likelihood tables are addressed by its bits -- pgbart_spec.h, pgb_lphi_t). */
 int pgb_set_response(pgb_handle* h, const double* y_dev);
 
 /* Per-row offset of the linear predictor(s) for the per-row families (everything but NORMAL, where
  * the caller subtracts the other terms from the response instead): the likelihood sees
  * offset + sum_trees -- the contribution of the other additive terms of the model at the current
  * point (a second BART variable, a log-exposure, ...).  EXACTLY K*n doubles, layout [K][n] (the call takes
- * no size: the caller guarantees it, as the ctypes stub does); NULL resets to 0. */
+ * no size: the caller guarantees it, as the ctypes stub does); NULL resets to 0.  A non-finite value is refused with
+ * PGB_E_INVALID and the offset is reset to 0 (the chain stays usable). */
 int pgb_set_offset(pgb_handle* h, const double* offset_dev);
 
 /* Likelihood parameters at the current point of the other model variables
