@@ -39,6 +39,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   constexpr int NRED = LIN ? 15 : 7;  // values reduced per particle
   __shared__ long long s_red[MAXP * NRED * 4];
+  // constant leaves, split column without missing values: the sums of a particle go straight into LDS with atomic
+  // adds (lane l to entry l mod NE of the value) instead of through a wave butterfly -- one ds_add per value in
+  // place of 21-42 vector instructions per wave and particle; the reducer threads add the NE entries up
+  constexpr int NVA = LIN ? 1 : (NORMAL ? 4 : 2);
+  constexpr int NE = LIN ? 1 : (NORMAL ? 8 : 16) / (MAXP / 64);
+  __shared__ unsigned long long s_acc[MAXP * NVA * NE];
   __shared__ double s_lv[2][256];
   __shared__ LinP s_ll[LIN ? 2 : 1][LIN ? 256 : 1];  // label -> linear part: [0 new | 1 next]
   __shared__ RJob s_job[MAXP];
@@ -85,11 +91,14 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   const gptr<double> st_out = as_global(S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad);
 
   if (do_part) {
+    if constexpr (!LIN)
+      for (int i = tid; i < MAXP * NVA * NE; i += BT) s_acc[i] = 0ull;
     const Job* jobs = jobs_all + (size_t)par * MAXP;
     // list of particles with work in this pass (split or forced label refresh); their job
     // fields are cached in LDS once per workgroup
     if (tid < 64) {
       int nlist = 0;  // (wave 0 lists the particles with work: lanes' particles tid, tid + 64, ... one block after the other)
+      bool plain = true;  // every particle with work splits the root of a fresh stump on a continuous column without NaNs
 #pragma unroll
       for (int hq = 0; hq < MAXP / 64; ++hq) {
       const int q = tid + 64 * hq;
@@ -99,6 +108,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       if (q >= 1 && q < S.P) j = jobs[q];  // one round trip: the whole job
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
+      if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
+        plain = false;
       if (has) {
         const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
@@ -119,11 +130,15 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       }
       nlist += __popcll(m);
       }
-      if (tid == 0) s_n[0] = nlist;
+      if (tid == 0) {
+        s_n[0] = nlist;
+        s_n[1] = plain ? 1 : 0;
+      }
     }
     __syncthreads();
     TRR(13, 0);
     const int nact = s_n[0];
+    const bool all_plain = !LIN && s_n[1] != 0;
     if (nact == 0 && !do_init) { PROF_END(); return; }
     const int target = do_init ? S.rows_target_init : S.rows_target;
     int G = (nact * S.nchunks + target - 1) / target;
@@ -260,32 +275,112 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       for (int e = 0; e < RPT; ++e)
         if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
       const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
-      // software pipeline over the particles of the group: the labels and split-column values of
+      const bool full_chunk = (long long)(chunk + 1) * CH <= n;  // every row of the chunk is a row of the data
+      int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
+      // ---- plain round: EVERY particle of the pass splits the root of a fresh stump (implicit root labels: all
+      // rows of a full chunk are in the leaf) on a continuous column without missing values -- the slot that starts
+      // a tree, half of this kernel's time at cfg4, where one workgroup walks ONE item of 39 particles.  One stage
+      // of prefetch left that walk waiting a whole memory round trip per particle (~1.4 us x 39; fewer bytes
+      // -- 16-bit keys -- and fewer instructions -- no label compare, LDS atomics for butterflies -- changed
+      // nothing: profiles/r04_experiments.md): here the split columns of PD particles are in flight, in registers
+      // that are never moved (the loop is unrolled by PD: a register shift would wait for the loads it moves).
+      if constexpr (!LIN && F32) {  // (F32: the data sets beyond the Infinity Cache; the smaller ones keep their registers)
+        if (all_plain && g1 > g0) {
+          constexpr int PD = 4;
+          double2 pa[PD], pb[PD];
+          float4 pf[PD];
+          // (every load and store of the loop is unconditional -- past the end the last particle's column is
+          //  requested again and dropped -- so that the number of operations in flight behind the one being
+          //  waited for is the same on every path and the wait can leave them in flight)
+          auto fetch = [&](int gg, double2& f0, double2& f1, float4& ff) {
+            const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
+            if constexpr (F32) {
+              ff = gload_f4(XT32 + xo + base);
+            } else {
+              f0 = gload_d2(XT + xo + base);
+              f1 = gload_d2(XT + xo + base + 2);
+            }
+          };
+          // one particle from its stage registers; `more`: request the column of particle g + PD into them
+          auto stage = [&](int g, double2& f0, double2& f1, float4& ff, bool more) {
+            const RJob& rj = s_job[g];
+            const double r_v = uni(rj.v);
+            const float r_vf = (float)r_v;
+            const uint32_t nw = uni((uint32_t)rj.new_label);
+            const long long xo = uni(rj.xoff);
+            const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
+            const double x[RPT] = {f0.x, f0.y, f1.x, f1.y};
+            const float xf[RPT] = {ff.x, ff.y, ff.z, ff.w};
+            bool L[RPT];
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xf[e] < r_vf) : (x[e] <= r_v);
+            if constexpr (F32) {  // float32 ties (a few rows of the whole column) are decided on the float64 values
+              if (__any((xf[0] == r_vf) | (xf[1] == r_vf) | (xf[2] == r_vf) | (xf[3] == r_vf))) {
+#pragma unroll
+                for (int e = 0; e < RPT; ++e)
+                  if (xf[e] == r_vf) L[e] = XT[xo + base + e] <= r_v;
+              }
+            }
+            if (more) fetch(g + PD, f0, f1, ff);
+            uint32_t out = root_ids, cl = 0, cr = RPT;
+            long long a1 = 0, a2 = 0, a3 = 0;
+            if (full_chunk) {
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                out |= L[e] ? 0u : (nw << (8 * e));
+                cl += L[e] ? 1u : 0u;
+                a1 += L[e] ? qa[e] : 0ll;
+                if constexpr (NORMAL) { a2 += L[e] ? qb[e] : 0ll; a3 += L[e] ? qc[e] : 0ll; }
+              }
+              cr -= cl;
+            } else {  // the last chunk of the data: rows past the end carry the orphan label and count nowhere
+              cr = 0;
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const bool in = base + e < n;
+                out |= (in && !L[e]) ? (nw << (8 * e)) : 0u;
+                cl += (in && L[e]) ? 1u : 0u;
+                cr += (in && !L[e]) ? 1u : 0u;
+                a1 += (in && L[e]) ? qa[e] : 0ll;
+                if constexpr (NORMAL) { a2 += (in && L[e]) ? qb[e] : 0ll; a3 += (in && L[e]) ? qc[e] : 0ll; }
+              }
+            }
+            *gcast<uint32_t>(dp) = out;
+            unsigned long long* ap = &s_acc[(g - g0) * (NVA * NE) + (lane & (NE - 1))];
+            atomicAdd(ap, (unsigned long long)(cl | (cr << 20)));
+            atomicAdd(ap + NE, (unsigned long long)a1);
+            if constexpr (NORMAL) {
+              atomicAdd(ap + 2 * NE, (unsigned long long)a2);
+              atomicAdd(ap + 3 * NE, (unsigned long long)a3);
+            }
+          };
+#pragma unroll
+          for (int d = 0; d < PD; ++d) {
+            pa[d] = pb[d] = double2{0.0, 0.0};
+            pf[d] = float4{0.f, 0.f, 0.f, 0.f};
+            fetch(g0 + d, pa[d], pb[d], pf[d]);
+          }
+          const int g_main = g0 + (g1 - g0) / PD * PD;  // whole blocks of PD particles, then the rest from their stages
+          for (int gb = g0; gb < g_main; gb += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) stage(gb + d, pa[d], pb[d], pf[d], true);
+          }
+#pragma unroll
+          for (int d = 0; d < PD; ++d)
+            if (g_main + d < g1) stage(g_main + d, pa[d], pb[d], pf[d], false);
+          g_first = g1;
+        }
+      }
+      // general rounds: software pipeline over the particles of the group -- the labels and split-column values of
       // particle g + 1 are requested before particle g is relabelled and reduced
       uint32_t nx_ids = root_ids;
       double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
       float4 nxf = {0.f, 0.f, 0.f, 0.f};
-      if (g0 < g1) {
-        const RJob& rn = s_job[g0];
-        if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
-        if (rn.active) {
-          if constexpr (F32) {
-            nxf = gload_f4(XT32 + rn.xoff + base);
-          } else {
-            const gptr<const double> xn = XT + rn.xoff + base;
-            nx0 = gload_d2(xn);
-            nx1 = gload_d2(xn + 2);
-          }
-        }
-      }
-      for (int g = g0; g < g1; ++g) {
-        const RJob& rj = s_job[g];
-        const uint32_t ids = nx_ids;
-        const double2 t0 = nx0, t1 = nx1;
-        const float4 tf = nxf;
-        if (g + 1 < g1) {
-          const RJob& rn = s_job[g + 1];
-          nx_ids = rn.src < 0 ? root_ids : *gcast<const uint32_t>(lid0 + rn.src + base);
+      auto fetch1 = [&](int gg) {
+        nx_ids = root_ids;
+        if (gg < g1) {
+          const RJob& rn = s_job[gg];
+          if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
           if (rn.active) {
             if constexpr (F32) {
               nxf = gload_f4(XT32 + rn.xoff + base);
@@ -296,6 +391,14 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             }
           }
         }
+      };
+      fetch1(g_first);
+      for (int g = g_first; g < g1; ++g) {
+        const RJob& rj = s_job[g];
+        const uint32_t ids = nx_ids;
+        const double2 t0 = nx0, t1 = nx1;
+        const float4 tf = nxf;
+        fetch1(g + 1);
         uint32_t out = ids;
         const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)rj.p * n_pad + base;
         // (the particle's split in registers: read through the LDS record, the value, the rule and the labels
@@ -338,16 +441,21 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             }
           }
           *gcast<uint32_t>(dp) = out;
-          if constexpr (NORMAL || LIN) {
+          if constexpr (LIN) {
             const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
             if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
-          } else {
+          } else if (v0 != 0) {  // (lanes that hold a row of the leaf)
             // per-row families: the weights come from the likelihood pass, a split only needs the children's counts
-            // and the left child's sum of sum_trees -- two values through the butterfly (30 vector instructions, 42
-            // for four).  (Measured and dropped, round 4: counts as wave votes with a one-value reduction, 20.8 ->
-            // 22.9 us at cfg4: the votes serialise on the scalar unit; one loop for both NaN cases: 21.9 us.)
-            const long long tot = wave_sum2(v0, v1);  // lane l: total of value l & 1
-            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
+            // and the left child's sum of sum_trees -- two values.  (Measured and dropped, round 4: counts as wave
+            // votes with a one-value reduction, 20.8 -> 22.9 us at cfg4: the votes serialise on the scalar unit;
+            // one loop for both NaN cases: 21.9 us.)
+            unsigned long long* ap = &s_acc[(g - g0) * (NVA * NE) + (lane & (NE - 1))];
+            atomicAdd(ap, (unsigned long long)v0);
+            atomicAdd(ap + NE, (unsigned long long)v1);
+            if constexpr (NORMAL) {
+              atomicAdd(ap + 2 * NE, (unsigned long long)v2);
+              atomicAdd(ap + 3 * NE, (unsigned long long)v3);
+            }
           }
         } else {
           long long v[7] = {0, 0, 0, 0, 0, 0, 0};  // cnts(L | R<<20 | N<<40), aL, bL, c2L, aN, bN, c2N
@@ -406,7 +514,19 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         if (!rj.active || (i >= 4 && i < 7 && !rj.check_nan)) continue;
         if constexpr (!NORMAL && !LIN)
           if (i == 2 || i == 3 || i == 5 || i == 6) continue;  // (no residual algebra: nothing was reduced)
-        const long long s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        long long s;
+        if (!LIN && !rj.check_nan) {  // (i < NVA here: the other values were skipped above)
+          unsigned long long* ap = &s_acc[(gi * NVA + i) * NE];
+          unsigned long long u = 0;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            u += ap[e];
+            ap[e] = 0ull;
+          }
+          s = (long long)u;
+        } else {
+          s = s_red[t * 4] + s_red[t * 4 + 1] + s_red[t * 4 + 2] + s_red[t * 4 + 3];
+        }
         if constexpr (LIN) {
           if (i >= 7) {
             AccU* au = &S.accu[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];

@@ -44,6 +44,22 @@ def test_hip_equals_oracle_and_golden(hip, oracle, name):
     assert g["counters"]["saturations"] == 0
 
 
+@pytest.mark.parametrize("name", ["cfg1_friedman", "nan_onehot_prior", "max_particles", "one_tree_two_particles", "probit_cfg4_small",
+                                  "categorical_k3_reference", "categorical_k12", "linear_response", "subset_rule"])
+def test_two_particles_per_lane_build_gives_the_same_chain(hip, name):
+    """`libpgbart_hip_p128.so` (the same source with two particles per lane of the control kernel) run on cases of
+    <= 64 particles reproduces the committed fingerprints of the default build: the build parameter is a capacity,
+    not a numeric choice (`pgb_weights_scan` adds an all-zero second block)."""
+    from pymc_bart_amd import _abi
+    from pymc_bart_amd.sampler import Backend
+
+    big = Backend(lib=_abi.load_hip_library(128), mem=hip.mem)
+    assert big.lib.max_particles == 128 and hip.lib.max_particles == 64
+    c = make_case(name)
+    assert c["P"] <= 64
+    assert digest(run_case(c, big)) == GOLD[name]
+
+
 @pytest.mark.parametrize("name", ["cfg1_friedman", "nan_onehot_prior", "duplicates", "onehot_fail_nan",
                                   "probit_cfg4_small", "logit_nan_onehot", "categorical_k3_reference",
                                   "categorical_k4_cfg5_small", "meanscale_k2_reference"])

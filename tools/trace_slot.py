@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--define", action="append", default=[])
     ap.add_argument("--stamps", action="store_true", help="also per-workgroup first/last clock readings of the row pass")
     ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
     a = ap.parse_args()
     if a.build:
         build([f"-D{d}" for d in a.define], a.lib)
@@ -58,11 +59,12 @@ def main():
     lib = _abi.PGBLibrary(a.lib)
     lib.lib.pgb_debug_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     be = Backend(lib=lib, mem=TorchHipMemory(0))
-    w = workloads.cfg2()
+    w = getattr(workloads, a.workload)()
     X, Y = w["X"], w["Y"]
-    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=3415)
+    st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=3415, family=w["family"],
+                                  n_outputs=w.get("K", 1))
     s = PySampler(st, X, Y, np.zeros(X.shape[1], np.int32), np.ones(X.shape[1]), backend=be)
-    s.set_likelihood([1.0])
+    s.set_likelihood([1.0] if w["family"] == "normal" else [])
     for _ in range(a.burnin):
         s.step(True)
     c0 = s.counters.as_dict()
