@@ -14,8 +14,11 @@
 // F32: the split column from the float32 shadow of the design matrix (see k_rows<..., F32>); continuous /
 // one-hot rules only.
 // (the compile-time-K instances are held to 4 workgroups per CU, <= 128 VGPRs: K = 4 sits at that edge)
+#ifndef PGB_MK_WGS
+#define PGB_MK_WGS(KT) ((KT) == 4 ? 3 : 4) /* K = 4: 149 registers without a spill (3 per CU) beat 128 with eight spilled (4 per CU): 723 k against 687 k at cfg5 */
+#endif
 template <int KT, bool LIN, bool F32 = false>
-__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
   constexpr int TW = KT > 0 ? KT : 4;  // outputs per tile (= K for the compile-time instances: one tile)
@@ -27,6 +30,13 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
   __shared__ int s_n[2];
   const Cmd* cmd = &S.cmd[par];
   const int kind = cmd->kind;
+  TRR_BIND(S.ctrl[par ^ 1].slot_no - 1);  // (stamp 12: entry; 13 jobs listed, 14 rows of the last item loaded, 15 items done)
+  long long* pstamp = nullptr;            // profiling: first / last device-clock reading of every workgroup (see k_rows)
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+    pstamp = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
+    pstamp[0] = wall_clock64();
+    pstamp[1] = pstamp[0];
+  }
   if (kind == CMD_NOOP) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const bool do_final = (kind & CMD_FINAL) != 0, do_init = (kind & CMD_INIT) != 0;
@@ -57,6 +67,9 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
   const uint8_t* sel_lid =
       (do_final && cmd->sel_slot >= 0) ? S.lid + ((size_t)cmd->sel_gen * MAXP + cmd->sel_slot) * S.n_pad : nullptr;
   const double cntf = (double)cmd->rs_count;
+  // (fields of the command read ONCE: behind a store the compiler has to assume they changed and loads them again)
+  const int c_sel_slot = cmd->sel_slot, c_tune = cmd->tune;
+  const bool c_same_tree = cmd->tree_new == cmd->tree_old;
   // sum_trees buffers [2][K][n_pad]
   const double* st_in = S.st + (size_t)cmd->st_cur * K * S.n_pad;
   double* st_out = S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * K * S.n_pad;
@@ -78,6 +91,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
     const Job* jobs = S.jobs + (size_t)par * MAXP;
     if (tid < 64) {
       int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
+      bool plain = true;  // every particle with work splits the root of a fresh stump on a continuous column without NaNs
 #pragma unroll
       for (int hq = 0; hq < MAXP / 64; ++hq) {
       const int q = tid + 64 * hq;
@@ -87,6 +101,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
       if (q >= 1 && q < S.P) j = jobs[q];
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
+      if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
+        plain = false;
       if (has) {
         const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
@@ -105,11 +121,19 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
       }
       nlist += __popcll(m);
       }
-      if (tid == 0) s_n[0] = nlist;
+      if (tid == 0) {
+        s_n[0] = nlist;
+        s_n[1] = plain ? 1 : 0;
+      }
     }
     __syncthreads();
+    TRR(13, 0);
     const int nact = s_n[0];
-    if (nact == 0 && !do_init) return;
+    const bool all_plain = !LIN && s_n[1] != 0;
+    if (nact == 0 && !do_init) {
+      if (pstamp) pstamp[1] = wall_clock64();
+      return;
+    }
     const int target = do_init ? S.rows_target_init : S.rows_target;
     int G = (nact * S.nchunks + target - 1) / target;
     if (G < 1) G = 1;
@@ -129,6 +153,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) ivA[kk] = ivQ[kk] = 0;
       for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        TRR(23, 0);
         const int chunk = item % S.nchunks, grp = item / S.nchunks;
         const long long base = (long long)chunk * CH + tid * RPT;
         double stv[RPT][KB];  // sum_trees of this thread's rows, per output of the tile
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
           uint32_t ids_next = *(const uint32_t*)(tl_new + base);
           uint32_t ids_sel = 0;
           if (do_final) {
-            if (cmd->sel_slot == -2) {
+            if (c_sel_slot == -2) {
               ids_sel = *(const uint32_t*)(tl_old + base);
             } else {
               if (sel_lid) {
@@ -150,45 +175,97 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
               //  derives ids_sel from the selected particle's labels, so the first tile's store is the only one)
               if (writer && first) *(uint32_t*)(tl_old + base) = ids_sel;
             }
-            if (cmd->tree_new == cmd->tree_old) ids_next = ids_sel;
+            if (c_same_tree) ids_next = ids_sel;
           }
-          for (int e = 0; e < RPT; ++e) {
-            const long long row = base + e;
+          // every input of the thread's rows is requested BEFORE the first result is stored: the stores below may
+          // alias the loads as far as the compiler knows, and loads left inside the loops were issued one at a time
+          // -- one memory round trip per (row, output): 36 of the 48 us of the slot that starts a tree at cfg5
+          // (round 4, in-kernel stamps; profiles/r04_experiments.md)
+          TRR(20, 0);
+          double stl[RPT][KB];
+          const bool upd = do_final && c_tune && writer;
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) stv[e][kk] = 0.0;
-            if (row >= n) continue;
+          for (int kk = 0; kk < KB; ++kk) {
+            const int k = k0 + kk < K ? k0 + kk : K - 1;  // (a tile's outputs past K: loaded again, never used)
+            const double2* sp = (const double2*)(st_in + (size_t)k * n_pad + base);
+            const double2 s01 = sp[0], s23 = sp[1];
+            stl[0][kk] = s01.x; stl[1][kk] = s01.y; stl[2][kk] = s23.x; stl[3][kk] = s23.y;
+          }
+          // sum_trees of the rows with the finished tree added (registers only) ...
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            const bool in = base + e < n;
+            const uint32_t id_s = (ids_sel >> (8 * e)) & 255u;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const int k = k0 + kk;
+              double st = stl[e][kk];
+              if (do_final) st = st + lin_pred(s_lv[0][id_s][kk], 0, id_s, k < K ? k : K - 1, in ? base + e : 0);
+              stv[e][kk] = (in && k < K) ? st : 0.0;
+            }
+          }
+          // ... and, by the first group of the chunk only, everything that is stored, in one block: the four rows of
+          // a thread are adjacent in every array, so they leave as 16-byte stores (rows past the end of the data
+          // store zeros: nothing reads them as data)
+          if (writer) {
+            const auto pk = S.pack;  // (pointers of the argument block read once, not behind every store)
+            const auto pkx = S.packx;
+            uint32_t id_n[RPT];
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) id_n[e] = (ids_next >> (8 * e)) & 255u;
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
               const int k = k0 + kk;
               if (k >= K) continue;
-              double st = st_in[(size_t)k * n_pad + row];
-              if (do_final) {
-                const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][kk], 0, (ids_sel >> (8 * e)) & 255u, k, row);
-                st = st + nv;
-                if (cmd->tune && writer) {  // [U] RunningSd.update (Welford), per output
-                  const size_t ri = (size_t)k * n_pad + row;
-                  const double mean0 = S.rs_mean[ri], m20 = S.rs_m2[ri];
-                  const double delta = nv - mean0;
-                  const double mean = mean0 + delta / cntf;
-                  const double delta2 = nv - mean;
-                  const double m2 = m20 + delta * delta2;
-                  S.rs_mean[ri] = mean;
-                  S.rs_m2[ri] = m2;
-                  ivQ[kk] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
-                }
+              double noi[RPT];
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const long long row = base + e;
+                const bool in = row < n;
+                const double o = lin_pred(s_lv[1][id_n[e]][kk], 1, id_n[e], k, in ? row : 0);
+                noi[e] = in ? stv[e][kk] - o : 0.0;
+                if (in) ivA[kk] += pgb_quant(stv[e][kk], c1, &sat);
               }
-              const double o = lin_pred(s_lv[1][(ids_next >> (8 * e)) & 255u][kk], 1, (ids_next >> (8 * e)) & 255u, k, row);
-              const double noi = st - o;
-              stv[e][kk] = st;
-              if (writer) {
-                if (k == 0) S.pack[row] = make_double2(st, 0.0);
-                else S.packx[(size_t)(k - 1) * n_pad + row] = st;
-                st_out[(size_t)k * n_pad + row] = noi;
-                ivA[kk] += pgb_quant(st, c1, &sat);
+              if (first && kk == 0) {
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) pk[base + e] = make_double2(stv[e][kk], 0.0);
+              } else {
+                double2* px = (double2*)(pkx + (size_t)(k - 1) * n_pad + base);
+                px[0] = make_double2(stv[0][kk], stv[1][kk]);
+                px[1] = make_double2(stv[2][kk], stv[3][kk]);
+              }
+              double2* po = (double2*)(st_out + (size_t)k * n_pad + base);
+              po[0] = make_double2(noi[0], noi[1]);
+              po[1] = make_double2(noi[2], noi[3]);
+            }
+          }
+          // (C, the log-likelihood of a fresh stump, and E0, of the current tree, are summed by k_loglik,
+          //  which runs after this pass and is compiled per number of outputs)
+          TRR(21, 0);
+          if (upd) {  // [U] RunningSd.update (Welford), per output: the four rows' inputs of an output requested together
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const int k = k0 + kk;
+              if (k >= K) continue;
+              const double2* mp = (const double2*)(S.rs_mean + (size_t)k * n_pad + base);
+              const double2* qp = (const double2*)(S.rs_m2 + (size_t)k * n_pad + base);
+              const double2 m01 = mp[0], m23 = mp[1], q01 = qp[0], q23 = qp[1];
+              const double mean_l[RPT] = {m01.x, m01.y, m23.x, m23.y}, m2_l[RPT] = {q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const long long row = base + e;
+                if (row >= n) continue;
+                const double nv = lin_pred(s_lv[0][(ids_sel >> (8 * e)) & 255u][kk], 0, (ids_sel >> (8 * e)) & 255u, k, row);
+                const size_t ri = (size_t)k * n_pad + row;
+                const double delta = nv - mean_l[e];
+                const double mean = mean_l[e] + delta / cntf;
+                const double delta2 = nv - mean;
+                const double m2 = m2_l[e] + delta * delta2;
+                S.rs_mean[ri] = mean;
+                S.rs_m2[ri] = m2;
+                ivQ[kk] += pgb_quant(PGB_SQRT(m2 / cntf), c1, &sat);
               }
             }
-            // (C, the log-likelihood of a fresh stump, and E0, of the current tree, are summed by k_loglik,
-            //  which runs after this pass and is compiled per number of outputs)
           }
         } else {
           for (int e = 0; e < RPT; ++e) {
@@ -199,6 +276,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
             }
           }
         }
+        TRR(22, 0);
         uint32_t root_ids = 0;
         for (int e = 0; e < RPT; ++e)
           if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
@@ -207,8 +285,94 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
         for (int e = 0; e < RPT; ++e)
 #pragma unroll
           for (int kk = 0; kk < KB; ++kk) qst[e][kk] = k0 + kk < K ? pgb_quant(stv[e][kk], c1, nullptr) : 0;
+        TRR(14, 0);
         const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
-        for (int g = g0; g < g1; ++g) {
+        int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
+        // ---- plain round (see k_rows): every particle of the pass splits the root of a fresh stump on a continuous
+        // column without missing values -- the slot that starts a tree.  The split columns of PD particles are in
+        // flight in stage registers that are never moved (loop unrolled by PD, every load and store unconditional),
+        // no label compare, no per-row control flow.  (The general loop below requests a particle's column and
+        // uses it at once: a memory round trip per particle.)
+        if constexpr (!LIN) {
+          if (all_plain && g1 > g0) {
+            constexpr int PD = F32 ? (KB == 4 ? 3 : 4) : 2;  // (float64 columns: 8 registers per stage; K = 4 sits at its register edge)
+            const bool full_chunk = (long long)(chunk + 1) * CH <= n;
+            double2 pa[PD], pb[PD];
+            float4 pf[PD];
+            auto fetch = [&](int gg, double2& f0, double2& f1, float4& ff) {
+              const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
+              if constexpr (F32) {
+                ff = *(const float4*)(S.XT32 + xo + base);
+              } else {
+                const double2* xp = (const double2*)(S.XT + xo + base);
+                f0 = xp[0];
+                f1 = xp[1];
+              }
+            };
+            auto stage = [&](int g, double2& f0, double2& f1, float4& ff, bool more) {
+              const RJob& rj = s_job[g];
+              const double r_v = uni(rj.v);
+              const float r_vf = (float)r_v;
+              const uint32_t nw = uni((uint32_t)rj.new_label);
+              const long long xo = uni(rj.xoff);
+              uint8_t* const dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
+              const double x[RPT] = {f0.x, f0.y, f1.x, f1.y};
+              const float xf[RPT] = {ff.x, ff.y, ff.z, ff.w};
+              bool L[RPT];
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xf[e] < r_vf) : (x[e] <= r_v);
+              if constexpr (F32) {  // float32 ties are decided on the float64 values
+                if (__any((xf[0] == r_vf) | (xf[1] == r_vf) | (xf[2] == r_vf) | (xf[3] == r_vf))) {
+#pragma unroll
+                  for (int e = 0; e < RPT; ++e)
+                    if (xf[e] == r_vf) L[e] = S.XT[xo + base + e] <= r_v;
+                }
+              }
+              if (more) fetch(g + PD, f0, f1, ff);
+              uint32_t out = root_ids, cl = 0, cr = 0;
+              long long aL[KB];
+#pragma unroll
+              for (int kk = 0; kk < KB; ++kk) aL[kk] = 0;
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const bool in = full_chunk || base + e < n;  // (rows past the end: orphan label, counted nowhere)
+                const bool le = in && L[e], ri = in && !L[e];
+                out |= ri ? (nw << (8 * e)) : 0u;
+                cl += le ? 1u : 0u;
+                cr += ri ? 1u : 0u;
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) aL[kk] += le ? qst[e][kk] : 0ll;
+              }
+              if (first) *(uint32_t*)dp = out;
+              const int slot = (g - g0) * NVT;
+              if constexpr (KB == 4) {
+                const long long tot = wave_sum4(aL[0], aL[1], aL[2], aL[3]);
+                if (lane < 4) s_red[(slot + 1 + lane) * 4 + w] = tot;
+                const long long c = wave_sum_dpp((long long)(cl | (cr << 20)));  // (lane 63 holds the total)
+                if (lane == 63) s_red[slot * 4 + w] = c;
+              } else {
+                const long long tot = wave_sum4((long long)(cl | (cr << 20)), aL[0], aL[KB > 1 ? 1 : 0], aL[KB > 2 ? 2 : 0]);
+                if (lane < 1 + KB) s_red[(slot + lane) * 4 + w] = tot;
+              }
+            };
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+              pa[d] = pb[d] = double2{0.0, 0.0};
+              pf[d] = float4{0.f, 0.f, 0.f, 0.f};
+              fetch(g0 + d, pa[d], pb[d], pf[d]);
+            }
+            const int g_main = g0 + (g1 - g0) / PD * PD;
+            for (int gb = g0; gb < g_main; gb += PD) {
+#pragma unroll
+              for (int d = 0; d < PD; ++d) stage(gb + d, pa[d], pb[d], pf[d], true);
+            }
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+              if (g_main + d < g1) stage(g_main + d, pa[d], pb[d], pf[d], false);
+            g_first = g1;
+          }
+        }
+        for (int g = g_first; g < g1; ++g) {
           const RJob& rj = s_job[g];
           // (a later tile finds the rows of the leaf in the labels as they were BEFORE this pass -- the source
           //  generation is never the one being written -- and re-derives the sides from the split column)
@@ -351,6 +515,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
         }
         __syncthreads();
       }
+      TRR(15, 0);  // items of this tile done
       if (do_init) {  // A[k], QSTD[k] of this tile's outputs -> InitAcc (k = 0) / iax (k >= 1)
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
@@ -373,6 +538,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
       }
     }
     if (do_init && sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+    if (pstamp) pstamp[1] = wall_clock64();
     return;
   }
 
@@ -436,5 +602,6 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? 4 : 2) void k_rows_mk(const
     }
   }
   if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
+  if (pstamp) pstamp[1] = wall_clock64();
 }
 

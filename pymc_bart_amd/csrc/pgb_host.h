@@ -37,6 +37,7 @@ struct pgb_handle {
   int has_subset;  // any SubsetSplit column: selects the row-pass instance
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int ll_grid;     // ... of the log-likelihood pass
+  int rows_mk_cap; // K-vector row pass: workgroups its instance keeps resident (0: not queried yet)
   void (*ll_kernel)(const Dev*, int);  // the instance of k_loglik this sampler launches (family / outputs / response)
   int sigma_dirty;
   double inv_sigma2;
@@ -223,6 +224,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   h->slot = 0;
   h->has_subset = 0;
   h->rows_grid = 1024;
+  h->rows_mk_cap = 0;
   h->prof_buf = nullptr;
   h->prof = 0;
   for (int k = 0; k < PK_COUNT; ++k) {
@@ -576,6 +578,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
         if (rc32 != PGB_OK) return rc32;
         transient(h);
         d.XT32 = x32;
+        h->rows_mk_cap = 0;  // (another instance of the K-vector row pass from here on)
       }
       hipLaunchKernelGGL(k_f32_shadow, dim3(2048), dim3(BT), 0, sm, d.XT, (float*)d.XT32, (long long)count);
     }
@@ -723,15 +726,34 @@ static int prof_events(pgb_handle* h, int k, hipEvent_t* e0, hipEvent_t* e1) {
 
 static int enqueue_slots(pgb_handle* h, int count) {
   Dev& d = h->d;
+  const bool lin = d.response != PGB_RESPONSE_CONSTANT;
   long long want = (long long)d.nchunks * (d.P - 1);
   if (want < d.n_pad / BT) want = d.n_pad / BT;
   if (want > h->rows_grid) want = h->rows_grid;
+  if (d.K > 1) {
+    // the K-vector instances differ in registers (K = 4: 3 workgroups per CU, the run-time-K instance 2-3): a
+    // persistent grid larger than what stays resident leaves the surplus workgroups waiting for a first round of
+    // items to finish (cfg5, in-kernel stamps: the last quarter of a 1024 grid started 22 us into a 27 us launch)
+    if (h->rows_mk_cap == 0) {
+      const bool f32 = d.XT32 != nullptr;
+      const void* kf = lin ? (const void*)k_rows_mk<0, true>
+                       : d.K == 2 ? (f32 ? (const void*)k_rows_mk<2, false, true> : (const void*)k_rows_mk<2, false>)
+                       : d.K == 3 ? (f32 ? (const void*)k_rows_mk<3, false, true> : (const void*)k_rows_mk<3, false>)
+                       : d.K == 4 ? (f32 ? (const void*)k_rows_mk<4, false, true> : (const void*)k_rows_mk<4, false>)
+                                  : (const void*)k_rows_mk<0, false>;
+      int per_cu = 0, cus = 0;
+      h->rows_mk_cap = h->rows_grid;
+      if (!getenv("PGB_ROWS_GRID") && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, BT, 0) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && per_cu > 0 && cus > 0)
+        h->rows_mk_cap = per_cu * cus < h->rows_grid ? per_cu * cus : h->rows_grid;
+    }
+    if (want > h->rows_mk_cap) want = h->rows_mk_cap;
+  }
   dim3 gctrl((unsigned)(d.P - 1)), grows((unsigned)want);
   long long wantl = (long long)d.nchunks * (d.P - 1);
   if (wantl > h->ll_grid) wantl = h->ll_grid;
   dim3 gll((unsigned)wantl);
   const Dev* dd = (const Dev*)h->d_dev;
-  const bool lin = d.response != PGB_RESPONSE_CONSTANT;
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
 #define CTRL_ARGS(nwg) dd, par, (int)(nwg), d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
