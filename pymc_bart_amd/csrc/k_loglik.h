@@ -144,6 +144,17 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops (run-time K: guarded by k < K)
   typedef LJobT<MK, LIN, KT> LJob;
+#ifdef PGB_STAMP_LL  // experiment builds: this kernel, not the row pass, leaves the per-workgroup clock readings
+  struct StampEnd {
+    long long* p;
+    __device__ ~StampEnd() { if (p) p[1] = wall_clock64(); }
+  } stamp_end{nullptr};
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+    stamp_end.p = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
+    stamp_end.p[0] = wall_clock64();
+    stamp_end.p[1] = stamp_end.p[0];
+  }
+#endif
   // per (particle of the span, side): the four waves ADD their totals (LDS atomics; the reducer thread reads the sum
   // and leaves a zero) -- a quarter of the storage of one cell per wave, which is what fits a fifth workgroup of the
   // probit instance into the CU next to its 18.6 KB table

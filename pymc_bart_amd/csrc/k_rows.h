@@ -42,9 +42,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   // constant leaves, split column without missing values: the sums of a particle go straight into LDS with atomic
   // adds (lane l to entry l mod NE of the value) instead of through a wave butterfly -- one ds_add per value in
   // place of 21-42 vector instructions per wave and particle; the reducer threads add the NE entries up
-  constexpr int NVA = LIN ? 1 : (NORMAL ? 4 : 2);
-  constexpr int NE = LIN ? 1 : (NORMAL ? 8 : 16) / (MAXP / 64);
-  __shared__ unsigned long long s_acc[MAXP * NVA * NE];
+  // (F32 instances only: at cfg2 -- float64 columns in the Infinity Cache, items of five particles -- the
+  //  butterflies are faster: k_rows 6.62 us against 6.82 with the atomics, A/B on one box)
+  constexpr bool ATOM = F32 && !LIN;
+  constexpr int NVA = !ATOM ? 1 : (NORMAL ? 4 : 2);
+  constexpr int NE = !ATOM ? 1 : (NORMAL ? 8 : 16) / (MAXP / 64);
+  __shared__ unsigned long long s_acc[ATOM ? MAXP * NVA * NE : 1];
   __shared__ double s_lv[2][256];
   __shared__ LinP s_ll[LIN ? 2 : 1][LIN ? 256 : 1];  // label -> linear part: [0 new | 1 next]
   __shared__ RJob s_job[MAXP];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   // profiling: every workgroup leaves its first and last device-clock reading; the host takes
   // min(start) .. max(end) per launch -- the interval rocprofv3 reports for the dispatch
   long long* pstamp = nullptr;
-  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS && !PGB_STAMP_LL_ON) {
     pstamp = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
     pstamp[0] = wall_clock64();
     pstamp[1] = pstamp[0];
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   const gptr<double> st_out = as_global(S.st + (size_t)(do_init ? cmd->st_cur ^ 1 : cmd->st_cur) * S.n_pad);
 
   if (do_part) {
-    if constexpr (!LIN)
+    if constexpr (ATOM)
       for (int i = tid; i < MAXP * NVA * NE; i += BT) s_acc[i] = 0ull;
     const Job* jobs = jobs_all + (size_t)par * MAXP;
     // list of particles with work in this pass (split or forced label refresh); their job
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       if (q >= 1 && q < S.P) j = jobs[q];  // one round trip: the whole job
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
-      if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
-        plain = false;
+      if constexpr (F32 && !LIN)
+        if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
+          plain = false;
       if (has) {
         const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
@@ -132,13 +136,13 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       }
       if (tid == 0) {
         s_n[0] = nlist;
-        s_n[1] = plain ? 1 : 0;
+        if constexpr (F32 && !LIN) s_n[1] = plain ? 1 : 0;
       }
     }
     __syncthreads();
     TRR(13, 0);
     const int nact = s_n[0];
-    const bool all_plain = !LIN && s_n[1] != 0;
+    const bool all_plain = F32 && !LIN && s_n[1] != 0;  // (the plain round exists in the F32 instances only)
     if (nact == 0 && !do_init) { PROF_END(); return; }
     const int target = do_init ? S.rows_target_init : S.rows_target;
     int G = (nact * S.nchunks + target - 1) / target;
@@ -269,12 +273,35 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           qc[e] = normal ? pgb_quant(sr.y * sr.y, c2, nullptr) : 0;
         }
       }
-      TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
       uint32_t root_ids = 0;
 #pragma unroll
       for (int e = 0; e < RPT; ++e)
         if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
       const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+      // general rounds: software pipeline over the particles of the group -- the labels and split-column values of
+      // particle g + 1 are requested before particle g is relabelled and reduced
+      uint32_t nx_ids = root_ids;
+      double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
+      float4 nxf = {0.f, 0.f, 0.f, 0.f};
+      auto fetch1 = [&](int gg) {
+        nx_ids = root_ids;
+        if (gg < g1) {
+          const RJob& rn = s_job[gg];
+          if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
+          if (rn.active) {
+            if constexpr (F32) {
+              nxf = gload_f4(XT32 + rn.xoff + base);
+            } else {
+              const gptr<const double> xn = XT + rn.xoff + base;
+              nx0 = gload_d2(xn);
+              nx1 = gload_d2(xn + 2);
+            }
+          }
+        }
+      };
+      const bool plain_item = F32 && !LIN && all_plain && g1 > g0;
+      if (!plain_item) fetch1(g0);
+      TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
       const bool full_chunk = (long long)(chunk + 1) * CH <= n;  // every row of the chunk is a row of the data
       int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
       // ---- plain round: EVERY particle of the pass splits the root of a fresh stump (implicit root labels: all
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       // nothing: profiles/r04_experiments.md): here the split columns of PD particles are in flight, in registers
       // that are never moved (the loop is unrolled by PD: a register shift would wait for the loads it moves).
       if constexpr (!LIN && F32) {  // (F32: the data sets beyond the Infinity Cache; the smaller ones keep their registers)
-        if (all_plain && g1 > g0) {
+        if (plain_item) {
           constexpr int PD = 4;
           double2 pa[PD], pb[PD];
           float4 pf[PD];
@@ -371,28 +398,6 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           g_first = g1;
         }
       }
-      // general rounds: software pipeline over the particles of the group -- the labels and split-column values of
-      // particle g + 1 are requested before particle g is relabelled and reduced
-      uint32_t nx_ids = root_ids;
-      double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
-      float4 nxf = {0.f, 0.f, 0.f, 0.f};
-      auto fetch1 = [&](int gg) {
-        nx_ids = root_ids;
-        if (gg < g1) {
-          const RJob& rn = s_job[gg];
-          if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
-          if (rn.active) {
-            if constexpr (F32) {
-              nxf = gload_f4(XT32 + rn.xoff + base);
-            } else {
-              const gptr<const double> xn = XT + rn.xoff + base;
-              nx0 = gload_d2(xn);
-              nx1 = gload_d2(xn + 2);
-            }
-          }
-        }
-      };
-      fetch1(g_first);
       for (int g = g_first; g < g1; ++g) {
         const RJob& rj = s_job[g];
         const uint32_t ids = nx_ids;
@@ -441,9 +446,12 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
             }
           }
           *gcast<uint32_t>(dp) = out;
-          if constexpr (LIN) {
+          if constexpr (!ATOM && (NORMAL || LIN)) {
             const long long tot = wave_sum4(v0, v1, v2, v3);  // lane l: total of value l & 3
             if (lane < 4) s_red[(slot + lane) * 4 + w] = tot;
+          } else if constexpr (!ATOM) {
+            const long long tot = wave_sum2(v0, v1);  // lane l: total of value l & 1
+            if (lane < 2) s_red[(slot + lane) * 4 + w] = tot;
           } else if (v0 != 0) {  // (lanes that hold a row of the leaf)
             // per-row families: the weights come from the likelihood pass, a split only needs the children's counts
             // and the left child's sum of sum_trees -- two values.  (Measured and dropped, round 4: counts as wave
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         if constexpr (!NORMAL && !LIN)
           if (i == 2 || i == 3 || i == 5 || i == 6) continue;  // (no residual algebra: nothing was reduced)
         long long s;
-        if (!LIN && !rj.check_nan) {  // (i < NVA here: the other values were skipped above)
+        if (ATOM && !rj.check_nan) {  // (i < NVA here: the other values were skipped above)
           unsigned long long* ap = &s_acc[(gi * NVA + i) * NE];
           unsigned long long u = 0;
 #pragma unroll

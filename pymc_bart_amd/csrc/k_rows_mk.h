@@ -32,7 +32,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
   const int kind = cmd->kind;
   TRR_BIND(S.ctrl[par ^ 1].slot_no - 1);  // (stamp 12: entry; 13 jobs listed, 14 rows of the last item loaded, 15 items done)
   long long* pstamp = nullptr;            // profiling: first / last device-clock reading of every workgroup (see k_rows)
-  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS) {
+  if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS && !PGB_STAMP_LL_ON) {
     pstamp = S.prof_stamps + ((size_t)((S.ctrl[par ^ 1].slot_no - 1) % PROF_RING) * PROF_BLOCKS + blockIdx.x) * 2;
     pstamp[0] = wall_clock64();
     pstamp[1] = pstamp[0];
@@ -280,21 +280,42 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
         uint32_t root_ids = 0;
         for (int e = 0; e < RPT; ++e)
           if (base + e >= n) root_ids |= (uint32_t)PGB_ORPHAN << (8 * e);
+        const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
+        const bool plain_item = !LIN && all_plain && g1 > g0;  // (the plain round below takes all particles of the item)
+        int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
+        uint32_t nx_ids = root_ids;
+        double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
+        float4 nxf = {0.f, 0.f, 0.f, 0.f};
+        auto fetch1 = [&](int gg) {
+          nx_ids = root_ids;
+          if (gg < g1) {
+            const RJob& rn = s_job[gg];
+            if (rn.src >= 0) nx_ids = *(const uint32_t*)(S.lid + rn.src + base);
+            if (rn.active) {
+              if constexpr (F32) {
+                nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+              } else {
+                const double2* xn = (const double2*)(S.XT + rn.xoff + base);
+                nx0 = xn[0];
+                nx1 = xn[1];
+              }
+            }
+          }
+        };
+        if (!plain_item) fetch1(g0);  // (next to the loads of the rows' sum_trees, before anything waits for those)
         long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
 #pragma unroll
         for (int e = 0; e < RPT; ++e)
 #pragma unroll
           for (int kk = 0; kk < KB; ++kk) qst[e][kk] = k0 + kk < K ? pgb_quant(stv[e][kk], c1, nullptr) : 0;
         TRR(14, 0);
-        const int g0 = grp * G, g1 = (g0 + G < nact) ? g0 + G : nact;
-        int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
         // ---- plain round (see k_rows): every particle of the pass splits the root of a fresh stump on a continuous
         // column without missing values -- the slot that starts a tree.  The split columns of PD particles are in
         // flight in stage registers that are never moved (loop unrolled by PD, every load and store unconditional),
         // no label compare, no per-row control flow.  (The general loop below requests a particle's column and
         // uses it at once: a memory round trip per particle.)
         if constexpr (!LIN) {
-          if (all_plain && g1 > g0) {
+          if (plain_item) {
             constexpr int PD = F32 ? (KB == 4 ? 3 : 4) : 2;  // (float64 columns: 8 registers per stage; K = 4 sits at its register edge)
             const bool full_chunk = (long long)(chunk + 1) * CH <= n;
             double2 pa[PD], pb[PD];
@@ -372,11 +393,18 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
             g_first = g1;
           }
         }
+        // general rounds: the labels and the split column of particle g + 1 are requested before particle g is
+        // relabelled and reduced (the values just arrived move to the working registers, the next loads go out
+        // behind them: no register with a load in flight is moved).  Rounds >= 2 are short chains of a few particles
+        // per item, each a memory round trip before this.
         for (int g = g_first; g < g1; ++g) {
           const RJob& rj = s_job[g];
           // (a later tile finds the rows of the leaf in the labels as they were BEFORE this pass -- the source
           //  generation is never the one being written -- and re-derives the sides from the split column)
-          const uint32_t ids = rj.src < 0 ? root_ids : *(const uint32_t*)(S.lid + rj.src + base);
+          const uint32_t ids = nx_ids;
+          const double2 t0 = nx0, t1 = nx1;
+          const float4 tf = nxf;
+          fetch1(g + 1);
           uint32_t out = ids;
           uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
           if (!rj.active) {
@@ -391,10 +419,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
           double x[RPT] = {0.0, 0.0, 0.0, 0.0};
           float xf[RPT] = {0.f, 0.f, 0.f, 0.f};
           if constexpr (F32) {
-            const float4 tf = *(const float4*)(S.XT32 + rj.xoff + base);
             xf[0] = tf.x; xf[1] = tf.y; xf[2] = tf.z; xf[3] = tf.w;
           } else {
-            const double2 t0 = xp[0], t1 = xp[1];
             x[0] = t0.x; x[1] = t0.y; x[2] = t1.x; x[3] = t1.y;
           }
           const float r_vf = (float)r_v;

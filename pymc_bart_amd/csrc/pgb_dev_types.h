@@ -262,6 +262,11 @@ static_assert(sizeof(Dev) == sizeof(DevG), "the two views of the argument block 
 #define TRR_BIND(slot_no) ((void)0)
 #define TRR(i, blk) ((void)0)
 #endif
+#ifdef PGB_STAMP_LL
+#define PGB_STAMP_LL_ON 1
+#else
+#define PGB_STAMP_LL_ON 0
+#endif
 
 // A read of a wave-uniform, kernel-invariant record (written by an EARLIER launch) through the
 // constant address space: the compiler can then use scalar (SMEM) loads and keep the record in

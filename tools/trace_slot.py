@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="also per-workgroup first/last clock readings of the row pass")
     ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--ll", action="store_true", help="the library was built with -DPGB_STAMP_LL: the per-workgroup stamps are k_loglik's")
     a = ap.parse_args()
     if a.build:
         build([f"-D{d}" for d in a.define], a.lib)
@@ -125,7 +126,7 @@ def main():
             for i in idx:
                 st, en = sb[i, :, 0], sb[i, :, 1]
                 m = (st > 0) & (en > st)
-                if m.sum() < 8 or abs(st[m].min() - t[i, 12]) > 50:
+                if m.sum() < 8 or abs(st[m].min() - t[i, 12]) > (400 if a.ll else 50):
                     continue  # stale ring entry
                 t0 = st[m].min()
                 dur = en[m] - st[m]
@@ -147,7 +148,7 @@ def main():
             for i in idx:
                 st, en = sb[i, :, 0], sb[i, :, 1]
                 m = (st > 0) & (en > st)
-                if m.sum() < 1024 or abs(st[m].min() - t[i, 12]) > 50:
+                if m.sum() < 1024 or abs(st[m].min() - t[i, 12]) > (400 if a.ll else 50):
                     continue
                 t0 = st.min()
                 acc_d += en - st
