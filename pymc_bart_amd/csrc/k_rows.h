@@ -30,6 +30,16 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
 // float32 is monotone, so x32 < v32 implies x < v and x32 > v32 implies x > v; only a float32 TIE needs the
 // float64 value, which that lane then fetches.  Same decisions, bit for bit.  (Continuous / one-hot rules,
 // constant leaves.)
+#ifdef PGB_EXP_HALFX  // timing experiment only (wrong results): half the bytes of the split-column stream
+__device__ __forceinline__ float4 gload_half(gptr<const float> col, long long base) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f v = *(gptr<const v2f>)(col + base / 2);
+  return make_float4(v.x, v.y, v.x, v.y);
+}
+#define PGB_XLOAD(col, base) gload_half((col), (base))
+#else
+#define PGB_XLOAD(col, base) gload_f4((col) + (base))
+#endif
 template <bool SUB, bool NORMAL, bool LIN, bool F32 = false>
 __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
                                                               const Cmd* __restrict__ cmds,
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
           if (rn.active) {
             if constexpr (F32) {
-              nxf = gload_f4(XT32 + rn.xoff + base);
+              nxf = PGB_XLOAD(XT32 + rn.xoff, base);
             } else {
               const gptr<const double> xn = XT + rn.xoff + base;
               nx0 = gload_d2(xn);
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           auto fetch = [&](int gg, double2& f0, double2& f1, float4& ff) {
             const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
             if constexpr (F32) {
-              ff = gload_f4(XT32 + xo + base);
+              ff = PGB_XLOAD(XT32 + xo, base);
             } else {
               f0 = gload_d2(XT + xo + base);
               f1 = gload_d2(XT + xo + base + 2);
