@@ -390,11 +390,11 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
         G = max(1, -(-int(round(nact * nchunks)) // 640))
         ngroups = max(1.0, nact / G)
         # what THIS layout moves per launch: every active particle streams its n labels in and out
-        # (1 B each) and the split column (8 B per row; 4 B from the float32 shadow when the matrix exceeds
+        # (1 B each) and the split column (8 B per row; 2 B of order keys when the matrix exceeds
         # the Infinity Cache); each particle group re-reads {sum_trees, r} (16 B per row); a tree-boundary
         # pass adds the INIT/FINAL streams (~26 B read per row and group, 25 B written per row)
         shadow = K_out <= 4 and response == "constant" and p * (nchunks * 1024) * 8 >= (192 << 20)
-        xbytes = 4.0 if shadow else 8.0
+        xbytes = 2.0 if shadow else 8.0
         impl = parts * (2.0 + xbytes) * n + launches * ngroups * 16.0 * n + tu * (ngroups * 26.0 + 25.0) * n
         avg_us = ms_rows * 1e3 / max(launches, 1)
         traffic = (pmc.get("k_rows") or pmc.get("k_rows_mk") or {}).get("hbm_bytes_per_launch_corrected")

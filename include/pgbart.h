@@ -39,7 +39,7 @@
  *   response linear/mix  any split rule (a leaf regresses on the column its parent split on, upstream's
  *                        fast_linear_fit; on a SubsetSplit column that is the category code)
  *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory: per row the device holds 8 p bytes
- *                        of the design matrix (+ 4 p for its float32 shadow when it exceeds the Infinity Cache),
+ *                        of the design matrix (+ 2 p for its 16-bit order keys when it exceeds the Infinity Cache),
  *                        m bytes of tree labels, 8 x pgb_max_particles() bytes of particle labels (8 generations) and
  *                        ~ 64 K bytes of running statistics -- 30 M rows x 4 columns x 5 trees: 17 GB, in the suite)
  */

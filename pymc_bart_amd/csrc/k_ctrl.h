@@ -193,16 +193,19 @@ __device__ __forceinline__ void lin_children_x(const DevG& S, LinKids& lk, Child
 // pre-drawn uniforms of the tries ([1 + try]).  Returns found and the split value in every lane.
 struct SplitRow {
   int found;
+  int vkey;  // order key of the value (XK16), 0 without keys
   double v;
 };
 __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool subset_rule, int src_gen, int src_slot,
                                                      int ncnt, int ncc, int nlabel, const double* pre0,
-                                                     const double* pre1, long long* tr_rec = nullptr) {
+                                                     const double* pre1, const uint16_t* xk16, long long* tr_rec = nullptr) {
   const double* xc = S.XT + (size_t)j * S.n_pad;
   const uint8_t* lid = src_slot >= 0 ? S.lid + ((size_t)src_gen * MAXP + src_slot) * S.n_pad : nullptr;
   const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
+  const uint16_t* kc = xk16 ? xk16 + (size_t)j * S.n_pad : nullptr;  // (xk16 = S.XK16 as a preloaded kernel argument)
   SplitRow out;
   out.found = 0;
+  out.vkey = 0;
   out.v = 0.0;
   // per-lane partial sums of the node's per-chunk row counts (independent of the retry); the counts of a
   // lane's chunks stay in registers (<= 4 chunks per lane, i.e. n <= 262144: one 8-byte load, no re-read
@@ -298,6 +301,7 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
     }
     TRS(21);
     const double x = xc[row];
+    if (kc) out.vkey = kc[row];  // (requested with the value: the same round trip)
     out.found = (x == x) ? 1 : 0;
     TRS(22);
     out.v = x;
@@ -310,7 +314,8 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
 template <bool MK, bool LIN>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
 void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias,
-            const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all) {
+            const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all,
+            const uint16_t* __restrict__ xk16) {
   // nwg repeats gridDim.x as an explicit argument (it takes the padding after `par`): explicit arguments arrive
   // preloaded in SGPRs, gridDim.x is a HIDDEN one and cost a scalar load with its wait in front of the first batch
   // of global loads of every launch
@@ -873,11 +878,12 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       TR(5);
       SplitRow sr;
       sr.found = 0;
+      sr.vkey = 0;
       sr.v = 0.0;
       if (attempt) {
         TR(6);
         sr = select_split_row(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
-                              s_pre1[0], TR_REC);
+                              s_pre1[0], xk16, TR_REC);
       }
       TR(7);
       Job job;
@@ -901,6 +907,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
         job.ccL = ((r * MAXP + p) * 2);
         job.ccR = job.ccL + 1;
         job.cnt = nd.cnt;
+        job.vkey = sr.vkey;
         job.v = sr.v;
         // parent statistics and the children's leaf noise travel with the job
         job.p_q_st = nd.q_st;
@@ -1287,9 +1294,10 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
     if (tid < 64) {
       TR(6);
       const SplitRow sr = select_split_row(S, s_i[8 + set], s_i[10 + set] == PGB_RULE_SUBSET, job.src_gen, job.src_slot,
-                                           ncnt, ncc, nlabel, s_pre[set], s_pre1[set]);
+                                           ncnt, ncc, nlabel, s_pre[set], s_pre1[set], xk16);
       if (tid == 0) {
         s_i[14] = sr.found;  // (not s_i[0]: waves 1..3 read s_i[0..1] after the resampling barrier and no later barrier orders them)
+        s_i[15] = sr.vkey;
         s_d[0] = sr.v;
       }
     }
@@ -1306,6 +1314,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       job.ccL = ((rr * MAXP + p) * 2);
       job.ccR = job.ccL + 1;
       job.cnt = ncnt;
+      job.vkey = s_i[15];
       job.v = s_d[0];
     }
   }

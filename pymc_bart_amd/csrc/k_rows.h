@@ -21,25 +21,22 @@ struct RJob {  // the fields of a Job the row pass needs, cached in LDS
   double v;
   double uscale;  // linear response: 2^-ex of the split column
   int32_t p, active, check_nan, rule, label, new_label, ccL, ccR;
+  int32_t vkey, pad;  // order key of v (shadow instances)
 };
 
 // LIN: linear response (Normal family only): leaves predict value + slope (x[svar] - xbar); the
 // partition additionally reduces the sums pgb_lin_fit needs for both children.
-// F32: the split column is read from a float32 shadow of the design matrix -- half the bytes of the
-// pass's largest stream when the matrix does not fit the Infinity Cache (cfg4: 800 MB).  Rounding to
-// float32 is monotone, so x32 < v32 implies x < v and x32 > v32 implies x > v; only a float32 TIE needs the
-// float64 value, which that lane then fetches.  Same decisions, bit for bit.  (Continuous / one-hot rules,
-// constant leaves.)
-#ifdef PGB_EXP_HALFX  // timing experiment only (wrong results): half the bytes of the split-column stream
-__device__ __forceinline__ float4 gload_half(gptr<const float> col, long long base) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const v2f v = *(gptr<const v2f>)(col + base / 2);
-  return make_float4(v.x, v.y, v.x, v.y);
+// F32 ("shadow" instances): the split column is read as 16-BIT ORDER KEYS (XK16, built by pgb_set_data when the
+// design matrix does not fit the Infinity Cache -- cfg4: 800 MB): a quarter of the bytes of the pass's largest stream.
+// key(x) = number of the column's 65 534 equi-depth boundaries (of its float32-rounded values) that are <= x, so
+// key(x) < key(v) implies x < v and key(x) > key(v) implies x > v; only EQUAL keys -- one row in 65 536 -- need the
+// float64 value, which that lane then fetches.  A missing value has key 0xFFFF.  Same decisions, bit for bit.
+// (Continuous / one-hot rules, constant leaves.  Round 3 / early round 4: a float32 shadow, half the bytes.)
+__device__ __forceinline__ uint2 gload_k4(gptr<const uint16_t> p) {  // the keys of four adjacent rows: one 8-byte load
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  const v2u v = *(gptr<const v2u>)p;
+  return make_uint2(v.x, v.y);
 }
-#define PGB_XLOAD(col, base) gload_half((col), (base))
-#else
-#define PGB_XLOAD(col, base) gload_f4((col) + (base))
-#endif
 template <bool SUB, bool NORMAL, bool LIN, bool F32 = false>
 __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev* __restrict__ Sp, int par,
                                                               const Cmd* __restrict__ cmds,
@@ -111,7 +108,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     // fields are cached in LDS once per workgroup
     if (tid < 64) {
       int nlist = 0;  // (wave 0 lists the particles with work: lanes' particles tid, tid + 64, ... one block after the other)
-      bool plain = true;  // every particle with work splits the root of a fresh stump on a continuous column without NaNs
+      bool plain = true;   // every particle with work splits the root of a fresh stump on a continuous column without NaNs
+      bool common = true;  // every split is on a continuous column without NaNs (label-refresh-only jobs allowed)
 #pragma unroll
       for (int hq = 0; hq < MAXP / 64; ++hq) {
       const int q = tid + 64 * hq;
@@ -121,9 +119,11 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       if (q >= 1 && q < S.P) j = jobs[q];  // one round trip: the whole job
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
-      if constexpr (F32 && !LIN)
-        if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
-          plain = false;
+      if constexpr (F32 && !LIN) {
+        const bool cont = !j.check_nan && j.rule == PGB_RULE_CONTINUOUS;
+        if (__any(has && j.active && !cont)) common = false;
+        if (__any(has && !(j.active && cont && j.src_slot < 0 && j.label == 0))) plain = false;
+      }
       if (has) {
         const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
@@ -136,6 +136,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         rj.ccL = j.ccL;
         rj.ccR = j.ccR;
         rj.v = j.v;
+        rj.vkey = j.vkey;
+        rj.pad = 0;
         rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
         rj.xoff = (long long)((size_t)j.var * S.n_pad);
         rj.uscale = 1.0;
@@ -146,13 +148,14 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       }
       if (tid == 0) {
         s_n[0] = nlist;
-        if constexpr (F32 && !LIN) s_n[1] = plain ? 1 : 0;
+        if constexpr (F32 && !LIN) s_n[1] = plain ? 2 : common ? 1 : 0;
       }
     }
     __syncthreads();
     TRR(13, 0);
     const int nact = s_n[0];
-    const bool all_plain = F32 && !LIN && s_n[1] != 0;  // (the plain round exists in the F32 instances only)
+    const int pass_kind = (F32 && !LIN) ? s_n[1] : 0;  // 2: plain round, 1: common round, 0: general (shadow instances only)
+    const bool all_plain = pass_kind == 2;
     if (nact == 0 && !do_init) { PROF_END(); return; }
     const int target = do_init ? S.rows_target_init : S.rows_target;
     int G = (nact * S.nchunks + target - 1) / target;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
     const gptr<uint8_t> __restrict__ dst0 = as_global(S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad);
     const gptr<const uint8_t> __restrict__ lid0 = as_global((const uint8_t*)S.lid);
     const gptr<const double> __restrict__ XT = as_global(S.XT);
-    const gptr<const float> __restrict__ XT32 = as_global(S.XT32);
+    const gptr<const uint16_t> __restrict__ XK = as_global(S.XK16);
     const gptr<const double> __restrict__ yarr = as_global(S.y);
     const gptr<uint16_t> ccp = as_global(S.cc);
     const double c1 = S.sc.c1, c2 = S.sc.c2;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       // particle g + 1 are requested before particle g is relabelled and reduced
       uint32_t nx_ids = root_ids;
       double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
-      float4 nxf = {0.f, 0.f, 0.f, 0.f};
+      uint2 nxk = {0u, 0u};
       auto fetch1 = [&](int gg) {
         nx_ids = root_ids;
         if (gg < g1) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           if (rn.src >= 0) nx_ids = *gcast<const uint32_t>(lid0 + rn.src + base);
           if (rn.active) {
             if constexpr (F32) {
-              nxf = PGB_XLOAD(XT32 + rn.xoff, base);
+              nxk = gload_k4(XK + rn.xoff + base);
             } else {
               const gptr<const double> xn = XT + rn.xoff + base;
               nx0 = gload_d2(xn);
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         }
       };
       const bool plain_item = F32 && !LIN && all_plain && g1 > g0;
-      if (!plain_item) fetch1(g0);
+      const bool common_item = pass_kind == 1 && g1 > g0;
+      if (!plain_item && !common_item) fetch1(g0);
       TRR(14, 0);  // rows of the item loaded and quantised (INIT part done)
       const bool full_chunk = (long long)(chunk + 1) * CH <= n;  // every row of the chunk is a row of the data
       int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
@@ -325,37 +329,37 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         if (plain_item) {
           constexpr int PD = 4;
           double2 pa[PD], pb[PD];
-          float4 pf[PD];
+          uint2 pf[PD];
           // (every load and store of the loop is unconditional -- past the end the last particle's column is
           //  requested again and dropped -- so that the number of operations in flight behind the one being
           //  waited for is the same on every path and the wait can leave them in flight)
-          auto fetch = [&](int gg, double2& f0, double2& f1, float4& ff) {
+          auto fetch = [&](int gg, double2& f0, double2& f1, uint2& ff) {
             const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
             if constexpr (F32) {
-              ff = PGB_XLOAD(XT32 + xo, base);
+              ff = gload_k4(XK + xo + base);
             } else {
               f0 = gload_d2(XT + xo + base);
               f1 = gload_d2(XT + xo + base + 2);
             }
           };
           // one particle from its stage registers; `more`: request the column of particle g + PD into them
-          auto stage = [&](int g, double2& f0, double2& f1, float4& ff, bool more) {
+          auto stage = [&](int g, double2& f0, double2& f1, uint2& ff, bool more) {
             const RJob& rj = s_job[g];
             const double r_v = uni(rj.v);
-            const float r_vf = (float)r_v;
+            const uint32_t r_vk = uni((uint32_t)rj.vkey);
             const uint32_t nw = uni((uint32_t)rj.new_label);
             const long long xo = uni(rj.xoff);
             const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
             const double x[RPT] = {f0.x, f0.y, f1.x, f1.y};
-            const float xf[RPT] = {ff.x, ff.y, ff.z, ff.w};
+            const uint32_t xk[RPT] = {ff.x & 0xFFFFu, ff.x >> 16, ff.y & 0xFFFFu, ff.y >> 16};
             bool L[RPT];
 #pragma unroll
-            for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xf[e] < r_vf) : (x[e] <= r_v);
-            if constexpr (F32) {  // float32 ties (a few rows of the whole column) are decided on the float64 values
-              if (__any((xf[0] == r_vf) | (xf[1] == r_vf) | (xf[2] == r_vf) | (xf[3] == r_vf))) {
+            for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xk[e] < r_vk) : (x[e] <= r_v);
+            if constexpr (F32) {  // equal keys (the row of the split value and its bin mates) are decided on the float64 values
+              if (__any((xk[0] == r_vk) | (xk[1] == r_vk) | (xk[2] == r_vk) | (xk[3] == r_vk))) {
 #pragma unroll
                 for (int e = 0; e < RPT; ++e)
-                  if (xf[e] == r_vf) L[e] = XT[xo + base + e] <= r_v;
+                  if (xk[e] == r_vk) L[e] = XT[xo + base + e] <= r_v;
               }
             }
             if (more) fetch(g + PD, f0, f1, ff);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
 #pragma unroll
           for (int d = 0; d < PD; ++d) {
             pa[d] = pb[d] = double2{0.0, 0.0};
-            pf[d] = float4{0.f, 0.f, 0.f, 0.f};
+            pf[d] = uint2{0u, 0u};
             fetch(g0 + d, pa[d], pb[d], pf[d]);
           }
           const int g_main = g0 + (g1 - g0) / PD * PD;  // whole blocks of PD particles, then the rest from their stages
@@ -408,11 +412,87 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           g_first = g1;
         }
       }
+      // ---- common round (shadow instances): every split of the pass is on a continuous column without missing
+      // values (particles that only carry their labels forward included).  The later rounds walk ONE item of 20-39
+      // particles per workgroup with an L2 / Infinity-Cache round trip per particle behind one stage of prefetch; here
+      // the labels and keys of PD particles are in flight (same construction as the plain round).
+      if constexpr (!LIN && F32) {
+        if (common_item) {
+          constexpr int PD = 4;
+          uint2 ck[PD];
+          uint32_t cl4[PD];
+          auto fetchc = [&](int gg, uint2& ff, uint32_t& fl) {
+            const RJob& rn = s_job[gg < g1 ? gg : g1 - 1];
+            ff = gload_k4(XK + uni(rn.xoff) + base);  // (a label-only job: column 0, not used)
+            const long long so = uni(rn.src);
+            fl = *gcast<const uint32_t>(lid0 + (so < 0 ? 0ll : so) + base);  // (an implicit root: loaded, not used)
+          };
+          auto stagec = [&](int g, uint2& ff, uint32_t& fl, bool more) {
+            const RJob& rj = s_job[g];
+            const bool act = uni(rj.active) != 0;
+            const double r_v = uni(rj.v);
+            const uint32_t r_vk = uni((uint32_t)rj.vkey);
+            const uint32_t nw = uni((uint32_t)rj.new_label), lb = uni((uint32_t)rj.label);
+            const long long xo = uni(rj.xoff);
+            const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
+            const uint32_t ids = uni(rj.src) < 0 ? root_ids : fl;
+            const uint32_t xk[RPT] = {ff.x & 0xFFFFu, ff.x >> 16, ff.y & 0xFFFFu, ff.y >> 16};
+            bool in[RPT], L[RPT];
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              in[e] = act && ((ids >> (8 * e)) & 255u) == lb;  // row of the leaf being split
+              L[e] = xk[e] < r_vk;
+            }
+            if (__any((in[0] && xk[0] == r_vk) | (in[1] && xk[1] == r_vk) | (in[2] && xk[2] == r_vk) | (in[3] && xk[3] == r_vk))) {
+#pragma unroll
+              for (int e = 0; e < RPT; ++e)
+                if (in[e] && xk[e] == r_vk) L[e] = XT[xo + base + e] <= r_v;  // equal keys: the float64 values decide
+            }
+            if (more) fetchc(g + PD, ff, fl);
+            uint32_t out = ids, cl = 0, cr = 0;
+            long long a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              const bool le = in[e] && L[e], ri = in[e] && !L[e];
+              out = ri ? ((out & ~(255u << (8 * e))) | (nw << (8 * e))) : out;
+              cl += le ? 1u : 0u;
+              cr += ri ? 1u : 0u;
+              a1 += le ? qa[e] : 0ll;
+              if constexpr (NORMAL) { a2 += le ? qb[e] : 0ll; a3 += le ? qc[e] : 0ll; }
+            }
+            *gcast<uint32_t>(dp) = out;
+            if ((cl | cr) != 0) {  // (lanes that hold a row of the leaf)
+              unsigned long long* ap = &s_acc[(g - g0) * (NVA * NE) + (lane & (NE - 1))];
+              atomicAdd(ap, (unsigned long long)(cl | (cr << 20)));
+              atomicAdd(ap + NE, (unsigned long long)a1);
+              if constexpr (NORMAL) {
+                atomicAdd(ap + 2 * NE, (unsigned long long)a2);
+                atomicAdd(ap + 3 * NE, (unsigned long long)a3);
+              }
+            }
+          };
+#pragma unroll
+          for (int d = 0; d < PD; ++d) {
+            ck[d] = uint2{0u, 0u};
+            cl4[d] = 0u;
+            fetchc(g0 + d, ck[d], cl4[d]);
+          }
+          const int g_main = g0 + (g1 - g0) / PD * PD;
+          for (int gb = g0; gb < g_main; gb += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) stagec(gb + d, ck[d], cl4[d], true);
+          }
+#pragma unroll
+          for (int d = 0; d < PD; ++d)
+            if (g_main + d < g1) stagec(g_main + d, ck[d], cl4[d], false);
+          g_first = g1;
+        }
+      }
       for (int g = g_first; g < g1; ++g) {
         const RJob& rj = s_job[g];
         const uint32_t ids = nx_ids;
         const double2 t0 = nx0, t1 = nx1;
-        const float4 tf = nxf;
+        const uint2 tk = nxk;
         fetch1(g + 1);
         uint32_t out = ids;
         const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)rj.p * n_pad + base;
@@ -427,13 +507,13 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           continue;
         }
         const double x[RPT] = {t0.x, t0.y, t1.x, t1.y};
-        const float xf[RPT] = {tf.x, tf.y, tf.z, tf.w};
-        const float r_vf = (float)r_v;
-        const gptr<const double> __restrict__ xcol = XT + rj.xoff + base;  // (F32: float32 ties only)
-        // go left?  F32: decided on the float32 values unless they tie (see the template comment)
+        const uint32_t xk[RPT] = {tk.x & 0xFFFFu, tk.x >> 16, tk.y & 0xFFFFu, tk.y >> 16};
+        const uint32_t r_vk = (uint32_t)rj.vkey;
+        const gptr<const double> __restrict__ xcol = XT + rj.xoff + base;  // (F32: equal keys only)
+        // go left?  F32: decided on the order keys unless they are equal (see the template comment)
         auto left_of = [&](int e) -> bool {
           if constexpr (F32) {
-            if (xf[e] != r_vf) return r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
+            if (xk[e] != r_vk) return r_rule == PGB_RULE_CONTINUOUS ? xk[e] < r_vk : false;
             return go_left_t<SUB>(r_rule, xcol[e], r_v);
           } else {
             return go_left_t<SUB>(r_rule, x[e], r_v);
@@ -480,7 +560,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
 #pragma unroll
           for (int e = 0; e < RPT; ++e) {
             if (((ids >> (8 * e)) & 255u) == r_label) {
-              const bool missing = F32 ? (xf[e] != xf[e]) : (x[e] != x[e]);  // (NaN stays NaN in float32)
+              const bool missing = F32 ? (xk[e] == 0xFFFFu) : (x[e] != x[e]);  // (the key of a missing value)
               if (missing) {
                 out = (out & ~(255u << (8 * e))) | ((uint32_t)PGB_ORPHAN << (8 * e));
                 v[0] += 1ll << 40;

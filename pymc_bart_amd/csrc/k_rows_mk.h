@@ -11,7 +11,7 @@
 // whatever K is (round 3: 576-736 B of scratch, 72 KB of LDS at K <= 8; round-3 VERDICT #2 / #6).
 // LIN: linear response; the label -> (slope, xbar, column) tables are read from global memory
 // (lvl for output 0 and the shared parts, lsx for the slopes of outputs 1..K-1)
-// F32: the split column from the float32 shadow of the design matrix (see k_rows<..., F32>); continuous /
+// F32: the split column as 16-bit order keys of the design matrix (see k_rows<..., F32>); continuous /
 // one-hot rules only.
 // (the compile-time-K instances are held to 4 workgroups per CU, <= 128 VGPRs: K = 4 sits at that edge)
 #ifndef PGB_MK_WGS
@@ -115,6 +115,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
         rj.ccL = j.ccL;
         rj.ccR = j.ccR;
         rj.v = j.v;
+        rj.vkey = j.vkey;
+        rj.pad = 0;
         rj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
         rj.xoff = (long long)((size_t)j.var * S.n_pad);
         s_job[k] = rj;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
         int g_first = g0;  // particles g0 .. g_first - 1 of this item went through the plain round
         uint32_t nx_ids = root_ids;
         double2 nx0 = {0.0, 0.0}, nx1 = {0.0, 0.0};
-        float4 nxf = {0.f, 0.f, 0.f, 0.f};
+        uint2 nxk = {0u, 0u};
         auto fetch1 = [&](int gg) {
           nx_ids = root_ids;
           if (gg < g1) {
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
             if (rn.src >= 0) nx_ids = *(const uint32_t*)(S.lid + rn.src + base);
             if (rn.active) {
               if constexpr (F32) {
-                nxf = *(const float4*)(S.XT32 + rn.xoff + base);
+                nxk = gload_k4(S.XK16 + rn.xoff + base);
               } else {
                 const double2* xn = (const double2*)(S.XT + rn.xoff + base);
                 nx0 = xn[0];
@@ -319,34 +321,34 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
             constexpr int PD = F32 ? (KB == 4 ? 3 : 4) : 2;  // (float64 columns: 8 registers per stage; K = 4 sits at its register edge)
             const bool full_chunk = (long long)(chunk + 1) * CH <= n;
             double2 pa[PD], pb[PD];
-            float4 pf[PD];
-            auto fetch = [&](int gg, double2& f0, double2& f1, float4& ff) {
+            uint2 pf[PD];
+            auto fetch = [&](int gg, double2& f0, double2& f1, uint2& ff) {
               const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
               if constexpr (F32) {
-                ff = *(const float4*)(S.XT32 + xo + base);
+                ff = gload_k4(S.XK16 + xo + base);
               } else {
                 const double2* xp = (const double2*)(S.XT + xo + base);
                 f0 = xp[0];
                 f1 = xp[1];
               }
             };
-            auto stage = [&](int g, double2& f0, double2& f1, float4& ff, bool more) {
+            auto stage = [&](int g, double2& f0, double2& f1, uint2& ff, bool more) {
               const RJob& rj = s_job[g];
               const double r_v = uni(rj.v);
-              const float r_vf = (float)r_v;
+              const uint32_t r_vk = uni((uint32_t)rj.vkey);
               const uint32_t nw = uni((uint32_t)rj.new_label);
               const long long xo = uni(rj.xoff);
               uint8_t* const dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
               const double x[RPT] = {f0.x, f0.y, f1.x, f1.y};
-              const float xf[RPT] = {ff.x, ff.y, ff.z, ff.w};
+              const uint32_t xk[RPT] = {ff.x & 0xFFFFu, ff.x >> 16, ff.y & 0xFFFFu, ff.y >> 16};
               bool L[RPT];
 #pragma unroll
-              for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xf[e] < r_vf) : (x[e] <= r_v);
-              if constexpr (F32) {  // float32 ties are decided on the float64 values
-                if (__any((xf[0] == r_vf) | (xf[1] == r_vf) | (xf[2] == r_vf) | (xf[3] == r_vf))) {
+              for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xk[e] < r_vk) : (x[e] <= r_v);
+              if constexpr (F32) {  // equal order keys are decided on the float64 values
+                if (__any((xk[0] == r_vk) | (xk[1] == r_vk) | (xk[2] == r_vk) | (xk[3] == r_vk))) {
 #pragma unroll
                   for (int e = 0; e < RPT; ++e)
-                    if (xf[e] == r_vf) L[e] = S.XT[xo + base + e] <= r_v;
+                    if (xk[e] == r_vk) L[e] = S.XT[xo + base + e] <= r_v;
                 }
               }
               if (more) fetch(g + PD, f0, f1, ff);
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
               pa[d] = pb[d] = double2{0.0, 0.0};
-              pf[d] = float4{0.f, 0.f, 0.f, 0.f};
+              pf[d] = uint2{0u, 0u};
               fetch(g0 + d, pa[d], pb[d], pf[d]);
             }
             const int g_main = g0 + (g1 - g0) / PD * PD;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
           //  generation is never the one being written -- and re-derives the sides from the split column)
           const uint32_t ids = nx_ids;
           const double2 t0 = nx0, t1 = nx1;
-          const float4 tf = nxf;
+          const uint2 tk = nxk;
           fetch1(g + 1);
           uint32_t out = ids;
           uint8_t* const dp = dst0 + (size_t)rj.p * n_pad + base;
@@ -417,13 +419,13 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
           const int r_rule = rj.rule;
           const uint32_t r_label = (uint32_t)rj.label, r_new = (uint32_t)rj.new_label;
           double x[RPT] = {0.0, 0.0, 0.0, 0.0};
-          float xf[RPT] = {0.f, 0.f, 0.f, 0.f};
+          uint32_t xk[RPT] = {0u, 0u, 0u, 0u};
           if constexpr (F32) {
-            xf[0] = tf.x; xf[1] = tf.y; xf[2] = tf.z; xf[3] = tf.w;
+            xk[0] = tk.x & 0xFFFFu; xk[1] = tk.x >> 16; xk[2] = tk.y & 0xFFFFu; xk[3] = tk.y >> 16;
           } else {
             x[0] = t0.x; x[1] = t0.y; x[2] = t1.x; x[3] = t1.y;
           }
-          const float r_vf = (float)r_v;
+          const uint32_t r_vk = (uint32_t)rj.vkey;
           int side[RPT];  // 0: not in the leaf, 1: left, 2: right, 3: dropped (missing value)
           long long cnts = 0;
           for (int e = 0; e < RPT; ++e) {
@@ -431,8 +433,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
             if (((ids >> (8 * e)) & 255u) == r_label) {
               bool missing, left;
               if constexpr (F32) {  // decided on the float32 values unless they tie
-                missing = xf[e] != xf[e];
-                if (xf[e] != r_vf) left = r_rule == PGB_RULE_CONTINUOUS ? xf[e] < r_vf : false;
+                missing = xk[e] == 0xFFFFu;
+                if (xk[e] != r_vk) left = r_rule == PGB_RULE_CONTINUOUS ? xk[e] < r_vk : false;
                 else left = go_left(r_rule, ((const double*)xp)[e], r_v);
               } else {
                 missing = x[e] != x[e];

@@ -2,10 +2,44 @@
 // ------------------------------------------------------------------ setup kernels
 // X row-major [n][ldx] -> XT column-major [p][n_pad]; LDS-tiled 32x32 transpose so that both
 // the read and the write are coalesced.  Also flags columns that contain NaN.
-// float32 shadow of the column-major design matrix (see k_rows<..., F32>)
-__global__ __launch_bounds__(BT) void k_f32_shadow(const double* __restrict__ XT, float* __restrict__ XT32, long long count) {
-  for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < count; i += (long long)gridDim.x * BT)
-    XT32[i] = (float)XT[i];
+// 16-bit order keys of the column-major design matrix (see k_rows<..., F32>), one column at a time:
+//   k_key_stage   the column's values rounded to float32 (a missing value: the canonical positive NaN, which a
+//                 radix sort of the bit patterns puts behind +inf), the number of missing values counted;
+//   (hipcub radix sort of the staged values)
+//   k_key_bounds  boundary i (1 .. PGB_KEY_BOUNDS) = the value at rank i m / (PGB_KEY_BOUNDS + 1) of the m
+//                 non-missing values: equi-depth bins, so that a split value shares its key with m / 65 535 rows;
+//   k_key_assign  key(x) = number of boundaries <= float32(x) (binary search; non-decreasing in x), 0xFFFF if missing.
+#define PGB_KEY_BOUNDS 65534
+__global__ __launch_bounds__(BT) void k_key_stage(const double* __restrict__ col, float* __restrict__ out, long long n,
+                                                  unsigned* __restrict__ n_missing) {
+  unsigned miss = 0;
+  for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < n; i += (long long)gridDim.x * BT) {
+    const double x = col[i];
+    const bool m = x != x;
+    out[i] = m ? __uint_as_float(0x7FC00000u) : (float)x;
+    miss += m ? 1u : 0u;
+  }
+  if (miss) atomicAdd(n_missing, miss);
+}
+__global__ __launch_bounds__(BT) void k_key_bounds(const float* __restrict__ sorted, long long n,
+                                                   const unsigned* __restrict__ n_missing, float* __restrict__ bnd) {
+  const long long m = n - (long long)*n_missing;
+  for (int i = blockIdx.x * BT + threadIdx.x; i < PGB_KEY_BOUNDS; i += gridDim.x * BT)
+    bnd[i] = m > 0 ? sorted[((long long)(i + 1) * m) / (PGB_KEY_BOUNDS + 1)] : __uint_as_float(0x7F800000u);
+}
+__global__ __launch_bounds__(BT) void k_key_assign(const double* __restrict__ col, const float* __restrict__ bnd,
+                                                   uint16_t* __restrict__ key, long long n_pad) {
+  for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < n_pad; i += (long long)gridDim.x * BT) {
+    const double xd = col[i];
+    const float x = (float)xd;
+    int lo = 0, hi = PGB_KEY_BOUNDS;  // first boundary > x
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bnd[mid] <= x) lo = mid + 1;
+      else hi = mid;
+    }
+    key[i] = xd != xd ? (uint16_t)0xFFFFu : (uint16_t)lo;
+  }
 }
 
 __global__ __launch_bounds__(BT) void k_transpose(const double* __restrict__ X, long long ldx,

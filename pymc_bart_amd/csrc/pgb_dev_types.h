@@ -31,6 +31,7 @@ struct Job {  // one particle's work for a PARTITION row pass + what the next k_
   int32_t var, rule, check_nan;
   int32_t ccL, ccR;
   int32_t cnt;
+  int32_t vkey;  // 16-bit order key of the split value (shadow instances of the row pass: XK16)
   double v;
   // statistics of the node being split (the parent of the children the pass creates)
   long long p_q_st, p_q_r, p_q_r2;
@@ -164,7 +165,7 @@ struct DevT {  // kernel argument block (by value)
   pgb_scales sc;
   dptr<G, const double> prior_leaf;  // [PGB_MAX_DEPTH] device copy
   dptr<G, const double> XT;  // [p][n_pad]
-  dptr<G, const float> XT32; // [p][n_pad] float32 shadow of XT (null unless the matrix is larger than the Infinity Cache)
+  dptr<G, const uint16_t> XK16; // [p][n_pad] 16-bit order keys of XT (null unless the matrix is larger than the Infinity Cache)
   dptr<G, const double> y;   // [n_pad]
   dptr<G, const double> off; // [K][n_pad] offset of the linear predictor (per-row families; 0 by default)
   dptr<G, double> st;        // [2][n_pad] sum_trees (ping-pong, see k_rows)

@@ -564,23 +564,51 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
       return fail(PGB_E_INVALID, msg);
     }
   }
-  // A design matrix that does not fit the 256 MiB Infinity Cache streams from HBM in every row pass: the
-  // row pass (single output, K = 2..4) then reads a float32 shadow of the split column (k_rows<..., F32>); smaller
-  // matrices stay on the float64 path (cache-resident, latency-bound: the shadow only adds conversions).
+  // A design matrix that does not fit the 256 MiB Infinity Cache streams from HBM in every row pass: the row pass
+  // (single output, K = 2..4) then reads 16-bit order keys of the split column (k_rows<..., F32>: a quarter of the
+  // bytes; built here, one column at a time: stage as float32, sort, equi-depth boundaries, keys); smaller matrices
+  // stay on the float64 path (cache-resident, latency-bound: keys only add work).
   {
     size_t min_bytes = (size_t)192 << 20;
     if (const char* e = getenv("PGB_X32_MIN_MB")) min_bytes = (size_t)atoll(e) << 20;
     const size_t count = (size_t)d.p * d.n_pad;
     if (d.K <= 4 && d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
-      if (!d.XT32) {
-        float* x32 = nullptr;
-        int rc32 = dalloc(h, &x32, count);
-        if (rc32 != PGB_OK) return rc32;
+      if (!d.XK16) {
+        uint16_t* xk = nullptr;
+        int rck = dalloc(h, &xk, count);
+        if (rck != PGB_OK) return rck;
         transient(h);
-        d.XT32 = x32;
+        d.XK16 = xk;
         h->rows_mk_cap = 0;  // (another instance of the K-vector row pass from here on)
       }
-      hipLaunchKernelGGL(k_f32_shadow, dim3(2048), dim3(BT), 0, sm, d.XT, (float*)d.XT32, (long long)count);
+      // scratch of the build: [n] staged | [n] sorted | boundaries | counter | the sort's temporary storage
+      const size_t nn = (size_t)d.n;
+      size_t tmp_bytes = 0;
+      hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (const float*)nullptr, (float*)nullptr, (int)nn, 0, 32, sm);
+      if (e != hipSuccess) return fail_hip(e, "hipcub::DeviceRadixSort (size query)");
+      const size_t fl = (2 * nn + PGB_KEY_BOUNDS + 64) * sizeof(float);
+      char* scratch = nullptr;
+      e = hipMalloc((void**)&scratch, fl + tmp_bytes + 256);
+      if (e != hipSuccess) return fail_hip(e, "hipMalloc (order-key scratch)");
+      float* staged = (float*)scratch;
+      float* sorted = staged + nn;
+      float* bnd = sorted + nn;
+      unsigned* miss = (unsigned*)(bnd + PGB_KEY_BOUNDS);
+      void* tmp = scratch + fl;
+      for (int c = 0; c < d.p && e == hipSuccess; ++c) {
+        const double* col = d.XT + (size_t)c * d.n_pad;
+        e = hipMemsetAsync(miss, 0, sizeof(unsigned), sm);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_key_stage, dim3(1024), dim3(BT), 0, sm, col, staged, (long long)d.n, miss);
+        e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, (const float*)staged, sorted, (int)nn, 0, 32, sm);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_key_bounds, dim3(256), dim3(BT), 0, sm, (const float*)sorted, (long long)d.n, (const unsigned*)miss, bnd);
+        hipLaunchKernelGGL(k_key_assign, dim3(2048), dim3(BT), 0, sm, col, (const float*)bnd, (uint16_t*)d.XK16 + (size_t)c * d.n_pad,
+                           (long long)d.n_pad);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(sm);
+      hipFree(scratch);
+      if (e != hipSuccess) return fail_hip(e, "order keys of the design matrix");
     }
   }
   double* prior_stage = nullptr;
@@ -735,7 +763,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
     // persistent grid larger than what stays resident leaves the surplus workgroups waiting for a first round of
     // items to finish (cfg5, in-kernel stamps: the last quarter of a 1024 grid started 22 us into a 27 us launch)
     if (h->rows_mk_cap == 0) {
-      const bool f32 = d.XT32 != nullptr;
+      const bool f32 = d.XK16 != nullptr;
       const void* kf = lin ? (const void*)k_rows_mk<0, true>
                        : d.K == 2 ? (f32 ? (const void*)k_rows_mk<2, false, true> : (const void*)k_rows_mk<2, false>)
                        : d.K == 3 ? (f32 ? (const void*)k_rows_mk<3, false, true> : (const void*)k_rows_mk<3, false>)
@@ -756,7 +784,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
   const Dev* dd = (const Dev*)h->d_dev;
   for (int i = 0; i < count; ++i) {
     int par = (int)(h->slot & 1);
-#define CTRL_ARGS(nwg) dd, par, (int)(nwg), d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts
+#define CTRL_ARGS(nwg) dd, par, (int)(nwg), d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts, (const uint16_t*)d.XK16
     if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS(gctrl.x));
     else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS(gctrl.x));
     else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS(gctrl.x));
@@ -766,13 +794,13 @@ static int enqueue_slots(pgb_handle* h, int count) {
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
       LAUNCH_K(PK_ROWS, (k_rows_mk<0, true>), grows, dd, par);
     } else if (d.K == 2) {
-      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<2, false, true>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<2, false, true>), grows, dd, par);
       else LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par);
     } else if (d.K == 3) {
-      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<3, false, true>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<3, false, true>), grows, dd, par);
       else LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par);
     } else if (d.K == 4) {
-      if (d.XT32) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par);
       else LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
     } else if (d.K > 1) {
       LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
@@ -787,7 +815,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
       } else if (h->has_subset) {
         if (nrm) LAUNCH_K(PK_ROWS, (k_rows<true, true, false>), grows, ROWS_ARGS);
         else LAUNCH_K(PK_ROWS, (k_rows<true, false, false>), grows, ROWS_ARGS);
-      } else if (d.XT32 != nullptr) {  // float32 shadow of the split columns (matrix larger than the Infinity Cache)
+      } else if (d.XK16 != nullptr) {  // 16-bit order keys of the split columns (matrix larger than the Infinity Cache)
         if (nrm) LAUNCH_K(PK_ROWS, (k_rows<false, true, false, true>), grows, ROWS_ARGS);
         else LAUNCH_K(PK_ROWS, (k_rows<false, false, false, true>), grows, ROWS_ARGS);
       } else {

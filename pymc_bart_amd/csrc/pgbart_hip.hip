@@ -27,6 +27,7 @@
 //
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hipcub/hipcub.hpp>  // (device radix sort: the order keys of the design matrix, pgb_set_data)
 
 #include <cstdint>
 #include <cstdio>

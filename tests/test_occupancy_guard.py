@@ -37,7 +37,7 @@ def test_every_kernel_instance_keeps_its_budgeted_occupancy():
     by = {r["kernel"]: r for r in rows}
     # the instances the three BASELINE configs launch in their slots
     assert by["k_rows<false, true, false, false>"]["wgs_per_cu"] >= 4      # cfg2 row pass
-    assert by["k_rows<false, false, false, true>"]["wgs_per_cu"] >= 4      # cfg4 row pass (float32 shadow)
+    assert by["k_rows<false, false, false, true>"]["wgs_per_cu"] >= 4      # cfg4 row pass (16-bit order keys)
     assert by["k_loglik<1, 1, false>"]["wgs_per_cu"] >= 5                   # cfg4 probit likelihood
     assert by["k_rows_mk<4, false, true>"]["wgs_per_cu"] >= 3              # cfg5 row pass (round 4: 3 without spills beat 4 with)
     assert by["k_rows_mk<4, false, true>"]["scratch_bytes"] == 0

@@ -64,10 +64,11 @@ def test_two_particles_per_lane_build_gives_the_same_chain(hip, name):
                                   "probit_cfg4_small", "logit_nan_onehot", "categorical_k3_reference",
                                   "categorical_k4_cfg5_small", "meanscale_k2_reference"])
 def test_float32_shadow_of_the_split_columns_changes_nothing(hip, monkeypatch, name):
-    """A design matrix larger than the Infinity Cache is partitioned on a float32 shadow of its columns
-    (k_rows / k_rows_mk <F32>: monotone rounding decides, float32 ties fetch the float64 value).  Forced on
-    at test sizes (PGB_X32_MIN_MB=0, read when the data are set): missing values, one-hot columns, heavy
-    ties, every row-pass instance that has the variant -- the committed fingerprints still hold."""
+    """A design matrix larger than the Infinity Cache is partitioned on 16-bit order keys of its columns
+    (k_rows / k_rows_mk <F32>: key(x) = number of the column's equi-depth boundaries <= x decides, equal keys
+    fetch the float64 value; round 3: a float32 shadow).  Forced on at test sizes (PGB_X32_MIN_MB=0, read when
+    the data are set): missing values, one-hot columns, heavy ties (many rows per key), every row-pass instance
+    that has the variant -- the committed fingerprints still hold."""
     monkeypatch.setenv("PGB_X32_MIN_MB", "0")
     g = run_case(make_case(name), hip)
     assert digest(g) == GOLD[name]

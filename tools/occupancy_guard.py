@@ -94,6 +94,8 @@ def table(so_path: str = SO) -> list[dict]:
     names = demangle([k[".name"] for k in kernels])
     rows = []
     for k, name in zip(kernels, names):
+        if not name.startswith("k_"):  # library kernels (rocPRIM's radix sort, used once in pgb_set_data) are not ours to budget
+            continue
         vg, ag = int(k[".vgpr_count"]), int(k.get(".agpr_count", 0))
         lds = int(k[".group_segment_fixed_size"])
         threads = 64 if name.startswith("k_predict") else 256  # k_predict: one wave per workgroup (+ dynamic LDS)

@@ -166,6 +166,29 @@ def main():
                 print(f"  blocks {lo:4d}..{hi - 1:4d}: start {st_[lo:hi].mean():.2f}  duration {d[lo:hi].mean():.2f} (max {d[lo:hi].max():.2f})  end {en_[lo:hi].mean():.2f} (max {en_[lo:hi].max():.2f})")
             print("  by blockIdx % 8: duration", np.round([d[k::8].mean() for k in range(8)], 2), "end", np.round([en_[k::8].max() for k in range(8)], 2))
 
+        def tails(name, sel, show_n=6):
+            idx = np.nonzero(sel)[0]
+            shown = 0
+            pct = []
+            for i in idx:
+                st, en = sb[i, :, 0], sb[i, :, 1]
+                m = (st > 0) & (en > st)
+                if m.sum() < 512 or abs(st[m].min() - t[i, 12]) > (400 if a.ll else 50):
+                    continue
+                dur = np.where(m, en - st, 0.0)
+                q = np.percentile(dur[m], [50, 90, 99, 100])
+                pct.append(q)
+                if shown < show_n:
+                    top = np.argsort(dur)[-5:][::-1]
+                    print(f"  {name} launch {i}: p50 {q[0]:.2f} p90 {q[1]:.2f} p99 {q[2]:.2f} max {q[3]:.2f} | slowest blocks "
+                          + " ".join(f"{b}:{dur[b]:.1f}(start {st[b] - st[m].min():.1f})" for b in top))
+                    shown += 1
+            if pct:
+                pq = np.median(np.array(pct), axis=0)
+                print(f"  {name}: median over {len(pct)} launches of p50 / p90 / p99 / max = {pq[0]:.2f} / {pq[1]:.2f} / {pq[2]:.2f} / {pq[3]:.2f}")
+
+        tails("plain round", (rnd >= 2) & ~fresh & ~stop)
+        tails("round 1", (rnd == 1) & ~fresh & ~stop)
         by_block("plain round", (rnd >= 2) & ~fresh & ~stop)
         by_block("tree start", fresh & stop)
         print("-- row pass, per-workgroup stamps (us)")
