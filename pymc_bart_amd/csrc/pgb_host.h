@@ -517,6 +517,38 @@ extern "C" int pgb_destroy(pgb_handle* h) {
   return PGB_OK;
 }
 
+// 16-bit order keys of p columns of a column-major matrix ([p][n_pad] doubles -> [p][n_pad] keys; see k_rows<..., F32>
+// and k_key_*): one column at a time -- stage as float32, radix sort, equi-depth boundaries, keys.  Scratch:
+// [n] staged | [n] sorted | boundaries | counter | the sort's temporary storage, allocated and freed here.
+static hipError_t order_keys_build(const double* XT, long long n, long long n_pad, int p, uint16_t* keys, hipStream_t sm) {
+  const size_t nn = (size_t)n;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (const float*)nullptr, (float*)nullptr, (int)nn, 0, 32, sm);
+  if (e != hipSuccess) return e;
+  const size_t fl = (2 * nn + PGB_KEY_BOUNDS + 64) * sizeof(float);
+  char* scratch = nullptr;
+  e = hipMalloc((void**)&scratch, fl + tmp_bytes + 256);
+  if (e != hipSuccess) return e;
+  float* staged = (float*)scratch;
+  float* sorted = staged + nn;
+  float* bnd = sorted + nn;
+  unsigned* miss = (unsigned*)(bnd + PGB_KEY_BOUNDS);
+  void* tmp = scratch + fl;
+  for (int c = 0; c < p && e == hipSuccess; ++c) {
+    const double* col = XT + (size_t)c * n_pad;
+    e = hipMemsetAsync(miss, 0, sizeof(unsigned), sm);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(k_key_stage, dim3(1024), dim3(BT), 0, sm, col, staged, n, miss);
+    e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, (const float*)staged, sorted, (int)nn, 0, 32, sm);
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(k_key_bounds, dim3(256), dim3(BT), 0, sm, (const float*)sorted, n, (const unsigned*)miss, bnd);
+    hipLaunchKernelGGL(k_key_assign, dim3(2048), dim3(BT), 0, sm, col, (const float*)bnd, keys + (size_t)c * n_pad, n_pad);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(sm);
+  (void)hipFree(scratch);
+  return e;
+}
+
 extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, const int32_t* rules_host,
                             const double* split_prior_host) {
   if (!h || !X_dev || !rules_host || !split_prior_host) return fail(PGB_E_INVALID, "null argument");
@@ -581,33 +613,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
         d.XK16 = xk;
         h->rows_mk_cap = 0;  // (another instance of the K-vector row pass from here on)
       }
-      // scratch of the build: [n] staged | [n] sorted | boundaries | counter | the sort's temporary storage
-      const size_t nn = (size_t)d.n;
-      size_t tmp_bytes = 0;
-      hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, (const float*)nullptr, (float*)nullptr, (int)nn, 0, 32, sm);
-      if (e != hipSuccess) return fail_hip(e, "hipcub::DeviceRadixSort (size query)");
-      const size_t fl = (2 * nn + PGB_KEY_BOUNDS + 64) * sizeof(float);
-      char* scratch = nullptr;
-      e = hipMalloc((void**)&scratch, fl + tmp_bytes + 256);
-      if (e != hipSuccess) return fail_hip(e, "hipMalloc (order-key scratch)");
-      float* staged = (float*)scratch;
-      float* sorted = staged + nn;
-      float* bnd = sorted + nn;
-      unsigned* miss = (unsigned*)(bnd + PGB_KEY_BOUNDS);
-      void* tmp = scratch + fl;
-      for (int c = 0; c < d.p && e == hipSuccess; ++c) {
-        const double* col = d.XT + (size_t)c * d.n_pad;
-        e = hipMemsetAsync(miss, 0, sizeof(unsigned), sm);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_key_stage, dim3(1024), dim3(BT), 0, sm, col, staged, (long long)d.n, miss);
-        e = hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, (const float*)staged, sorted, (int)nn, 0, 32, sm);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_key_bounds, dim3(256), dim3(BT), 0, sm, (const float*)sorted, (long long)d.n, (const unsigned*)miss, bnd);
-        hipLaunchKernelGGL(k_key_assign, dim3(2048), dim3(BT), 0, sm, col, (const float*)bnd, (uint16_t*)d.XK16 + (size_t)c * d.n_pad,
-                           (long long)d.n_pad);
-      }
-      if (e == hipSuccess) e = hipStreamSynchronize(sm);
-      hipFree(scratch);
+      hipError_t e = order_keys_build(d.XT, (long long)d.n, (long long)d.n_pad, d.p, (uint16_t*)d.XK16, sm);
       if (e != hipSuccess) return fail_hip(e, "order keys of the design matrix");
     }
   }

@@ -210,6 +210,17 @@ int pgbh_loglik_multi_lds(int family, int K, const double* y, const double* mu /
   if (rc == PGB_OK) st.back(out, A.o0, n);
   return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");
 }
+// the order keys pgb_set_data builds for a column (k_key_* + the radix sort), on a column the caller supplies
+int pgbh_order_keys(const double* x, int64_t n, uint16_t* keys) {  // (tests/test_spec_device_gpu.py)
+  probe::Stage st;
+  double* dx = st.in(x, n);
+  uint16_t* dk = st.out<uint16_t>(n);
+  if (!st.ok) return fail(PGB_E_DEVICE, "probe: allocation / copy failed");
+  const hipError_t e = order_keys_build(dx, (long long)n, (long long)n, 1, dk, nullptr);
+  if (e != hipSuccess) return fail_hip(e, "probe: order keys");
+  st.back(keys, dk, n);
+  return st.ok ? PGB_OK : fail(PGB_E_DEVICE, "probe: copy failed");
+}
 int pgbh_math_t(const double* x, int64_t n, double* e, double* l) {
   probe::Stage st;
   ProbeArgs A{};

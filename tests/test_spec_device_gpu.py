@@ -293,3 +293,45 @@ def test_leaf_algebra_device_equals_host_and_numpy(hip, oracle):
         host[i, 3] = lin_sse(float(sse_c[i]), o3[0], o3[1], o3[2], int(q_ur[i]), int(q_r[i]), sc["inv_c1"])
     for k, name in enumerate(("slope_u", "ubar", "var_u", "lin_sse")):
         _same_bits(outs[k], host[:, k], "pgb_lin_fit/" + name)
+
+
+# ------------------------------------------------------------------------------------------------
+# 16-bit order keys of a split column (pgb_set_data builds them for matrices beyond the Infinity Cache; k_rows<F32>)
+@pytest.mark.parametrize("kind", ["normal", "heavy_ties", "missing_and_inf", "constant", "tiny", "few_distinct_wide_range"])
+def test_order_keys_decide_like_the_values_or_abstain(hip, kind):
+    """key(x) < key(v) must imply x < v, key(x) > key(v) must imply x > v (equal keys abstain: the row pass then
+    compares the float64 values), a missing value has key 0xFFFF and nothing else has; on a continuous column the
+    bins are equi-depth, i.e. a value shares its key with about n / 65 535 rows."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    if kind == "normal":
+        x = rng.standard_normal(n)
+    elif kind == "heavy_ties":
+        x = rng.integers(0, 7, n).astype(float)
+    elif kind == "missing_and_inf":
+        x = rng.standard_normal(n) * 1e30
+        x[rng.random(n) < 0.1] = np.nan
+        x[:5] = [np.inf, -np.inf, 0.0, -0.0, 1e308]
+    elif kind == "constant":
+        x = np.full(n, 3.25)
+    elif kind == "tiny":
+        x = np.array([2.0, np.nan, -1.0])
+        n = 3
+    else:
+        x = np.where(rng.random(n) < 0.5, 1e-300, 1.0) * rng.integers(1, 4, n)
+    x = np.ascontiguousarray(x, float)
+    keys = np.zeros(n, np.uint16)
+    f = _fn(hip.lib.lib, "pgbh_order_keys", C.c_void_p, C.c_int64, C.c_void_p)
+    assert f(x.ctypes.data, n, keys.ctypes.data) == 0
+    miss = np.isnan(x)
+    assert np.array_equal(keys == 0xFFFF, miss)
+    xs, ks = x[~miss], keys[~miss].astype(np.int64)
+    order = np.argsort(xs, kind="stable")
+    assert np.all(np.diff(ks[order]) >= 0)                      # non-decreasing in x ...
+    # ... which is the property the row pass uses: for any v, key(x) < key(v) => x < v and key(x) > key(v) => x > v
+    for v_i in rng.integers(0, xs.size, 25):
+        v, kv = xs[v_i], ks[v_i]
+        assert np.all(xs[ks < kv] < v) and np.all(xs[ks > kv] > v)
+    if kind == "normal":
+        share = np.bincount(ks).max() / xs.size
+        assert share < 20 / 65535                               # equi-depth: ~3 rows per key here, never dozens

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Resident single-chain rate of a workload under the current environment knobs (median of REPS blocks of 20
-asteps after the standard burn-in).  usage (GPU box): [PGB_...=v] python tools/knob_probe.py [cfg2|cfg4|cfg5] [REPS] [K=6]   (K: outputs of cfg5)"""
+asteps after the standard burn-in).  usage (GPU box): [PGB_...=v] python tools/knob_probe.py [cfg2|cfg4|cfg5] [REPS] [K=6] [T=1]
+(K: outputs of cfg5; T=1: measure tuning asteps instead of draws)"""
 import os
 import sys
 import time
@@ -17,6 +18,7 @@ from pymc_bart_amd.sampler import PyBartSettings, PySampler, default_backend  # 
 wn = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[3:] if "=" in a}
+tune = bool(kw.pop("T", 0))
 w = getattr(workloads, wn)(**kw)
 X, Y = w["X"], w["Y"]
 st = PyBartSettings.from_data(X, Y, m=w["m"], num_particles=w["num_particles"], seed=3415, family=w["family"],
@@ -33,8 +35,8 @@ for _ in range(reps):
     c0 = s.sync()["particle_steps"]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    s.step_async(False, steps)
+    s.step_async(tune, steps)
     c1 = s.sync()["particle_steps"]
     rates.append((c1 - c0) / (time.perf_counter() - t0))
 knobs = {k: v for k, v in os.environ.items() if k.startswith("PGB_")}
-print(f"{wn} {kw} {knobs}: {np.median(rates) / 1e6:.4f} M (min {min(rates) / 1e6:.4f}, max {max(rates) / 1e6:.4f})")
+print(f"{wn} {kw} tune={int(tune)} {knobs}: {np.median(rates) / 1e6:.4f} M (min {min(rates) / 1e6:.4f}, max {max(rates) / 1e6:.4f})")
