@@ -91,7 +91,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
     const Job* jobs = S.jobs + (size_t)par * MAXP;
     if (tid < 64) {
       int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
-      bool plain = true;  // every particle with work splits the root of a fresh stump on a continuous column without NaNs
+      bool plain = true;   // every particle with work splits the root of a fresh stump on a continuous column without NaNs
+      bool common = true;  // every split is on a continuous column without NaNs (label-refresh-only jobs allowed)
 #pragma unroll
       for (int hq = 0; hq < MAXP / 64; ++hq) {
       const int q = tid + 64 * hq;
@@ -101,8 +102,11 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
       if (q >= 1 && q < S.P) j = jobs[q];
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
-      if (__any(has && !(j.active && j.src_slot < 0 && !j.check_nan && j.rule == PGB_RULE_CONTINUOUS && j.label == 0)))
-        plain = false;
+      {
+        const bool cont = !j.check_nan && j.rule == PGB_RULE_CONTINUOUS;
+        if (__any(has && j.active && !cont)) common = false;
+        if (__any(has && !(j.active && cont && j.src_slot < 0 && j.label == 0))) plain = false;
+      }
       if (has) {
         const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
         RJob rj;
@@ -125,13 +129,14 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
       }
       if (tid == 0) {
         s_n[0] = nlist;
-        s_n[1] = plain ? 1 : 0;
+        s_n[1] = plain ? 2 : common ? 1 : 0;
       }
     }
     __syncthreads();
     TRR(13, 0);
     const int nact = s_n[0];
-    const bool all_plain = !LIN && s_n[1] != 0;
+    const bool all_plain = !LIN && s_n[1] == 2;
+    const bool all_common = !LIN && F32 && s_n[1] == 1;  // (the pipelined common round: shadow instances only)
     if (nact == 0 && !do_init) {
       if (pstamp) pstamp[1] = wall_clock64();
       return;
@@ -304,7 +309,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
             }
           }
         };
-        if (!plain_item) fetch1(g0);  // (next to the loads of the rows' sum_trees, before anything waits for those)
+        const bool common_item = all_common && g1 > g0;
+        if (!plain_item && !common_item) fetch1(g0);  // (next to the loads of the rows' sum_trees, before anything waits for those)
         long long qst[RPT][KB];  // quantised once per row, reused by every particle of the group
 #pragma unroll
         for (int e = 0; e < RPT; ++e)
@@ -399,6 +405,85 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
         // relabelled and reduced (the values just arrived move to the working registers, the next loads go out
         // behind them: no register with a load in flight is moved).  Rounds >= 2 are short chains of a few particles
         // per item, each a memory round trip before this.
+        // ---- common round (shadow instances; see k_rows): every split of the pass is on a continuous column without
+        // missing values (label-refresh-only particles included): labels and keys of PD particles in flight.
+        if constexpr (!LIN && F32) {
+          if (common_item) {
+            constexpr int PD = KB == 4 ? 3 : 4;
+            uint2 ck[PD];
+            uint32_t cl4[PD];
+            auto fetchc = [&](int gg, uint2& ff, uint32_t& fl) {
+              const RJob& rn = s_job[gg < g1 ? gg : g1 - 1];
+              ff = gload_k4(S.XK16 + uni(rn.xoff) + base);  // (a label-only job: column 0, not used)
+              const long long so = uni(rn.src);
+              fl = *(const uint32_t*)(S.lid + (so < 0 ? 0ll : so) + base);  // (an implicit root: loaded, not used)
+            };
+            auto stagec = [&](int g, uint2& ff, uint32_t& fl, bool more) {
+              const RJob& rj = s_job[g];
+              const bool act = uni(rj.active) != 0;
+              const double r_v = uni(rj.v);
+              const uint32_t r_vk = uni((uint32_t)rj.vkey);
+              const uint32_t nw = uni((uint32_t)rj.new_label), lb = uni((uint32_t)rj.label);
+              const long long xo = uni(rj.xoff);
+              uint8_t* const dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
+              const uint32_t ids = uni(rj.src) < 0 ? root_ids : fl;
+              const uint32_t xk[RPT] = {ff.x & 0xFFFFu, ff.x >> 16, ff.y & 0xFFFFu, ff.y >> 16};
+              bool in[RPT], L[RPT];
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                in[e] = act && ((ids >> (8 * e)) & 255u) == lb;
+                L[e] = xk[e] < r_vk;
+              }
+              if (__any((in[0] && xk[0] == r_vk) | (in[1] && xk[1] == r_vk) | (in[2] && xk[2] == r_vk) | (in[3] && xk[3] == r_vk))) {
+#pragma unroll
+                for (int e = 0; e < RPT; ++e)
+                  if (in[e] && xk[e] == r_vk) L[e] = S.XT[xo + base + e] <= r_v;  // equal keys: the float64 values decide
+              }
+              if (more) fetchc(g + PD, ff, fl);
+              uint32_t out = ids, cl = 0, cr = 0;
+              long long aL[KB];
+#pragma unroll
+              for (int kk = 0; kk < KB; ++kk) aL[kk] = 0;
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const bool le = in[e] && L[e], ri = in[e] && !L[e];
+                out = ri ? ((out & ~(255u << (8 * e))) | (nw << (8 * e))) : out;
+                cl += le ? 1u : 0u;
+                cr += ri ? 1u : 0u;
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) aL[kk] += le ? qst[e][kk] : 0ll;
+              }
+              if (first) *(uint32_t*)dp = out;
+              if (act) {
+                const int slot = (g - g0) * NVT;
+                if constexpr (KB == 4) {
+                  const long long tot = wave_sum4(aL[0], aL[1], aL[2], aL[3]);
+                  if (lane < 4) s_red[(slot + 1 + lane) * 4 + w] = tot;
+                  const long long c = wave_sum_dpp((long long)(cl | (cr << 20)));  // (lane 63 holds the total)
+                  if (lane == 63) s_red[slot * 4 + w] = c;
+                } else {
+                  const long long tot = wave_sum4((long long)(cl | (cr << 20)), aL[0], aL[KB > 1 ? 1 : 0], aL[KB > 2 ? 2 : 0]);
+                  if (lane < 1 + KB) s_red[(slot + lane) * 4 + w] = tot;
+                }
+              }
+            };
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+              ck[d] = uint2{0u, 0u};
+              cl4[d] = 0u;
+              fetchc(g0 + d, ck[d], cl4[d]);
+            }
+            const int g_main = g0 + (g1 - g0) / PD * PD;
+            for (int gb = g0; gb < g_main; gb += PD) {
+#pragma unroll
+              for (int d = 0; d < PD; ++d) stagec(gb + d, ck[d], cl4[d], true);
+            }
+#pragma unroll
+            for (int d = 0; d < PD; ++d)
+              if (g_main + d < g1) stagec(g_main + d, ck[d], cl4[d], false);
+            g_first = g1;
+          }
+        }
         for (int g = g_first; g < g1; ++g) {
           const RJob& rj = s_job[g];
           // (a later tile finds the rows of the leaf in the labels as they were BEFORE this pass -- the source
