@@ -393,7 +393,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
         # (1 B each) and the split column (8 B per row; 2 B of order keys when the matrix exceeds
         # the Infinity Cache); each particle group re-reads {sum_trees, r} (16 B per row); a tree-boundary
         # pass adds the INIT/FINAL streams (~26 B read per row and group, 25 B written per row)
-        shadow = K_out <= 4 and response == "constant" and p * (nchunks * 1024) * 8 >= (192 << 20)
+        shadow = response == "constant" and p * (nchunks * 1024) * 8 >= (192 << 20)
         xbytes = 2.0 if shadow else 8.0
         impl = parts * (2.0 + xbytes) * n + launches * ngroups * 16.0 * n + tu * (ngroups * 26.0 + 25.0) * n
         avg_us = ms_rows * 1e3 / max(launches, 1)

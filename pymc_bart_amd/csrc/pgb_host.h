@@ -604,7 +604,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
     size_t min_bytes = (size_t)192 << 20;
     if (const char* e = getenv("PGB_X32_MIN_MB")) min_bytes = (size_t)atoll(e) << 20;
     const size_t count = (size_t)d.p * d.n_pad;
-    if (d.K <= 4 && d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
+    if (d.response == PGB_RESPONSE_CONSTANT && !h->has_subset && count * sizeof(double) >= min_bytes) {
       if (!d.XK16) {
         uint16_t* xk = nullptr;
         int rck = dalloc(h, &xk, count);
@@ -774,7 +774,7 @@ static int enqueue_slots(pgb_handle* h, int count) {
                        : d.K == 2 ? (f32 ? (const void*)k_rows_mk<2, false, true> : (const void*)k_rows_mk<2, false>)
                        : d.K == 3 ? (f32 ? (const void*)k_rows_mk<3, false, true> : (const void*)k_rows_mk<3, false>)
                        : d.K == 4 ? (f32 ? (const void*)k_rows_mk<4, false, true> : (const void*)k_rows_mk<4, false>)
-                                  : (const void*)k_rows_mk<0, false>;
+                                  : (f32 ? (const void*)k_rows_mk<0, false, true> : (const void*)k_rows_mk<0, false>);
       int per_cu = 0, cus = 0;
       h->rows_mk_cap = h->rows_grid;
       if (!getenv("PGB_ROWS_GRID") && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kf, BT, 0) == hipSuccess &&
@@ -809,7 +809,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
       if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par);
       else LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
     } else if (d.K > 1) {
-      LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<0, false, true>), grows, dd, par);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (lin && h->has_subset) {  // (a linear leaf regresses on whatever column its parent split on)
