@@ -311,7 +311,9 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
 }
 
 // MK: K-vector leaves (K > 1).  The single-output instantiation contains none of that code.
-template <bool MK, bool LIN>
+// KEYS: the data set has 16-bit order keys (XK16): the key of a split value is read with the value.  A separate
+// instance, so that the one the small data sets launch (cfg2) carries none of it (0.07 us per launch otherwise).
+template <bool MK, bool LIN, bool KEYS = false>
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(1, 1)))  // latency kernel: registers, not occupancy
 void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctrls, const InitAcc* __restrict__ ias,
             const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const DPart* __restrict__ parts_all,
@@ -883,7 +885,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       if (attempt) {
         TR(6);
         sr = select_split_row(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
-                              s_pre1[0], xk16, TR_REC);
+                              s_pre1[0], KEYS ? xk16 : nullptr, TR_REC);
       }
       TR(7);
       Job job;
@@ -1294,7 +1296,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
     if (tid < 64) {
       TR(6);
       const SplitRow sr = select_split_row(S, s_i[8 + set], s_i[10 + set] == PGB_RULE_SUBSET, job.src_gen, job.src_slot,
-                                           ncnt, ncc, nlabel, s_pre[set], s_pre1[set], xk16);
+                                           ncnt, ncc, nlabel, s_pre[set], s_pre1[set], KEYS ? xk16 : nullptr);
       if (tid == 0) {
         s_i[14] = sr.found;  // (not s_i[0]: waves 1..3 read s_i[0..1] after the resampling barrier and no later barrier orders them)
         s_i[15] = sr.vkey;

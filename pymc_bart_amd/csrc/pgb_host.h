@@ -792,8 +792,10 @@ static int enqueue_slots(pgb_handle* h, int count) {
     int par = (int)(h->slot & 1);
 #define CTRL_ARGS(nwg) dd, par, (int)(nwg), d.ctrl, (const InitAcc*)d.initacc, (const Job*)d.jobs, (const Acc*)d.acc, (const DPart*)d.parts, (const uint16_t*)d.XK16
     if (d.K > 1 && lin) LAUNCH_K(PK_CTRL, (k_ctrl<true, true>), gctrl, CTRL_ARGS(gctrl.x));
+    else if (d.K > 1 && d.XK16) LAUNCH_K(PK_CTRL, (k_ctrl<true, false, true>), gctrl, CTRL_ARGS(gctrl.x));
     else if (d.K > 1) LAUNCH_K(PK_CTRL, (k_ctrl<true, false>), gctrl, CTRL_ARGS(gctrl.x));
     else if (lin) LAUNCH_K(PK_CTRL, (k_ctrl<false, true>), gctrl, CTRL_ARGS(gctrl.x));
+    else if (d.XK16) LAUNCH_K(PK_CTRL, (k_ctrl<false, false, true>), dim3((unsigned)d.P), CTRL_ARGS(d.P));
     else LAUNCH_K(PK_CTRL, (k_ctrl<false, false>), dim3((unsigned)d.P), CTRL_ARGS(d.P));  // + the workgroup that builds the label tables ahead
 #undef CTRL_ARGS
 #define ROWS_ARGS dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs

@@ -22,7 +22,7 @@
 //     launch geometry and atomics order, and identical to the CPU oracle.
 //   * Kernel instances are compiled per data set where the hot loop has no registers or
 //     instructions to spare: k_rows<SubsetSplit columns?, Normal family?, linear response?>,
-//     k_rows_mk<K>, k_loglik<K, family>, k_ctrl<multi-output?, linear response?>.
+//     k_rows_mk<K>, k_loglik<K, family>, k_ctrl<multi-output?, linear response?, order keys?>.
 //   * No MFMA: the path is gather / partition / reduce (HBM / L2 bound).
 //
 #include <hip/hip_runtime.h>
