@@ -439,14 +439,32 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         off_c[k] = goff + (size_t)kc * S.n_pad + cbase;
       }
       const bool has_off = S.has_off != 0;
-      for (int g = g0; g < g1; ++g) {
-        const LJob& lj = s_job[g];
+      // a lane's OWN four rows (y and the K predictors without the leaf value): what every particle whose leaf still
+      // holds most of the wave's rows evaluates, lane by row -- in the slot that starts a tree that is every particle
+      // of the span, and the same 20 values were fetched again for each of them, pass by pass.  Compile-time K:
+      // loaded once per item, when the first such particle comes up, and kept in registers.
+      constexpr bool OWN = KT > 0;
+      double own_y[OWN ? RPT : 1], own_nk[OWN ? RPT : 1][OWN ? KB : 1];
+      bool own_have = false;
+      // the label words of particle g + 1 are requested before particle g's passes (each of which is hundreds of
+      // instructions): requested where they are used, they cost every particle of the span a memory round trip in
+      // front of its first ballot -- with the first pass's inputs behind it, half of the wave-cycles of the launch
+      // that starts a tree at cfg5 (three waves per SIMD: nothing else to issue meanwhile)
+      const uint32_t base32 = (uint32_t)base;  // (n < 2^31)
+      uint32_t ids_nx = root_ids, nid_nx = 0;
+      auto fetch_labels = [&](int gg) {
+        const LJob& ln = s_job[gg];
         // (the record is the same in every lane: its offsets and labels go to scalar registers, the label words
         //  are fetched at scalar base + 32-bit row offset)
-        const long long src_u = uni(lj.src), dst_u = uni(lj.dst);
-        const uint32_t base32 = (uint32_t)base;  // (n < 2^31)
-        const uint32_t ids = src_u < 0 ? root_ids : gload_u32_off(glid + src_u, base32);
-        const uint32_t nid = gload_u32_off(newl + dst_u, base32);
+        const long long src_u = uni(ln.src), dst_u = uni(ln.dst);
+        ids_nx = src_u < 0 ? root_ids : gload_u32_off(glid + src_u, base32);
+        nid_nx = gload_u32_off(newl + dst_u, base32);
+      };
+      if (g0 < g1) fetch_labels(g0);
+      for (int g = g0; g < g1; ++g) {
+        const LJob& lj = s_job[g];
+        const uint32_t ids = ids_nx, nid = nid_nx;
+        if (g + 1 < g1) fetch_labels(g + 1);
         const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
         // (compile-time K: the particle's leaf values in registers; run-time K: read from its LDS record where used)
         constexpr int KV = KT > 0 ? KT : 1;
@@ -483,6 +501,21 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if constexpr (OWN) {
+          if (!dense && !own_have) {  // (wave-uniform)
+#pragma unroll
+            for (int e = 0; e < RPT; ++e) {
+              const uint32_t ro = (uint32_t)(tid * RPT + e) * 8u;
+              own_y[e] = gload_d_off(gy_c, ro);
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                const double nk = gload_d_off(noi_c[k], ro);
+                own_nk[e][k] = has_off ? nk + gload_d_off(off_c[k], ro) : nk;
+              }
+            }
+            own_have = true;
+          }
+        }
         const int npass = dense ? (M + 63) >> 6 : RPT;
         // (only a split on a column with missing values drops rows -- uniform per particle: the pass loop is
         //  compiled with and without the third side, see the single-output loop below)
@@ -517,6 +550,18 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
             in.ro = r * 8u;  // (r < 1024)
 #pragma unroll
             for (int k = 0; k < KB; ++k) in.nk[k] = 0.0;
+            if constexpr (OWN) {
+              if (!dense) {  // the lane's own row ps: in registers (the pass loop is unrolled over ps below)
+#pragma unroll
+                for (int e = 0; e < RPT; ++e)
+                  if (e == ps) {
+                    in.y = own_y[e];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) in.nk[k] = own_nk[e][k];
+                  }
+                return in;
+              }
+            }
             if (in.act) {
               in.y = gload_d_off(gy_c, in.ro);
 #pragma unroll
