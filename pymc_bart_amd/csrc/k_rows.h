@@ -321,48 +321,37 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       // ---- plain round: EVERY particle of the pass splits the root of a fresh stump (implicit root labels: all
       // rows of a full chunk are in the leaf) on a continuous column without missing values -- the slot that starts
       // a tree, half of this kernel's time at cfg4, where one workgroup walks ONE item of 39 particles.  One stage
-      // of prefetch left that walk waiting a whole memory round trip per particle (~1.4 us x 39; fewer bytes
-      // -- 16-bit keys -- and fewer instructions -- no label compare, LDS atomics for butterflies -- changed
-      // nothing: profiles/r04_experiments.md): here the split columns of PD particles are in flight, in registers
-      // that are never moved (the loop is unrolled by PD: a register shift would wait for the loads it moves).
+      // of prefetch left that walk waiting a whole memory round trip per particle (~1.4 us x 39; fewer bytes and
+      // fewer instructions -- no label compare, LDS atomics for butterflies -- changed nothing before that was gone:
+      // profiles/r04_experiments.md section 8): here the keys of PD particles' split columns are in flight, in
+      // registers that are never moved (the loop is unrolled by PD: a register shift would wait for the loads it moves).
       if constexpr (!LIN && F32) {  // (F32: the data sets beyond the Infinity Cache; the smaller ones keep their registers)
         if (plain_item) {
           constexpr int PD = 4;
-          double2 pa[PD], pb[PD];
           uint2 pf[PD];
           // (every load and store of the loop is unconditional -- past the end the last particle's column is
           //  requested again and dropped -- so that the number of operations in flight behind the one being
           //  waited for is the same on every path and the wait can leave them in flight)
-          auto fetch = [&](int gg, double2& f0, double2& f1, uint2& ff) {
-            const long long xo = uni(s_job[gg < g1 ? gg : g1 - 1].xoff);
-            if constexpr (F32) {
-              ff = gload_k4(XK + xo + base);
-            } else {
-              f0 = gload_d2(XT + xo + base);
-              f1 = gload_d2(XT + xo + base + 2);
-            }
-          };
+          auto fetch = [&](int gg, uint2& ff) { ff = gload_k4(XK + uni(s_job[gg < g1 ? gg : g1 - 1].xoff) + base); };
           // one particle from its stage registers; `more`: request the column of particle g + PD into them
-          auto stage = [&](int g, double2& f0, double2& f1, uint2& ff, bool more) {
+          auto stage = [&](int g, uint2& ff, bool more) {
             const RJob& rj = s_job[g];
             const double r_v = uni(rj.v);
             const uint32_t r_vk = uni((uint32_t)rj.vkey);
             const uint32_t nw = uni((uint32_t)rj.new_label);
             const long long xo = uni(rj.xoff);
             const gptr<uint8_t> __restrict__ dp = dst0 + (size_t)uni(rj.p) * n_pad + base;
-            const double x[RPT] = {f0.x, f0.y, f1.x, f1.y};
             const uint32_t xk[RPT] = {ff.x & 0xFFFFu, ff.x >> 16, ff.y & 0xFFFFu, ff.y >> 16};
             bool L[RPT];
 #pragma unroll
-            for (int e = 0; e < RPT; ++e) L[e] = F32 ? (xk[e] < r_vk) : (x[e] <= r_v);
-            if constexpr (F32) {  // equal keys (the row of the split value and its bin mates) are decided on the float64 values
-              if (__any((xk[0] == r_vk) | (xk[1] == r_vk) | (xk[2] == r_vk) | (xk[3] == r_vk))) {
+            for (int e = 0; e < RPT; ++e) L[e] = xk[e] < r_vk;
+            // equal keys (the row of the split value and its bin mates) are decided on the float64 values
+            if (__any((xk[0] == r_vk) | (xk[1] == r_vk) | (xk[2] == r_vk) | (xk[3] == r_vk))) {
 #pragma unroll
-                for (int e = 0; e < RPT; ++e)
-                  if (xk[e] == r_vk) L[e] = XT[xo + base + e] <= r_v;
-              }
+              for (int e = 0; e < RPT; ++e)
+                if (xk[e] == r_vk) L[e] = XT[xo + base + e] <= r_v;
             }
-            if (more) fetch(g + PD, f0, f1, ff);
+            if (more) fetch(g + PD, ff);
             uint32_t out = root_ids, cl = 0, cr = RPT;
             long long a1 = 0, a2 = 0, a3 = 0;
             if (full_chunk) {
@@ -397,18 +386,17 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
           };
 #pragma unroll
           for (int d = 0; d < PD; ++d) {
-            pa[d] = pb[d] = double2{0.0, 0.0};
             pf[d] = uint2{0u, 0u};
-            fetch(g0 + d, pa[d], pb[d], pf[d]);
+            fetch(g0 + d, pf[d]);
           }
           const int g_main = g0 + (g1 - g0) / PD * PD;  // whole blocks of PD particles, then the rest from their stages
           for (int gb = g0; gb < g_main; gb += PD) {
 #pragma unroll
-            for (int d = 0; d < PD; ++d) stage(gb + d, pa[d], pb[d], pf[d], true);
+            for (int d = 0; d < PD; ++d) stage(gb + d, pf[d], true);
           }
 #pragma unroll
           for (int d = 0; d < PD; ++d)
-            if (g_main + d < g1) stage(g_main + d, pa[d], pb[d], pf[d], false);
+            if (g_main + d < g1) stage(g_main + d, pf[d], false);
           g_first = g1;
         }
       }
