@@ -117,6 +117,11 @@ typedef struct {
   double* slope;      /* [total_nodes * n_outputs]                              */
   double* xbar;       /* [total_nodes]                                          */
   int32_t* svar;      /* [total_nodes]                                          */
+  /* The trees describe themselves: the PGB_RULE_* each split node was grown under (0 for a leaf), so that a
+   * history rebuilt by the reference's unmodified call PosteriorSampler.from_history(batches, baseline_forest,
+   * op.m, op.n_outputs) (utils.py:124-127 -- it passes no split rules) predicts one-hot / subset splits
+   * correctly.  Filled by every export; read by pgb_predict (NULL there = every split is continuous).        */
+  int32_t* rule;      /* [total_nodes]                                          */
 } pgb_tree_arrays;
 
 const char* pgb_last_error(void);
@@ -222,12 +227,14 @@ int pgb_get_split_weights(pgb_handle* h, double* alpha_vec_host_out);
  * out[d][k][row] = sum over the trees of forest d of the leaf value reached by
  * X[row,:]; at a split on an excluded variable or a NaN value the result is the
  * count-weighted mean of both subtrees.  `forest_tree_idx` is [n_forests][m]
- * indices into `trees`.  X_dev row-major n_rows x p; out_dev n_forests*K*n_rows;
- * rules_host[p] are the PGB_RULE_* of the columns.                              */
+ * indices into `trees`.  X_dev row-major n_rows x p; out_dev n_forests*K*n_rows.
+ * How a split sends a row left (x <= v, x == v, x in the subset v) is read from the
+ * node itself (trees_host->rule): the call takes no per-column rules, as the
+ * reference's from_history / sample_posterior take none.                        */
 int pgb_predict(const pgb_tree_arrays* trees_host, const int32_t* forest_tree_idx_host,
                 int32_t n_forests, int32_t m, const double* X_dev, int64_t n_rows, int32_t p,
-                int64_t ldx, const int32_t* rules_host, const int32_t* excluded_host,
-                int32_t n_excluded, double* out_dev, void* stream);
+                int64_t ldx, const int32_t* excluded_host, int32_t n_excluded, double* out_dev,
+                void* stream);
 
 /* Profiling aid for bench.py: when enabled, the backend brackets every launch of
  * its dominant kernel with events on its stream and accumulates their duration. */

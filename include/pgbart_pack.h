@@ -3,8 +3,10 @@
  * backend-independent implementation on top of pgb_export_trees.  Included by both backends.
  *
  * Record (little endian, every array contiguous):
- *   int32  n_trees, n_outputs (K), total_nodes (N), flags (bit 0: the linear-response arrays are present)
- *   int32  tree_id[n_trees], node_off[n_trees + 1], var[N], left[N], right[N], (svar[N])
+ *   int32  n_trees, n_outputs (K), total_nodes (N), flags (bit 0: the linear-response arrays are present;
+ *          bit 1: the per-node split rules are present -- always set by this version, records written before
+ *          round 5 lack the array and every split of theirs reads as continuous)
+ *   int32  tree_id[n_trees], node_off[n_trees + 1], var[N], left[N], right[N], rule[N], (svar[N])
  *   -- zero padding to a multiple of 8 bytes --
  *   double split[N];  int64 count[N];  double value[N * K];  (double slope[N * K];  double xbar[N])
  * Counterpart of the reference's TreeArrays crossing the PyO3 boundary in one object
@@ -19,9 +21,10 @@
 #include "pgbart.h"
 
 #define PGB_PACK_LINEAR 1
+#define PGB_PACK_RULES 2
 
 static inline int64_t pgb_packed_bytes(int32_t nt, int32_t N, int32_t K, int lin) {
-  int64_t ints = 4 + (int64_t)nt + (nt + 1) + 3 * (int64_t)N + (lin ? N : 0);
+  int64_t ints = 4 + (int64_t)nt + (nt + 1) + 4 * (int64_t)N + (lin ? N : 0);
   int64_t head = (ints * 4 + 7) & ~(int64_t)7;
   return head + 8 * ((int64_t)N * 2 + (int64_t)N * K + (lin ? (int64_t)N * K + N : 0));
 }
@@ -29,7 +32,7 @@ static inline int64_t pgb_packed_bytes(int32_t nt, int32_t N, int32_t K, int lin
 /* Point the arrays of `out` into a record buffer laid out for (nt, N, K, lin) and write its header. */
 static inline void pgb_packed_bind(void* buf, int32_t nt, int32_t N, int32_t K, int lin, pgb_tree_arrays* out) {
   int32_t* ip = (int32_t*)buf;
-  ip[0] = nt; ip[1] = K; ip[2] = N; ip[3] = lin ? PGB_PACK_LINEAR : 0;
+  ip[0] = nt; ip[1] = K; ip[2] = N; ip[3] = PGB_PACK_RULES | (lin ? PGB_PACK_LINEAR : 0);
   int32_t* q = ip + 4;
   out->n_trees = nt; out->n_outputs = K; out->total_nodes = N;
   out->tree_id = q; q += nt;
@@ -37,6 +40,7 @@ static inline void pgb_packed_bind(void* buf, int32_t nt, int32_t N, int32_t K, 
   out->var = q; q += N;
   out->left = q; q += N;
   out->right = q; q += N;
+  out->rule = q; q += N;
   out->svar = lin ? q : (int32_t*)0; q += lin ? N : 0;
   int64_t ints = (int64_t)(q - ip);
   if (ints & 1) *q = 0; /* the padding word */

@@ -941,6 +941,8 @@ int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* out) {
       out->left[off + k] = z->left;
       out->right[off + k] = z->right;
       out->count[off + k] = z->cnt;
+      /* the trees describe themselves (include/pgbart.h): utils.py:124-127 rebuilds predictors without rules */
+      if (out->rule) out->rule[off + k] = z->var >= 0 ? h->rules[z->var] : PGB_RULE_CONTINUOUS;
       const int K = h->s.n_outputs;
       out->value[(size_t)(off + k) * K] = z->var < 0 ? z->value : 0.0;
       if (out->slope && out->xbar && out->svar) {
@@ -988,8 +990,7 @@ int pgb_get_split_weights(pgb_handle* h, double* out) {
 /* [U] Tree.predict with `excluded` (CHANGELOG.md:410-411): at a split on an excluded
  * variable or a NaN value, the count-weighted mean of both subtrees. */
 static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const double* x,
-                          const uint8_t* excl, const int32_t* rules, int K, double w,
-                          double* acc) {
+                          const uint8_t* excl, int K, double w, double* acc) {
   for (;;) {
     int g = base + k;
     if (T->var[g] < 0) {
@@ -1009,18 +1010,19 @@ static void o_predict_rec(const pgb_tree_arrays* T, int base, int k, const doubl
       double cl = (double)T->count[base + l], cr = (double)T->count[base + r];
       double tot = cl + cr;
       if (!(tot > 0.0)) return;
-      o_predict_rec(T, base, l, x, excl, rules, K, w * (cl / tot), acc);
-      o_predict_rec(T, base, r, x, excl, rules, K, w * (cr / tot), acc);
+      o_predict_rec(T, base, l, x, excl, K, w * (cl / tot), acc);
+      o_predict_rec(T, base, r, x, excl, K, w * (cr / tot), acc);
       return;
     }
-    int rule = rules[j];
+    int rule = T->rule ? T->rule[g] : PGB_RULE_CONTINUOUS; /* the node's own rule */
     int go_left = pgb_go_left(rule, xv, T->split[g]);
     k = go_left ? T->left[g] : T->right[g];
   }
 }
 
 /* A malformed history (truncated file, mismatched m) must be an error, not an out-of-bounds walk:
- * 1 = forest index outside the tree list, 2 = inconsistent node arrays, 3 = split column >= p. */
+ * 1 = forest index outside the tree list, 2 = inconsistent node arrays, 3 = split column >= p,
+ * 4 = unknown split rule on a node. */
 static int pgb_validate_forest(const pgb_tree_arrays* T, const int32_t* fidx, int32_t n_forests, int32_t m,
                                int32_t p) {
   for (int64_t i = 0; i < (int64_t)n_forests * m; ++i)
@@ -1032,6 +1034,8 @@ static int pgb_validate_forest(const pgb_tree_arrays* T, const int32_t* fidx, in
     for (int g = base; g < end; ++g) {
       if (T->var[g] < 0) continue;
       if (T->var[g] >= p) return 3;
+      if (T->rule && T->rule[g] != PGB_RULE_CONTINUOUS && T->rule[g] != PGB_RULE_ONEHOT && T->rule[g] != PGB_RULE_SUBSET)
+        return 4;
       if (T->left[g] < 0 || T->right[g] < 0 || T->left[g] >= end - base || T->right[g] >= end - base) return 2;
     }
   }
@@ -1040,17 +1044,16 @@ static int pgb_validate_forest(const pgb_tree_arrays* T, const int32_t* fidx, in
 
 int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
                 int32_t m, const double* X, int64_t n_rows, int32_t p, int64_t ldx,
-                const int32_t* rules, const int32_t* excluded, int32_t n_excluded, double* out,
-                void* stream) {
+                const int32_t* excluded, int32_t n_excluded, double* out, void* stream) {
   (void)stream;
-  if (!trees || !forest_tree_idx || !X || !out || !rules)
-    return fail(PGB_E_INVALID, "null argument");
+  if (!trees || !forest_tree_idx || !X || !out) return fail(PGB_E_INVALID, "null argument");
   int K = trees->n_outputs;
   {
     int vrc = pgb_validate_forest(trees, forest_tree_idx, n_forests, m, p);
     if (vrc == 1) return fail(PGB_E_INVALID, "forest_tree_idx entry outside [0, n_trees)");
     if (vrc == 2) return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
     if (vrc == 3) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
+    if (vrc == 4) return fail(PGB_E_INVALID, "a split node carries an unknown split rule");
   }
   uint8_t* excl = (uint8_t*)calloc(p, 1);
   for (int e = 0; e < n_excluded; ++e)
@@ -1061,7 +1064,7 @@ int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, in
       for (int o = 0; o < K; ++o) acc[o] = 0.0;
       for (int t = 0; t < m; ++t) {
         int ti = forest_tree_idx[(size_t)d * m + t];
-        o_predict_rec(trees, trees->node_off[ti], 0, X + i * ldx, excl, rules, K, 1.0, acc);
+        o_predict_rec(trees, trees->node_off[ti], 0, X + i * ldx, excl, K, 1.0, acc);
       }
       for (int o = 0; o < K; ++o) out[((size_t)d * K + o) * n_rows + i] = acc[o];
     }

@@ -141,6 +141,7 @@ class TreeArraysC(C.Structure):
         ("slope", C.POINTER(C.c_double)),
         ("xbar", C.POINTER(C.c_double)),
         ("svar", C.POINTER(C.c_int32)),
+        ("rule", C.POINTER(C.c_int32)),
     ]
 
 
@@ -189,7 +190,7 @@ class PGBLibrary:
         lib.pgb_get_split_weights.argtypes = [vp, vp]
         lib.pgb_predict.argtypes = [
             C.POINTER(TreeArraysC), vp, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32,
-            C.c_int64, vp, vp, C.c_int32, vp, vp,
+            C.c_int64, vp, C.c_int32, vp, vp,
         ]
         lib.pgb_profile.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.pgb_profile_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

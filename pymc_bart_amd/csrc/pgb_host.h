@@ -68,6 +68,7 @@ struct pgb_handle {
   pgb_loglik_fn cb_fn;
   void* cb_ctx;
   std::vector<double> y_host, off_host;
+  std::vector<int32_t> rules_host;  // the PGB_RULE_* of the columns: every exported split node carries its own
   int device;
   std::thread worker;
   int job_running, job_rc;
@@ -568,6 +569,7 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
   }
   d.max_prior = mx;
   d.alpha_unit = pgb_alpha_unit(mx);
+  h->rules_host.assign(rules_host, rules_host + d.p);
   hipStream_t sm = h->stream;
   HIPCHK(hipMemcpyAsync((void*)d.rules, rules_host, d.p * sizeof(int32_t), hipMemcpyHostToDevice, sm));
   // the prior is staged in the (not yet used) running-sd buffer and quantised on the device
@@ -1244,6 +1246,16 @@ extern "C" int pgb_sync(pgb_handle* h, pgb_counters* counters_out) {
   return fetch_counters(h, counters_out);
 }
 
+// the trees describe themselves (include/pgbart.h, pgb_tree_arrays::rule): how each split node sends a row left
+static void fill_node_rules(const pgb_handle* h, pgb_tree_arrays* out, int total) {
+  if (!out->rule) return;
+  const int p = (int)h->rules_host.size();
+  for (int g = 0; g < total; ++g) {
+    const int j = out->var[g];
+    out->rule[g] = j >= 0 && j < p ? h->rules_host[j] : PGB_RULE_CONTINUOUS;
+  }
+}
+
 // the trees of the last pgb_step_host, already in host memory (k_export_step)
 static int export_from_block(pgb_handle* h, pgb_tree_arrays* out) {
   const StepOutHdr* H = (const StepOutHdr*)h->out_host;
@@ -1265,6 +1277,7 @@ static int export_from_block(pgb_handle* h, pgb_tree_arrays* out) {
   memcpy(out->split, B + L.split, (size_t)total * 8);
   memcpy(out->count, B + L.count, (size_t)total * 8);
   memcpy(out->value, B + L.value, (size_t)total * 8 * K);
+  fill_node_rules(h, out, total);
   if (out->slope && out->xbar && out->svar) {
     if (H->lin) {
       memcpy(out->slope, B + L.slope, (size_t)total * 8 * K);
@@ -1347,6 +1360,7 @@ extern "C" int pgb_export_trees(pgb_handle* h, int32_t which, pgb_tree_arrays* o
     off += T.n_nodes;
   }
   out->node_off[nt] = off;
+  fill_node_rules(h, out, total);
   return PGB_OK;
 }
 
@@ -1412,10 +1426,9 @@ extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
 
 extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_tree_idx, int32_t n_forests,
                            int32_t m, const double* X_dev, int64_t n_rows, int32_t p, int64_t ldx,
-                           const int32_t* rules_host, const int32_t* excluded_host, int32_t n_excluded,
+                           const int32_t* excluded_host, int32_t n_excluded,
                            double* out_dev, void* stream) {
-  if (!trees || !forest_tree_idx || !X_dev || !out_dev || !rules_host)
-    return fail(PGB_E_INVALID, "null argument");
+  if (!trees || !forest_tree_idx || !X_dev || !out_dev) return fail(PGB_E_INVALID, "null argument");
   if (trees->n_outputs < 1 || trees->n_outputs > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "n_outputs");
   if (n_forests < 1 || n_rows < 1) return PGB_OK;
   // a malformed history (truncated file, mismatched m) is an error, not an out-of-bounds walk
@@ -1430,6 +1443,9 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
     for (int g = base; g < end; ++g) {
       if (trees->var[g] < 0) continue;
       if (trees->var[g] >= p) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
+      if (trees->rule && trees->rule[g] != PGB_RULE_CONTINUOUS && trees->rule[g] != PGB_RULE_ONEHOT &&
+          trees->rule[g] != PGB_RULE_SUBSET)
+        return fail(PGB_E_INVALID, "a split node carries an unknown split rule");
       if (trees->left[g] < 0 || trees->right[g] < 0 || trees->left[g] >= end - base || trees->right[g] >= end - base)
         return fail(PGB_E_INVALID, "tree arrays are inconsistent (node_off / left / right)");
     }
@@ -1454,6 +1470,7 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   FNode* hf = (FNode*)(hb.data() + o_fn);
   int2* hroot = (int2*)(hb.data() + o_root);
   std::vector<int> depth_of;
+  bool cont = true;  // every split of every tree is `x <= v`: the instance without the rule dispatch
   int32_t* hsvar = (int32_t*)(hb.data() + o_svar);
   for (int t = 0; t < NT; ++t) {
     const int base = trees->node_off[t], end = trees->node_off[t + 1];
@@ -1480,7 +1497,9 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
       if (z.var >= p) return fail(PGB_E_INVALID, "a tree splits on a column X does not have");
       z.left = z.var >= 0 ? base + trees->left[g] : -1;
       z.right = z.var >= 0 ? base + trees->right[g] : -1;
-      z.flags = z.var >= 0 ? ((rules_host[z.var] << 1) | (excl[z.var] ? 1 : 0)) : 0;
+      const int rule = z.var >= 0 && trees->rule ? trees->rule[g] : PGB_RULE_CONTINUOUS;  // the node's own
+      if (rule != PGB_RULE_CONTINUOUS) cont = false;
+      z.flags = z.var >= 0 ? ((rule << 1) | (excl[z.var] ? 1 : 0)) : 0;
       z.split = trees->split[g];
       z.cnt = (double)trees->count[g];
       hn[g] = z;
@@ -1524,8 +1543,6 @@ extern "C" int pgb_predict(const pgb_tree_arrays* trees, const int32_t* forest_t
   if (gy > n_forests) gy = n_forests;
   if (gy < 1) gy = 1;
   dim3 grid((unsigned)gx, (unsigned)gy);
-  bool cont = true;
-  for (int j = 0; j < p; ++j) cont = cont && rules_host[j] == PGB_RULE_CONTINUOUS;
 #define LAUNCH_PRED(L_, C_, LDS_)                                                                               \
   hipLaunchKernelGGL((k_predict<L_, C_>), grid, dim3(PRED_BT), (LDS_), sm, T, (const int32_t*)(db + o_f), n_forests, \
                      m, K, (int)p, X_dev, (long long)n_rows, (long long)ldx, out_dev)

@@ -270,6 +270,26 @@ def _pick_device():
         return None
 
 
+def _set_on_op(op, name, value):
+    """The op is a mailbox: reference ``utils.py:125`` reads ``op.n_outputs``, which nothing in ``bart.py`` sets --
+    the step method does.  WHERE matters: the reference's reader is ``BARTRV.rng_fn``, a *classmethod*
+    (``bart.py:47-49``) that hands ``cls`` -- the per-variable class ``BART_<name>`` built at ``bart.py:141-158``
+    with ``all_trees``, ``X``, ``m``, ... as CLASS attributes -- to ``_get_posterior_sampler(cls)`` (``:66``), while
+    the step method holds ``rv.owner.op``, an *instance* of that class.  An attribute set on the instance is
+    invisible from ``cls``; so when the op's class is such a per-variable class (it carries its own
+    ``all_trees``), the attribute goes on the class as well.  A shared class (this package's :class:`BARTOp`)
+    is left alone: its instances are separate variables."""
+    setattr(op, name, value)
+    if isinstance(op, type):
+        return
+    cls = type(op)
+    if "all_trees" in vars(cls):
+        try:
+            setattr(cls, name, value)
+        except (AttributeError, TypeError):  # a class that refuses attributes: the instance has it
+            pass
+
+
 def _eval(x):
     return x.eval() if hasattr(x, "eval") and not isinstance(x, np.ndarray) else x
 
@@ -374,9 +394,7 @@ class PGBART(_Base):
         self._sampler = None
         if self._keyed:
             self._sampler = self._build_sampler()
-        # the op is a mailbox: utils.py:125 reads op.n_outputs, which the step method sets
-        op.n_outputs = n_outputs
-        op._rule_ids = rule_ids
+        _set_on_op(op, "n_outputs", n_outputs)
         self.tune = True
         self._baseline = None
         self._batches = []
@@ -414,21 +432,24 @@ class PGBART(_Base):
         a step method pickled mid-run resumes bit-identically in the process that unpickles it
         (on that process's current GPU)."""
         d = dict(self.__dict__)
-        smp = self.sampler  # (builds it if nobody has yet)
         d.pop("_sampler", None)
-        d["_checkpoint"] = smp.checkpoint()
         d.pop("_backend_arg", None)
+        # A chain that has not stepped has no state beyond its settings: it travels WITHOUT an image and without a
+        # native sampler ever being built here -- this is how PyMC sends the step method to its spawn / forkserver
+        # workers, and building one only to photograph it cost an upload + transpose of X in the parent and a second
+        # sampler in the worker once its key arrived (round-4 ADVICE).
+        d["_checkpoint"] = self._sampler.checkpoint() if self._stepped and self._sampler is not None else None
         return d
 
     def __setstate__(self, d):
         blob = d.pop("_checkpoint")
         self.__dict__.update(d)
         self._backend_arg = None
+        self._sampler = None
         _pick_device()
-        self.sampler = PySampler(self.settings, self._X, self._y_obs, self._rule_ids,
-                                 self._split_prior, backend=None)
-        if self.likelihood.family == "callback":
-            self.sampler.set_loglik_callback(self.likelihood.logp)
+        if blob is None:  # un-stepped: the sampler is built on first use, when this copy's Philox key is final
+            return
+        self.sampler = self._build_sampler()
         self.sampler.restore(blob)
         if self._offset is not None:  # the image carries the chain, not the caller-owned response
             self._apply_offset(self._offset)
@@ -463,15 +484,13 @@ class PGBART(_Base):
     def _rekey(self, seed: int) -> None:
         """The same sampler on another Philox key (before its first step: there is no state to lose)."""
         self.settings.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        if self._sampler is not None:  # somebody looked at the sampler before the key was final: rebuild it
-            self._sampler = None
-            _ = self.sampler
+        self._sampler = None  # (somebody looked at the sampler before the key was final: the next use rebuilds it)
 
     def _key_for_this_process(self) -> None:
         """Older PyMC has no `set_rng`: it seeds NumPy's global generator per chain (`np.random.seed(chain_seed)`)
         in the process that runs the chain.  At the first astep of a chain that nobody keyed, the key is therefore
-        mixed with one draw from that generator and with the worker's ordinal in its pool -- different in every
-        chain, reproducible under `pm.sample(random_seed=...)`."""
+        mixed with the STATE of that generator (read, not advanced) and with the worker's ordinal in its pool --
+        different in every chain, reproducible under `pm.sample(random_seed=...)`."""
         import multiprocessing as mp
 
         ident = getattr(mp.current_process(), "_identity", ()) or (0,)

@@ -36,9 +36,15 @@ class TreeArrays:
     slope: np.ndarray = None  # float64 [nodes, n_outputs]
     xbar: np.ndarray = None   # float64 [nodes]
     svar: np.ndarray = None   # int32 [nodes]
+    # The trees describe themselves: the rule (``_abi.RULE_*``) every split node was grown under, 0 for a leaf.
+    # The reference rebuilds its predictors with ``from_history(batches, baseline_forest, op.m, op.n_outputs)``
+    # (``utils.py:124-127``) -- no split rules in sight -- so a one-hot / subset split has to say so itself.
+    rule: np.ndarray = None   # int32 [nodes]
 
     def __post_init__(self):
         nn = int(np.asarray(self.var).shape[0])
+        if self.rule is None:  # a record written before the trees carried their rules: every split is `x <= v`
+            self.rule = np.zeros(nn, np.int32)
         if self.slope is None:
             self.slope = np.zeros((nn, self.n_outputs), np.float64)
         self.slope = np.ascontiguousarray(self.slope, np.float64).reshape(nn, self.n_outputs)
@@ -70,6 +76,7 @@ class TreeArrays:
             slope=np.zeros((total_nodes, n_outputs), np.float64),
             xbar=np.zeros(total_nodes, np.float64),
             svar=np.full(total_nodes, -1, np.int32),
+            rule=np.zeros(total_nodes, np.int32),
         )
 
     def as_c(self) -> _abi.TreeArraysC:
@@ -88,6 +95,7 @@ class TreeArrays:
         c.slope = _abi._ptr(self.slope, C.c_double)
         c.xbar = _abi._ptr(self.xbar, C.c_double)
         c.svar = _abi._ptr(self.svar, C.c_int32)
+        c.rule = _abi._ptr(self.rule, C.c_int32)
         return c
 
     def split_variables(self, t: int) -> np.ndarray:
@@ -101,7 +109,7 @@ class TreeArrays:
         ``raw`` (read-only when ``raw`` is ``bytes``)."""
         hdr = np.frombuffer(raw, np.int32, 4)
         nt, K, N, flags = (int(v) for v in hdr)
-        lin = bool(flags & 1)
+        lin, has_rules = bool(flags & 1), bool(flags & 2)
         o = 16
 
         def take(dtype, count):
@@ -112,6 +120,7 @@ class TreeArrays:
 
         tree_id, node_off = take(np.int32, nt), take(np.int32, nt + 1)
         var, left, right = take(np.int32, N), take(np.int32, N), take(np.int32, N)
+        rule = take(np.int32, N) if has_rules else None
         svar = take(np.int32, N) if lin else None
         o = (o + 7) & ~7
         split, count = take(np.float64, N), take(np.int64, N)
@@ -119,7 +128,7 @@ class TreeArrays:
         slope = take(np.float64, N * K).reshape(N, K) if lin else None
         xbar = take(np.float64, N) if lin else None
         return cls(n_outputs=K, tree_id=tree_id, node_off=node_off, var=var, split=split, left=left, right=right,
-                   count=count, value=value, slope=slope, xbar=xbar, svar=svar)
+                   count=count, value=value, slope=slope, xbar=xbar, svar=svar, rule=rule)
 
     @staticmethod
     def concat(parts: list["TreeArrays"]) -> "TreeArrays":
@@ -143,6 +152,7 @@ class TreeArrays:
             slope=np.concatenate([p.slope for p in parts], axis=0).astype(np.float64),
             xbar=np.concatenate([p.xbar for p in parts]).astype(np.float64),
             svar=np.concatenate([p.svar for p in parts]).astype(np.int32),
+            rule=np.concatenate([p.rule for p in parts]).astype(np.int32),
         )
 
 
@@ -178,10 +188,12 @@ def _as_list(batches) -> list:
     return batches if isinstance(batches, list) else list(batches[:])
 
 
-_HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "slope", "xbar", "svar")
+_HISTORY_FIELDS = ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "slope", "xbar", "svar",
+                   "rule")
+_HISTORY_FORMATS = ("pgbart-history-1", "pgbart-history-2")  # -1: before the nodes carried their split rules
 
 
-def save_history(path, all_trees, m: int, rules=None) -> None:
+def save_history(path, all_trees, m: int) -> None:
     """Write the per-chain tree histories ``[(baseline_forest, batches), ...]`` -- the list the
     step method keeps on ``op.all_trees`` (reference ``bart.py:134-135``, ``utils.py:124-127``) --
     to ONE ``.npz`` file (the reference has no on-disk format).
@@ -189,8 +201,7 @@ def save_history(path, all_trees, m: int, rules=None) -> None:
     Layout: every chain's forests are concatenated (baseline first, then the per-draw batches);
     ``c<i>_<field>`` holds the SoA arrays of chain ``i`` and ``c<i>_sizes`` the number of trees of
     each forest, which is all that is needed to cut the concatenation apart again."""
-    out = {"format": np.array("pgbart-history-1"), "n_chains": np.array(len(all_trees)), "m": np.array(int(m)),
-           "rules": np.asarray([] if rules is None else rules, np.int32)}
+    out = {"format": np.array(_HISTORY_FORMATS[-1]), "n_chains": np.array(len(all_trees)), "m": np.array(int(m))}
     for i, (baseline, batches) in enumerate(all_trees):
         parts = [baseline] + _as_list(batches)
         cat = TreeArrays.concat(parts)
@@ -202,15 +213,21 @@ def save_history(path, all_trees, m: int, rules=None) -> None:
 
 
 def load_history(path):
-    """Inverse of :func:`save_history`: returns ``(all_trees, m, rules)`` with ``all_trees`` in the
-    layout ``PosteriorSampler.from_history`` / ``_get_posterior_sampler`` consume."""
+    """Inverse of :func:`save_history`: returns ``(all_trees, m)`` with ``all_trees`` in the layout
+    ``PosteriorSampler.from_history`` / ``_get_posterior_sampler`` consume.  The split rules are part of the
+    trees; a file of format 1 (per-column rules beside the trees) is read into the same form."""
     z = np.load(path, allow_pickle=False)
-    if str(z["format"]) != "pgbart-history-1":
+    if str(z["format"]) not in _HISTORY_FORMATS:
         raise ValueError("not a pgbart tree-history file")
+    col_rules = z["rules"] if "rules" in z.files and z["rules"].size else None  # format 1 only
     all_trees = []
     for i in range(int(z["n_chains"])):
         K = int(z[f"c{i}_n_outputs"])
-        arrs = {f: z[f"c{i}_{f}"] for f in _HISTORY_FIELDS}
+        arrs = {f: z[f"c{i}_{f}"] for f in _HISTORY_FIELDS if f"c{i}_{f}" in z.files}
+        if "rule" not in arrs:
+            var = arrs["var"].astype(np.int64)
+            arrs["rule"] = np.zeros(var.shape[0], np.int32) if col_rules is None else \
+                np.where(var >= 0, np.asarray(col_rules, np.int32)[np.maximum(var, 0)], 0).astype(np.int32)
         sizes = z[f"c{i}_sizes"].tolist()
         forests, t0 = [], 0
         for nt in sizes:
@@ -224,16 +241,14 @@ def load_history(path):
                 count=arrs["count"][a:b].astype(np.int64),
                 value=arrs["value"][a:b].reshape(b - a, K).astype(np.float64),
                 slope=arrs["slope"].reshape(-1, K)[a:b].astype(np.float64), xbar=arrs["xbar"][a:b].astype(np.float64),
-                svar=arrs["svar"][a:b].astype(np.int32),
+                svar=arrs["svar"][a:b].astype(np.int32), rule=arrs["rule"][a:b].astype(np.int32),
             ))
             t0 += nt
         all_trees.append((forests[0], forests[1:]))
-    rules = z["rules"]
-    return all_trees, int(z["m"]), (rules if rules.size else None)
+    return all_trees, int(z["m"])
 
 
-def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rules: np.ndarray,
-                  excluded=None) -> np.ndarray:
+def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, excluded=None) -> np.ndarray:
     """Slow host restatement of ``pgb_predict`` used by tests only (tiny inputs)."""
     X = np.asarray(X, np.float64)
     n_rows, p = X.shape
@@ -256,9 +271,9 @@ def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rule
                 rec(base, l, x, w * (cl / tot), acc)
                 rec(base, r, x, w * (cr / tot), acc)
                 return
-            if rules[j] == _abi.RULE_CONTINUOUS:
+            if trees.rule[g] == _abi.RULE_CONTINUOUS:
                 go_left = x[j] <= trees.split[g]
-            elif rules[j] == _abi.RULE_ONEHOT:
+            elif trees.rule[g] == _abi.RULE_ONEHOT:
                 go_left = x[j] == trees.split[g]
             else:  # subset: the split value is the bit mask of the categories that go left
                 code = min(max(int(x[j]), 0), _abi.SUBSET_BITS - 1)
@@ -283,24 +298,23 @@ def predict_numpy(trees: TreeArrays, forest_idx: np.ndarray, X: np.ndarray, rule
 class PosteriorSampler:
     """Prediction-only sampler rebuilt from one chain's tree history.
 
-    ``from_history(batches, baseline_forest, m, n_outputs)`` mirrors the call at
-    reference ``utils.py:124-127``.  Draw ``d`` is the baseline forest with batches
-    ``0..d`` applied (each batch replaces the trees at its ``tree_id`` slots).
-    Prediction runs in the HIP library (``pgb_predict``).
+    ``from_history(batches, baseline_forest, m, n_outputs)`` IS the call at reference
+    ``utils.py:124-127`` -- nothing else is needed: the split rules travel inside the trees
+    (``TreeArrays.rule``).  Draw ``d`` is the baseline forest with batches ``0..d`` applied (each
+    batch replaces the trees at its ``tree_id`` slots).  Prediction runs in the HIP library
+    (``pgb_predict``); ``backend`` is a test hook (the oracle library as the checker).
     """
 
-    def __init__(self, pool: TreeArrays, forest_idx: np.ndarray, m: int, n_outputs: int,
-                 rules: np.ndarray, backend=None):
+    def __init__(self, pool: TreeArrays, forest_idx: np.ndarray, m: int, n_outputs: int, backend=None):
         self.pool = pool
         self.forest_idx = np.ascontiguousarray(forest_idx, dtype=np.int32)
         self.m = int(m)
         self._n_outputs = int(n_outputs)
-        self.rules = np.ascontiguousarray(rules, dtype=np.int32)
         self._backend = backend
 
     @classmethod
     def from_history(cls, batches, baseline_forest: TreeArrays, m: int, n_outputs: int,
-                     rules=None, backend=None) -> "PosteriorSampler":
+                     backend=None) -> "PosteriorSampler":
         batches = _as_list(batches)
         parts = [baseline_forest] + batches
         pool = TreeArrays.concat(parts)
@@ -312,10 +326,7 @@ class PosteriorSampler:
             cur[b.tree_id] = off + np.arange(b.n_trees)
             off += b.n_trees
             table[d] = cur
-        if rules is None:
-            p = int(pool.var.max()) + 1 if pool.total_nodes else 1
-            rules = np.zeros(max(p, 1), np.int32)
-        return cls(pool, table, m, n_outputs, rules, backend=backend)
+        return cls(pool, table, m, n_outputs, backend=backend)
 
     @property
     def n_draws(self) -> int:
@@ -351,9 +362,6 @@ class PosteriorSampler:
             if X.ndim == 1:
                 X = X[:, None]
         n_rows, p = (int(v) for v in X.shape)
-        rules = self.rules
-        if rules.shape[0] < p:
-            rules = np.concatenate([rules, np.zeros(p - rules.shape[0], np.int32)])
         idx = np.asarray(draw_indices, dtype=np.int64)
         fidx = np.ascontiguousarray(self.forest_idx[idx], dtype=np.int32)
         excl = np.ascontiguousarray(np.asarray([] if excluded is None else excluded, dtype=np.int32))
@@ -363,7 +371,7 @@ class PosteriorSampler:
         carr = self.pool.as_c()
         rc = be.lib.lib.pgb_predict(
             C.byref(carr), fidx.ctypes.data, fidx.shape[0], self.m, be.mem.ptr(xd), n_rows, p, p,
-            rules.ctypes.data, excl.ctypes.data if excl.size else None, int(excl.size),
+            excl.ctypes.data if excl.size else None, int(excl.size),
             be.mem.ptr(outd), be.mem.stream_ptr,
         )
         be.lib.check(rc, "pgb_predict")

@@ -142,10 +142,8 @@ def _get_posterior_sampler(op, backend=None) -> _MultiChainSampler:
         ref, c_chains, c_batches, c_backend, sampler = cached
         if ref() is op and c_chains == n_chains and c_batches == n_batches and c_backend is backend:
             return sampler
-    rules = getattr(op, "_rule_ids", None)
-    chain_samplers = [
-        PosteriorSampler.from_history(batches, baseline, op.m, op.n_outputs, rules=rules,
-                                      backend=backend)
+    chain_samplers = [  # the reference's call (utils.py:124-127); the trees carry their own split rules
+        PosteriorSampler.from_history(batches, baseline, op.m, op.n_outputs, backend=backend)
         for baseline, batches in op.all_trees
     ]
     sampler = _MultiChainSampler(chain_samplers)

@@ -79,7 +79,7 @@ def test_sum_trees_equals_sum_of_tree_predictions(oracle):
     for it in range(40):
         st, _ = s.step(tune=it < 20)
     forest = s.export_trees(1)
-    pred = predict_numpy(forest, np.arange(12)[None, :], X, np.zeros(3, np.int32))[0, 0]
+    pred = predict_numpy(forest, np.arange(12)[None, :], X)[0, 0]
     np.testing.assert_allclose(pred, st, rtol=0, atol=1e-9)
     # structural invariants of every tree
     for t in range(forest.n_trees):
@@ -119,7 +119,7 @@ def test_posterior_draw_reproduces_the_sampled_sum_trees(oracle):
     op = BARTOp(X, Y, m=6)
     res = sample_chain(op, tune=15, draws=12, random_seed=11, backend=oracle)
     base, batches = res["history"]
-    ps = PosteriorSampler.from_history(batches, base, 6, 1, rules=np.zeros(3, np.int32), backend=oracle)
+    ps = PosteriorSampler.from_history(batches, base, 6, 1, backend=oracle)
     pred = ps.sample_posterior(res["step"].sampler.settings and X, list(range(12)))
     np.testing.assert_allclose(pred[:, 0, :], res["mu"], rtol=0, atol=1e-9)
 
@@ -132,11 +132,11 @@ def test_excluded_variable_is_marginalised(oracle):
     op = BARTOp(X, Y, m=5)
     res = sample_chain(op, tune=30, draws=5, random_seed=1, backend=oracle)
     base, batches = res["history"]
-    ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
+    ps = PosteriorSampler.from_history(batches, base, 5, 1, backend=oracle)
     full = ps.sample_posterior(X, [4])
     excl_all = ps.sample_posterior(X, [4], excluded=[0, 1])
     assert np.allclose(excl_all, excl_all[..., :1])  # no covariate left => constant prediction
-    ref = predict_numpy(ps.pool, ps.forest_idx[[4]], X, np.zeros(2, np.int32), excluded=[0])
+    ref = predict_numpy(ps.pool, ps.forest_idx[[4]], X, excluded=[0])
     np.testing.assert_allclose(ps.sample_posterior(X, [4], excluded=[0]), ref, atol=1e-12)
     assert not np.allclose(full, excl_all)
     # NaN in a used covariate behaves like an exclusion for that row
@@ -192,7 +192,7 @@ def test_single_tree_and_two_particles_corner(oracle):
     for it in range(30):
         st, _ = s.step(tune=it < 10)
     f = s.export_trees(1)
-    pred = predict_numpy(f, np.zeros((1, 1), np.int64), X, np.zeros(2, np.int32))[0, 0]
+    pred = predict_numpy(f, np.zeros((1, 1), np.int64), X)[0, 0]
     np.testing.assert_allclose(pred, st, atol=1e-12)
 
 
@@ -239,7 +239,7 @@ def test_leaf_sd_is_the_running_sd_of_the_accepted_trees_recomputed_in_numpy(ora
         assert np.array_equal(w_after - w_before, np.bincount(used[used >= 0], minlength=3))
         w_before = w_after
         for k in range(m):
-            nv = predict_numpy(step_trees, np.array([[k]]), X, rules)[0, 0]
+            nv = predict_numpy(step_trees, np.array([[k]]), X)[0, 0]
             count += 1
             delta = nv - mean
             mean = mean + delta / count
@@ -414,7 +414,7 @@ def test_categorical_model_recovers_classes(oracle, split_rule):
     assert op.n_outputs == 3
     # stored trees reproduce the K-vector prediction (reference shape (…, 9, 3) after transpose)
     base, batches = op.all_trees[0]
-    ps = PosteriorSampler.from_history(batches, base, 2, 3, rules=op._rule_ids, backend=oracle)
+    ps = PosteriorSampler.from_history(batches, base, 2, 3, backend=oracle)
     pred = ps.sample_posterior(step.sampler and np.asarray(X, float), [599])
     assert pred.shape == (1, 3, 9)
     # X was jittered for the continuous rule inside PGBART: compare on the sampler's own matrix
@@ -564,10 +564,10 @@ def test_subset_rule_recovers_a_set_valued_effect(oracle):
         inner = ta.var >= 0
         assert np.all(ta.count[ta.left[inner] + off[inner]] > 0)
         assert np.all(ta.count[ta.right[inner] + off[inner]] > 0)
-    ps = PosteriorSampler.from_history(batches, base, 10, 1, rules=rules, backend=oracle)
+    ps = PosteriorSampler.from_history(batches, base, 10, 1, backend=oracle)
     pred = ps.sample_posterior(X, list(range(40)))
     np.testing.assert_allclose(pred[:, 0, :], res["mu"], rtol=0, atol=1e-9)
-    ref = predict_numpy(ps.pool, ps.forest_idx[[7]], X, rules)
+    ref = predict_numpy(ps.pool, ps.forest_idx[[7]], X)
     np.testing.assert_allclose(pred[7], ref[0], atol=1e-12)
     # invalid category codes are rejected up front
     Xbad = X.copy()
@@ -792,16 +792,17 @@ def test_tree_history_round_trips_through_a_file(oracle, tmp_path):
     assert len(op.all_trees) == 2
     ref = _sample_posterior(_get_posterior_sampler(op, backend=oracle), X, np.random.default_rng(5), size=9)
     path = tmp_path / "history.npz"
-    save_history(path, op.all_trees, m=6, rules=op._rule_ids)
-    all_trees, m, rules = load_history(path)
-    assert m == 6 and np.array_equal(rules, [0, 0, 1]) and len(all_trees) == 2
+    save_history(path, op.all_trees, m=6)
+    all_trees, m = load_history(path)
+    assert m == 6 and len(all_trees) == 2
     for (b0, bs0), (b1, bs1) in zip(op.all_trees, all_trees):
         assert len(bs0) == len(bs1) == 7
         for t0, t1 in zip([b0] + list(bs0), [b1] + list(bs1)):
-            for f in ("tree_id", "node_off", "var", "split", "left", "right", "count", "value"):
+            for f in ("tree_id", "node_off", "var", "split", "left", "right", "count", "value", "rule"):
                 assert np.array_equal(getattr(t0, f), getattr(t1, f)), f
-    op2 = BARTOp(X, Y, m=6, split_rules=["ContinuousSplit", "ContinuousSplit", "OneHotSplit"], all_trees=all_trees)
-    op2.n_outputs, op2._rule_ids = 1, rules
+            assert np.array_equal(t1.rule, np.where(t1.var == 2, 1, 0))  # the one-hot column's splits say so
+    op2 = BARTOp(X, Y, m=6, all_trees=all_trees)  # (no split rules on the op: the trees carry them)
+    op2.n_outputs = 1
     again = _sample_posterior(_get_posterior_sampler(op2, backend=oracle), X, np.random.default_rng(5), size=9)
     assert np.array_equal(ref, again)
     with pytest.raises(ValueError):
@@ -837,15 +838,15 @@ def test_linear_response_fits_slopes_and_stays_consistent(oracle, response):
     assert np.all(forest.slope[forest.svar < 0] == 0.0)
     # the running sum is the sum of the stored trees evaluated WITH their linear parts ...
     rules = np.zeros(3, np.int32)
-    pred = predict_numpy(forest, np.arange(10)[None, :], X, rules)[0, 0]
+    pred = predict_numpy(forest, np.arange(10)[None, :], X)[0, 0]
     np.testing.assert_allclose(pred, mu, rtol=0, atol=1e-9)
     # ... and the prediction entry point agrees with the host restatement, incl. excluded / missing
-    ps = PosteriorSampler(forest, np.arange(10, dtype=np.int32)[None, :], 10, 1, rules, backend=oracle)
+    ps = PosteriorSampler(forest, np.arange(10, dtype=np.int32)[None, :], 10, 1, backend=oracle)
     np.testing.assert_allclose(ps.sample_posterior(X, [0])[0, 0], pred, atol=1e-12)
     Xn = X[:50].copy()
     Xn[::3, 0] = np.nan
     np.testing.assert_allclose(ps.sample_posterior(Xn, [0], excluded=[1])[0, 0],
-                               predict_numpy(forest, np.arange(10)[None, :], Xn, rules, excluded=[1])[0, 0],
+                               predict_numpy(forest, np.arange(10)[None, :], Xn, excluded=[1])[0, 0],
                                atol=1e-12)
     assert s.counters.saturations == 0
 
@@ -859,7 +860,7 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     res = sample_chain(op, tune=40, draws=10, random_seed=2, backend=oracle)
     base, batches = res["history"]
     assert any((ta.svar >= 0).any() for ta in [base] + batches)
-    ps = PosteriorSampler.from_history(batches, base, 5, 1, rules=np.zeros(2, np.int32), backend=oracle)
+    ps = PosteriorSampler.from_history(batches, base, 5, 1, backend=oracle)
     np.testing.assert_allclose(ps.sample_posterior(X, list(range(10)))[:, 0, :], res["mu"], rtol=0, atol=1e-9)
     assert res["vi_counts"].sum(axis=0)[0] > res["vi_counts"].sum(axis=0)[1]
     # categorical rules next to linear leaves: a leaf regresses on whatever column its parent split on, as
@@ -871,7 +872,7 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     resc = sample_chain(opc, tune=40, draws=10, random_seed=2, backend=oracle)
     basec, batchesc = resc["history"]
     rules_c = np.array([_abi.RULE_ONEHOT, _abi.RULE_CONTINUOUS], np.int32)
-    psc = PosteriorSampler.from_history(batchesc, basec, 5, 1, rules=rules_c, backend=oracle)
+    psc = PosteriorSampler.from_history(batchesc, basec, 5, 1, backend=oracle)
     np.testing.assert_allclose(psc.sample_posterior(Xc, list(range(10)))[:, 0, :], resc["mu"], rtol=0, atol=1e-9)
     last = psc.pool
     onehot_leaf = (last.svar == 0)
@@ -890,9 +891,9 @@ def test_linear_response_through_the_step_method_and_its_limits(oracle):
     lin_leaves = forest.svar >= 0
     assert lin_leaves.any() and (forest.slope[lin_leaves, 0] != 0).any() and (forest.slope[lin_leaves, 1] != 0).any()
     assert np.all(forest.slope[~lin_leaves] == 0.0)
-    pred = predict_numpy(forest, np.arange(6)[None, :], X, np.zeros(2, np.int32))[0]
+    pred = predict_numpy(forest, np.arange(6)[None, :], X)[0]
     np.testing.assert_allclose(pred, w, rtol=0, atol=1e-9)          # sum_trees == sum of per-tree predictions
-    ps2 = PosteriorSampler(forest, np.arange(6, dtype=np.int32)[None, :], 6, 2, np.zeros(2, np.int32), backend=oracle)
+    ps2 = PosteriorSampler(forest, np.arange(6, dtype=np.int32)[None, :], 6, 2, backend=oracle)
     np.testing.assert_allclose(ps2.sample_posterior(X, [0])[0], pred, atol=1e-12)
     assert s2.counters.saturations == 0
     # every single-output family takes them

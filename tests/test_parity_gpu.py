@@ -161,8 +161,8 @@ def test_predict_kernel_matches_oracle_and_numpy(hip, oracle):
     assert np.array_equal(res_g["mu"], res_o["mu"])
     rid = np.array([0, 0, 0, 1], np.int32)
     base, batches = res_g["history"]
-    pg = PosteriorSampler.from_history(batches, base, 8, 1, rules=rid, backend=hip)
-    po = PosteriorSampler.from_history(batches, base, 8, 1, rules=rid, backend=oracle)
+    pg = PosteriorSampler.from_history(batches, base, 8, 1, backend=hip)
+    po = PosteriorSampler.from_history(batches, base, 8, 1, backend=oracle)
     Xn = rng.normal(size=(333, 4))
     Xn[:, 3] = rng.integers(0, 3, 333)
     Xn[::7, 0] = np.nan
@@ -171,7 +171,7 @@ def test_predict_kernel_matches_oracle_and_numpy(hip, oracle):
         b = po.sample_posterior(Xn, [0, 3, 9, 9], excl)
         assert a.shape == (4, 1, 333)
         assert np.array_equal(a, b)
-    ref = predict_numpy(pg.pool, pg.forest_idx[[2]], Xn[:40], rid, excluded=[1])
+    ref = predict_numpy(pg.pool, pg.forest_idx[[2]], Xn[:40], excluded=[1])
     np.testing.assert_allclose(pg.sample_posterior(Xn[:40], [2], [1]), ref, atol=1e-12)
     # every stored draw evaluated on the training X is the sampled sum_trees
     np.testing.assert_allclose(pg.sample_posterior(X, list(range(10)))[:, 0, :], res_g["mu"], atol=1e-9)
@@ -220,8 +220,7 @@ def test_full_size_cfg2_parity_and_invariants(hip, oracle):
     base = np.repeat(forest.node_off[:-1], np.diff(forest.node_off))
     assert np.all(forest.count[base[inner] + forest.left[inner]] + forest.count[base[inner] + forest.right[inner]]
                   == forest.count[inner])              # children partition their parent (no NaN here)
-    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, np.zeros(p, np.int32),
-                          backend=hip)
+    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, backend=hip)
     pred = ps.sample_posterior(X, [0])[0, 0]
     np.testing.assert_allclose(pred, st_dev, rtol=0, atol=1e-8)  # sum_trees == sum of its trees
     assert g.counters.saturations == 0
@@ -260,8 +259,7 @@ def test_full_size_cfg4_probit_parity_and_invariants(hip, oracle):
     assert np.all(forest.count[base[inner] + forest.left[inner]] + forest.count[base[inner] + forest.right[inner]]
                   == forest.count[inner])
     sub = np.arange(0, n, 97)
-    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, np.zeros(p, np.int32),
-                          backend=hip)
+    ps = PosteriorSampler(forest, np.arange(200, dtype=np.int32)[None, :], 200, 1, backend=hip)
     pred = ps.sample_posterior(X[sub], [0])[0, 0]
     np.testing.assert_allclose(pred, st_dev[sub], rtol=0, atol=1e-8)
     assert g.counters.saturations == 0
@@ -294,8 +292,7 @@ def test_full_size_cfg5_categorical_parity_and_invariants(hip, oracle):
     forest = g.export_trees(1)
     assert forest.n_outputs == 4 and forest.value.shape[1] == 4
     sub = np.arange(0, n, 53)
-    ps = PosteriorSampler(forest, np.arange(100, dtype=np.int32)[None, :], 100, 4, np.zeros(p, np.int32),
-                          backend=hip)
+    ps = PosteriorSampler(forest, np.arange(100, dtype=np.int32)[None, :], 100, 4, backend=hip)
     pred = ps.sample_posterior(X[sub], [0])[0]
     np.testing.assert_allclose(pred, st_dev[:, sub], rtol=0, atol=1e-8)
     assert g.counters.saturations == 0
@@ -451,7 +448,7 @@ def test_k_vector_linear_leaves_on_gpu(hip, oracle):
         for it in range(30):
             w, _ = s.step(it < 20)
         forest = s.export_trees(1)
-        ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 2, rules, backend=be)
+        ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 2, backend=be)
         Xn = X[:400].copy()
         Xn[::4, 0] = np.nan
         out[name] = (w, forest, ps.sample_posterior(X[:400], [0]), ps.sample_posterior(Xn, [0], excluded=[2]))
@@ -466,7 +463,7 @@ def test_k_vector_linear_leaves_on_gpu(hip, oracle):
     np.testing.assert_allclose(pxh, pxo, rtol=0, atol=1e-12)
     full = ~np.isnan(X[:400]).any(axis=1)  # (training rows with a missing split value leave their tree)
     np.testing.assert_allclose(ph[0][:, full], wh[:, :400][:, full], rtol=0, atol=1e-9)  # sum_trees == predictions
-    host = predict_numpy(fh, np.arange(m)[None, :], Xn[:60], rules, excluded=[2])
+    host = predict_numpy(fh, np.arange(m)[None, :], Xn[:60], excluded=[2])
     np.testing.assert_allclose(pxh[0][:, :60], host[0], rtol=0, atol=1e-12)
 
 
@@ -551,7 +548,7 @@ def test_prediction_kernel_paths_agree_with_the_oracle(hip, oracle):
             for it in range(12):
                 s.step(it < 8)
             forest = s.export_trees(1)
-            ps = PosteriorSampler(forest, np.arange(12, dtype=np.int32)[None, :], 12, 1, rules, backend=be)
+            ps = PosteriorSampler(forest, np.arange(12, dtype=np.int32)[None, :], 12, 1, backend=be)
             Xn = X[:700].copy()
             Xn[100:140:3, 0] = np.nan                      # some waves carry missing values, others do not
             out[name] = (ps.sample_posterior(X, [0]), ps.sample_posterior(Xn, [0]),
@@ -619,7 +616,7 @@ def test_thirty_million_rows_stay_consistent(hip):
         assert np.all(kids <= count[inner]) and np.all(count[inner] - kids <= np.isnan(X[:, 2]).sum())   # only NaN rows drop out
     rows = rng.integers(0, n, 50_000)
     rows[:3] = [0, n - 1, 2 ** 24 + 1]
-    ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 1, np.zeros(p, np.int32), backend=hip)
+    ps = PosteriorSampler(forest, np.arange(m, dtype=np.int32)[None, :], m, 1, backend=hip)
     pred = ps.sample_posterior(X[rows], [0])[0, 0]
     ok = ~np.isnan(X[rows, 2])                                                # (a dropped row is predicted by its parent's mixture)
     np.testing.assert_allclose(pred[ok], mu[rows][ok], rtol=0, atol=1e-9)
