@@ -74,7 +74,8 @@ typedef struct {
   int32_t batch_draw;     /* trees updated per step after tuning                */
   int32_t range_exp;      /* fixed-point range: |sum_trees|,|y - mu| < 2^range_exp */
   int32_t response;       /* PGB_RESPONSE_*: how leaf values are computed (bart.py:88-90)   */
-  int32_t reserved0;
+  int32_t compat;         /* PGB_COMPAT_* bits (pgbart_spec.h): 0 = this sampler; bit 0 / bit 1 switch one of
+                             the two distribution-changing deviations from upstream back */
   uint64_t seed;          /* Philox key                                         */
   double init_sum;        /* initial sum_trees value = mean(Y)   (bart.py:148)  */
   double init_leaf;       /* initial leaf value      = mean(Y)/m                */

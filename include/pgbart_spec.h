@@ -74,6 +74,20 @@
 #define PGB_RULE_SUBSET 2     /* go left iff category x is in the set v (bart.py:100-103)   */
 #define PGB_SUBSET_BITS 52    /* categories are integer codes 0..51; the set is a bit mask  */
 
+/* Upstream-semantics switches (pgb_settings.compat).  The default sampler (compat = 0) differs from pymc-bart
+ * <= 0.12 as SURVEY.md Appendix A recalls it in two ways that change the sampled distribution (DESIGN.md section
+ * 0, deviations 2 and 13); each bit puts upstream's behaviour back, on every backend alike, so that whoever can
+ * run the reference binary (bartrs is not in the reference tree) can tell which semantics it follows.
+ *   bit 0  a particle that has never grown (a root-only tree) keeps log-weight 0 -- upstream initialises
+ *          ParticleTree.log_weight = 0 and calls update_weight only after a successful grow -- instead of the
+ *          likelihood of its stump.  The reference particle keeps its likelihood, as upstream (init_particles).
+ *   bit 1  a one-hot split whose right child would be empty (every row of the leaf holds the split value) is
+ *          grown, with an empty right leaf that predicts 0, instead of failing.  (The subset rule still fails:
+ *          upstream redraws the subset until it is proper.)                                                   */
+#define PGB_COMPAT_FRESH_WEIGHT_ZERO 1
+#define PGB_COMPAT_ONEHOT_EMPTY_CHILD 2
+#define PGB_COMPAT_ALL 3
+
 /* likelihood families (closed family; SURVEY.md 7 "Hard parts") */
 #define PGB_FAMILY_NORMAL 0           /* y ~ N(mu, sigma)      params: sigma */
 #define PGB_FAMILY_BERNOULLI_PROBIT 1 /* y ~ Bern(Phi(mu))                   */
@@ -178,6 +192,12 @@ PGB_HD double pgb_subset_value(double u1, double x) {
   uint64_t M = (uint64_t)(u1 * 4503599627370496.0); /* 2^52 */
   M |= (uint64_t)1 << pgb_subset_code(x);
   return (double)M;
+}
+/* A partition that sent no row right: does the grow fail (the node stays a leaf)?  Never under the continuous
+ * rule (upstream grows the empty child); always under the subset rule; under the one-hot rule unless
+ * PGB_COMPAT_ONEHOT_EMPTY_CHILD asks for upstream's behaviour as recalled. */
+PGB_HD int pgb_empty_right_fails(int rule, int compat) {
+  return rule == PGB_RULE_SUBSET || (rule == PGB_RULE_ONEHOT && !(compat & PGB_COMPAT_ONEHOT_EMPTY_CHILD));
 }
 /* x is not NaN */
 PGB_HD int pgb_go_left(int rule, double x, double v) {

@@ -38,7 +38,8 @@
  *   prediction ................. pgb_predict       utils.py:60-71, CHANGELOG.md:410-411
  * Deviations from upstream, all deliberate and documented in DESIGN.md:
  *   - counter-based RNG instead of the NumPy stream;
- *   - a fresh particle's weight is the likelihood of its stump (upstream leaves 0);
+ *   - a fresh particle's weight is the likelihood of its stump (upstream leaves 0; pgb_settings.compat bit 0
+ *     restores upstream's rule, bit 1 the empty right child of a one-hot split);
  *   - the final particle is one categorical draw (same distribution as upstream's
  *     systematic()[randint]);
  *   - trees are capped at PGB_MAX_NODES nodes and PGB_MAX_DEPTH depth.
@@ -53,6 +54,8 @@
 #include "pgbart_spec.h"
 
 #define MAXN PGB_MAX_NODES
+#define PGB_STR2(x) #x
+#define PGB_STR(x) PGB_STR2(x)
 
 static __thread char g_err[256];
 static int fail(int code, const char* msg) {
@@ -180,7 +183,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     return fail(PGB_E_INVALID, "num_particles must be in [2, PGB_MAX_PARTICLES]");
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
-      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= " PGB_STR(PGB_MAX_OUTPUTS));
   } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
@@ -195,6 +198,7 @@ int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  if (s->compat & ~PGB_COMPAT_ALL) return fail(PGB_E_INVALID, "unknown compat bits (pgbart_spec.h: PGB_COMPAT_*)");
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
@@ -595,8 +599,9 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
   double zero_v[PGB_MAX_OUTPUTS] = {0};
   /* give back the unused tail of the two segments */
   /* (segments are [offL, offL+cL) and [offR, offR+cR); the slack is simply wasted) */
-  if (rule != PGB_RULE_CONTINUOUS && cR == 0) {
+  if (cR == 0 && pgb_empty_right_fails(rule, s->compat)) {
     /* [U] a one-hot / subset split needs two distinct values: the grow fails and the node stays a leaf.
+       (PGB_COMPAT_ONEHOT_EMPTY_CHILD: a one-hot split grows its empty right leaf like a continuous one.)
        Rows with a missing split value have been dropped by the partition; the leaf sheds them
        (an identity when there are none).  Same arithmetic as the HIP backend. */
     onode* pn = &T->nd[l];
@@ -724,6 +729,8 @@ static void o_particle_step(pgb_handle* h, int q, uint32_t round) {
 }
 
 static double o_logw(const pgb_handle* h, const otree* T) {
+  /* [U] ParticleTree.log_weight = 0 until the particle's first successful grow (compat bit 0) */
+  if ((h->s.compat & PGB_COMPAT_FRESH_WEIGHT_ZERO) && T->n_nodes == 1) return 0.0;
   if (h->s.family != PGB_FAMILY_NORMAL) return (double)(T->ll_tot + T->ll_orph) * h->sc.inv_cl;
   return (T->sse_tot + T->sse_orph) * (-0.5 * h->inv_sigma2);
 }

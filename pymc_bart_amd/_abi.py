@@ -99,7 +99,7 @@ class Settings(C.Structure):
         ("batch_draw", C.c_int32),
         ("range_exp", C.c_int32),
         ("response", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("compat", C.c_int32),
         ("seed", C.c_uint64),
         ("init_sum", C.c_double),
         ("init_leaf", C.c_double),

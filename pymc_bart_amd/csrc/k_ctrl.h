@@ -674,6 +674,9 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
         pending = f.next_pop < f.n_nodes;
         lw = normal ? (f.sse_tot + f.sse_orph) * (-0.5 * c.inv_sigma2)
                     : (double)(f.ll_tot + f.ll_orph) * S.sc.inv_cl;
+        // [U] ParticleTree.log_weight = 0 until the particle's first successful grow (upstream-semantics switch,
+        // pgbart_spec.h; a root-only tree has never grown, and copies made by the resampling carry the tree)
+        if ((S.compat & PGB_COMPAT_FRESH_WEIGHT_ZERO) && f.n_nodes == 1) lw = 0.0;
       }
       lwv[hq] = lw;
       popv[hq] = popn;
@@ -737,7 +740,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
           for (int cpy = 0; cpy < ACC_SLOTS; ++cpy)
             cnts += S.acc[((size_t)(par ^ 1) * MAXP + q) * ACC_PER + cpy * ACC_STRIDE].cnts;
           const int cL = (int)(cnts & 0xFFFFFFFFull), cN = (int)(cnts >> 32), cR = JP[q].cnt - cL - cN;
-          const int ok = (JP[q].rule != PGB_RULE_CONTINUOUS && cR == 0) ? -1 : 1;  // as child_values decides
+          const int ok = (cR == 0 && pgb_empty_right_fails(JP[q].rule, S.compat)) ? -1 : 1;  // as child_values decides
           for (int k = wv - 1; k < KX; k += 3) {
             const long long pq = r1 ? root_A_x(S, par ^ 1, k) : S.jqx[((size_t)(par ^ 1) * MAXP + q) * KX + k];
             const double pv = r1 ? S.init_leaf : S.jvx[((size_t)(par ^ 1) * MAXP + q) * KX + k];

@@ -159,7 +159,8 @@ struct DevT {  // kernel argument block (by value)
   int32_t batch_tune, batch_draw;
   int32_t family, K;  // K = n_outputs; KX = K - 1 extension outputs live in the *x arrays below
   int32_t rows_target, rows_target_init;  // work items the row passes aim for (tuning knobs)
-  int32_t ll_target, ll_pad;              // ... and the log-likelihood pass
+  int32_t ll_target;                      // ... and the log-likelihood pass
+  int32_t compat;                         // PGB_COMPAT_* (pgb_settings.compat): upstream-semantics switches
   unsigned long long seed;
   double init_leaf, mdouble;
   pgb_scales sc;

@@ -179,6 +179,8 @@ static ll_kernel_t select_ll_kernel(int K, bool lin, int family) {
   }
 }
 
+#define PGB_STR2(x) #x
+#define PGB_STR(x) PGB_STR2(x)
 extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out) {
   if (!s || !out) return fail(PGB_E_INVALID, "null argument");
   if (s->n < 1 || s->p < 1 || s->m < 1) return fail(PGB_E_INVALID, "n, p, m must be >= 1");
@@ -189,7 +191,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
                                    : "num_particles must be in [2, 128]");
   if (s->family == PGB_FAMILY_CATEGORICAL) {
     if (s->n_outputs < 2 || s->n_outputs > PGB_MAX_OUTPUTS)
-      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= 8");
+      return fail(PGB_E_INVALID, "CATEGORICAL needs 2 <= n_outputs <= " PGB_STR(PGB_MAX_OUTPUTS));
   } else if (s->family == PGB_FAMILY_NORMAL_MEANSCALE) {
     if (s->n_outputs != 2) return fail(PGB_E_INVALID, "NORMAL_MEANSCALE needs n_outputs == 2");
   } else if (s->family == PGB_FAMILY_NORMAL || s->family == PGB_FAMILY_BERNOULLI_PROBIT ||
@@ -204,6 +206,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     return fail(PGB_E_UNSUPPORTED, "unknown family");
   }
   if (s->batch_tune < 1 || s->batch_draw < 1) return fail(PGB_E_INVALID, "batch sizes must be >= 1");
+  if (s->compat & ~PGB_COMPAT_ALL) return fail(PGB_E_INVALID, "unknown compat bits (pgbart_spec.h: PGB_COMPAT_*)");
   if (s->response != PGB_RESPONSE_CONSTANT) {
     if (s->response != PGB_RESPONSE_LINEAR && s->response != PGB_RESPONSE_MIX)
       return fail(PGB_E_UNSUPPORTED, "unknown response");
@@ -278,7 +281,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.rows_target_init = ROWS_TARGET_ITEMS_INIT;
   if (const char* e = getenv("PGB_ROWS_TARGET")) d.rows_target = atoi(e) > 0 ? atoi(e) : d.rows_target;
   d.ll_target = d.rows_target;
-  d.ll_pad = 0;
+  d.compat = s->compat;
   if (const char* e = getenv("PGB_LL_TARGET")) d.ll_target = atoi(e) > 0 ? atoi(e) : d.ll_target;
   // The likelihood pass is a persistent grid too, and its instances differ a lot in registers (probit 88
   // VGPRs, K = 4 softmax 154): the grid is what the chosen instance can keep resident -- 5 workgroups per

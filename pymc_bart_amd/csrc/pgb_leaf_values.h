@@ -40,7 +40,7 @@ __device__ __forceinline__ ChildVals child_values(const DevG& S, int rule, int c
   c.cR = cnt - c.cL - c.cN;
   c.aL = a_aL;
   c.aR = p_q_st - a_aL - a_aN;
-  if (rule != PGB_RULE_CONTINUOUS && c.cR == 0) {
+  if (c.cR == 0 && pgb_empty_right_fails(rule, S.compat)) {
     c.ok = -1;
     c.vL = p_value;
     c.vR = 0.0;

@@ -290,6 +290,26 @@ def _set_on_op(op, name, value):
             pass
 
 
+def _compat_bits(semantics) -> int:
+    """``semantics``: ``None`` (or ``PGBART_SEMANTICS`` unset) = this sampler; ``"upstream"`` = both upstream-semantics
+    switches of ``include/pgbart_spec.h`` (fresh particles at log-weight 0, empty right leaves of one-hot splits);
+    an ``int`` = the ``PGB_COMPAT_*`` bits themselves.  The environment variable lets a model that builds its step
+    method through ``pm.sample()`` -- which passes no such argument -- pick the mode
+    (``tools/pymc_selfcheck.py`` runs both and reports which one ``bartrs`` agrees with)."""
+    import os
+
+    if semantics is None:
+        semantics = os.environ.get("PGBART_SEMANTICS") or 0
+    if isinstance(semantics, str):
+        if semantics.lstrip("-").isdigit():
+            return int(semantics)
+        try:
+            return {"default": 0, "native": 0, "upstream": 3}[semantics.lower()]
+        except KeyError:
+            raise ValueError(f"semantics must be 'default', 'upstream' or the PGB_COMPAT_* bits, got {semantics!r}") from None
+    return int(semantics)
+
+
 def _eval(x):
     return x.eval() if hasattr(x, "eval") and not isinstance(x, np.ndarray) else x
 
@@ -316,7 +336,7 @@ class PGBART(_Base):
 
     def __init__(self, vars=None, num_particles=10, batch=(0.1, 0.1), model=None,  # noqa: A002
                  initial_point=None, compile_kwargs=None, *, likelihood=None, observed=None, shared=None,
-                 random_seed=None, chain=0, backend=None, range_exp=None):
+                 random_seed=None, chain=0, backend=None, range_exp=None, semantics=None):
         self._binding = None
         duck = vars is not None and len(vars) == 1 and getattr(vars[0], "owner", None) is None
         if _HAVE_PYMC and not duck and likelihood is None:
@@ -381,6 +401,7 @@ class PGBART(_Base):
             X, Y, m=self.m, num_particles=num_particles, n_outputs=n_outputs,
             family=self.likelihood.family, alpha=float(op.alpha), beta=float(op.beta),
             batch=batch, seed=seed, response=self.response, y_obs=y_obs, range_exp=range_exp,
+            compat=_compat_bits(semantics),
         )
         self._X, self._rule_ids, self._split_prior = X, rule_ids, split_prior
         self._backend_arg = backend  # (not pickled: a worker process builds on its own default backend)

@@ -106,12 +106,16 @@ class PyBartSettings:
     init_leaf_sd: float = 1.0
     range_exp: int = 4
     response: str = "constant"
+    # Upstream-semantics switches (``include/pgbart_spec.h``, ``PGB_COMPAT_*``): 0 = this sampler; bit 0: a particle
+    # that has not grown keeps log-weight 0 (upstream's ``ParticleTree.log_weight``); bit 1: a one-hot split grows
+    # an empty right leaf.  ``"upstream"`` in :class:`PGBART` sets both.
+    compat: int = 0
     prior_leaf: np.ndarray = field(default_factory=lambda: np.ones(_abi.MAX_DEPTH))
 
     @classmethod
     def from_data(cls, X, Y, m=50, num_particles=10, n_outputs=1, family="normal", alpha=0.95,
                   beta=2.0, batch=(0.1, 0.1), seed=0, response="constant", y_obs=None,
-                  range_exp=None) -> "PyBartSettings":
+                  range_exp=None, compat=0) -> "PyBartSettings":
         """``y_obs``: the observed response when it is not ``Y`` itself (it enters the fixed-point
         range); ``range_exp``: override the range, e.g. for additive models whose offsets move the
         partial residuals far outside the data's own range."""
@@ -129,7 +133,7 @@ class PyBartSettings:
         return cls(
             n=n, p=p, m=m, num_particles=num_particles, n_outputs=n_outputs, family=family,
             alpha=alpha, beta=beta, batch=tuple(batch), seed=int(seed), init_sum=mean,
-            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=rexp, response=response,
+            init_leaf=mean / m, init_leaf_sd=leaf_sd, range_exp=rexp, response=response, compat=int(compat),
             prior_leaf=prior_leaf_table(alpha, beta),
         )
 
@@ -154,6 +158,7 @@ class PyBartSettings:
         s.batch_tune, s.batch_draw = self.batch_sizes()
         s.range_exp = self.range_exp
         s.response = _abi.RESPONSES[self.response]
+        s.compat = int(self.compat)
         s.seed = self.seed & 0xFFFFFFFFFFFFFFFF
         s.init_sum = self.init_sum
         s.init_leaf = self.init_leaf

@@ -9,6 +9,10 @@ from pymc_bart_amd.sampler import PyBartSettings, PySampler
 
 
 def make_case(name: str):
+    if name.startswith("upstream/"):  # the same case under the upstream-semantics switches (PGB_COMPAT_*: both bits)
+        c = make_case(name[len("upstream/"):])
+        c.update(name=name, compat=3)
+        return c
     rng = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else int(hashlib.sha1(name.encode()).hexdigest()[:8], 16))
     c = dict(name=name, m=10, P=10, steps=24, batch=(0.1, 0.1), rules=None, prior=None, seed=3415)
     if name == "cfg1_friedman":  # BASELINE.json configs[0]
@@ -289,7 +293,11 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "categorical_k12", "categorical_k16_linear", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
          "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
          "linear_mixed_rules", "mix_probit_mixed_rules", "categorical_k3_linear_mixed_rules",
-         "stump_first_probit", "stump_first_categorical", "stump_first_poisson"]
+         "stump_first_probit", "stump_first_categorical", "stump_first_poisson",
+         # pgb_settings.compat = 3: fresh particles at log-weight 0, empty right leaves of one-hot splits
+         "upstream/cfg1_friedman", "upstream/nan_onehot_prior", "upstream/onehot_fail_nan", "upstream/probit_cfg4_small",
+         "upstream/categorical_k3_reference", "upstream/subset_rule", "upstream/linear_mixed_rules",
+         "upstream/categorical_k3_linear_mixed_rules", "upstream/particles_128", "upstream/logit_nan_onehot"]
 
 
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
@@ -301,7 +309,8 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
     family = c.get("family", "normal")
     st = PyBartSettings.from_data(X, c.get("bart_Y", Y), m=c["m"], num_particles=c["P"], seed=c["seed"], batch=c["batch"],
                                   alpha=c.get("alpha", 0.95), beta=c.get("beta", 2.0), family=family,
-                                  n_outputs=c.get("K", 1), response=c.get("response", "constant"))
+                                  n_outputs=c.get("K", 1), response=c.get("response", "constant"),
+                                  compat=c.get("compat", 0))
     rules = np.zeros(p, np.int32) if c["rules"] is None else c["rules"]
     prior = np.ones(p) if c["prior"] is None else c["prior"]
     s = PySampler(st, X, Y, rules, prior, backend=backend)
@@ -358,7 +367,7 @@ def digest(res) -> dict:
     }
 
 
-def random_case(seed, large=False):
+def random_case(seed, large=False, compat=0):
     """A random configuration for the fuzz parity test: sizes around the chunk / wave boundaries,
     every family, every split rule, NaNs, ties, priors, batch sizes, alpha / beta.
     `large`: hundreds of chunks per pass (work items beyond one per workgroup, particle groups of
@@ -428,6 +437,6 @@ def random_case(seed, large=False):
         extra["offset"] = rng.normal(0, 0.3, n)  # another additive term of the linear predictor
     elif fam in ("categorical", "normal_meanscale") and rng.random() < 0.3:
         extra["offset"] = rng.normal(0, 0.3, (K, n))  # ... of every linear predictor of a K-vector model
-    return dict(**extra, name=f"fuzz{seed}", response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(2, 5) if large else rng.integers(4, 14)), batch=batch, rules=rules,
+    return dict(**extra, name=f"fuzz{seed}", compat=int(compat), response=response, X=X, Y=Y, m=m, P=P, steps=int(rng.integers(2, 5) if large else rng.integers(4, 14)), batch=batch, rules=rules,
                 prior=rng.uniform(0.5, 3.0, p), seed=int(rng.integers(0, 2**31)), family=fam, K=K,
                 alpha=float(rng.choice([0.95, 0.5, 0.999])), beta=float(rng.choice([2.0, 0.5, 1.0])))

@@ -405,6 +405,15 @@ def test_fuzz_parity_over_random_configurations(hip, oracle):
         assert g == o, (seed, c["family"], c["X"].shape, c["m"], c["P"], c["K"], c["rules"].tolist())
 
 
+def test_fuzz_parity_under_the_upstream_semantics_switches(hip, oracle):
+    """The same generator with pgb_settings.compat = 1, 2, 3 in turn (fresh particles at log-weight 0 until they grow;
+    empty right leaves of one-hot splits; both): bit for bit."""
+    for seed in range(7000, 7075):
+        c = random_case(seed, compat=1 + seed % 3)
+        g, o = digest(run_case(c, hip)), digest(run_case(c, oracle))
+        assert g == o, (seed, c["compat"], c["family"], c["X"].shape, c["m"], c["P"], c["K"], c["rules"].tolist())
+
+
 @pytest.mark.filterwarnings("ignore:response=")
 def test_linear_leaves_predict_the_same_on_gpu_and_host(hip, oracle):
     """response="linear": the chain, its exported slopes and the prediction kernel (with excluded and

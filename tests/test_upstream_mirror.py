@@ -6,7 +6,8 @@ unbounded trees, full-n ``update_weight`` -- and shares no code with the oracle.
 small problems of the reference's own tests over many seeds; what a user sees must agree within Monte-Carlo error:
 posterior-mean error, normalised variable inclusion, leaves per tree, tuned ``leaf_sd``, class recovery.
 
-Each problem is run by THREE samplers: the oracle; the mirror with ONE deviation switched on (`fresh_weight="stump"`:
+Each problem is run by FOUR samplers (the fourth: the oracle under the upstream-semantics switches of
+`include/pgbart_spec.h`, `PGB_COMPAT_*` -- it must land on the mirror as upstream is recalled): the oracle; the mirror with ONE deviation switched on (`fresh_weight="stump"`:
 deviation 2, a fresh particle carries the likelihood of its stump) -- the two must agree within Monte-Carlo error,
 which bounds the other eleven deviations in distribution; and the mirror as upstream is recalled
 (`fresh_weight="zero"`), whose distance from the other two MEASURES deviation 2 (a fresh particle that fails its first
@@ -22,10 +23,10 @@ from pymc_bart_amd.pgbart import PGBART, BARTOp, CategoricalLikelihood, NormalLi
 SEEDS = list(range(100, 124))  # 24 seeds per problem and sampler
 
 
-def _oracle_chain(oracle, X, Y, m, P, tune, draws, seed, family="normal", K=1, rules=None):
+def _oracle_chain(oracle, X, Y, m, P, tune, draws, seed, family="normal", K=1, rules=None, semantics=None):
     lik = NormalLikelihood(1.0) if family == "normal" else CategoricalLikelihood(K)
     op = BARTOp(X, Y, m=m, split_rules=rules)
-    step = PGBART([op], num_particles=P, likelihood=lik, random_seed=seed, backend=oracle)
+    step = PGBART([op], num_particles=P, likelihood=lik, random_seed=seed, backend=oracle, semantics=semantics)
     p = X.shape[1]
     vi, mu, leaves = np.zeros(p), 0.0, []
     for it in range(tune + draws):
@@ -37,13 +38,17 @@ def _oracle_chain(oracle, X, Y, m, P, tune, draws, seed, family="normal", K=1, r
             vi += np.asarray(step.last_vi_counts if hasattr(step, "last_vi_counts") else _decode(stats, p))
     step.flush_history()
     _, batches = step._baseline, step._batches
+    filled = []
     for b in batches:
         ta = b.decoded() if hasattr(b, "decoded") else b
         for t in range(ta.n_trees):
             lo, hi = ta.node_off[t], ta.node_off[t + 1]
             leaves.append(int((ta.var[lo:hi] < 0).sum()))
+            filled.append(int(((ta.var[lo:hi] < 0) & (ta.count[lo:hi] > 0)).sum()))
+    # (under the one-hot rule the default sampler never makes an empty leaf -- deviation 13 -- the upstream-semantics
+    #  mode does)
     return {"mu": mu / draws, "vi": vi, "leaves": float(np.mean(leaves)), "leaf_sd": step.sampler.state()["leaf_sd"].copy(),
-            "filled_leaves": float(np.mean(leaves))}  # (this sampler never makes an empty leaf: deviation 13)
+            "filled_leaves": float(np.mean(filled))}
 
 
 def _decode(stats, p):
@@ -89,12 +94,15 @@ def _friedman(seed, n=500, p=5):
 
 def _three(oracle, problem, seeds, metrics):
     """Run the three samplers over the seeds; returns {sampler: array [seeds, metrics]}."""
-    out = {"oracle": [], "mirror+dev2": [], "upstream": []}
+    out = {"oracle": [], "mirror+dev2": [], "upstream": [], "oracle/upstream": []}
     for seed in seeds:
         args, kw, truth = problem(seed)
         runs = (("oracle", lambda: _oracle_chain(oracle, *args, seed, **kw)),
                 ("mirror+dev2", lambda: _mirror_chain(*args, seed, fresh="stump", **kw)),
-                ("upstream", lambda: _mirror_chain(*args, seed, fresh="zero", **kw)))
+                ("upstream", lambda: _mirror_chain(*args, seed, fresh="zero", **kw)),
+                # the oracle with both upstream-semantics switches on (pgb_settings.compat, PGB_COMPAT_*): it has to
+                # land on the mirror-as-recalled, the way the default lands on the mirror with deviation 2
+                ("oracle/upstream", lambda: _oracle_chain(oracle, *args, seed, semantics="upstream", **kw)))
         for key, run in runs:
             out[key].append(metrics(run(), truth))
     return {k: np.array(v) for k, v in out.items()}
@@ -127,6 +135,11 @@ def test_friedman_fit_inclusion_tree_size_and_leaf_sd_against_upstream_semantics
     assert o[:, 0].mean() < 1.6 and s[:, 0].mean() < 1.6 and o[:, 1].mean() > 0.75  # (sd of f is 4.9)
     # deviation 2, measured: upstream's zero-weight stumps cost it fit and tree size in a chain of this length
     assert z[:, 0].mean() > o[:, 0].mean() + 0.3 and z[:, 2].mean() < o[:, 2].mean() - 0.3
+    # ... and switched back: the oracle under the upstream-semantics switches lands on the mirror as recalled
+    u = res["oracle/upstream"]
+    for i, (name, fl) in enumerate(zip(names, (0.03, 0.02, 0.08, 0.01))):
+        _agree(u[:, i], z[:, i], name + " [upstream semantics]", floor=fl)
+    assert u[:, 2].mean() < o[:, 2].mean() - 0.3
 
 
 def test_missing_values_case_against_upstream_semantics(oracle):
@@ -149,6 +162,7 @@ def test_missing_values_case_against_upstream_semantics(oracle):
     o, s = res["oracle"], res["mirror+dev2"]
     for i, (name, fl) in enumerate(zip(names, (0.04, 0.05, 0.12, 0.015))):
         _agree(o[:, i], s[:, i], name, floor=fl)
+        _agree(res["oracle/upstream"][:, i], res["upstream"][:, i], name + " [upstream semantics]", floor=fl)
 
 
 def test_three_class_softmax_case_against_upstream_semantics(oracle):
@@ -179,3 +193,8 @@ def test_three_class_softmax_case_against_upstream_semantics(oracle):
         else:
             _agree(o[:, 3], s[:, 1], f"leaves with rows per tree ({rule})", floor=0.06)
         _agree(o[:, 2], s[:, 2], f"leaf_sd ({rule})", floor=0.05)
+        # upstream semantics on both sides: recovery, leaves with rows, leaf_sd and ALL leaves -- the empty right
+        # leaves of one-hot splits included (PGB_COMPAT_ONEHOT_EMPTY_CHILD)
+        u = res["oracle/upstream"]
+        for i, fl in ((0, 0.05), (1, 0.06), (2, 0.05), (3, 0.06)):
+            _agree(u[:, i], z[:, i], f"{names[i]} ({rule}) [upstream semantics]", floor=fl)

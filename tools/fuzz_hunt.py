@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Parity hunt on a GPU box: random configurations (tests/_cases.random_case) through the HIP library and
 the CPU oracle, bit-for-bit digests compared.
-usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS] [large]   (large: n = 50k .. 1M, few trees)"""
+usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS] [large] [compat]
+(large: n = 50k .. 1M, few trees; compat: the upstream-semantics switches on, PGB_COMPAT_* = 1 + seed % 3)"""
 import os
 import sys
 import time
@@ -16,14 +17,15 @@ from pymc_bart_amd.sampler import default_backend  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
-large = len(sys.argv) > 4 and sys.argv[4] == "large"
+large = "large" in sys.argv[4:]
+compat_on = "compat" in sys.argv[4:]
 hip, orc = default_backend(0), oracle_backend()
 t0, bad, done = time.time(), [], 0
 fam = {}
 for seed in range(first, first + count):
     if time.time() - t0 > budget:
         break
-    c = random_case(seed, large)
+    c = random_case(seed, large, compat=(1 + seed % 3) if compat_on else 0)
     g, o = digest(run_case(c, hip)), digest(run_case(c, orc))
     done += 1
     key = (c["family"], int(c["K"]), str(c.get("response", "constant")))

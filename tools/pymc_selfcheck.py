@@ -5,7 +5,13 @@ data), :84-104 (shared X, posterior predictive shapes), :107-123 (shape=(2, n)),
 split rules), :167-208 (two BART variables, automatic step assignment), :211-241 (manual ``PGBART([mu],
 num_particles=5)``), :244-256 (mutable named dim) -- run through ``pymc_bart_amd`` on cuda:0.
 
-    python tools/pymc_selfcheck.py [--quick] [--only NAME ...]
+    python tools/pymc_selfcheck.py [--quick] [--only NAME ...] [--semantics]
+
+``--semantics`` (needs the real ``bartrs`` wheel as well): which of this sampler's two modes does ``bartrs`` follow --
+the default, or the upstream-semantics switches (``PGBART_SEMANTICS=upstream``: fresh particles at log-weight 0, empty
+right leaves of one-hot splits)?  Runs the reference's sampler and both modes on BASELINE's cfg1
+problem over 8 seeds and compares leaves per accepted tree (from the ``variable_inclusion`` stat: splits + 1), the
+metric the two modes differ most in (3.24 +- 0.03 against 2.41 +- 0.03).
 
 Needs: pymc, pymc_bart (the reference package, unmodified: this script answers its ``import bartrs`` with
 ``pymc_bart_amd``, which is the one-line change INTEGRATION.md section 3 describes), a MI355X.  Prints one
@@ -22,7 +28,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+REAL_BARTRS = None
+
+
 def _imports():
+    global REAL_BARTRS
+    try:  # the reference's own native sampler, if this box has it: kept aside for --semantics
+        import importlib
+
+        REAL_BARTRS = importlib.import_module("bartrs")
+        for k in [k for k in sys.modules if k == "bartrs" or k.startswith("bartrs.")]:
+            del sys.modules[k]
+    except Exception:  # noqa: BLE001
+        REAL_BARTRS = None
     import pymc_bart_amd
 
     # the reference imports its native sampler as `bartrs` (pymc_bart/pymc_bart.py:2, __init__.py:15,
@@ -170,6 +188,47 @@ def check_named_dim(pm, pmb, amd, q):  # :244-256
         pm.sample(tune=20, draws=20, chains=1, progressbar=False)
 
 
+def leaves_per_tree(idata, p, m, batch=0.1):
+    """Mean leaves per accepted tree of the draws: every draw re-samples max(1, int(m * batch)) trees and reports
+    their split counts per column; a tree with s splits has s + 1 leaves."""
+    from pymc_bart_amd.utils import _decode_vi
+
+    vals = idata["sample_stats"]["variable_inclusion"].values.ravel()
+    splits = np.array([sum(_decode_vi(v, p)) for v in vals], float)
+    return float(splits.mean() / max(1, int(m * batch)) + 1.0)
+
+
+def semantics_report(pm, pmb, amd, q):
+    """Which mode does bartrs follow?  (Not a PASS / FAIL item: prints the three numbers and the verdict.)"""
+    if REAL_BARTRS is None:
+        print("SKIP semantics: the real `bartrs` wheel is not importable here")
+        return
+    rows = {"bartrs": [], "pymc_bart_amd default": [], "pymc_bart_amd upstream": []}
+    for seed in range(8 // q):
+        rng = np.random.default_rng(1000 + seed)
+        X = rng.uniform(0, 1, (500, 10))
+        Y = (10 * np.sin(np.pi * X[:, 0] * X[:, 1]) + 20 * (X[:, 2] - 0.5) ** 2 + 10 * X[:, 3] + 5 * X[:, 4]
+             + rng.normal(0, 1, 500))
+        for key in rows:
+            os.environ.pop("PGBART_SEMANTICS", None)
+            if key.endswith("upstream"):
+                os.environ["PGBART_SEMANTICS"] = "upstream"
+            with pm.Model():
+                mu = pmb.BART("mu", X, Y, m=50)
+                pm.Normal("y", mu, 1.0, observed=Y)
+                step = (REAL_BARTRS if key == "bartrs" else amd).PGBART([mu], num_particles=10)
+                idata = pm.sample(tune=60, draws=40, chains=1, step=[step], random_seed=seed, progressbar=False)
+            rows[key].append(leaves_per_tree(idata, 10, 50))
+    os.environ.pop("PGBART_SEMANTICS", None)
+    stat = {k: (float(np.mean(v)), float(np.std(v, ddof=1) / np.sqrt(len(v)))) for k, v in rows.items()}
+    for k, (mean, se) in stat.items():
+        print(f"  leaves per tree  {k:24s} {mean:.3f} +- {se:.3f}")
+    ref = stat["bartrs"][0]
+    near = min(("default", "upstream"), key=lambda mode: abs(stat[f"pymc_bart_amd {mode}"][0] - ref))
+    print(f"semantics: bartrs is closest to the `{near}` mode"
+          + ("" if near == "default" else "  (run models with PGBART_SEMANTICS=upstream to match it)"))
+
+
 CHECKS = [("registration", check_registration), ("variable_inclusion", check_vi),
           ("variable_inclusion_linear", check_vi_linear), ("missing_data", check_missing),
           ("shared_variable", check_shared), ("shape_2xn", check_shape), ("categorical", check_categorical),
@@ -181,6 +240,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="halve tune / draws where the reference's counts allow")
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--semantics", action="store_true", help="compare both sampler modes with the real bartrs wheel")
     a = ap.parse_args()
     try:
         pm, pmb, amd = _imports()
@@ -202,6 +262,11 @@ def main():
         except Exception:  # noqa: BLE001
             fails += 1
             print(f"FAIL {name}\n" + "".join("    " + ln for ln in traceback.format_exc(limit=4).splitlines(True)))
+    if a.semantics:
+        try:
+            semantics_report(pm, pmb, amd, 2 if a.quick else 1)
+        except Exception:  # noqa: BLE001
+            print("semantics: could not be determined\n" + "".join("    " + ln for ln in traceback.format_exc(limit=4).splitlines(True)))
     print(f"{fails} failure(s)")
     return fails
 
