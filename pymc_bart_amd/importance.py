@@ -6,7 +6,12 @@ part -- posterior predictions with a set of covariates marginalised out (``exclu
 for "VI" and O(p^2) for the backward search -- runs in the ``k_predict`` kernel through
 ``PosteriorSampler.sample_posterior``; the correlations are a few n-vectors of NumPy per sweep.
 
-The ranking logic is restated from the reference's documented behaviour:
+The ranking logic is held to vectors produced by RUNNING the reference's own functions against deterministic
+stand-ins (``tests/golden/variable_importance.json``, generator ``tests/golden/make_utils_golden.py``,
+``tests/test_utils_golden.py``): same signature, same draws consumed in the same order, same ``indices``,
+``r2_mean``, ``preds`` layout.  Two calls the reference's own code cannot finish work here: ``method="backward"``
+on a single-output variable (upstream stops with a ValueError assigning a squeezed array, ``utils.py:1053``) and
+``method="backward_VI"`` (upstream never computes ``predicted_all`` on that path, ``utils.py:956-959``: NameError).
 
 * ``"VI"``: variables ordered by how often they were used for splitting; prediction j keeps only the
   j + 1 most used variables (the rest are excluded), the last keeps them all.
@@ -54,12 +59,27 @@ def hdi(x, prob: float = CI_PROB) -> np.ndarray:
     return np.array([x[i], x[i + k]])
 
 
-def inclusion_counts(vi, n_vars: int) -> np.ndarray:
+def inclusion_counts(vi, n_vars: int, model=None, bart_var_name=None) -> np.ndarray:
     """Total split-variable counts from whatever carries them: an InferenceData-like mapping
     (``idata["sample_stats"]["variable_inclusion"]``), a sequence of the base64 stat strings the
-    step method emits, or an array of counts ``(draws, p)`` / ``(p,)``."""
+    step method emits, or an array of counts ``(draws, p)`` / ``(p,)``.
+
+    A model with several BART variables stores one string per variable and draw (``variable_inclusion_dim_0``);
+    as upstream (``utils.py:779-789, 964-988``) the variable is then picked by its position among
+    ``model.free_RVs``; ``bart_var_name`` may be a list of names, whose counts are added."""
     if hasattr(vi, "__getitem__") and not isinstance(vi, (list, tuple, np.ndarray)):
         vi = vi["sample_stats"]["variable_inclusion"]
+        n_bart = int(getattr(getattr(vi, "variable_inclusion_dim_0", None), "size", 1))
+        if n_bart > 1:
+            if model is None or bart_var_name is None:
+                raise ValueError(
+                    "The InferenceData was generated from a model with multiple BART variables, \n"
+                    "please provide the model and also the name of the BART variable \n"
+                    "for which you want to compute the variable inclusion.")
+            free = [var.name for var in model.free_RVs]
+            names = bart_var_name if isinstance(bart_var_name, (list, tuple)) else [bart_var_name]
+            return sum(inclusion_counts(vi.sel({"variable_inclusion_dim_0": free.index(nm)}).values, n_vars)
+                       for nm in names)
         vi = getattr(vi, "values", vi)
     arr = np.asarray(vi)
     if arr.dtype.kind in "OUS":
@@ -72,19 +92,32 @@ def _r2_against(full: np.ndarray, part: np.ndarray) -> np.ndarray:
     return np.array([pearsonr2(full[j], part[j]) for j in range(full.shape[0])])
 
 
-def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0, samples: int = 50,
-                                random_seed=None, backend=None) -> dict:
+def compute_variable_importance(idata, bartrv, X, model=None, method: str = "VI", fixed: int = 0, samples: int = 50,
+                                random_seed=None, *, backend=None) -> dict:
     """Rank the covariates of a fitted BART variable and report how well the model restricted to
-    the top-k of them reproduces the full posterior predictions.
+    the top-k of them reproduces the full posterior predictions.  Signature of the reference
+    (``utils.py:868-877``; uses ``tests/test_bart.py:164,200-203``, ``tests/test_utils.py:78-80``).
 
-    ``vi``: see :func:`inclusion_counts` (ignored by ``method="backward"``).  ``bart``: the BART
-    variable or its op (needs ``all_trees``).  Returns the reference's dictionary: ``indices``
-    (most important first), ``labels``, ``r2_mean``, ``r2_hdi``, ``preds`` and ``preds_all``.
+    ``idata``: see :func:`inclusion_counts` (ignored by ``method="backward"``).  ``bartrv``: the BART variable,
+    its op (needs ``all_trees``), or a list of 1-D BART variables whose predictions are stacked side by side
+    (``utils.py:917-922``).  ``model``: only for models with several BART variables.  Returns the reference's
+    dictionary: ``indices`` (most important first), ``labels``, ``r2_mean``, ``r2_hdi``, ``preds``, ``preds_all``.
     """
     if method not in ("VI", "backward", "backward_VI"):
         raise ValueError("method must be 'VI', 'backward' or 'backward_VI'")
-    op = bart.owner.op if getattr(bart, "owner", None) is not None else bart
-    sampler = _get_posterior_sampler(op, backend=backend)
+
+    def op_of(rv):
+        return rv.owner.op if getattr(rv, "owner", None) is not None else rv
+
+    if isinstance(bartrv, list):
+        if not all(getattr(rv, "ndim", 1) == 1 for rv in bartrv):
+            raise ValueError("List inputs must contain only 1D BART variables")
+        sampler = [_get_posterior_sampler(op_of(rv), backend=backend) for rv in bartrv]
+        bart_var_name = [getattr(rv, "name", None) for rv in bartrv]
+    else:
+        sampler = _get_posterior_sampler(op_of(bartrv), backend=backend)
+        bart_var_name = getattr(bartrv, "name", None)
+    vi = idata
     rng = np.random.default_rng(random_seed)
     if hasattr(X, "columns") and hasattr(X, "to_numpy"):
         names = np.asarray(X.columns).astype(str)
@@ -108,7 +141,8 @@ def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0,
     stages: list[tuple] = []    # (r2 sample, predictions) once the variables of `order` so far are excluded
 
     if method in ("VI", "backward_VI"):
-        by_use = np.argsort(inclusion_counts(vi, p), kind="stable")  # least used first
+        # least used first; the reference's own call (`np.argsort(counts)`, default kind), so that ties fall as there
+        by_use = np.argsort(inclusion_counts(vi, p, model, bart_var_name))
         n_by_vi = p if method == "VI" else fixed
         order = [int(v) for v in by_use[:n_by_vi]]
     n_seed = len(order)
@@ -161,15 +195,15 @@ def compute_variable_importance(vi, bart, X, method: str = "VI", fixed: int = 0,
     }
 
 
-def get_variable_inclusion(vi, X, labels=None, to_kulprit: bool = False):
-    """Normalised variable inclusion, most used covariate first (reference ``utils.py:747-806``).
+def get_variable_inclusion(idata, X, model=None, bart_var_name=None, labels=None, to_kulprit: bool = False):
+    """Normalised variable inclusion, most used covariate first (reference ``utils.py:747-806``, same signature;
+    use: ``tests/test_bart.py:205-208``).
 
-    ``vi``: see :func:`inclusion_counts` -- for a model with several BART variables pass the stat
-    strings of the one in question (upstream selects it from the InferenceData by model / name).
-    Returns ``(shares, labels)``, or with ``to_kulprit=True`` the nested list of label prefixes
-    ``[[], [l0], [l0, l1], ...]`` that Kulprit's ``project`` takes as a path."""
+    ``idata``: see :func:`inclusion_counts`; ``model`` / ``bart_var_name`` select the variable when the model has
+    several BART variables.  Returns ``(shares, labels)``, or with ``to_kulprit=True`` the nested list of label
+    prefixes ``[[], [l0], [l0, l1], ...]`` that Kulprit's ``project`` takes as a path."""
     p = int(np.shape(X)[1])
-    counts = inclusion_counts(vi, p).astype(np.float64)
+    counts = inclusion_counts(idata, p, model, bart_var_name).astype(np.float64)
     order = np.argsort(counts / counts.sum())[::-1]
     if hasattr(X, "columns") and hasattr(X, "to_numpy"):
         names = [str(c) for c in np.asarray(X.columns)[order]]

@@ -85,7 +85,8 @@ def _resident_rows(sampler, X):
     """``X`` uploaded once for a sweep of predictions on the same rows (see
     ``PosteriorSampler.resident_rows``); a list of samplers shares the handle of its first chain."""
     first = sampler[0] if isinstance(sampler, list) else sampler
-    return first._chain_samplers[0].resident_rows(X)
+    upload = getattr(first._chain_samplers[0], "resident_rows", None)
+    return upload(X) if upload is not None else X
 
 
 class _MultiChainSampler:
