@@ -671,10 +671,10 @@ def main():
         else:
             s.step(tune, fetch=False)  # one synchronous step: the device buffer holds this chain's last draw
             draw = s.sum_trees_device().clone()  # (K*n,)
-        outs = [torch.empty_like(draw) for _ in range(world)]
+        outs = [torch.empty_like(draw) for _ in range(world)] if rank == 0 else None
         barrier()
         g0 = time.perf_counter()
-        dist.all_gather(outs, draw)  # direct all-gather over xGMI: every rank's shard moves in parallel
+        dist.gather(draw, outs, dst=0)  # as chains.gather_chains: every shard goes to rank 0 over its own xGMI link
         if not dry:
             torch.cuda.synchronize()
         line["gather_ms"] = (time.perf_counter() - g0) * 1e3
@@ -830,9 +830,12 @@ def workload_leg(wn, make_chain, be, args, torch):
         _, st1 = make_chain(wn, dict(seed=3415), 3415, be, batch=(1, 1), wl=w)
         s1 = st1.sampler
         run_all([s1], False, 1)
-        (el_c, u_c), _, _ = median_block(resident_blocks([s1], False, 8, 3, sync))
+        cs_blocks = resident_blocks([s1], False, 8, 3, sync)
+        (el_c, u_c), _, _ = median_block(cs_blocks)
         d["chain_start"] = {"gpu_value": u_c["particle_steps"] / el_c, "path": "resident, one tree per step",
-                            "tree_updates": 24,
+                            # tree updates the chain has seen when the timed blocks end (1 warm-up + what ran)
+                            "tree_updates": 1 + int(sum(b[1]["tree_updates"] for b in cs_blocks)),
+                            "tree_updates_in_reported_block": int(u_c["tree_updates"]),
                             "rows_touched_per_particle_step": u_c["rows_touched"] / max(u_c["particle_steps"], 1)}
         del s1
         st1.sampler = None

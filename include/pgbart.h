@@ -38,6 +38,10 @@
  *                        pgb_set_data checks every value and returns PGB_E_INVALID naming the column
  *   response linear/mix  any split rule (a leaf regresses on the column its parent split on, upstream's
  *                        fast_linear_fit; on a SubsetSplit column that is the category code)
+ *   tree updates         < 2^32 per chain: the Philox counter takes the low 32 bits of the tree-update counter
+ *                        (pgb_get_state's iter), so the random numbers of update i + 2^32 repeat those of update i
+ *                        (about 4 days of cfg2-sized asteps at 12 k tree updates/s); nothing is refused
+ *   offsets              |offset| <= 1e6 (PGB_MAX_OFFSET), finite; responses finite (pgb_set_offset / pgb_set_response)
  *   n                    < 2^31 - 1024 rows;  p, m >= 1 (bounded by memory: per row the device holds 8 p bytes
  *                        of the design matrix (+ 2 p for its 16-bit order keys when it exceeds the Infinity Cache),
  *                        m bytes of tree labels, 8 x pgb_max_particles() bytes of particle labels (8 generations) and
@@ -152,8 +156,9 @@ int pgb_set_response(pgb_handle* h, const double* y_dev);
  * the caller subtracts the other terms from the response instead): the likelihood sees
  * offset + sum_trees -- the contribution of the other additive terms of the model at the current
  * point (a second BART variable, a log-exposure, ...).  EXACTLY K*n doubles, layout [K][n] (the call takes
- * no size: the caller guarantees it, as the ctypes stub does); NULL resets to 0.  A non-finite value is refused with
- * PGB_E_INVALID and the offset is reset to 0 (the chain stays usable). */
+ * no size: the caller guarantees it, as the ctypes stub does); NULL resets to 0.  A non-finite value, or one beyond
+ * +-PGB_MAX_OFFSET = 1e6 (the per-row likelihood tables are addressed by the bits of the linear predictor, without a
+ * clamp), is refused with PGB_E_INVALID and the offset is reset to 0 (the chain stays usable). */
 int pgb_set_offset(pgb_handle* h, const double* offset_dev);
 
 /* Likelihood parameters at the current point of the other model variables

@@ -88,6 +88,12 @@
 #define PGB_COMPAT_ONEHOT_EMPTY_CHILD 2
 #define PGB_COMPAT_ALL 3
 
+/* Largest |offset| of a linear predictor pgb_set_offset accepts.  The table-driven exp / log-Phi of the per-row
+ * families (pgb_exp_t, pgb_lphi_t) take their table index from the bits of the argument without a clamp; they are
+ * exact in their saturation (0 / inf) only for |x| < 4.6e7, beyond which the index wraps.  sum_trees is bounded by
+ * the fixed-point range (|sum_trees| < 2^range_exp <= 2^20), so bounding the offset bounds the argument. */
+#define PGB_MAX_OFFSET 1.0e6
+
 /* likelihood families (closed family; SURVEY.md 7 "Hard parts") */
 #define PGB_FAMILY_NORMAL 0           /* y ~ N(mu, sigma)      params: sigma */
 #define PGB_FAMILY_BERNOULLI_PROBIT 1 /* y ~ Bern(Phi(mu))                   */

@@ -331,9 +331,9 @@ int pgb_set_offset(pgb_handle* h, const double* off) {
     return fail(PGB_E_UNSUPPORTED, "offsets are for the per-row families (a Normal model fits observed - offset)");
   if (off) {
     for (int64_t i = 0; i < h->s.n * h->s.n_outputs; ++i)
-      if (!(off[i] - off[i] == 0.0)) {  /* (a linear predictor must be finite; the offset is zeroed) */
+      if (!(off[i] - off[i] == 0.0) || !(fabs(off[i]) <= PGB_MAX_OFFSET)) {  /* (a linear predictor must be finite and of bounded size; the offset is zeroed) */
         memset(h->off, 0, sizeof(double) * h->s.n * h->s.n_outputs);
-        return fail(PGB_E_INVALID, "the offset has non-finite values");
+        return fail(PGB_E_INVALID, "the offset has non-finite values or values beyond +-1e6 (PGB_MAX_OFFSET)");
       }
     memcpy(h->off, off, sizeof(double) * h->s.n * h->s.n_outputs);
   } else {

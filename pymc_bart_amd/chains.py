@@ -100,10 +100,11 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
 def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool = False):
     """The single end-of-run collective: gather every rank's draws and tree history on ``dst``.
 
-    Dense draws travel as one tensor per rank (``all_gather`` over RCCL/xGMI on GPUs: each rank's
-    shard moves over its own links in parallel); the small ragged pieces (VI strings, tree
-    history) travel pickled with ``gather_object``.  Returns the list of per-chain results on
-    ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``; a group of ONE rank
+    Dense draws travel as one tensor per rank with ``gather`` to ``dst`` (over RCCL/xGMI on GPUs every rank's
+    shard reaches ``dst`` over its own direct link; only ``dst`` allocates the ``world`` receive buffers -- an
+    ``all_gather`` would land 7/8 of the traffic, 7 x 80 MB per rank at cfg2, on ranks that drop it); the small
+    ragged pieces (VI strings, tree history) travel pickled with ``gather_object``.  Returns the list of
+    per-chain results on ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``; a group of ONE rank
     skips the collectives too unless ``force_collective`` is set (the GPU suite sets it to run the RCCL
     calls of this function at world size 1 before an 8-GPU job meets them for the first time).
     """
@@ -117,8 +118,8 @@ def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool 
     # keep_draws=False: only sigma travels densely
     mu = result["mu"] if result["mu"] is not None else np.empty((result["sigma"].shape[0], 0))
     dense = torch.from_numpy(np.concatenate([mu, result["sigma"][:, None]], axis=1)).to(dev)
-    parts = [torch.empty_like(dense) for _ in range(world)]
-    dist.all_gather(parts, dense)
+    parts = [torch.empty_like(dense) for _ in range(world)] if rank == dst else None
+    dist.gather(dense, parts, dst=dst)
     small = {k: result[k] for k in ("chain", "variable_inclusion", "vi_counts", "history", "counters")}
     gathered = [None] * world if rank == dst else None
     dist.gather_object(small, gathered, dst=dst)

@@ -102,15 +102,16 @@ __global__ __launch_bounds__(BT) void k_subset_check(const double* __restrict__ 
   }
   if (b) atomicMax(bad, (int)blockIdx.x + 1);
 }
-// any non-finite value in `rows` rows of n values, `stride` apart?  -> *flag = 1 (the host's mapped word).
-// The linear predictor of a row must be finite: the likelihood tables are addressed by its bits (pgb_lphi_t).
+// any non-finite value, or one beyond +-limit, in `rows` rows of n values, `stride` apart?  -> *flag = 1 (the
+// host's mapped word).  The linear predictor of a row must be finite and of bounded size: the likelihood tables are
+// addressed by its bits (pgb_lphi_t, pgb_exp_t; PGB_MAX_OFFSET).
 __global__ __launch_bounds__(BT) void k_nonfinite(const double* __restrict__ a, long long n, long long stride, int rows,
-                                                  unsigned long long* __restrict__ flag) {
+                                                  double limit, unsigned long long* __restrict__ flag) {
   bool b = false;
   for (int r = 0; r < rows; ++r)
     for (long long i = (long long)blockIdx.x * BT + threadIdx.x; i < n; i += (long long)gridDim.x * BT) {
       const double v = a[(size_t)r * stride + i];
-      if (!(v - v == 0.0)) b = true;
+      if (!(v - v == 0.0) || !(__builtin_fabs(v) <= limit)) b = true;
     }
   if (__ballot(b) && (threadIdx.x & 63) == 0) *flag = 1ull;
 }

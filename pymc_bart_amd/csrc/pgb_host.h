@@ -660,7 +660,7 @@ extern "C" int pgb_set_response(pgb_handle* h, const double* y_dev) {
     HIPCHK(hipMemcpyAsync(h->y_host.data(), y_dev, h->d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   h->flag[4] = 0;
   hipLaunchKernelGGL(k_nonfinite, dim3(256), dim3(BT), 0, h->stream, (const double*)h->d.y, (long long)h->d.n,
-                     (long long)h->d.n_pad, 1, h->d.host_flag + 4);
+                     (long long)h->d.n_pad, 1, __builtin_inf(), h->d.host_flag + 4);
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->flag[4]) {
     h->have_y = 0;
@@ -694,12 +694,12 @@ extern "C" int pgb_set_offset(pgb_handle* h, const double* offset_dev) {
   h->flag[4] = 0;
   if (offset_dev)
     hipLaunchKernelGGL(k_nonfinite, dim3(256), dim3(BT), 0, h->stream, (const double*)h->d.off, (long long)h->d.n,
-                       (long long)h->d.n_pad, (int)h->d.K, h->d.host_flag + 4);
+                       (long long)h->d.n_pad, (int)h->d.K, (double)PGB_MAX_OFFSET, h->d.host_flag + 4);
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->flag[4]) {  // (a linear predictor must be finite; the offset is zeroed so that the chain stays usable)
     HIPCHK(hipMemsetAsync((void*)h->d.off, 0, (size_t)h->d.K * h->d.n_pad * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return fail(PGB_E_INVALID, "the offset has non-finite values");
+    return fail(PGB_E_INVALID, "the offset has non-finite values or values beyond +-1e6 (PGB_MAX_OFFSET)");
   }
   return PGB_OK;
 }
@@ -1169,15 +1169,24 @@ extern "C" int pgb_step_host(pgb_handle* h, int32_t tune, double* sum_trees_host
   if (early) {
     int extra = 0;
     long long polls = 0;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
+    auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
+    long long seen2 = (long long)h->flag[2];
     while (h->flag[1] < (unsigned long long)h->steps_target) {
       // (a device that faults between "last tree accepted" and the first idle slot would otherwise hold this
-      //  loop for ever, with the GIL released)
-      if ((++polls & 0x3FFF) == 0 && std::chrono::steady_clock::now() > deadline) {
-        hipError_t e = hipStreamQuery(h->stream);
-        h->poisoned = 1;
-        if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "device stopped before the step-complete word");
-        return fail(PGB_E_STATE, "the step-complete word never fired");
+      //  loop for ever, with the GIL released.  As in feed_until_flag the deadline MOVES while the device
+      //  publishes progress -- slots starting -- so that a FINAL pass that takes longer than PGB_WATCHDOG_S on a
+      //  time-sliced GPU, under a profiler or at very large n does not poison a healthy chain: round-4 ADVICE)
+      if ((++polls & 0x3FFF) == 0) {
+        const auto now = std::chrono::steady_clock::now();
+        if ((long long)h->flag[2] != seen2) {
+          seen2 = (long long)h->flag[2];
+          deadline = now + std::chrono::milliseconds((long long)(watchdog_seconds() * 1e3));
+        } else if (now > deadline) {
+          hipError_t e = hipStreamQuery(h->stream);
+          h->poisoned = 1;
+          if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "device stopped before the step-complete word");
+          return fail(PGB_E_STATE, "the step-complete word never fired");
+        }
       }
       // every enqueued slot has started and none of them was an idle one behind the finishing slot: one more
       if ((long long)h->flag[2] >= h->slot) {

@@ -467,7 +467,7 @@ class PGBART(_Base):
         self.__dict__.update(d)
         self._backend_arg = None
         self._sampler = None
-        _pick_device()
+        self._device_index = _pick_device()  # (None without a GPU) -- what the launcher tests assert per rank
         if blob is None:  # un-stepped: the sampler is built on first use, when this copy's Philox key is final
             return
         self.sampler = self._build_sampler()

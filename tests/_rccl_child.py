@@ -34,9 +34,18 @@ def main():
     res_nd = sample_chain(BARTOp(X, Y, m=6), tune=10, draws=8, random_seed=3415, chain=rank, backend=be,
                           keep_draws=False)
     got_nd = gather_chains(res_nd, dist, dst=0, force_collective=True)
+    # a step method unpickled in this rank (how PyMC hands it to a worker) lands on THIS rank's GPU and resumes
+    # the chain bit for bit
+    import pickle
+
+    twin = pickle.loads(pickle.dumps(res["step"]))
+    a = res["step"].astep(None, {"sigma": 0.5})[0]
+    b = twin.astep(None, {"sigma": 0.5})[0]
     ones = torch.ones(4, device="cuda")
     dist.all_reduce(ones)
-    out = {"backend": dist.get_backend(), "world": world, "allreduce": float(ones[0].item())}
+    out = {"backend": dist.get_backend(), "world": world, "allreduce": float(ones[0].item()),
+           "unpickled_device": twin._device_index, "local_rank": local, "current_device": torch.cuda.current_device(),
+           "unpickled_resumes": bool(np.array_equal(a, b))}
     if rank == 0:
         out["chains"] = len(got)
         out["mu_equal"] = bool(np.array_equal(got[0]["mu"], res["mu"]))

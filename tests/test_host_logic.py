@@ -285,3 +285,38 @@ def test_packed_tree_record_equals_the_array_export(oracle, response, K):
     # the history a step publishes is made of these records and the predictor reads them
     ps = PosteriorSampler.from_history(st._batches, st._baseline, 7, K, backend=oracle)
     assert ps.n_draws == 4 and ps.sample_posterior(X[:5], [0, 3], []).shape == (2, K, 5)
+
+
+def test_offsets_and_responses_the_likelihood_tables_cannot_address_are_refused(oracle):
+    """``pgb_set_offset`` refuses non-finite values and values beyond +-PGB_MAX_OFFSET = 1e6 (the table-driven exp /
+    log-Phi take their index from the bits of the linear predictor without a clamp: exact saturation only below
+    4.6e7 -- round-4 ADVICE); the offset is reset and the chain stays usable.  ``pgb_set_response`` refuses
+    non-finite values.  (The same assertions run against the HIP library in tests/test_parity_gpu.py.)"""
+    _refusals(oracle)
+
+
+def _refusals(backend):
+    from pymc_bart_amd.sampler import PyBartSettings, PySampler
+
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(300, 2))
+    Y = (rng.random(300) < 0.5).astype(float)
+    st = PyBartSettings.from_data(X, Y, m=3, num_particles=4, family="bernoulli_logit", seed=1)
+    s = PySampler(st, X, Y, np.zeros(2, np.int32), np.ones(2), backend=backend)
+    s.set_likelihood([])
+    ok = rng.normal(0, 1, 300)
+    s.set_offset(ok)
+    ref, _ = s.step(True)
+    for bad in (np.inf, -np.inf, np.nan, 1.5e8, -1.0e6 * 1.0000001):
+        off = ok.copy()
+        off[17] = bad
+        with pytest.raises(_abi.PGBError, match="offset has non-finite values or values beyond"):
+            s.set_offset(off)
+    s.set_offset(np.full(300, 1.0e6))      # the bound itself is inside
+    s.set_offset(ok)                        # ... and after a refusal the chain goes on
+    again, _ = s.step(True)
+    assert np.isfinite(again).all() and again.shape == ref.shape
+    yb = Y.copy()
+    yb[3] = np.nan
+    with pytest.raises(_abi.PGBError, match="response has non-finite"):
+        s.set_response(yb)

@@ -748,3 +748,10 @@ def test_soak_of_every_stepping_api_in_random_alternation(hip, oracle):
 
     calls, steps, kinds = soak_parity.run(6.0, 11, backs={"hip": hip, "oracle": oracle})
     assert calls > 200 and steps > 200 and len(kinds) >= 6
+
+
+def test_offsets_and_responses_the_likelihood_tables_cannot_address_are_refused_on_gpu(hip):
+    """k_nonfinite with its bound (PGB_MAX_OFFSET): the HIP library refuses what the oracle refuses."""
+    from test_host_logic import _refusals
+
+    _refusals(hip)

@@ -1,5 +1,5 @@
 """First contact with RCCL happens HERE, not in the driver's 8-GPU run (round-2 VERDICT, missing #1):
-``init_process_group("nccl")``, the device ``all_reduce`` / ``all_gather`` of ``bench.py`` and the collective
+``init_process_group("nccl")``, the device ``all_reduce`` / ``all_gather`` / ``gather`` of ``bench.py`` and the collective
 branch of ``chains.gather_chains`` on ``cuda`` tensors, at world size 1 on the one GPU of the test box.
 Every rank is a fresh CHILD process started by ``torch.distributed.run`` (the pytest process, which has
 touched the GPU, is never exec'ed).  Reference model of the exchange: ``bart.py:133-135`` (per-chain
@@ -38,7 +38,7 @@ def test_bench_rank_under_torchrun_initialises_rccl_and_runs_its_collectives():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["ranks_reported_by_collective"] == 1           # an all_reduce of ones on a cuda tensor over RCCL
-    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 100_000 * 8   # the end-of-run all_gather
+    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 100_000 * 8   # the end-of-run gather to rank 0
     assert d["per_rank_ms_per_step"] and len(d["per_rank_ms_per_step"]) == 1
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["data"] == "synthetic"
     assert d["roofline"]["kernel"] == "k_rows"              # the HIP path ran under the launcher
@@ -51,6 +51,8 @@ def test_gather_chains_collective_branch_on_cuda_over_rccl():
     assert len(out) == 1, r.stdout[-2000:]
     d = json.loads(out[0][len("RCCL_CHILD "):])
     assert d["backend"] == "nccl" and d["world"] == 1 and d["allreduce"] == 1.0
+    # the device an unpickled step method picks is its rank's (LOCAL_RANK), and the chain resumes there bit for bit
+    assert d["unpickled_device"] == d["local_rank"] == d["current_device"] and d["unpickled_resumes"]
     assert d["chains"] == 1 and d["mu_equal"] and d["sigma_equal"] and d["vi_equal"] and d["n_batches"] == 8
     # keep_draws=False through the same collectives (round-3 VERDICT #5)
     assert d["nodraws_mu_none"] and d["nodraws_sigma_equal"] and d["nodraws_vi_equal"] and d["nodraws_n_batches"] == 8
