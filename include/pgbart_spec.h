@@ -585,6 +585,83 @@ PGB_HD double pgb_loglik_cat_t(int K, double y, const double* mu, const pgb_llta
   return PGB_CLAMP_LL(ll, 0.0);
 }
 
+/* The same softmax log-likelihood for CONSTANT leaves, factorised (round 5).  During one tree update a row i is
+ * evaluated once per (particle, round) that re-labels it -- ~ 48 times per tree at 40 particles -- and every time
+ * with predictors mu_k = eta_k(i) + v_k: a part that belongs to the ROW (eta_k = sum_trees_noi_k + offset_k, fixed
+ * while the tree is updated) and a part that belongs to the (particle, child) (the K leaf values).  With
+ *     M = max_k eta_k,  a_k = eta_k - M,  E_k = exp(a_k)        per row, once per tree update
+ *     d_k = v_k - v_0,  w_k = exp(d_k)                          per (particle, child), once per round
+ * the log-likelihood is (a_c + d_c) - log S with S = sum_k E_k w_k: K fma and ONE logarithm per evaluation instead
+ * of K exponentials and one logarithm (the exponentials were two thirds of the likelihood pass at K = 4).
+ * The child's part is taken relative to output 0, not to the largest leaf value: each output's d_k, w_k then depends
+ * on its own leaf value and output 0's alone (the kernels compute the outputs of a child side by side), and
+ * w_0 = exp(0) = 1 exactly.  A child is FAST when every |d_k| <= PGB_CAT_DMAX = 300: then every w_k is a normal
+ * double, S >= E_j w_j >= e^-300 for the output j with E_j = 1, S <= K e^300, and a term whose E_k underflowed
+ * (a_k < -708) is below e^-408 S -- the factorised value is exact to the last few ulp of log S for ANY row, no
+ * per-row test needed.  A child that is not fast (leaf values hundreds of units apart: a chain that has left every
+ * sane regime) takes the unfactorised pgb_loglik_cat_t on mu_k = eta_k + v_k for all of its rows.
+ * (Linear leaves keep pgb_loglik_cat_t: their leaf value changes from row to row.)
+ * Maxima and sums are serial in output order, like everywhere in this contract. */
+#ifndef PGB_CAT_DMAX
+#define PGB_CAT_DMAX 300.0 /* (a test build of BOTH backends with a tiny value sends every child down the slow path) */
+#endif
+/* the (particle, child) part: d[k], w[k] from the K leaf values v[k]; returns 1 when the child is fast */
+PGB_HD int pgb_cat_side(int K, const double* v, const double* expt, double* d, double* w) {
+  int fast = 1;
+  for (int k = 0; k < K; ++k) {
+    d[k] = v[k] - v[0];
+    w[k] = pgb_exp_t(d[k], expt);
+    if (!(d[k] <= PGB_CAT_DMAX && d[k] >= -PGB_CAT_DMAX)) fast = 0;
+  }
+  return fast;
+}
+/* the row part: E[k] and a_c (c = the observed class, clamped like pgb_loglik_cat_t clamps it) from eta[k] */
+PGB_HD int pgb_cat_class(int K, double y) {
+  int c = (int)y;
+  if (c < 0) c = 0;
+  if (c > K - 1) c = K - 1;
+  return c;
+}
+/* (E may be eta itself; the class is matched by compares, not by an index: a register array on the device) */
+PGB_HD double pgb_cat_row(int K, int c, const double* eta, const double* expt, double* E) {
+  double M = eta[0];
+  for (int k = 1; k < K; ++k)
+    if (eta[k] > M) M = eta[k];
+  double a_c = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double ak = eta[k] - M;
+    if (k == c) a_c = ak;
+    E[k] = pgb_exp_t(ak, expt);
+  }
+  return a_c;
+}
+/* S = sum_k E[k] w[k], one fma per output in output order */
+PGB_HD double pgb_cat_sum(int K, const double* E, const double* w) {
+  double S = E[0] * w[0];
+  for (int k = 1; k < K; ++k) S = PGB_FMA(E[k], w[k], S);
+  return S;
+}
+/* the value of a row of a fast child */
+PGB_HD double pgb_cat_value(double a_c, double d_c, double S, const double* logt) {
+  const double ll = (a_c + d_c) - pgb_log_pos_t(S, logt);
+  return PGB_CLAMP_LL(ll, 0.0);
+}
+/* everything together, as the oracle evaluates one row (the kernels keep E / a_c per row and d / w per child) */
+PGB_HD double pgb_loglik_cat_f(int K, double y, const double* eta, const double* v, const double* d, const double* w,
+                               int fast, const pgb_lltabs* tb) {
+  if (fast) {
+    double E[PGB_MAX_OUTPUTS];
+    E[0] = 0.0; /* (K >= 1: always overwritten; quiets a compiler that cannot know) */
+    const int c = pgb_cat_class(K, y);
+    const double a_c = pgb_cat_row(K, c, eta, tb->expt, E);
+    return pgb_cat_value(a_c, d[c], pgb_cat_sum(K, E, w), tb->logt);
+  }
+  double mu[PGB_MAX_OUTPUTS];
+  mu[0] = 0.0; /* (see E above) */
+  for (int k = 0; k < K; ++k) mu[k] = eta[k] + v[k];
+  return pgb_loglik_cat_t(K, y, mu, tb);
+}
+
 /* Normal with BART mean and BART scale (reference tests/test_bart.py:118: Normal(w[0], |w[1]|)):
  * -log|s| - 0.5 ((y - m)/s)^2 (the constant -0.5 log 2pi cancels in the particle weights).
  * |s| is floored at 1e-8; clamped to [-2047, 2047]. */

@@ -442,6 +442,18 @@ static void o_tree_begin(pgb_handle* h, int tree_id) {
         mu_cur[k] = stk + h->off[(size_t)k * n + i];
       }
       h->r[i] = 0.0;
+      if (s->family == PGB_FAMILY_CATEGORICAL && s->response == PGB_RESPONSE_CONSTANT) {
+        /* softmax, constant leaves: the stump in the factorised form of the contract (pgb_loglik_cat_f) -- every
+           output predicts init_leaf, so d = 0 and w = 1 exactly and the value is a_c - log sum_k E_k */
+        const pgb_lltabs tb = pgb_lltabs_default();
+        double eta[PGB_MAX_OUTPUTS], v0[PGB_MAX_OUTPUTS], d0[PGB_MAX_OUTPUTS], w0[PGB_MAX_OUTPUTS];
+        eta[0] = noi + h->off[i];
+        for (int k = 1; k < K; ++k)
+          eta[k] = (h->st[(size_t)k * n + i] - h->oldv[(size_t)k * n + i]) + h->off[(size_t)k * n + i];
+        for (int k = 0; k < K; ++k) v0[k] = s->init_leaf;
+        const int fast = pgb_cat_side(K, v0, tb.expt, d0, w0);
+        C += pgb_quant(pgb_loglik_cat_f(K, h->y[i], eta, v0, d0, w0, fast, &tb), h->sc.cl, &sat);
+      } else
       C += pgb_quant(o_loglik(h, i, h->y[i], mu_stump), h->sc.cl, &sat);
       E0 += pgb_quant(o_loglik(h, i, h->y[i], mu_cur), h->sc.cl, &sat);
     }
@@ -489,6 +501,22 @@ static int64_t o_seg_loglik_lin(pgb_handle* h, const int32_t* seg, int64_t cnt, 
   int64_t acc = 0;
   const int K = h->s.n_outputs;
   const int64_t n = h->s.n;
+  if (h->s.family == PGB_FAMILY_CATEGORICAL && h->s.response == PGB_RESPONSE_CONSTANT) {
+    /* softmax, constant leaves: the factorised form of the contract (pgb_loglik_cat_f) -- the part of the
+       (particle, child) once per segment, the part of the row per row */
+    const pgb_lltabs tb = pgb_lltabs_default();
+    double d[PGB_MAX_OUTPUTS], w[PGB_MAX_OUTPUTS];
+    const int fast = pgb_cat_side(K, v, tb.expt, d, w);
+    for (int64_t k = 0; k < cnt; ++k) {
+      int32_t i = seg[k];
+      double eta[PGB_MAX_OUTPUTS];
+      for (int o = 0; o < K; ++o)
+        eta[o] = (h->st[(size_t)o * n + i] - h->oldv[(size_t)o * n + i]) + h->off[(size_t)o * n + i];
+      acc += pgb_quant(pgb_loglik_cat_f(K, h->y[i], eta, v, d, w, fast, &tb), h->sc.cl, &sat);
+    }
+    h->ctr.saturations += sat;
+    return acc;
+  }
   for (int64_t k = 0; k < cnt; ++k) {
     int32_t i = seg[k];
     double mu[PGB_MAX_OUTPUTS];
@@ -1276,6 +1304,13 @@ void pgbo_math_t(const double* x, int64_t n, double* e, double* l) {
 }
 void pgbo_loglik_multi(int family, int K, const double* y, const double* mu /* [n][K] */, int64_t n, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik(family, K, y[i], mu + i * K);
+}
+/* the factorised softmax of constant leaves (pgb_loglik_cat_f): eta [n][K] row parts, v [K] leaf values */
+void pgbo_loglik_cat_f(int K, const double* y, const double* eta, const double* v, int64_t n, double* out) {
+  const pgb_lltabs tb = pgb_lltabs_default();
+  double d[PGB_MAX_OUTPUTS], w[PGB_MAX_OUTPUTS];
+  const int fast = pgb_cat_side(K, v, tb.expt, d, w);
+  for (int64_t i = 0; i < n; ++i) out[i] = pgb_loglik_cat_f(K, y[i], eta + i * K, v, d, w, fast, &tb);
 }
 void pgbo_lin_fit(int64_t cnt, int64_t q_u, int64_t q_uu, int64_t q_us, int64_t q_st, double inv_c1, double inv_R,
                   double m, double* out3) {

@@ -73,6 +73,22 @@ __device__ __forceinline__ int wave_pick(const double (&lw)[NH], int first, int 
 // [U] SampleSplittingVariable.rvs on one wave, from stored prefix sums (pgb_sample_var)
 __device__ __forceinline__ int sample_var_prefix(const long long* Sarr, int p, double u) {
   const int lane = threadIdx.x & 63;
+  if (p > 64 && p <= 256) {
+    // 65 .. 256 columns (cfg4: 100, cfg5: 200): the blocks of 64 prefix sums are requested TOGETHER with the total;
+    // the loop below pays a memory round trip per block, one after the other, before the wave can go on to what
+    // the slot is waiting for (at cfg5 the pre-draw waves reached the barrier 1.4 us after wave 0)
+    long long v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = Sarr[lane + 64 * i < p ? lane + 64 * i : p - 1];
+    const double thr = u * (double)Sarr[p - 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = lane + 64 * i;
+      const unsigned long long m = __ballot(j < p && thr <= (double)v[i]);
+      if (m) return 64 * i + (int)__ffsll((long long)m) - 1;
+    }
+    return p - 1;
+  }
   const double thr = u * (double)Sarr[p - 1];
   for (int base = 0; base < p; base += 64) {
     const int j = base + lane;
@@ -467,12 +483,14 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
     const int set = (tid >> 6) - 1, l = tid & 63;
     const pgb_u2 u = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p,
                                l == 0 ? PGB_RNG_PROPOSE : PGB_RNG_SELECT, l == 0 ? 0u : (uint32_t)(l - 1));
+    TRX(32 + set, blockIdx.x == 1 && l == 0);
     if (l <= PGB_SELECT_TRIES) {
       s_pre[set][l] = u.u0;
       s_pre1[set][l] = u.u1;
     }
     const double u1 = readlane_d(u.u1, 0);
     const int jj = (set && rebuild) ? sample_var_weights(alpha, S.p, u1) : sample_var_prefix(cdfS, S.p, u1);
+    TRX(34 + set, blockIdx.x == 1 && l == 0);
     if (l == 0) {
       s_i[8 + set] = jj;
       // the column's rule and NaN flag: fetched here, off the critical path (they used to be two dependent

@@ -10,7 +10,7 @@ struct LJobLin {  // linear response: the children's linear parts
   int32_t svarL, svarR;
 };
 struct LJobNone {};
-template <bool MK, bool LIN, int KT>
+template <bool MK, bool LIN, int KT, bool CATF = false>
 struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant leaves: none of the linear fields in LDS)
   long long src, xoff, dst;  // byte offsets: the particle's labels before the split, its split column, its new labels
   double v, vL, vR;
@@ -19,6 +19,13 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
   static constexpr int NX = !MK ? 1 : KT > 0 ? KT - 1 : KXMAX;
   double vLx[NX], vRx[NX];
   double sLx[MK && LIN ? NX : 0], sRx[MK && LIN ? NX : 0];  // ... slopes of outputs 1..K-1
+  // softmax with constant leaves: the (particle, child) part of the factorised log-likelihood (pgb_cat_side),
+  // [0] the left child, [1] the right one: d = v - v of output 0, w = exp(d); slowx[k - 1]: bit 0 / 1 = output k makes
+  // the left / right child a slow one (|d| > PGB_CAT_DMAX: its rows take the unfactorised form)
+  static constexpr int NK = !CATF ? 0 : KT > 0 ? KT : PGB_MAX_OUTPUTS;
+  __attribute__((aligned(16))) double w2[CATF ? 2 : 0][NK];
+  double d2[CATF ? 2 : 0][NK];
+  int32_t slowx[CATF ? NX : 0];
 };
 
 // Dense evaluation of sparse leaves (single output, constant leaves): a wave owns 256 rows, 4 per lane, and the
@@ -39,10 +46,14 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
 // is K table-driven exponentials and one logarithm, fully unrolled (pgb_loglik_cat_t; round 4 -- the K - 1
 // exponentials of the previous form cost more in selects than the exponential they saved).
 // (The run-time-K instances, KT = 0, keep the spec's own dispatcher: K = 5..8 and K-vector linear leaves.)
-template <int KT>
+template <int KT, int FAM = -1>
 __device__ __forceinline__ double loglik_mk(int family, int K, double y, const double* mu, const pgb_lltabs* tb) {
   if constexpr (KT == 0) {
     return pgb_loglikq_t(family, K, y, mu, 0.0, 1.0, tb);
+  } else if constexpr (FAM == PGB_FAMILY_CATEGORICAL) {
+    return pgb_loglik_cat_t(KT, y, mu, tb);
+  } else if constexpr (FAM == PGB_FAMILY_NORMAL_MEANSCALE) {
+    return pgb_loglik_meanscale_t(y, mu, tb);
   } else {
     if (KT >= 3 || family == PGB_FAMILY_CATEGORICAL) return pgb_loglik_cat_t(KT, y, mu, tb);
     return pgb_loglik_meanscale_t(y, mu, tb);
@@ -116,9 +127,32 @@ __device__ __forceinline__ double loglik_arr(int family, int K, double y, const 
 // pairs [PAIRS][entries][2], one 16-byte read per pair at an immediate offset of ONE address).
 // (Measured and dropped, round 4: the coefficient-major layout [9][entries] with nine 8-byte reads -- lanes with
 //  different entries then collide only when the entries are 32 apart instead of 16 -- 24.6 -> 32.3 us at cfg4.)
-__device__ __forceinline__ void lphi_stage(double* s_tab /* LDS, PGB_LPHI_SIZE */) {
-  const double* g = pgb_tab_lphi();
-  for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += BT) s_tab[i] = g[i];
+// A table of N doubles (16-byte aligned, N even) on its way into LDS in two halves: every thread REQUESTS its 16-byte
+// pieces (stage_load: all of them in flight at once), and stores them once they are needed (stage_store).  The
+// requests go out at the head of the kernel, next to the command word: the tables are read once per launch by every
+// workgroup and the row passes between two launches push them out of the L2 -- in-kernel stamps (round 5) showed a
+// workgroup waiting 1.9 us (exp / log) and 3.6 us (log Phi, 18.5 KB, nine dependent iterations) for them AFTER it
+// had learnt that the slot has work.
+template <int N>
+struct StageRegs {
+  static constexpr int PER = (N / 2 + BT - 1) / BT;
+  double2 v[PER];
+};
+template <int N>
+__device__ __forceinline__ void stage_load(const double* g, StageRegs<N>& r) {
+#pragma unroll
+  for (int i = 0; i < StageRegs<N>::PER; ++i) {
+    const int idx = (int)threadIdx.x + i * BT;
+    r.v[i] = idx < N / 2 ? gload_d2(as_global(g) + 2 * idx) : double2{0.0, 0.0};
+  }
+}
+template <int N>
+__device__ __forceinline__ void stage_store(double* s_tab, const StageRegs<N>& r) {
+#pragma unroll
+  for (int i = 0; i < StageRegs<N>::PER; ++i) {
+    const int idx = (int)threadIdx.x + i * BT;
+    if (idx < N / 2) ((double2*)s_tab)[idx] = r.v[i];
+  }
 }
 __device__ __forceinline__ double lphi_lds(double s, const double* s_tab) { return pgb_lphi_t(s, s_tab); }
 
@@ -139,11 +173,32 @@ template <int KT, int FAM, bool LIN>
 //  register more costs it a third of its waves -- 32 -> 40 us per launch at cfg5;
 //  the probit instance -- cfg4's dominant kernel -- for 5: <= 96 VGPRs, where a 97th costs it a fifth)
 __global__ __launch_bounds__(BT, (KT == 1 && FAM == PGB_FAMILY_BERNOULLI_PROBIT && !LIN) ? 5 : (KT >= 2 && !LIN) ? PGB_LLK_WGS : KT == 0 ? 2 : 3)
-void k_loglik(const Dev* __restrict__ Sp, int par) {
+void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restrict__ cmds, const Ctrl* __restrict__ ctrls,
+              const Job* __restrict__ jobs_all, const Acc* __restrict__ acc_all, const InitAcc* __restrict__ ias) {
+  // cmds / ctrls / jobs_all / acc_all / ias repeat S.cmd / S.ctrl / S.jobs / S.acc / S.initacc as kernel arguments
+  // (preloaded into SGPRs): the first loads of the launch -- the command word, the control word, the job records and
+  // their statistics -- go out together, at once, instead of behind a load of their pointers from the argument block
+  // S (in-kernel stamps, round 5: 4.1 - 4.9 us from the entry of a workgroup to the end of its job list, in every
+  // launch of every instance: four dependent memory round trips and a few hundred instructions)
+  // nwg repeats gridDim.x as an explicit argument (it takes the padding after `par`): gridDim.x is a HIDDEN argument,
+  // a scalar load from the kernel-argument segment with its wait in front of the first item of the passes
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
+  // what the passes need of the argument block, requested with everything else at the head of the launch (read
+  // where they are used, these scalar loads and the hidden grid size stood between the job list and the first
+  // label words: 2.6 us at cfg5, in-kernel stamps)
+  const long long n = S.n;
+  const int nchunks_h = S.nchunks;
+  const double cl = S.sc.cl;
+  const gptr<const double> gy = as_global(S.y), goff = as_global(S.off);
+  const gptr<const uint8_t> glid = as_global((const uint8_t*)S.lid);
+  const double* const st_h = S.st;
+  const long long n_pad_h = S.n_pad;
   constexpr bool MK = KT != 1;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops (run-time K: guarded by k < K)
-  typedef LJobT<MK, LIN, KT> LJob;
+  // softmax with constant leaves: the factorised evaluation (pgbart_spec.h, pgb_loglik_cat_f)
+  constexpr bool CATF = MK && !LIN && FAM == PGB_FAMILY_CATEGORICAL;
+  constexpr int FAMK = MK ? FAM : -1;  // the family of a K-vector instance when it is known at compile time
+  typedef LJobT<MK, LIN, KT, CATF> LJob;
 #ifdef PGB_STAMP_LL  // experiment builds: this kernel, not the row pass, leaves the per-workgroup clock readings
   struct StampEnd {
     long long* p;
@@ -169,7 +224,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   constexpr bool EXPLOG = !(KT == 1 && (FAM == PGB_FAMILY_BERNOULLI_PROBIT || FAM == PGB_FAMILY_ASYMLAPLACE ||
                                         FAM == PGB_FAMILY_CALLBACK));
   __shared__ __attribute__((aligned(16))) double s_lphi[PROBIT ? PGB_LPHI_SIZE : 2];
-  __shared__ double s_expt[EXPLOG ? PGB_EXPT_SIZE : 1];
+  __shared__ __attribute__((aligned(16))) double s_expt[EXPLOG ? PGB_EXPT_SIZE : 2];
   __shared__ __attribute__((aligned(16))) double s_logt[EXPLOG ? PGB_LOGT_SIZE : 2];
   pgb_lltabs tb;
   tb.lphi = pgb_tab_lphi();  // (the probit instance evaluates through lphi_lds on its staged copy)
@@ -192,18 +247,53 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   // list densely -- per particle, or through a per-wave queue with three interleaved passes -- is
   // SLOWER at cfg4, 184 k / 171 k vs 223 k particle-steps/s: with a quarter of the lanes active the
   // rare branches of the evaluation are skipped wave-wide, with every lane active they never are.)
-  const Cmd* cmd = &S.cmd[par];
-  if (!(cmd->kind & CMD_PARTITION)) return;
-  if constexpr (PROBIT) lphi_stage(s_lphi);
-  if constexpr (EXPLOG) {
-    const double* ge = pgb_tab_exp();
-    const double* gl = pgb_tab_log();
-    for (int i = threadIdx.x; i < PGB_EXPT_SIZE; i += BT) s_expt[i] = ge[i];
-    for (int i = threadIdx.x; i < PGB_LOGT_SIZE; i += BT) s_logt[i] = gl[i];
+  const Cmd* cmd = &cmds[par];
+  // The job records and split statistics of this lane's particles are requested FIRST, next to the command word
+  // (their addresses depend on `par` alone; the records exist for every index below MAXP): by the time the command
+  // says that this slot has a round to evaluate, they are on their way.  (k_ctrl starts the same way.)
+#ifndef PGB_LL_XW
+#define PGB_LL_XW 0 /* experiment knob: 1 = the extension outputs of a K-vector job on waves 1..3, side by side (measured SLOWER at cfg5: 727 / 723 k against 756 / 749 k, same box -- four waves loading the job records) */
+#endif
+  constexpr bool XW = MK && !LIN && PGB_LL_XW != 0;  // K-vector constant leaves: the extension outputs on waves 1..3 (see the job list)
+  Job j_pre[MAXP / 64];
+  Acc a_pre[MAXP / 64];
+  if (threadIdx.x < 64 || XW) {
+#pragma unroll
+    for (int hq = 0; hq < MAXP / 64; ++hq) {
+      const int q = (int)(threadIdx.x & 63) + 64 * hq;
+      j_pre[hq] = jobs_all[(size_t)par * MAXP + q];
+      a_pre[hq] = load_acc(&acc_all[((size_t)par * MAXP + q) * ACC_PER]);
+    }
   }
+  // ... and so are the tables (see stage_load)
+  StageRegs<PROBIT ? PGB_LPHI_SIZE : 2> st_lphi;
+  StageRegs<EXPLOG ? PGB_EXPT_SIZE : 2> st_exp;
+  StageRegs<EXPLOG ? PGB_LOGT_SIZE : 2> st_log;
+  if constexpr (PROBIT) stage_load<PGB_LPHI_SIZE>(pgb_tab_lphi(), st_lphi);
+  if constexpr (EXPLOG) {
+    stage_load<PGB_EXPT_SIZE>(pgb_tab_exp(), st_exp);
+    stage_load<PGB_LOGT_SIZE>(pgb_tab_log(), st_log);
+  }
+  // the head of the command record -- kind .. st_cur, 32 bytes -- in ONE scalar load: dst_gen is needed for the first
+  // label words of the passes, and read where it is used it was another memory round trip in front of them (stamps)
+  struct CmdHead {
+    int32_t kind, tree_old, tree_new, sel_gen, sel_slot, tune, dst_gen, st_cur;
+  };
+  static_assert(offsetof(Cmd, st_cur) == offsetof(CmdHead, st_cur), "CmdHead mirrors the head of Cmd");
+  const CmdHead ch = load_uniform(reinterpret_cast<const CmdHead*>(cmd));
+  if (!(ch.kind & CMD_PARTITION)) return;
+  TRL_BIND(ctrls[par ^ 1].slot_no - 1);
+  TRL(24);
+  if constexpr (PROBIT) stage_store<PGB_LPHI_SIZE>(s_lphi, st_lphi);
+  if constexpr (EXPLOG) {
+    stage_store<PGB_EXPT_SIZE>(s_expt, st_exp);
+    stage_store<PGB_LOGT_SIZE>(s_logt, st_log);
+  }
+  if constexpr (CATF) __syncthreads();  // the job list below evaluates exponentials (the children's w) on the LDS table
   // (the barrier after the job list below also publishes the tables)
+  TRL(36);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const Ctrl cn = S.ctrl[par ^ 1];  // the state this slot's k_ctrl produced
+  const Ctrl cn = ctrls[par ^ 1];  // the state this slot's k_ctrl produced
   const int round = cn.round - 1;   // round of the proposals of this slot
   const uint32_t it = (uint32_t)cn.iter;
   // leaf_sd / root statistics in force for this round (k_ctrl of the NEXT slot resolves them the
@@ -211,7 +301,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
   double leaf_sd = cn.leaf_sd;
   long long rootA = 0;
   {
-    const InitAcc* src = S.initacc + (size_t)par * IA_SLOTS;
+    const InitAcc* src = ias + (size_t)par * IA_SLOTS;
     long long qstd = 0;
     for (int k = 0; k < IA_SLOTS; ++k) {
       qstd += src[k].QSTD;
@@ -219,22 +309,74 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
     }
     if (cn.pend_leafsd && cn.pend_iter > 2) leaf_sd = pgb_tuned_leaf_sd(cn.leaf_sd, cn.pend_iter, qstd, S.sc.inv_c1, S.n);
   }
-  const Job* jobs = S.jobs + (size_t)par * MAXP;
-  if (tid < 64) {
-    int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
+  // The list of this slot's active particles with their children's leaf values (the routines k_ctrl runs one launch
+  // later, same inputs).  Every launch starts with it, on its critical path (measured with in-kernel stamps at cfg5:
+  // 4.1 us of a 10 us launch in a plain round, 7.2 us in the slot that starts a tree -- one wave listing 39 particles,
+  // three extension outputs one after the other, every statistic loaded where it was used).  Now: wave 0 does output
+  // 0 and the fields of the record; K-vector constant leaves: extension output kx on wave 1 + kx % 3, side by side;
+  // and every statistic a lane may need is REQUESTED before anything is known about the particle (one round trip).
+  // (XW: the extension outputs on waves 1..3; linear leaves: wave 0, they chain)
+  if (tid < 64 || XW) {
+    const int wv = tid >> 6, ln = tid & 63;
+    const int KXr = MK ? (KT > 0 ? KT : S.K) - 1 : 0;
+    int nlist = 0;  // (lanes' particles ln, ln + 64, ...: one block of 64 after the other)
 #pragma unroll
     for (int hq = 0; hq < MAXP / 64; ++hq) {
-    const int q = tid + 64 * hq;
-    Job j;
-    j.active = 0;
-    if (q >= 1 && q < S.P) j = jobs[q];
-    const bool has = j.active != 0;
+    const int q = ln + 64 * hq;
+    const bool inr = q >= 1 && q < S.P;
+    const Job j = j_pre[hq];  // (requested at the head of the kernel)
+    const Acc a = a_pre[hq];
+    const bool has = inr && j.active != 0;
     const unsigned long long m = __ballot(has);
-    // the leaf noise of particle `tid` in this round: drawn by the control kernel of this slot, in the job
+    if (hq == 0) TRL(37);
+    const int k = nlist + __popcll(m & ((1ull << ln) - 1ull));
+    if constexpr (XW) {
+      if (wv >= 1) {  // (wave-uniform)
+        for (int kx = wv - 1; kx < KXr; kx += 3) {
+          long long axL = 0, axN = 0, pq = 0;
+          double pv = S.init_leaf, zz0 = 0.0, zz1 = 0.0;
+          if (inr) {  // requested for every particle of the range: a particle without a job never reads them
+            axL = load_accx(S.accx, par, q, kx);
+            axN = load_accx(S.accx, par, q, KXr + kx);
+            if (round == 0) {
+              pq = root_A_x(S, par, kx);
+            } else {
+              pq = S.jqx[((size_t)par * MAXP + q) * KXr + kx];
+              pv = S.jvx[((size_t)par * MAXP + q) * KXr + kx];
+            }
+            const double* zz = S.jzx + (((size_t)par * MAXP + q) * KXr + kx) * 2;  // drawn by this slot's control kernel
+            zz0 = zz[0];
+            zz1 = zz[1];
+          }
+          const double lsx = leaf_sd_x(S, cn, par ^ 1, par, kx);
+          if (has) {
+            const int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32), cR = j.cnt - cL - cN;
+            const int ok = (cR == 0 && pgb_empty_right_fails(j.rule, S.compat)) ? -1 : 1;  // as child_values decides
+            const ChildX cx = child_values_x(S, ok, cL, cR, axL, axN, pq, pv, zz0, zz1, lsx);
+            s_job[k].vLx[kx] = cx.vL;
+            s_job[k].vRx[kx] = cx.vR;
+            if constexpr (CATF) {
+              // the child's part of the factorised softmax for this output (pgb_cat_side): relative to output 0,
+              // whose leaf values this wave derives again -- the routine and the inputs wave 0 uses
+              const ChildVals c0 = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
+                                                a.aL, a.aN, j.z0, j.z1, leaf_sd);
+              const double dL = cx.vL - c0.vL, dR = cx.vR - c0.vR;
+              s_job[k].d2[0][kx + 1] = dL;
+              s_job[k].d2[1][kx + 1] = dR;
+              s_job[k].w2[0][kx + 1] = pgb_exp_t(dL, tb.expt);  // (the LDS copy: published by the barrier in front of this list)
+              s_job[k].w2[1][kx + 1] = pgb_exp_t(dR, tb.expt);
+              s_job[k].slowx[kx] = (!(dL <= PGB_CAT_DMAX && dL >= -PGB_CAT_DMAX) ? 1 : 0) |
+                                   (!(dR <= PGB_CAT_DMAX && dR >= -PGB_CAT_DMAX) ? 2 : 0);
+            }
+          }
+        }
+        nlist += __popcll(m);
+        continue;
+      }
+    }
+    // the leaf noise of particle `ln` in this round: drawn by the control kernel of this slot, in the job
     const double z0 = has ? j.z0 : 0.0, z1 = has ? j.z1 : 0.0;
     if (has) {
-      const int k = nlist + __popcll(m & ((1ull << tid) - 1ull));
-      const Acc a = load_acc(&S.acc[((size_t)par * MAXP + q) * ACC_PER]);
       const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
                                         a.aL, a.aN, z0, z1, leaf_sd);
       LJob& lj = s_job[k];  // (filled in place: a local record with its K-sized arrays would live in scratch)
@@ -247,6 +389,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       lj.v = j.v;
       lj.vL = cv.vL;
       lj.vR = cv.vR;
+      if constexpr (CATF) {  // output 0 of the children's part: d = v - v = 0, w = exp(0) = 1 exactly
+        lj.d2[0][0] = lj.d2[1][0] = 0.0;
+        lj.w2[0][0] = lj.w2[1][0] = 1.0;
+      }
       lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
       lj.xoff = (long long)((size_t)j.var * S.n_pad);
       lj.dst = (long long)((size_t)q * S.n_pad);
@@ -265,7 +411,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
       }
-      if constexpr (MK)
+      if constexpr (MK && !XW)
       for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
         const int KX = (KT > 0 ? KT : S.K) - 1;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + q) * KX + kx];
@@ -283,6 +429,15 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           lj.sLx[kx] = cx.sL;
           lj.sRx[kx] = cx.sR;
         }
+        if constexpr (CATF) {  // the child's part of the factorised softmax for this output (pgb_cat_side)
+          const double dL = cx.vL - cv.vL, dR = cx.vR - cv.vR;
+          lj.d2[0][kx + 1] = dL;
+          lj.d2[1][kx + 1] = dR;
+          lj.w2[0][kx + 1] = pgb_exp_t(dL, tb.expt);
+          lj.w2[1][kx + 1] = pgb_exp_t(dR, tb.expt);
+          lj.slowx[kx] = (!(dL <= PGB_CAT_DMAX && dL >= -PGB_CAT_DMAX) ? 1 : 0) |
+                         (!(dR <= PGB_CAT_DMAX && dR >= -PGB_CAT_DMAX) ? 2 : 0);
+        }
       }
       if constexpr (MK && LIN)
         if (cv.ok == 1) {  // a further output may have made the leaf linear
@@ -294,113 +449,32 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
     }
     if (tid == 0) s_n[0] = nlist;
   }
+  TRL(38);
   __syncthreads();
-  if constexpr (FAM != PGB_FAMILY_CALLBACK) {
-    // A slot that starts a tree ([U] init_particles): the log-likelihood of a fresh stump (C) and of the
-    // tree as it stands, the reference particle (E0), over ALL rows -- from the {sum_trees, sum_trees_noi}
-    // the INIT part of this slot's row pass just wrote.  Evaluated here, in the kernel that is compiled per
-    // family / number of outputs, and not in the row pass: with the evaluation inlined twice the row pass
-    // needed 163 (single output) / 256 (K = 4) VGPRs for a loop that does not use any of it.
-    const int fam = FAM >= 0 ? FAM : S.family;
-    if ((cmd->kind & CMD_INIT) && fam != PGB_FAMILY_CALLBACK) {
-      const int Kn = KT > 0 ? KT : S.K;
-      const double* __restrict__ const noi0 = S.st + (size_t)cn.st_cur * Kn * S.n_pad;
-      long long ce[2] = {0, 0};
-      for (int chunk = blockIdx.x; chunk < S.nchunks; chunk += gridDim.x) {
-        const long long base = (long long)chunk * CH + tid * RPT;
-        // (single output: the four rows' inputs are requested together -- the arrays are padded to whole
-        //  chunks -- instead of one dependent round trip per row and evaluation)
-        double yrr[RPT], noir[RPT], str_[RPT], offr[RPT];
-        const double init_leaf = S.init_leaf;
-        if constexpr (!MK) {
-          const double* __restrict__ const yp = S.y;
-          const double2* __restrict__ const pk = S.pack;
-          const double* __restrict__ const op = S.off;
-          const bool ho = S.has_off != 0;
-#pragma unroll
-          for (int e = 0; e < RPT; ++e) {
-            yrr[e] = yp[base + e];
-            noir[e] = noi0[base + e];
-            str_[e] = pk[base + e].x;
-            offr[e] = ho ? op[base + e] : 0.0;  // (x + 0.0 == x bit for bit)
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < RPT; ++e) {
-          const long long row = base + e;
-          if (row >= S.n) continue;
-          const double yr = MK ? S.y[row] : yrr[e];
-          if constexpr (MK) {
-            auto offk = [&](int k) { return S.has_off ? S.off[(size_t)k * S.n_pad + row] : 0.0; };  // (x + 0.0 == x)
-            auto mu_stump = [&](int k) { return (noi0[(size_t)k * S.n_pad + row] + offk(k)) + S.init_leaf; };
-            auto mu_cur = [&](int k) {
-              return (k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row]) + offk(k);
-            };
-            if constexpr (LIN && KT == 0) {  // (the rare instance keeps the predictors as functions, see loglik_fn)
-              ce[0] += quant_ll(loglik_fn(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
-              ce[1] += quant_ll(loglik_fn(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
-            } else {
-              double ms[KB], mc[KB];
-#pragma unroll
-              for (int k = 0; k < KB; ++k) {
-                ms[k] = mc[k] = 0.0;
-                if (k < Kn) {  // (wave-uniform; the loads behind the predictors go out together)
-                  ms[k] = mu_stump(k);
-                  mc[k] = mu_cur(k);
-                }
-              }
-              if constexpr (KT > 0) {
-                ce[0] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, ms, &tb), S.sc.cl);
-                ce[1] += quant_ll(loglik_mk<KT>(S.family, Kn, yr, mc, &tb), S.sc.cl);
-              } else {
-                ce[0] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, ms, &tb), S.sc.cl);
-                ce[1] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, mc, &tb), S.sc.cl);
-              }
-            }
-          } else {
-            const double offv = offr[e];
-            auto ll1 = [&](double mu1) -> double {
-              if constexpr (PROBIT) return lphi_lds(yr > 0.5 ? mu1 : -mu1, s_lphi);  // (the staged layout)
-              else return pgb_loglik1q(fam, yr, mu1, cn.inv_sigma2, cn.lik_param2, &tb);
-            };
-            ce[0] += quant_ll(ll1((noir[e] + offv) + init_leaf), S.sc.cl);
-            ce[1] += quant_ll(ll1(str_[e] + offv), S.sc.cl);
-          }
-        }
-      }
-      block_sum<2>(ce, s_red);
-      if (tid == 0) {
-        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
-        if (ce[0]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)ce[0]);
-        if (ce[1]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)ce[1]);
-      }
-    }
-  }
+  TRL(25);
+  unsigned sat = 0;
   const int nact = s_n[0];
-  if (nact == 0) return;
-  for (int i = tid; i < MAXP * 3; i += BT) s_red[i] = 0;  // (the waves add into it; block_sum above used it as scratch)
+  TRL(26);
+  if (nact != 0) {  // (the passes; a slot without an active particle goes straight to the INIT part)
+  for (int i = tid; i < MAXP * 3; i += BT) s_red[i] = 0;  // (the waves add into it; the INIT part uses it as scratch)
   __syncthreads();
+  TRL(39);
   // (arrays of the argument block as GLOBAL pointers -- see as_global: a flat load also counts in lgkmcnt, so
   //  the first LDS table read of an evaluation waited for the label words requested for the NEXT particle)
-  const gptr<const double> gy = as_global(S.y), goff = as_global(S.off);
-  const gptr<const uint8_t> glid = as_global((const uint8_t*)S.lid);
   // Work = nchunks x nact (chunk, particle) units.  The persistent grid takes them as ONE linear range cut into
   // gridDim.x equal spans (chunk-major): a workgroup gets a run of particles of one chunk and, if its span
   // crosses a chunk boundary, the first particles of the next.  (Whole items of G particles left the grid
   // unbalanced: cfg4, round 0: 977 chunks x 2 groups over 1280 workgroups = 674 workgroups with 39 units,
   // 606 with 30 or 9 -- 76 % of the pass's lanes.)
-  const int W = S.nchunks * nact;  // (< 2^31: n < 2^31 rows, at most 63 particles)
-  const int per = W / (int)gridDim.x, rem = W - per * (int)gridDim.x, bx = (int)blockIdx.x;
+  const int W = nchunks_h * nact;  // (< 2^31: n < 2^31 rows, at most 63 particles)
+  const int per = W / nwg, rem = W - per * nwg, bx = (int)blockIdx.x;
   const int u_lo = bx * per + (bx < rem ? bx : rem), u_hi = u_lo + per + (bx < rem ? 1 : 0);
   const int K = KT > 0 ? KT : S.K;
-  const gptr<const double> noi = as_global((const double*)S.st + (size_t)cn.st_cur * K * S.n_pad);
-  const double cl = S.sc.cl;
+  const gptr<const double> noi = as_global(st_h + (size_t)cn.st_cur * K * n_pad_h);
   // The row pass of this slot has already sorted the rows of every split leaf: left rows kept the
   // leaf's label, right rows carry the new one, dropped rows the orphan label.  Reading those
   // bytes back (1 B per row) replaces a second read of the split column (8 B per row).
-  const gptr<const uint8_t> newl = as_global((const uint8_t*)S.lid + (size_t)cmd->dst_gen * MAXP * S.n_pad);
-  const long long n = S.n;
-  unsigned sat = 0;
+  const gptr<const uint8_t> newl = glid + (size_t)ch.dst_gen * MAXP * n_pad_h;
   for (int u = u_lo; u < u_hi;) {
     const int chunk = u / nact, g0 = u - chunk * nact;
     const int g1 = nact - g0 < u_hi - u ? nact : g0 + (u_hi - u);
@@ -439,12 +513,29 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         off_c[k] = goff + (size_t)kc * S.n_pad + cbase;
       }
       const bool has_off = S.has_off != 0;
+      // softmax, constant leaves: the row parts E_k / a_c / class of the chunk (written by the slot that started the
+      // tree; output k of row r at e_c + k n_pad + r)
+      gptr<const double> e_c = nullptr, a_cb = nullptr;
+      gptr<const uint8_t> cls_c = nullptr;
+      uint32_t e_stride = 0;  // bytes between two outputs of a row
+      if constexpr (CATF) {
+        e_c = as_global((const double*)S.cat_e) + cbase;
+        a_cb = as_global((const double*)S.cat_a) + cbase;
+        cls_c = as_global((const uint8_t*)S.cat_c) + cbase;
+        e_stride = (uint32_t)(S.n_pad * 8);  // (K n_pad 8 < 2^32 is NOT assumed: see e_at)
+      }
+      auto e_at = [&](int k, uint32_t ro) -> double {  // E_k of the row at byte offset ro of its chunk
+        return gload_d_off(e_c + (size_t)k * S.n_pad, ro);
+      };
+      (void)e_stride;
       // a lane's OWN four rows (y and the K predictors without the leaf value): what every particle whose leaf still
       // holds most of the wave's rows evaluates, lane by row -- in the slot that starts a tree that is every particle
       // of the span, and the same 20 values were fetched again for each of them, pass by pass.  Compile-time K:
       // loaded once per item, when the first such particle comes up, and kept in registers.
       constexpr bool OWN = KT > 0;
+      // (softmax: own_y holds a_c, own_nk the E_k, own_cls the class -- the row part of the factorised form)
       double own_y[OWN ? RPT : 1], own_nk[OWN ? RPT : 1][OWN ? KB : 1];
+      uint32_t own_cls = 0;  // (the four rows' classes, a byte each)
       bool own_have = false;
       // the label words of particle g + 1 are requested before particle g's passes (each of which is hundreds of
       // instructions): requested where they are used, they cost every particle of the span a memory round trip in
@@ -461,20 +552,39 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         nid_nx = gload_u32_off(newl + dst_u, base32);
       };
       if (g0 < g1) fetch_labels(g0);
+      TRL(27);
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
         const uint32_t ids = ids_nx, nid = nid_nx;
+        if (g == g0 + 1) TRL(28);  // (the first particle of the item done: own rows loaded / computed with it)
         if (g + 1 < g1) fetch_labels(g + 1);
         const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
-        // (compile-time K: the particle's leaf values in registers; run-time K: read from its LDS record where used)
+        // (compile-time K: the particle's leaf values in registers; run-time K: read from its LDS record where used.
+        //  Softmax: what the evaluation needs of a child is its w_k -- the leaf values themselves only in the rare
+        //  fallback, which reads them from the LDS record)
         constexpr int KV = KT > 0 ? KT : 1;
         double vLr[KV], vRr[KV];
-        vLr[0] = lj.vL;
-        vRr[0] = lj.vR;
+        if constexpr (CATF) {
 #pragma unroll
-        for (int k = 1; k < KV; ++k) {
-          vLr[k] = lj.vLx[k - 1];
-          vRr[k] = lj.vRx[k - 1];
+          for (int k = 0; k < KV; ++k) {
+            vLr[k] = lj.w2[0][k];
+            vRr[k] = lj.w2[1][k];
+          }
+        } else {
+          vLr[0] = lj.vL;
+          vRr[0] = lj.vR;
+#pragma unroll
+          for (int k = 1; k < KV; ++k) {
+            vLr[k] = lj.vLx[k - 1];
+            vRr[k] = lj.vRx[k - 1];
+          }
+        }
+        uint32_t slowm = 0;  // softmax: bit 0 / 1 = the left / right child is a slow one (pgb_cat_side)
+        if constexpr (CATF) {
+#pragma unroll
+          for (int k = 0; k < LJob::NX; ++k)
+            if (k < K - 1) slowm |= (uint32_t)lj.slowx[k];
+          slowm = uni(slowm);
         }
         unsigned long long mk[RPT];
         int M = 0;
@@ -483,7 +593,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           mk[e] = __ballot(((ids >> (8 * e)) & 255u) == lab);
           M += __popcll(mk[e]);
         }
-        const bool dense = M <= LL_DENSE_MAX;  // (wave-uniform)
+        // (wave-uniform.  Softmax with K known at compile time: round 0 -- whose row parts are not in memory yet --
+        //  always takes the lane's own rows, computed once per item, also in the partial last chunk)
+        const bool dense = M <= LL_DENSE_MAX && !(CATF && KT > 0 && round == 0);
         if (dense && M > 0) {
           int off = 0;
 #pragma unroll
@@ -503,14 +615,37 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         }
         if constexpr (OWN) {
           if (!dense && !own_have) {  // (wave-uniform)
+            if (CATF && round > 0) {  // the row parts the slot that started the tree left in memory
+              if constexpr (CATF) {
 #pragma unroll
-            for (int e = 0; e < RPT; ++e) {
-              const uint32_t ro = (uint32_t)(tid * RPT + e) * 8u;
-              own_y[e] = gload_d_off(gy_c, ro);
+                for (int e = 0; e < RPT; ++e) {
+                  const uint32_t r = (uint32_t)(tid * RPT + e);
+                  own_y[e] = gload_d_off(a_cb, r * 8u);
+                  own_cls |= (uint32_t)cls_c[r] << (8 * e);
 #pragma unroll
-              for (int k = 0; k < KB; ++k) {
-                const double nk = gload_d_off(noi_c[k], ro);
-                own_nk[e][k] = has_off ? nk + gload_d_off(off_c[k], ro) : nk;
+                  for (int k = 0; k < KB; ++k) own_nk[e][k] = e_at(k, r * 8u);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < RPT; ++e) {
+                const uint32_t ro = (uint32_t)(tid * RPT + e) * 8u;
+                own_y[e] = gload_d_off(gy_c, ro);
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                  const double nk = gload_d_off(noi_c[k], ro);
+                  own_nk[e][k] = has_off ? nk + gload_d_off(off_c[k], ro) : nk;
+                }
+              }
+              if constexpr (CATF) {
+                // round 0 (this launch also writes the row parts, but for the whole data set, by other workgroups):
+                // the same values from the same inputs, pgb_cat_row
+#pragma unroll
+                for (int e = 0; e < RPT; ++e) {
+                  const int ce = pgb_cat_class(KT, own_y[e]);
+                  own_cls |= (uint32_t)ce << (8 * e);
+                  own_y[e] = pgb_cat_row(KT, ce, own_nk[e], tb.expt, own_nk[e]);
+                }
               }
             }
             own_have = true;
@@ -529,6 +664,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
           struct PassIn {
             bool act;
             uint32_t side, ro;  // (ro: the row's byte offset in its chunk -- what the run-time-K evaluation reads with)
+            int cls;            // softmax: the observed class (y then holds a_c and nk the E_k: the row part)
             double y, nk[KB];
           };
           auto fetch = [&](int ps) -> PassIn {
@@ -547,6 +683,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               in.side = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
             }
             in.y = 0.0;
+            in.cls = 0;
             in.ro = r * 8u;  // (r < 1024)
 #pragma unroll
             for (int k = 0; k < KB; ++k) in.nk[k] = 0.0;
@@ -556,6 +693,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
                 for (int e = 0; e < RPT; ++e)
                   if (e == ps) {
                     in.y = own_y[e];
+                    if constexpr (CATF) in.cls = (int)((own_cls >> (8 * e)) & 255u);
 #pragma unroll
                     for (int k = 0; k < KB; ++k) in.nk[k] = own_nk[e][k];
                   }
@@ -563,44 +701,163 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
               }
             }
             if (in.act) {
-              in.y = gload_d_off(gy_c, in.ro);
+              if constexpr (CATF) {
+                if (KT > 0 || round > 0) {  // the row part of the factorised softmax, as the slot that started the tree left it
+                  in.y = gload_d_off(a_cb, in.ro);
+                  in.cls = (int)*(cls_c + r);
 #pragma unroll
-              for (int k = 0; k < KB; ++k)
-                if (k < K) {  // (wave-uniform)
-                  const double nk = gload_d_off(noi_c[k], in.ro);
-                  in.nk[k] = has_off ? nk + gload_d_off(off_c[k], in.ro) : nk;
+                  for (int k = 0; k < KB; ++k)
+                    if (k < K) in.nk[k] = e_at(k, in.ro);  // (wave-uniform guard)
+                } else {
+                  // round 0 of the run-time-K instance: THIS launch writes the row parts (other workgroups, not
+                  // visible yet): computed here from the same inputs (pgb_cat_row).  (The compile-time-K instances
+                  // take their own rows from registers in this round, see above.)
+                  const double yv0 = gload_d_off(gy_c, in.ro);
+                  double Mx = 0.0;
+#pragma unroll
+                  for (int k = 0; k < KB; ++k)
+                    if (k < K) {
+                      const double nk = gload_d_off(noi_c[k], in.ro);
+                      in.nk[k] = has_off ? nk + gload_d_off(off_c[k], in.ro) : nk;
+                      if (k == 0 || in.nk[k] > Mx) Mx = in.nk[k];
+                    }
+                  in.cls = pgb_cat_class(K, yv0);
+#pragma unroll
+                  for (int k = 0; k < KB; ++k)
+                    if (k < K) {
+                      const double ak = in.nk[k] - Mx;
+                      if (k == in.cls) in.y = ak;
+                      in.nk[k] = pgb_exp_t(ak, tb.expt);
+                    }
                 }
+              } else {
+                in.y = gload_d_off(gy_c, in.ro);
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                  if (k < K) {  // (wave-uniform)
+                    const double nk = gload_d_off(noi_c[k], in.ro);
+                    in.nk[k] = has_off ? nk + gload_d_off(off_c[k], in.ro) : nk;
+                  }
+              }
             }
             return in;
           };
-          PassIn cur = fetch(0);
-          for (int ps = 0; ps < npass; ++ps) {
-            PassIn nxt = cur;
-            if (ps + 1 < npass) nxt = fetch(ps + 1);
-            if (cur.act) {
-              double mu[KB];
-#pragma unroll
-              for (int k = 0; k < KB; ++k) {
-                mu[k] = 0.0;
-                if (k < K) {
-                  double vk;
-                  if constexpr (KT > 0) vk = cur.side == 0 ? vLr[k] : vRr[k];
-                  else vk = k == 0 ? (cur.side == 0 ? vLr[0] : vRr[0])
-                                   : (cur.side == 0 ? uni(lj.vLx[k > 0 ? k - 1 : 0]) : uni(lj.vRx[k > 0 ? k - 1 : 0]));
-                  if constexpr (DROPS)
-                    if (cur.side == 2) vk = 0.0;
-                  mu[k] = cur.nk[k] + vk;
-                }
-              }
+          uint32_t fb = 0;  // softmax: passes of this lane whose factorised sum was lost (see below): bit = pass
+          // NB (the lane's own rows, softmax): the evaluation runs for every row slot and the result of a row that is
+          // not in the leaf is dropped by a select -- the four row slots of a lane are then four INDEPENDENT chains
+          // the compiler interleaves.  Under a branch per row slot each chain ran alone (exec-masked regions in
+          // sequence: a dependent fma / LDS-read chain per slot with three waves per SIMD to hide it -- 20 % of
+          // the wave-cycles issued a vector instruction).  The leaves that take this path hold most of the rows.
+          auto eval_pass = [&](const PassIn& cur, int psi, auto nb_c) {
+            constexpr bool NB = decltype(nb_c)::value;
+            if (NB || cur.act) {
               double llv;
-              if constexpr (KT > 0) llv = loglik_mk<KT>(S.family, K, cur.y, mu, &tb);
-              else llv = loglik_arr<KB>(S.family, K, cur.y, mu, &tb);
-              const long long q = quant_ll(llv, cl);
+              if constexpr (CATF) {
+                // softmax, constant leaves (pgb_loglik_cat_f): S = sum_k E_k w_k in output order, one fma each; the
+                // child's d_c from the particle's LDS record by (side, class).  A dropped row predicts 0 from this
+                // tree: w = exp(0 - 0) = 1 exactly, d = 0.
+                double Ssum = 0.0;
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                  if (k < K) {
+                    double wk;
+                    if constexpr (KT > 0) wk = cur.side == 0 ? vLr[k] : vRr[k];  // (the children's w_k: see above)
+                    else wk = cur.side == 0 ? uni(lj.w2[0][k]) : uni(lj.w2[1][k]);
+                    if constexpr (DROPS)
+                      if (cur.side == 2) wk = 1.0;
+                    Ssum = k == 0 ? cur.nk[0] * wk : PGB_FMA(cur.nk[k], wk, Ssum);
+                  }
+                double dc = lj.d2[cur.side == 0 ? 0 : 1][cur.cls];
+                if constexpr (DROPS)
+                  if (cur.side == 2) dc = 0.0;
+                // (a row of a SLOW child -- leaf values hundreds of units apart, pgb_cat_side -- is taken over by the
+                //  unfactorised form AFTER the passes, see `fb`; here it only leaves its mark.  One copy of that
+                //  code per instance, none of its registers in this loop.)
+                llv = pgb_cat_value(cur.y, dc, Ssum, tb.logt);
+                if (slowm != 0u) {  // (wave-uniform: this particle has a slow child)
+                  if ((!NB || cur.act) && ((slowm >> (cur.side == 0 ? 0 : 1)) & 1u) != 0u && cur.side != 2) {
+                    fb |= 1u << psi;
+                    llv = 0.0;  // (quantises to 0: nothing is added for this row here)
+                  }
+                }
+              } else {
+                double mu[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                  mu[k] = 0.0;
+                  if (k < K) {
+                    double vk;
+                    if constexpr (KT > 0) vk = cur.side == 0 ? vLr[k] : vRr[k];
+                    else vk = k == 0 ? (cur.side == 0 ? vLr[0] : vRr[0])
+                                     : (cur.side == 0 ? uni(lj.vLx[k > 0 ? k - 1 : 0]) : uni(lj.vRx[k > 0 ? k - 1 : 0]));
+                    if constexpr (DROPS)
+                      if (cur.side == 2) vk = 0.0;
+                    mu[k] = cur.nk[k] + vk;
+                  }
+                }
+                if constexpr (KT > 0) llv = loglik_mk<KT, FAMK>(S.family, K, cur.y, mu, &tb);
+                else llv = loglik_arr<KB>(S.family, K, cur.y, mu, &tb);
+              }
+              long long q = quant_ll(llv, cl);
+              if constexpr (NB) q = cur.act ? q : 0;
               vt += q;
               v0 += cur.side == 0 ? q : 0;
               if constexpr (DROPS) v2 += cur.side == 2 ? q : 0;
             }
-            cur = nxt;
+          };
+          bool done = false;
+          if constexpr (OWN && CATF) {
+            // the lane's own four rows: the row index is a compile-time constant in each copy, so that a pass takes
+            // its row part straight from the registers (with a run-time pass index the selection of one row's K + 2
+            // values out of four cost as many v_cndmask as the evaluation itself has arithmetic, now that it is K
+            // fma and a logarithm)
+            if (!dense) {  // (wave-uniform)
+#pragma unroll
+              for (int ps = 0; ps < RPT; ++ps) eval_pass(fetch(ps), ps, std::true_type{});
+              done = true;
+            }
+          }
+          if (!done) {
+            PassIn cur = fetch(0);
+            for (int ps = 0; ps < npass; ++ps) {
+              PassIn nxt = cur;
+              if (ps + 1 < npass) nxt = fetch(ps + 1);
+              eval_pass(cur, ps, std::false_type{});
+              cur = nxt;
+            }
+          }
+          if constexpr (CATF) {
+            if (__ballot(fb != 0u) != 0ull) {
+              // the unfactorised softmax (pgb_loglik_cat_t's operations, one output at a time) on mu_k = eta_k + v_k
+              // for the rows of a slow child.  Rare; the row, its side and its class are found again the way fetch()
+              // found them.
+              for (int ps = 0; ps < npass; ++ps)
+                if ((fb >> ps) & 1u) {
+                  uint32_t r, sd;
+                  if (dense) {
+                    const uint32_t ent = (uint32_t)s_lrow[w][lane + 64 * ps];
+                    r = ent & 1023u;
+                    sd = ent >> 10;
+                  } else {
+                    r = (uint32_t)(tid * RPT + ps);
+                    const uint32_t nl = (nid >> (8 * ps)) & 255u;
+                    sd = nl == lab ? 0u : (nl == nlab ? 1u : 2u);
+                  }
+                  const uint32_t ro = r * 8u;
+                  auto muf = [&](int k) -> double {
+                    const double nk = gload_d_off(noi_c[0] + (size_t)k * S.n_pad, ro);
+                    const double ek = has_off ? nk + gload_d_off(off_c[0] + (size_t)k * S.n_pad, ro) : nk;
+                    const double vk = sd == 0 ? (k == 0 ? lj.vL : lj.vLx[k > 0 ? k - 1 : 0])
+                                    : sd == 1 ? (k == 0 ? lj.vR : lj.vRx[k > 0 ? k - 1 : 0]) : 0.0;
+                    return ek + vk;
+                  };
+                  const double yv1 = gload_d_off(gy_c, ro);  // (its class index: loglik_fn clamps it like pgb_cat_class)
+                  const long long q = quant_ll(loglik_fn(PGB_FAMILY_CATEGORICAL, S.K, yv1, muf, &tb), cl);  // (S.K: rolled loops)
+                  vt += q;
+                  v0 += sd == 0 ? q : 0;
+                  if constexpr (DROPS) v2 += sd == 2 ? q : 0;
+                }
+            }
           }
           const int slot = (g - g0) * 3;
           if constexpr (DROPS) {
@@ -615,6 +872,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         else passes(std::false_type{});
         if (dense) __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
       }
+      TRL(29);
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
         const int gi = t / 3, i = t % 3;
@@ -626,6 +884,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
         }
       }
       __syncthreads();
+      TRL(30);
       continue;
     }
     if constexpr (MK) {  // run-time K (KT = 0): K = 5.. outputs and K-vector linear leaves
@@ -835,6 +1094,132 @@ void k_loglik(const Dev* __restrict__ Sp, int par) {
       }
     }
     __syncthreads();
+  }
+  }  // (nact != 0)
+  // The INIT part of a slot that starts a tree comes LAST: nothing in this launch reads what it produces (the
+  // stump / reference sums go to the next control kernel, the row parts to the later rounds), and in front of the
+  // passes it stood -- as code -- between the job list and the first item of EVERY launch.
+  TRL(31);
+  if constexpr (FAM != PGB_FAMILY_CALLBACK) {
+    // A slot that starts a tree ([U] init_particles): the log-likelihood of a fresh stump (C) and of the
+    // tree as it stands, the reference particle (E0), over ALL rows -- from the {sum_trees, sum_trees_noi}
+    // the INIT part of this slot's row pass just wrote.  Evaluated here, in the kernel that is compiled per
+    // family / number of outputs, and not in the row pass: with the evaluation inlined twice the row pass
+    // needed 163 (single output) / 256 (K = 4) VGPRs for a loop that does not use any of it.
+    const int fam = FAM >= 0 ? FAM : S.family;
+    if ((ch.kind & CMD_INIT) && fam != PGB_FAMILY_CALLBACK) {
+      const int Kn = KT > 0 ? KT : S.K;
+      const double* __restrict__ const noi0 = S.st + (size_t)cn.st_cur * Kn * S.n_pad;
+      long long ce[2] = {0, 0};
+      // K-vector leaves: units of BT rows, one row per thread -- a chunk is RPT units -- so that every workgroup of
+      // the grid takes part (cfg5: 245 chunks over 768 workgroups left a third of them four rows per thread, three
+      // exact evaluations each, before their share of the passes, and the launch waited for those)
+      constexpr int ISUB = MK ? RPT : 1, IROWS = MK ? 1 : RPT;
+      for (int unit = blockIdx.x; unit < S.nchunks * ISUB; unit += nwg) {
+        const int chunk = unit / ISUB;
+        const long long base = MK ? (long long)chunk * CH + (long long)(unit - chunk * ISUB) * BT + tid
+                                  : (long long)chunk * CH + tid * RPT;
+        // (single output: the four rows' inputs are requested together -- the arrays are padded to whole
+        //  chunks -- instead of one dependent round trip per row and evaluation)
+        double yrr[RPT], noir[RPT], str_[RPT], offr[RPT];
+        const double init_leaf = S.init_leaf;
+        if constexpr (!MK) {
+          const double* __restrict__ const yp = S.y;
+          const double2* __restrict__ const pk = S.pack;
+          const double* __restrict__ const op = S.off;
+          const bool ho = S.has_off != 0;
+#pragma unroll
+          for (int e = 0; e < RPT; ++e) {
+            yrr[e] = yp[base + e];
+            noir[e] = noi0[base + e];
+            str_[e] = pk[base + e].x;
+            offr[e] = ho ? op[base + e] : 0.0;  // (x + 0.0 == x bit for bit)
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < IROWS; ++e) {
+          const long long row = base + e;
+          if (row >= S.n) continue;
+          const double yr = MK ? S.y[row] : yrr[e];
+          if constexpr (MK) {
+            auto offk = [&](int k) { return S.has_off ? S.off[(size_t)k * S.n_pad + row] : 0.0; };  // (x + 0.0 == x)
+            auto eta0 = [&](int k) { return noi0[(size_t)k * S.n_pad + row] + offk(k); };  // the row part of predictor k
+            auto mu_stump = [&](int k) { return eta0(k) + S.init_leaf; };
+            auto mu_cur = [&](int k) {
+              return (k == 0 ? S.pack[row].x : S.packx[(size_t)(k > 0 ? k - 1 : 0) * S.n_pad + row]) + offk(k);
+            };
+            if constexpr (LIN && KT == 0) {  // (the rare instance keeps the predictors as functions, see loglik_fn)
+              ce[0] += quant_ll(loglik_fn(S.family, Kn, yr, mu_stump, &tb), S.sc.cl);
+              ce[1] += quant_ll(loglik_fn(S.family, Kn, yr, mu_cur, &tb), S.sc.cl);
+            } else {
+              double ms[KB], mc[KB];
+              double et[CATF ? KB : 1];  // softmax, constant leaves: the row part eta_k of the predictors
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                ms[k] = mc[k] = 0.0;
+                if constexpr (CATF) et[k] = 0.0;
+                if (k < Kn) {  // (wave-uniform; the loads behind the predictors go out together)
+                  if constexpr (CATF) {
+                    et[k] = eta0(k);
+                    ms[k] = et[k] + S.init_leaf;  // (= mu_stump(k))
+                  } else {
+                    ms[k] = mu_stump(k);
+                  }
+                  mc[k] = mu_cur(k);
+                }
+              }
+              if constexpr (CATF) {
+                // ... and what the later rounds of this tree read instead of them (pgb_cat_row): E_k, a_c and the
+                // class c.  (Round 0, in this very launch, computes the same values from the same inputs for its
+                // own rows: other workgroups' stores are not visible yet.)
+                double M = et[0];
+#pragma unroll
+                for (int k = 1; k < KB; ++k)
+                  if (k < Kn && et[k] > M) M = et[k];
+                const int c = pgb_cat_class(Kn, yr);
+                double ac = 0.0, Esum = 0.0;
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                  if (k < Kn) {
+                    const double ak = et[k] - M;
+                    if (k == c) ac = ak;
+                    const double Ek = pgb_exp_t(ak, tb.expt);
+                    S.cat_e[(size_t)k * S.n_pad + row] = Ek;
+                    Esum = k == 0 ? Ek * 1.0 : PGB_FMA(Ek, 1.0, Esum);  // (pgb_cat_sum with w = 1)
+                  }
+                S.cat_a[row] = ac;
+                S.cat_c[row] = (uint8_t)c;
+                // the stump in the factorised form (every output predicts init_leaf: d = 0, w = 1 exactly): no
+                // exponentials of its own
+                ce[0] += quant_ll(pgb_cat_value(ac, 0.0, Esum, tb.logt), S.sc.cl);
+                if constexpr (KT > 0) ce[1] += quant_ll(loglik_mk<KT, FAMK>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+                else ce[1] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              } else if constexpr (KT > 0) {
+                ce[0] += quant_ll(loglik_mk<KT, FAMK>(S.family, Kn, yr, ms, &tb), S.sc.cl);
+                ce[1] += quant_ll(loglik_mk<KT, FAMK>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              } else {
+                ce[0] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, ms, &tb), S.sc.cl);
+                ce[1] += quant_ll(loglik_arr<KB>(S.family, Kn, yr, mc, &tb), S.sc.cl);
+              }
+            }
+          } else {
+            const double offv = offr[e];
+            auto ll1 = [&](double mu1) -> double {
+              if constexpr (PROBIT) return lphi_lds(yr > 0.5 ? mu1 : -mu1, s_lphi);  // (the staged layout)
+              else return pgb_loglik1q(fam, yr, mu1, cn.inv_sigma2, cn.lik_param2, &tb);
+            };
+            ce[0] += quant_ll(ll1((noir[e] + offv) + init_leaf), S.sc.cl);
+            ce[1] += quant_ll(ll1(str_[e] + offv), S.sc.cl);
+          }
+        }
+      }
+      block_sum<2>(ce, s_red);
+      if (tid == 0) {
+        InitAcc* a = &S.initacc[(size_t)par * IA_SLOTS + (blockIdx.x % IA_SLOTS)];
+        if (ce[0]) atomicAdd((unsigned long long*)&a->C, (unsigned long long)ce[0]);
+        if (ce[1]) atomicAdd((unsigned long long*)&a->E0, (unsigned long long)ce[1]);
+      }
+    }
   }
   if (sat) atomicAdd(&S.counters[4], (unsigned long long)sat);
 }

@@ -205,6 +205,11 @@ struct DevT {  // kernel argument block (by value)
   dptr<G, double> jvx;        // [2][MAXP][KX]          per job: parent's leaf values
   dptr<G, double> jzx;        // [2][MAXP][KX][2]       per job: leaf noise of the children, outputs 1..K-1 (drawn one slot ahead like Job::z0 / z1)
   dptr<G, double> lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
+  // softmax with constant leaves: the ROW part of the factorised log-likelihood (pgbart_spec.h, pgb_loglik_cat_f),
+  // written by the likelihood pass of the slot that starts a tree, read by the passes of that tree's later rounds
+  dptr<G, double> cat_e;      // [K][n_pad]  E_k = exp(eta_k - max_k eta_k), eta_k = sum_trees_noi_k + offset_k
+  dptr<G, double> cat_a;      // [n_pad]     eta_c - max_k eta_k of the observed class c
+  dptr<G, uint8_t> cat_c;     // [n_pad]     the observed class c
   // ---- linear response (Normal family, K = 1, continuous columns)
   int32_t response, has_off;  // has_off: an offset of the linear predictor is set (else the array is all 0)
   double lin_R, inv_R;
@@ -234,7 +239,7 @@ static_assert(sizeof(Dev) == sizeof(DevG), "the two views of the argument block 
 
 #ifdef PGB_TRACE
 #define TRACE_SLOTS 4096
-#define TRACE_W 24 /* stamps 0..15, 16: attempt, 17: round of the proposal, 18: fresh (this slot starts a tree), 19: stop, 20..23: inside the split-row selection */
+#define TRACE_W 40 /* stamps 0..15, 16: attempt, 17: round of the proposal, 18: fresh (this slot starts a tree), 19: stop, 20..23: inside the split-row selection, 24..31: the likelihood pass (TRL) */
 // The record of a slot is addressed through `tr_rec` (set once per kernel from the slot number the kernel
 // has in registers anyway): a stamp is one clock read and one store, no load.  TR0() keeps the entry
 // reading in a register until the slot number is known.
@@ -252,6 +257,11 @@ static_assert(sizeof(Dev) == sizeof(DevG), "the two views of the argument block 
   long long* tr_rec = S.trace + (size_t)((slot_no) % TRACE_SLOTS) * TRACE_W;                 \
   if (blockIdx.x == 0 && threadIdx.x == 0) tr_rec[12] = tr_t12
 #define TRR(i, blk) do { if (blockIdx.x == (blk) && threadIdx.x == 0) tr_rec[(i)] = wall_clock64(); } while (0)
+// stamps of the likelihood pass (entries 24..31), taken by workgroup TRL_WG (one in the middle of the grid: it has
+// no INIT unit beyond its share and a full span of the passes)
+#define TRL_WG 100
+#define TRL_BIND(slot_no) long long* trl_rec = S.trace + (size_t)((slot_no) % TRACE_SLOTS) * TRACE_W
+#define TRL(i) do { if (blockIdx.x == TRL_WG && threadIdx.x == 0) trl_rec[(i)] = wall_clock64(); } while (0)
 #else
 #define TR_DECL() ((void)0)
 #define TR0() ((void)0)
@@ -263,6 +273,8 @@ static_assert(sizeof(Dev) == sizeof(DevG), "the two views of the argument block 
 #define TR_REC nullptr
 #define TRR_BIND(slot_no) ((void)0)
 #define TRR(i, blk) ((void)0)
+#define TRL_BIND(slot_no) ((void)0)
+#define TRL(i) ((void)0)
 #endif
 #ifdef PGB_STAMP_LL
 #define PGB_STAMP_LL_ON 1

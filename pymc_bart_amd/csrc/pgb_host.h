@@ -38,7 +38,8 @@ struct pgb_handle {
   int rows_grid;   // workgroups of the persistent row-pass grid (dispatch costs ~3.5 ns each)
   int ll_grid;     // ... of the log-likelihood pass
   int rows_mk_cap; // K-vector row pass: workgroups its instance keeps resident (0: not queried yet)
-  void (*ll_kernel)(const Dev*, int);  // the instance of k_loglik this sampler launches (family / outputs / response)
+  // the instance of k_loglik this sampler launches (family / outputs / response)
+  void (*ll_kernel)(const Dev*, int, int, const Cmd*, const Ctrl*, const Job*, const Acc*, const InitAcc*);
   int sigma_dirty;
   double inv_sigma2;
   double lik_param2;
@@ -155,15 +156,16 @@ extern "C" int32_t pgb_max_particles(void) { return PGB_MAX_PARTICLES; }
 
 // The instance of k_loglik a sampler launches, chosen once: per number of outputs (loops unrolled for
 // K = 2, 3, 4), per family for single-output constant leaves (one family's code per instance).
-typedef void (*ll_kernel_t)(const Dev*, int);
+typedef void (*ll_kernel_t)(const Dev*, int, int, const Cmd*, const Ctrl*, const Job*, const Acc*, const InitAcc*);
 static ll_kernel_t select_ll_kernel(int K, bool lin, int family) {
   if (K > 1 && lin) return k_loglik<0, -1, true>;
-  if (K > 1) {
+  if (K > 1) {  // constant K-vector leaves: softmax (factorised evaluation, any K) or Normal mean / scale (K = 2)
+    if (family != PGB_FAMILY_CATEGORICAL) return k_loglik<2, PGB_FAMILY_NORMAL_MEANSCALE, false>;
     switch (K) {
-      case 2: return k_loglik<2, -1, false>;
-      case 3: return k_loglik<3, -1, false>;
-      case 4: return k_loglik<4, -1, false>;
-      default: return k_loglik<0, -1, false>;
+      case 2: return k_loglik<2, PGB_FAMILY_CATEGORICAL, false>;
+      case 3: return k_loglik<3, PGB_FAMILY_CATEGORICAL, false>;
+      case 4: return k_loglik<4, PGB_FAMILY_CATEGORICAL, false>;
+      default: return k_loglik<0, PGB_FAMILY_CATEGORICAL, false>;
     }
   }
   if (lin) return k_loglik<1, -1, true>;  // linear leaves: one instance, family read at run time
@@ -345,6 +347,15 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.jvx, (size_t)2 * MAXP * KX);
     DA(d.jzx, (size_t)2 * MAXP * KX * 2);
     DA(d.lsdx, (size_t)2 * KXMAX);
+    if (s->family == PGB_FAMILY_CATEGORICAL && s->response == PGB_RESPONSE_CONSTANT) {
+      // the row part of the factorised softmax: scratch of one tree update (no checkpoint carries it)
+      DA(d.cat_e, (size_t)K * d.n_pad);
+      transient(h);
+      DA(d.cat_a, d.n_pad);
+      transient(h);
+      DA(d.cat_c, d.n_pad);
+      transient(h);
+    }
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
@@ -839,7 +850,8 @@ static int enqueue_slots(pgb_handle* h, int count) {
     }
 #undef ROWS_ARGS
     if (d.family != PGB_FAMILY_NORMAL)  // per-row log-likelihood of the rows this round re-labelled
-      LAUNCH_K(PK_LL, h->ll_kernel, gll, dd, par);
+      LAUNCH_K(PK_LL, h->ll_kernel, gll, dd, par, (int)gll.x, (const Cmd*)d.cmd, (const Ctrl*)d.ctrl, (const Job*)d.jobs,
+               (const Acc*)d.acc, (const InitAcc*)d.initacc);
     h->slot += 1;
   }
   HIPCHK(hipGetLastError());

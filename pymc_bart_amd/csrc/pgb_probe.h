@@ -35,6 +35,7 @@ enum {
   PROBE_GO_LEFT = 11,
   PROBE_MATH_T = 12,   // pgb_exp_t, pgb_log_t (the table-driven forms of the per-row likelihoods), tables in LDS
   PROBE_MULTI_LDS = 13,  // pgb_loglikq_t with every table in LDS (the form k_loglik<K> runs)
+  PROBE_CAT_F = 14,      // pgb_loglik_cat_f: the factorised softmax of constant leaves, tables in LDS
 };
 
 __global__ __launch_bounds__(256) void k_probe(ProbeArgs A) {
@@ -47,10 +48,19 @@ __global__ __launch_bounds__(256) void k_probe(ProbeArgs A) {
   lds.expt = s_expt;
   lds.logt = s_logt;
   const pgb_lltabs glob = pgb_lltabs_default();
-  if (A.what == PROBE_BERN_LDS || A.what == PROBE_MATH_T || A.what == PROBE_MULTI_LDS) {
+  if (A.what == PROBE_BERN_LDS || A.what == PROBE_MATH_T || A.what == PROBE_MULTI_LDS || A.what == PROBE_CAT_F) {
     for (int i = threadIdx.x; i < PGB_LPHI_SIZE; i += blockDim.x) s_lphi[i] = glob.lphi[i];
     for (int i = threadIdx.x; i < PGB_EXPT_SIZE; i += blockDim.x) s_expt[i] = glob.expt[i];
     for (int i = threadIdx.x; i < PGB_LOGT_SIZE; i += blockDim.x) s_logt[i] = glob.logt[i];
+    __syncthreads();
+  }
+  __shared__ double s_cat[3][PGB_MAX_OUTPUTS];  // PROBE_CAT_F: the leaf values v, and d, w of pgb_cat_side
+  __shared__ int s_cat_fast;
+  if (A.what == PROBE_CAT_F) {
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < A.K; ++k) s_cat[0][k] = A.c[k];
+      s_cat_fast = pgb_cat_side(A.K, s_cat[0], s_expt, s_cat[1], s_cat[2]);
+    }
     __syncthreads();
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (long long)gridDim.x * blockDim.x) {
@@ -75,6 +85,12 @@ __global__ __launch_bounds__(256) void k_probe(ProbeArgs A) {
         double mu[PGB_MAX_OUTPUTS];
         for (int k = 0; k < A.K; ++k) mu[k] = A.b[i * A.K + k];
         A.o0[i] = pgb_loglikq_t(A.family, A.K, A.a[i], mu, A.p0, A.p1, &lds);
+        break;
+      }
+      case PROBE_CAT_F: {  // a = y, b = eta [n][K], c = v [K]; the child's part: made once, in LDS (see below)
+        double eta[PGB_MAX_OUTPUTS];
+        for (int k = 0; k < A.K; ++k) eta[k] = A.b[i * A.K + k];
+        A.o0[i] = pgb_loglik_cat_f(A.K, A.a[i], eta, s_cat[0], s_cat[1], s_cat[2], s_cat_fast, &lds);
         break;
       }
       case PROBE_MATH_T:
@@ -206,6 +222,17 @@ int pgbh_loglik_multi_lds(int family, int K, const double* y, const double* mu /
   ProbeArgs A{};
   A.what = PROBE_MULTI_LDS; A.family = family; A.K = K; A.n = n; A.p0 = param; A.p1 = param2;
   A.a = st.in(y, n); A.b = st.in(mu, n * K); A.o0 = st.out<double>(n);
+  int rc = probe::run(A, st);
+  if (rc == PGB_OK) st.back(out, A.o0, n);
+  return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");
+}
+int pgbh_loglik_cat_f(int K, const double* y, const double* eta /* [n][K] */, const double* v /* [K] */, int64_t n,
+                      double* out) {
+  if (K < 1 || K > PGB_MAX_OUTPUTS) return fail(PGB_E_INVALID, "probe: K");
+  probe::Stage st;
+  ProbeArgs A{};
+  A.what = PROBE_CAT_F; A.K = K; A.n = n;
+  A.a = st.in(y, n); A.b = st.in(eta, n * K); A.c = st.in(v, (int64_t)K); A.o0 = st.out<double>(n);
   int rc = probe::run(A, st);
   if (rc == PGB_OK) st.back(out, A.o0, n);
   return st.ok ? rc : fail(PGB_E_DEVICE, "probe: copy failed");

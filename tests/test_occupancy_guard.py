@@ -41,7 +41,8 @@ def test_every_kernel_instance_keeps_its_budgeted_occupancy():
     assert by["k_loglik<1, 1, false>"]["wgs_per_cu"] >= 5                   # cfg4 probit likelihood
     assert by["k_rows_mk<4, false, true>"]["wgs_per_cu"] >= 3              # cfg5 row pass (round 4: 3 without spills beat 4 with)
     assert by["k_rows_mk<4, false, true>"]["scratch_bytes"] == 0
-    assert by["k_loglik<4, -1, false>"]["wgs_per_cu"] >= 3                  # cfg5 softmax likelihood
+    assert by["k_loglik<4, 3, false>"]["wgs_per_cu"] >= 3                   # cfg5 softmax likelihood (factorised, round 5)
+    assert by["k_loglik<4, 3, false>"]["scratch_bytes"] == 0
 
 
 def test_a_regression_is_reported():

@@ -755,3 +755,27 @@ def test_offsets_and_responses_the_likelihood_tables_cannot_address_are_refused_
     from test_host_logic import _refusals
 
     _refusals(hip)
+
+
+def test_softmax_slow_children_take_the_unfactorised_form_on_both_backends(hip):
+    """The factorised softmax of constant leaves (pgb_loglik_cat_f) sends a child whose leaf values lie more than
+    PGB_CAT_DMAX = 300 apart down the unfactorised form -- unreachable with sane leaf values.  TEST builds of both
+    backends with PGB_CAT_DMAX = 0.001 (``__graft_entry__.build``: build/variants/) make nearly every child a slow
+    one: the kernel's deferred fallback (rows marked in the passes, evaluated after them) must reproduce the oracle's
+    bit for bit, for K = 3, 4 and the run-time-K instance, with and without missing values and offsets."""
+    import __graft_entry__ as g
+    from _oracle import NumpyMemory
+    from pymc_bart_amd import _abi
+    from pymc_bart_amd.sampler import Backend
+
+    if not (os.path.exists(g.HIP_SO_CATSLOW) and os.path.exists(g.ORACLE_SO_CATSLOW)):
+        pytest.skip("the PGB_CAT_DMAX test builds are missing (python -c 'import __graft_entry__ as g; g.build()')")
+    hip_slow = Backend(lib=_abi.PGBLibrary(g.HIP_SO_CATSLOW), mem=hip.mem)
+    orc_slow = Backend(lib=_abi.PGBLibrary(g.ORACLE_SO_CATSLOW), mem=NumpyMemory())
+    assert hip_slow.lib.backend_name == "hip-gfx950" and orc_slow.lib.backend_name == "oracle-cpu"
+    for name in ("categorical_k3_reference", "categorical_k4_cfg5_small", "categorical_k6_generic", "categorical_k12",
+                 "categorical_k3_offset"):
+        c = make_case(name)
+        a, b = digest(run_case(c, hip_slow)), digest(run_case(c, orc_slow))
+        assert a == b, name
+        assert a["counters"]["particle_steps"] > 0

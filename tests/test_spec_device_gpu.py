@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 _SAME_SIGNATURE = {  # oracle hook -> device probe with the identical argument list
     "pgbo_loglikq": "pgbh_loglikq",
     "pgbo_loglik_multi": "pgbh_loglik_multi",
+    "pgbo_loglik_cat_f": "pgbh_loglik_cat_f",
     "pgbo_log_ndtr": "pgbh_log_ndtr",
     "pgbo_math": "pgbh_math",
     "pgbo_normal2": "pgbh_normal2",
@@ -55,6 +56,7 @@ class _DeviceSpec:
     T.test_gamma_log_link_against_scipy,
     T.test_count_families_against_scipy,
     T.test_multi_output_families_against_scipy,
+    T.test_factorised_softmax_of_constant_leaves_against_scipy,
 ], ids=lambda f: f.__name__.replace("test_", ""))
 def test_device_compile_against_scipy(hip, check):
     check(_DeviceSpec(hip))
@@ -199,6 +201,27 @@ def test_multi_output_loglikelihood_device_equals_host(hip, oracle):
                        C.c_double, C.c_void_p)(_abi.FAMILIES[fam], K, y.ctypes.data, mu.ctypes.data, n, 0.0, 1.0,
                                                dl_.ctypes.data) == 0
             _same_bits(dl_, h, f"pgb_loglikq_t[{fam}, K={K}] with LDS tables")
+
+
+def test_factorised_softmax_device_equals_host(hip, oracle):
+    """pgb_loglik_cat_f (the softmax of constant K-vector leaves as k_loglik<K, categorical> evaluates it): the
+    device compile against the host compile, bit for bit, over ordinary predictors, the edge values and the regime
+    where the factorised sum is lost and the unfactorised form takes over."""
+    dl, ol = hip.lib.lib, oracle.lib.lib
+    rng = np.random.default_rng(105)
+    sig = (C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    n = 60_000
+    for K in (2, 3, 4, 5, 8, 16):
+        for se, sv in ((3.0, 1.0), (300.0, 300.0)):
+            eta = np.ascontiguousarray(rng.normal(0, se, (n, K)))
+            eta[:EDGE.size, 0] = np.clip(EDGE, -1e6, 1e6)
+            eta[:EDGE.size, K - 1] = np.clip(EDGE[::-1], -1e6, 1e6)
+            v = rng.normal(0, sv, K)
+            y = rng.integers(0, K, n).astype(float)
+            d, h = np.zeros(n), np.zeros(n)
+            assert _fn(dl, "pgbh_loglik_cat_f", *sig)(K, y.ctypes.data, eta.ctypes.data, v.ctypes.data, n, d.ctypes.data) == 0
+            _fn(ol, "pgbo_loglik_cat_f", *sig, restype=None)(K, y.ctypes.data, eta.ctypes.data, v.ctypes.data, n, h.ctypes.data)
+            _same_bits(d, h, f"pgb_loglik_cat_f[K={K}, spread {se}/{sv}]")
 
 
 def test_random_stream_and_fixed_point_device_equals_host(hip, oracle):

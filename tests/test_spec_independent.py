@@ -105,6 +105,42 @@ def test_multi_output_families_against_scipy(oracle):
     assert np.max(np.abs(out[ok] - want[ok])) < 1e-10
 
 
+def test_factorised_softmax_of_constant_leaves_against_scipy(oracle):
+    """``pgb_loglik_cat_f`` (round 5): the row part (E_k, a_c) times the (particle, child) part (w_k, d_k), one
+    logarithm per evaluation; the unfactorised form below S = 2^-200.  Against ``scipy.special.log_softmax`` of
+    mu = eta + v over ordinary and over extreme spreads (the fallback regime), for K = 2..16: the same absolute
+    accuracy as the unfactorised routine, plus the rounding of eta + v itself at large magnitudes."""
+    f = _f(oracle, "pgbo_loglik_cat_f", None, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    rng = np.random.default_rng(11)
+    n = 20000
+    for K in (2, 3, 4, 7, 16):
+        for scale_eta, scale_v in ((0.3, 0.1), (3.0, 1.0), (30.0, 5.0), (300.0, 0.5), (1.0, 400.0), (500.0, 500.0)):
+            eta = np.ascontiguousarray(rng.normal(0, scale_eta, (n, K)))
+            v = rng.normal(0, scale_v, K)
+            y = rng.integers(0, K, n).astype(float)
+            out = np.zeros(n)
+            f(K, y.ctypes.data, eta.ctypes.data, v.ctypes.data, n, out.ctypes.data)
+            mu = eta + v
+            want = np.clip(special.log_softmax(mu, axis=1)[np.arange(n), y.astype(int)], -2047.0, 0.0)
+            tol = 2e-15 + 4 * np.spacing(np.abs(mu).max())  # (eta + v is rounded once before either form sees it)
+            assert np.max(np.abs(out - want)) < tol * max(1.0, K / 4), (K, scale_eta, scale_v)
+            assert out.max() <= 0.0 and out.min() >= -2047.0
+    # the two regimes meet: rows whose factorised sum is just above / below the threshold give the same values as
+    # the unfactorised routine to the last few ulp of log S
+    g = _f(oracle, "pgbo_loglik_multi", None, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+    K = 3
+    eta = np.zeros((4000, K))
+    eta[:, 1] = -np.linspace(120.0, 160.0, 4000)     # a_1 sweeps across -138.6 = log 2^-200 while the child's d
+    eta[:, 2] = -900.0                               # puts everything else far below: S ~ exp(a_1)
+    v = np.array([-800.0, 0.0, -1000.0])
+    y = np.ones(4000)
+    a, b = np.zeros(4000), np.zeros(4000)
+    f(K, y.ctypes.data, eta.ctypes.data, v.ctypes.data, 4000, a.ctypes.data)
+    mu = np.ascontiguousarray(eta + v)
+    g(_abi.FAMILIES["categorical"], K, y.ctypes.data, mu.ctypes.data, 4000, b.ctypes.data)
+    assert np.max(np.abs(a - b)) < 1e-12 and np.all(np.abs(a) < 1e-9)   # class 1 holds all the mass: ll ~ 0
+
+
 # ---------------------------------------------------------------------------------------------
 def _scales(oracle, n, range_exp):
     f = _f(oracle, "pgbo_scales", None, C.c_int64, C.c_int, C.c_void_p)

@@ -74,8 +74,11 @@ def demangle(names: list[str]) -> list[str]:
 
 def workgroups_per_cu(vgpr: int, agpr: int, lds: int, threads: int = 256) -> dict:
     waves_per_wg = (threads + 63) // 64
-    total = -(-(((vgpr + 3) // 4) * 4 + agpr) // VGPR_GRANULE) * VGPR_GRANULE
-    waves_simd = min(MAX_WAVES_PER_SIMD, VGPR_FILE // max(total, VGPR_GRANULE))
+    # (.vgpr_count of a kernel that uses accumulation registers is already the unified total: k_probe reports
+    #  512 with .agpr_count 256)
+    unified = vgpr if agpr and vgpr > 256 else ((vgpr + 3) // 4) * 4 + agpr
+    total = -(-unified // VGPR_GRANULE) * VGPR_GRANULE
+    waves_simd = max(1, min(MAX_WAVES_PER_SIMD, VGPR_FILE // max(total, VGPR_GRANULE)))
     by_vgpr = waves_simd * SIMDS_PER_CU // waves_per_wg
     by_lds = LDS_PER_CU // lds if lds > 0 else 1 << 30
     by_waves = MAX_WAVES_PER_SIMD * SIMDS_PER_CU // waves_per_wg
@@ -85,7 +88,7 @@ def workgroups_per_cu(vgpr: int, agpr: int, lds: int, threads: int = 256) -> dic
 
 def next_edge(total: int) -> int:
     """The largest allocation that keeps the current number of waves per SIMD."""
-    waves = min(MAX_WAVES_PER_SIMD, VGPR_FILE // max(total, VGPR_GRANULE))
+    waves = max(1, min(MAX_WAVES_PER_SIMD, VGPR_FILE // max(total, VGPR_GRANULE)))
     return (VGPR_FILE // waves) // VGPR_GRANULE * VGPR_GRANULE
 
 

@@ -79,7 +79,7 @@ def main():
     c1 = s.counters.as_dict()
     print({k: c1[k] - c0[k] for k in c1}, "sync astep ms", 1e3 * dt / a.asteps)
     NS = 4096
-    buf = np.zeros((NS, 24), np.int64)
+    buf = np.zeros((NS, 40), np.int64)
     lib.check(lib.lib.pgb_debug_trace(s._h, buf.ctypes.data, NS), "trace")
     # keep slots with a full set of k_ctrl stamps; stamp 15 = round of the proposal, 14 = attempt
     t = buf.astype(np.float64) * 0.01  # 100 MHz ticks -> us
@@ -97,7 +97,10 @@ def main():
             print(name, "too few slots", int(sel.sum()))
             return
         parts = []
-        for i in (1, 9, 10, 2, 3, 4, 5, 6, 20, 23, 21, 22, 7, 8, 11, 12, 13, 14, 15):
+        # (24..30: the likelihood pass, workgroup 100: entry | job list | INIT part done | first item: labels asked |
+        #  its first particle done | its particles done | its sums out -- the LAST item's stamps when there are two)
+        # (32 / 33: the pre-draw waves have their Philox draws, 34 / 35: their split variable)
+        for i in (1, 32, 33, 34, 35, 9, 10, 2, 3, 4, 5, 6, 20, 23, 21, 22, 7, 8, 11, 12, 13, 14, 15, 24, 36, 37, 38, 25, 26, 39, 27, 28, 29, 30, 31):
             d = t[sel, i] - t[sel, 0]
             d = d[(t[sel, i] > 0) & (d > -1) & (d < 200)]
             if d.size:
