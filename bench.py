@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # fp64 VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, a wave64 fp64 instruction occupies its SIMD for 4
 # cycles (78.6 TFLOP/s fp64 vector = 16 lanes x 2 flop per SIMD and clock)
 VALU_F64_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # G wave-instructions / s
-ROUND = "r04"
+ROUND = "r05"
 NOTES = "profiles/BENCH_NOTES.md"
 
 METRIC = {
@@ -352,7 +352,7 @@ def kernel_profile(s, tune, steps):
 def load_pmc(wname):
     """Per-launch counter averages of the hot kernels from the separate ``rocprofv3 --pmc`` passes
     (``tools/pmc_collect.sh``; the newest round's file that exists)."""
-    for rnd in (ROUND, "r03", "r02"):
+    for rnd in (ROUND, "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wname}.json")
         if os.path.exists(path):
             with open(path) as fh:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic / VALU instruction counts of the hot kernels, per launch, from separate rocprofv3 --pmc passes
-# (counters only: no trace domains), written to gpurun_out/${ROUND:-r04}_pmc_<workload>.json -- copy it to profiles/,
+# (counters only: no trace domains), written to gpurun_out/${ROUND:-r05}_pmc_<workload>.json -- copy it to profiles/,
 # where bench.py reads `roofline.traffic` / the instruction counts from.  Run on the GPU box from the repo root.
 # The run under the counters follows the HEADLINE protocol (100 tune=1 asteps of burn-in, then tune=0); the
 # averages are taken over the LAST 15 % of each kernel's dispatches, i.e. the steady-state tune=0 part.
@@ -34,6 +34,6 @@ for k, v in raw.items():
     if v.get("SQ_INSTS_VALU_avg_per_launch") is not None and v.get("launches", 0) >= e.get("valu_launches", 0):
         e.update(valu_launches=v["launches"], valu_wave_insts_per_launch=v["SQ_INSTS_VALU_avg_per_launch"],
                  waves_per_launch=v.get("SQ_WAVES_avg_per_launch"))
-json.dump(out, open("$R/gpurun_out/${ROUND:-r04}_pmc_${W}.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/${ROUND:-r05}_pmc_${W}.json", "w"), indent=1)
 print({k: v for k, v in out.items() if k.startswith("k_")})
 PY
