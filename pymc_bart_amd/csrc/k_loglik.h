@@ -355,6 +355,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
             const ChildX cx = child_values_x(S, ok, cL, cR, axL, axN, pq, pv, zz0, zz1, lsx);
             s_job[k].vLx[kx] = cx.vL;
             s_job[k].vRx[kx] = cx.vR;
+            if (blockIdx.x == 0) S.finx[((size_t)par * MAXP + q) * KXr + kx] = FinX{cx.vL, cx.vR, cx.aL, cx.aR};
             if constexpr (CATF) {
               // the child's part of the factorised softmax for this output (pgb_cat_side): relative to output 0,
               // whose leaf values this wave derives again -- the routine and the inputs wave 0 uses
@@ -422,6 +423,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
                                    leaf_sd_x(S, cn, par ^ 1, par, kx));
         lj.vLx[kx] = cx.vL;
         lj.vRx[kx] = cx.vR;
+        if constexpr (!LIN)  // handed to the next slot's control kernel (Dev::finx): it needs exactly these
+          if (blockIdx.x == 0) S.finx[((size_t)par * MAXP + q) * KX + kx] = FinX{cx.vL, cx.vR, cx.aL, cx.aR};
         if constexpr (LIN) {
           if (cv.ok == 1)
             lin_children_x(S, lk, cx, j.var, cv.cL, cv.cR, load_accx(S.accux, par, q, kx),

@@ -152,6 +152,13 @@ using gptr = T*;
 template <bool G, typename T>
 using dptr = typename std::conditional<G, gptr<T>, T*>::type;
 
+// children of one job, one extension output (what ChildX carries for a constant leaf), handed from the likelihood pass
+// of a slot to the control kernel of the next (Dev::finx)
+struct FinX {
+  double vL, vR;
+  long long aL, aR;
+};
+
 template <bool G>
 struct DevT {  // kernel argument block (by value)
   long long n, n_pad;
@@ -205,6 +212,11 @@ struct DevT {  // kernel argument block (by value)
   dptr<G, double> jvx;        // [2][MAXP][KX]          per job: parent's leaf values
   dptr<G, double> jzx;        // [2][MAXP][KX][2]       per job: leaf noise of the children, outputs 1..K-1 (drawn one slot ahead like Job::z0 / z1)
   dptr<G, double> lsdx;       // [2][KXMAX]             leaf_sd of outputs 1..K-1 (double-buffered like ctrl)
+  // constant K-vector leaves: the children's values / sums of outputs 1..K-1 of every job of a slot, as workgroup 0
+  // of the slot's likelihood pass derived them for its job list (child_values_x) -- the control kernel of the NEXT slot
+  // needs exactly these and used to derive them again from the same statistics (two dependent round trips of
+  // scattered loads per extension wave in front of its ancestor barrier); now one contiguous read
+  dptr<G, FinX> finx;         // [2][MAXP][KX]
   // softmax with constant leaves: the ROW part of the factorised log-likelihood (pgbart_spec.h, pgb_loglik_cat_f),
   // written by the likelihood pass of the slot that starts a tree, read by the passes of that tree's later rounds
   dptr<G, double> cat_e;      // [K][n_pad]  E_k = exp(eta_k - max_k eta_k), eta_k = sum_trees_noi_k + offset_k

@@ -347,6 +347,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.jvx, (size_t)2 * MAXP * KX);
     DA(d.jzx, (size_t)2 * MAXP * KX * 2);
     DA(d.lsdx, (size_t)2 * KXMAX);
+    DA(d.finx, (size_t)2 * MAXP * KX);
     if (s->family == PGB_FAMILY_CATEGORICAL && s->response == PGB_RESPONSE_CONSTANT) {
       // the row part of the factorised softmax: scratch of one tree update (no checkpoint carries it)
       DA(d.cat_e, (size_t)K * d.n_pad);
@@ -459,6 +460,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipMemsetAsync(d.jqx, 0, (size_t)2 * MAXP * KX * sizeof(long long), sm));
     HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.jzx, 0, (size_t)2 * MAXP * KX * 2 * sizeof(double), sm));
+    HC(hipMemsetAsync(d.finx, 0, (size_t)2 * MAXP * KX * sizeof(FinX), sm));
     hipLaunchKernelGGL(k_fill_f64, dim3(1), dim3(256), 0, sm, d.lsdx, (long long)2 * KXMAX, s->init_leaf_sd);
     // every accepted tree starts as a stump whose K-vector leaf is init_leaf
     hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,
