@@ -15,6 +15,7 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
   long long src, xoff, dst;  // byte offsets: the particle's labels before the split, its split column, its new labels
   double v, vL, vR;
   int32_t p, rule, label, check_nan, ok, new_label;
+  int32_t cL, cR;  // rows of the children (the extension outputs' lanes read them here, see the job list)
   // K-vector leaves: outputs 1..K-1 (sized by the instance: K - 1 when K is known at compile time)
   static constexpr int NX = !MK ? 1 : KT > 0 ? KT - 1 : KXMAX;
   double vLx[NX], vRx[NX];
@@ -251,13 +252,9 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   // The job records and split statistics of this lane's particles are requested FIRST, next to the command word
   // (their addresses depend on `par` alone; the records exist for every index below MAXP): by the time the command
   // says that this slot has a round to evaluate, they are on their way.  (k_ctrl starts the same way.)
-#ifndef PGB_LL_XW
-#define PGB_LL_XW 0 /* experiment knob: 1 = the extension outputs of a K-vector job on waves 1..3, side by side (measured SLOWER at cfg5: 727 / 723 k against 756 / 749 k, same box -- four waves loading the job records) */
-#endif
-  constexpr bool XW = MK && !LIN && PGB_LL_XW != 0;  // K-vector constant leaves: the extension outputs on waves 1..3 (see the job list)
   Job j_pre[MAXP / 64];
   Acc a_pre[MAXP / 64];
-  if (threadIdx.x < 64 || XW) {
+  if (threadIdx.x < 64) {
 #pragma unroll
     for (int hq = 0; hq < MAXP / 64; ++hq) {
       const int q = (int)(threadIdx.x & 63) + 64 * hq;
@@ -265,6 +262,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
       a_pre[hq] = load_acc(&acc_all[((size_t)par * MAXP + q) * ACC_PER]);
     }
   }
+#ifndef PGB_LL_PAIRS
+#define PGB_LL_PAIRS 1 /* experiment knob: 1 = job list: one lane per (active particle, extension output), see there */
+#endif
+  constexpr bool PAIRS = MK && !LIN && PGB_LL_PAIRS != 0;
   // ... and so are the tables (see stage_load)
   StageRegs<PROBIT ? PGB_LPHI_SIZE : 2> st_lphi;
   StageRegs<EXPLOG ? PGB_EXPT_SIZE : 2> st_exp;
@@ -316,8 +317,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   // 0 and the fields of the record; K-vector constant leaves: extension output kx on wave 1 + kx % 3, side by side;
   // and every statistic a lane may need is REQUESTED before anything is known about the particle (one round trip).
   // (XW: the extension outputs on waves 1..3; linear leaves: wave 0, they chain)
-  if (tid < 64 || XW) {
-    const int wv = tid >> 6, ln = tid & 63;
+  if (tid < 64) {
+    const int ln = tid;
     const int KXr = MK ? (KT > 0 ? KT : S.K) - 1 : 0;
     int nlist = 0;  // (lanes' particles ln, ln + 64, ...: one block of 64 after the other)
 #pragma unroll
@@ -330,50 +331,37 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
     const unsigned long long m = __ballot(has);
     if (hq == 0) TRL(37);
     const int k = nlist + __popcll(m & ((1ull << ln) - 1ull));
-    if constexpr (XW) {
-      if (wv >= 1) {  // (wave-uniform)
-        for (int kx = wv - 1; kx < KXr; kx += 3) {
-          long long axL = 0, axN = 0, pq = 0;
-          double pv = S.init_leaf, zz0 = 0.0, zz1 = 0.0;
-          if (inr) {  // requested for every particle of the range: a particle without a job never reads them
-            axL = load_accx(S.accx, par, q, kx);
-            axN = load_accx(S.accx, par, q, KXr + kx);
-            if (round == 0) {
-              pq = root_A_x(S, par, kx);
-            } else {
-              pq = S.jqx[((size_t)par * MAXP + q) * KXr + kx];
-              pv = S.jvx[((size_t)par * MAXP + q) * KXr + kx];
-            }
-            const double* zz = S.jzx + (((size_t)par * MAXP + q) * KXr + kx) * 2;  // drawn by this slot's control kernel
-            zz0 = zz[0];
-            zz1 = zz[1];
-          }
-          const double lsx = leaf_sd_x(S, cn, par ^ 1, par, kx);
-          if (has) {
-            const int cL = (int)(a.cnts & 0xFFFFFFFFull), cN = (int)(a.cnts >> 32), cR = j.cnt - cL - cN;
-            const int ok = (cR == 0 && pgb_empty_right_fails(j.rule, S.compat)) ? -1 : 1;  // as child_values decides
-            const ChildX cx = child_values_x(S, ok, cL, cR, axL, axN, pq, pv, zz0, zz1, lsx);
-            s_job[k].vLx[kx] = cx.vL;
-            s_job[k].vRx[kx] = cx.vR;
-            if (blockIdx.x == 0) S.finx[((size_t)par * MAXP + q) * KXr + kx] = FinX{cx.vL, cx.vR, cx.aL, cx.aR};
-            if constexpr (CATF) {
-              // the child's part of the factorised softmax for this output (pgb_cat_side): relative to output 0,
-              // whose leaf values this wave derives again -- the routine and the inputs wave 0 uses
-              const ChildVals c0 = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
-                                                a.aL, a.aN, j.z0, j.z1, leaf_sd);
-              const double dL = cx.vL - c0.vL, dR = cx.vR - c0.vR;
-              s_job[k].d2[0][kx + 1] = dL;
-              s_job[k].d2[1][kx + 1] = dR;
-              s_job[k].w2[0][kx + 1] = pgb_exp_t(dL, tb.expt);  // (the LDS copy: published by the barrier in front of this list)
-              s_job[k].w2[1][kx + 1] = pgb_exp_t(dR, tb.expt);
-              s_job[k].slowx[kx] = (!(dL <= PGB_CAT_DMAX && dL >= -PGB_CAT_DMAX) ? 1 : 0) |
-                                   (!(dR <= PGB_CAT_DMAX && dR >= -PGB_CAT_DMAX) ? 2 : 0);
-            }
-          }
-        }
-        nlist += __popcll(m);
-        continue;
-      }
+    // K-vector constant leaves: the extension outputs of the block's active particles, ONE per lane -- pair i =
+    // (i / KX-th active particle of the block, output 1 + i % KX), 64 pairs at a time.  (One lane per particle ran
+    // its K - 1 outputs one after the other: K - 1 dependent chains of two leaf values and two exponentials each,
+    // behind one another on a wave that has the SIMD to itself -- 2.5 us of a 10 us launch at cfg5, and all but ~10
+    // of the 64 lanes idle in a plain round.)  A pair's statistics are requested as soon as the ballot says which
+    // particles have a job, and arrive while the particles' own lanes derive output 0.
+    struct PairIn {
+      long long axL, axN, pq;
+      double pv, z0, z1;
+    };
+    const int npair = PAIRS ? __popcll(m) * KXr : 0;  // (wave-uniform)
+    auto pair_load = [&](int i, PairIn& x, int& kk, int& kx) {
+      if constexpr (!PAIRS) return;
+      kk = nlist + i / KXr;
+      kx = i - (i / KXr) * KXr;
+      const int q2 = s_job[kk].p;
+      const size_t e = ((size_t)par * MAXP + q2) * KXr + kx;
+      x.axL = load_accx(S.accx, par, q2, kx);
+      x.axN = load_accx(S.accx, par, q2, KXr + kx);
+      x.pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[e];
+      x.pv = round == 0 ? S.init_leaf : S.jvx[e];
+      x.z0 = S.jzx[e * 2];  // drawn by this slot's control kernel
+      x.z1 = S.jzx[e * 2 + 1];
+    };
+    PairIn x0 = {0, 0, 0, 0.0, 0.0, 0.0};
+    int kk0 = 0, kx0 = 0;
+    if constexpr (PAIRS) {
+      if (has) s_job[k].p = q;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (ln < npair) pair_load(ln, x0, kk0, kx0);
     }
     // the leaf noise of particle `ln` in this round: drawn by the control kernel of this slot, in the job
     const double z0 = has ? j.z0 : 0.0, z1 = has ? j.z1 : 0.0;
@@ -387,6 +375,8 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
       lj.new_label = j.new_label;
       lj.check_nan = j.check_nan;
       lj.ok = cv.ok;
+      lj.cL = cv.cL;
+      lj.cR = cv.cR;
       lj.v = j.v;
       lj.vL = cv.vL;
       lj.vR = cv.vR;
@@ -412,7 +402,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
       }
-      if constexpr (MK && !XW)
+      if constexpr (MK && !PAIRS)
       for (int kx = 0; kx < (KT > 0 ? KT : S.K) - 1; ++kx) {  // extension outputs: same routine as k_ctrl
         const int KX = (KT > 0 ? KT : S.K) - 1;
         const long long pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[((size_t)par * MAXP + q) * KX + kx];
@@ -447,6 +437,34 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
           lj.svarL = lk.svarL; lj.slopeL = lk.slopeL; lj.xbarL = lk.xbarL;
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
+    }
+    if constexpr (PAIRS) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // (the particles' lanes have written ok / cL / cR / vL / vR of their records)
+      for (int i0 = 0; i0 < npair; i0 += 64) {
+        const int i = i0 + ln;
+        PairIn x = x0;
+        int kk = kk0, kx = kx0;
+        if (i0 != 0 && i < npair) pair_load(i, x, kk, kx);
+        if (i < npair) {
+          LJob& lj = s_job[kk];
+          const ChildX cx = child_values_x(S, lj.ok, lj.cL, lj.cR, x.axL, x.axN, x.pq, x.pv, x.z0, x.z1,
+                                           leaf_sd_x(S, cn, par ^ 1, par, kx));  // same routine as k_ctrl
+          lj.vLx[kx] = cx.vL;
+          lj.vRx[kx] = cx.vR;
+          // handed to the next slot's control kernel (Dev::finx): it needs exactly these
+          if (blockIdx.x == 0) S.finx[((size_t)par * MAXP + lj.p) * KXr + kx] = FinX{cx.vL, cx.vR, cx.aL, cx.aR};
+          if constexpr (CATF) {  // the child's part of the factorised softmax for this output (pgb_cat_side)
+            const double dL = cx.vL - lj.vL, dR = cx.vR - lj.vR;
+            lj.d2[0][kx + 1] = dL;
+            lj.d2[1][kx + 1] = dR;
+            lj.w2[0][kx + 1] = pgb_exp_t(dL, tb.expt);
+            lj.w2[1][kx + 1] = pgb_exp_t(dR, tb.expt);
+            lj.slowx[kx] = (!(dL <= PGB_CAT_DMAX && dL >= -PGB_CAT_DMAX) ? 1 : 0) |
+                           (!(dR <= PGB_CAT_DMAX && dR >= -PGB_CAT_DMAX) ? 2 : 0);
+          }
+        }
+      }
     }
     nlist += __popcll(m);
     }

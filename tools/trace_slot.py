@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="also per-workgroup first/last clock readings of the row pass")
     ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--deltas", action="store_true", help="also the p10 / p50 / p90 of the stage-to-stage differences of k_loglik's stamps")
     ap.add_argument("--ll", action="store_true", help="the library was built with -DPGB_STAMP_LL: the per-workgroup stamps are k_loglik's")
     a = ap.parse_args()
     if a.build:
@@ -108,6 +109,17 @@ def main():
         v = nxt[sel]
         v = v[np.isfinite(v) & (v < 200)]
         print(f"{name:28s} n={int(sel.sum()):5d}  " + " ".join(parts) + f"  | next k_ctrl {np.median(v):.2f} (mean {v.mean():.2f})")
+        if a.deltas:  # distribution of the stage-to-stage differences of the likelihood pass (a median of offsets hides a two-humped stage)
+            seq = (24, 36, 37, 38, 25, 26, 39, 27, 29, 30, 31)
+            out = []
+            for i0, i1 in zip(seq[:-1], seq[1:]):
+                m = (t[sel, i0] > 0) & (t[sel, i1] > 0)
+                d = (t[sel, i1] - t[sel, i0])[m]
+                d = d[(d > -50) & (d < 200)]
+                if d.size:
+                    q = np.percentile(d, [10, 50, 90])
+                    out.append(f"{i0}>{i1}: {q[0]:.2f}/{q[1]:.2f}/{q[2]:.2f} (n={d.size})")
+            print("    deltas p10/p50/p90  " + "  ".join(out))
 
     fresh = buf[order, 18] != 0
     stop = buf[order, 19] != 0
