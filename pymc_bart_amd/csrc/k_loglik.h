@@ -47,6 +47,15 @@ struct LJobT : std::conditional<LIN, LJobLin, LJobNone>::type {  // (constant le
 // is K table-driven exponentials and one logarithm, fully unrolled (pgb_loglik_cat_t; round 4 -- the K - 1
 // exponentials of the previous form cost more in selects than the exponential they saved).
 // (The run-time-K instances, KT = 0, keep the spec's own dispatcher: K = 5..8 and K-vector linear leaves.)
+// (trace builds with -DPGB_TRACE_LIST: stamps 27..29 move from the passes into the job list -- 27: pair statistics
+//  requested, 28: output 0 of the particles' lanes done, 29: the pairs' statistics have arrived and their values are out)
+#ifdef PGB_TRACE_LIST
+#define TRLP(i) ((void)0)
+#define TRLL(i) TRL(i)
+#else
+#define TRLP(i) TRL(i)
+#define TRLL(i) ((void)0)
+#endif
 template <int KT, int FAM = -1>
 __device__ __forceinline__ double loglik_mk(int family, int K, double y, const double* mu, const pgb_lltabs* tb) {
   if constexpr (KT == 0) {
@@ -195,6 +204,13 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   const double* const st_h = S.st;
   const long long n_pad_h = S.n_pad;
   constexpr bool MK = KT != 1;
+  // (K-vector leaves: the arrays the job list reads per (particle, extension output) -- as pointers of the argument
+  //  block read where the list uses them, they were a scalar round trip in front of the list's own)
+  const long long* const accx_h = MK ? (const long long*)S.accx : nullptr;
+  const long long* const jqx_h = MK ? (const long long*)S.jqx : nullptr;
+  const double* const jvx_h = MK ? (const double*)S.jvx : nullptr;
+  const double* const jzx_h = MK ? (const double*)S.jzx : nullptr;
+  const double init_leaf_h = S.init_leaf;
   constexpr int KB = KT > 0 ? KT : PGB_MAX_OUTPUTS;  // compile-time bound of the K loops (run-time K: guarded by k < K)
   // softmax with constant leaves: the factorised evaluation (pgbart_spec.h, pgb_loglik_cat_f)
   constexpr bool CATF = MK && !LIN && FAM == PGB_FAMILY_CATEGORICAL;
@@ -266,6 +282,10 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
 #define PGB_LL_PAIRS 1 /* experiment knob: 1 = job list: one lane per (active particle, extension output), see there */
 #endif
   constexpr bool PAIRS = MK && !LIN && PGB_LL_PAIRS != 0;
+  // ... and the control word this slot's k_ctrl produced (the round decides where a K-vector job's parent sums are,
+  // the pending leaf_sd update what output 0 needs: read behind the command word, it was a round trip of its own in
+  // front of the list's requests -- 0.8 us from the job records' arrival to the first of them, stamps)
+  const Ctrl cn = ctrls[par ^ 1];
   // ... and so are the tables (see stage_load)
   StageRegs<PROBIT ? PGB_LPHI_SIZE : 2> st_lphi;
   StageRegs<EXPLOG ? PGB_EXPT_SIZE : 2> st_exp;
@@ -283,7 +303,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   static_assert(offsetof(Cmd, st_cur) == offsetof(CmdHead, st_cur), "CmdHead mirrors the head of Cmd");
   const CmdHead ch = load_uniform(reinterpret_cast<const CmdHead*>(cmd));
   if (!(ch.kind & CMD_PARTITION)) return;
-  TRL_BIND(ctrls[par ^ 1].slot_no - 1);
+  TRL_BIND(cn.slot_no - 1);
   TRL(24);
   if constexpr (PROBIT) stage_store<PGB_LPHI_SIZE>(s_lphi, st_lphi);
   if constexpr (EXPLOG) {
@@ -294,7 +314,6 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   // (the barrier after the job list below also publishes the tables)
   TRL(36);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const Ctrl cn = ctrls[par ^ 1];  // the state this slot's k_ctrl produced
   const int round = cn.round - 1;   // round of the proposals of this slot
   const uint32_t it = (uint32_t)cn.iter;
   // leaf_sd / root statistics in force for this round (k_ctrl of the NEXT slot resolves them the
@@ -317,76 +336,106 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
   // 0 and the fields of the record; K-vector constant leaves: extension output kx on wave 1 + kx % 3, side by side;
   // and every statistic a lane may need is REQUESTED before anything is known about the particle (one round trip).
   // (XW: the extension outputs on waves 1..3; linear leaves: wave 0, they chain)
+  // The list comes in two loops over the blocks of 64 particles (wave 0).  The first: which particles have a job, of
+  // each record the fields that say WHERE its rows are (they depend on the job record alone), and the requests for the
+  // extension outputs' statistics; the second: the children's values.  (Tried between the two: a barrier and every
+  // wave's request for the label words of its first unit, so that they travel under the second loop -- 0.28 us less in
+  // front of the passes, 0.42 us more in the list, cfg5 782 / 780 k against 791 / 785 k: dropped.)
+  const int KXr = MK ? (KT > 0 ? KT : S.K) - 1 : 0;
+  struct PairIn {
+    long long axL, axN, pq;
+    double pv, z0, z1;
+  };
+  constexpr int NHQ = MAXP / 64;
+  unsigned long long mm[NHQ];
+  int nl0[NHQ];  // list position of the first active particle of a block of 64
+  PairIn x0[NHQ];
+  int kk0[NHQ], kx0[NHQ];
+  auto pair_load = [&](int nlist, int i, PairIn& x, int& kk, int& kx) {
+    if constexpr (!PAIRS) return;
+    kk = nlist + i / KXr;
+    kx = i - (i / KXr) * KXr;
+    const int q2 = s_job[kk].p;
+    const size_t e = ((size_t)par * MAXP + q2) * KXr + kx;
+    x.axL = load_accx(accx_h, par, q2, kx);
+    x.axN = load_accx(accx_h, par, q2, KXr + kx);
+    x.pq = round == 0 ? root_A_x(S, par, kx) : jqx_h[e];
+    x.pv = round == 0 ? init_leaf_h : jvx_h[e];
+    x.z0 = jzx_h[e * 2];  // drawn by this slot's control kernel
+    x.z1 = jzx_h[e * 2 + 1];
+  };
   if (tid < 64) {
     const int ln = tid;
-    const int KXr = MK ? (KT > 0 ? KT : S.K) - 1 : 0;
     int nlist = 0;  // (lanes' particles ln, ln + 64, ...: one block of 64 after the other)
 #pragma unroll
-    for (int hq = 0; hq < MAXP / 64; ++hq) {
-    const int q = ln + 64 * hq;
-    const bool inr = q >= 1 && q < S.P;
-    const Job j = j_pre[hq];  // (requested at the head of the kernel)
-    const Acc a = a_pre[hq];
-    const bool has = inr && j.active != 0;
-    const unsigned long long m = __ballot(has);
-    if (hq == 0) TRL(37);
-    const int k = nlist + __popcll(m & ((1ull << ln) - 1ull));
-    // K-vector constant leaves: the extension outputs of the block's active particles, ONE per lane -- pair i =
-    // (i / KX-th active particle of the block, output 1 + i % KX), 64 pairs at a time.  (One lane per particle ran
-    // its K - 1 outputs one after the other: K - 1 dependent chains of two leaf values and two exponentials each,
-    // behind one another on a wave that has the SIMD to itself -- 2.5 us of a 10 us launch at cfg5, and all but ~10
-    // of the 64 lanes idle in a plain round.)  A pair's statistics are requested as soon as the ballot says which
-    // particles have a job, and arrive while the particles' own lanes derive output 0.
-    struct PairIn {
-      long long axL, axN, pq;
-      double pv, z0, z1;
-    };
-    const int npair = PAIRS ? __popcll(m) * KXr : 0;  // (wave-uniform)
-    auto pair_load = [&](int i, PairIn& x, int& kk, int& kx) {
-      if constexpr (!PAIRS) return;
-      kk = nlist + i / KXr;
-      kx = i - (i / KXr) * KXr;
-      const int q2 = s_job[kk].p;
-      const size_t e = ((size_t)par * MAXP + q2) * KXr + kx;
-      x.axL = load_accx(S.accx, par, q2, kx);
-      x.axN = load_accx(S.accx, par, q2, KXr + kx);
-      x.pq = round == 0 ? root_A_x(S, par, kx) : S.jqx[e];
-      x.pv = round == 0 ? S.init_leaf : S.jvx[e];
-      x.z0 = S.jzx[e * 2];  // drawn by this slot's control kernel
-      x.z1 = S.jzx[e * 2 + 1];
-    };
-    PairIn x0 = {0, 0, 0, 0.0, 0.0, 0.0};
-    int kk0 = 0, kx0 = 0;
-    if constexpr (PAIRS) {
-      if (has) s_job[k].p = q;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (ln < npair) pair_load(ln, x0, kk0, kx0);
+    for (int hq = 0; hq < NHQ; ++hq) {
+      const int q = ln + 64 * hq;
+      const bool inr = q >= 1 && q < S.P;
+      const Job& j = j_pre[hq];  // (requested at the head of the kernel)
+      const bool has = inr && j.active != 0;
+      const unsigned long long m = __ballot(has);
+      if (hq == 0) TRL(37);
+      mm[hq] = m;
+      nl0[hq] = nlist;
+      const int k = nlist + __popcll(m & ((1ull << ln) - 1ull));
+      if (has) {
+        LJob& lj = s_job[k];  // (filled in place: a local record with its K-sized arrays would live in scratch)
+        lj.p = q;
+        lj.rule = j.rule;
+        lj.label = j.label;
+        lj.new_label = j.new_label;
+        lj.check_nan = j.check_nan;
+        lj.v = j.v;
+        lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
+        lj.xoff = (long long)((size_t)j.var * S.n_pad);
+        lj.dst = (long long)((size_t)q * S.n_pad);
+      }
+      // K-vector constant leaves: the extension outputs of the block's active particles, ONE per lane -- pair i =
+      // (i / KX-th active particle of the block, output 1 + i % KX), 64 pairs at a time.  (One lane per particle ran
+      // its K - 1 outputs one after the other: K - 1 dependent chains of two leaf values and two exponentials each,
+      // behind one another on a wave that has the SIMD to itself -- 2.5 us of a 10 us launch at cfg5, and all but ~10
+      // of the 64 lanes idle in a plain round.)  A pair's statistics are requested as soon as the ballot says which
+      // particles have a job, and arrive while the particles' own lanes derive output 0.
+      x0[hq] = PairIn{0, 0, 0, 0.0, 0.0, 0.0};
+      kk0[hq] = kx0[hq] = 0;
+      if constexpr (PAIRS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ln < __popcll(m) * KXr) pair_load(nlist, ln, x0[hq], kk0[hq], kx0[hq]);
+      }
+      if (hq == 0) TRLL(27);
+      nlist += __popcll(m);
     }
+    if (tid == 0) s_n[0] = nlist;
+  }
+  unsigned sat = 0;
+  if (tid < 64) {
+    const int ln = tid;
+#pragma unroll
+    for (int hq = 0; hq < NHQ; ++hq) {
+    const int q = ln + 64 * hq;
+    const Job& j = j_pre[hq];
+    const Acc& a = a_pre[hq];
+    const unsigned long long m = mm[hq];
+    const bool has = (m >> ln) & 1ull;
+    const int nlist = nl0[hq];
+    const int k = nlist + __popcll(m & ((1ull << ln) - 1ull));
+    const int npair = PAIRS ? __popcll(m) * KXr : 0;  // (wave-uniform)
     // the leaf noise of particle `ln` in this round: drawn by the control kernel of this slot, in the job
     const double z0 = has ? j.z0 : 0.0, z1 = has ? j.z1 : 0.0;
     if (has) {
       const ChildVals cv = child_values(S, j.rule, j.cnt, round == 0 ? rootA : j.p_q_st, j.p_value, a.cnts,
                                         a.aL, a.aN, z0, z1, leaf_sd);
-      LJob& lj = s_job[k];  // (filled in place: a local record with its K-sized arrays would live in scratch)
-      lj.p = q;
-      lj.rule = j.rule;
-      lj.label = j.label;
-      lj.new_label = j.new_label;
-      lj.check_nan = j.check_nan;
+      LJob& lj = s_job[k];
       lj.ok = cv.ok;
       lj.cL = cv.cL;
       lj.cR = cv.cR;
-      lj.v = j.v;
       lj.vL = cv.vL;
       lj.vR = cv.vR;
       if constexpr (CATF) {  // output 0 of the children's part: d = v - v = 0, w = exp(0) = 1 exactly
         lj.d2[0][0] = lj.d2[1][0] = 0.0;
         lj.w2[0][0] = lj.w2[1][0] = 1.0;
       }
-      lj.src = j.src_slot < 0 ? -1ll : (long long)(((size_t)j.src_gen * MAXP + j.src_slot) * S.n_pad);
-      lj.xoff = (long long)((size_t)j.var * S.n_pad);
-      lj.dst = (long long)((size_t)q * S.n_pad);
       if constexpr (LIN) {
         lj.slopeL = lj.xbarL = lj.slopeR = lj.xbarR = 0.0;
         lj.svarL = lj.svarR = -1;
@@ -438,20 +487,22 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
           lj.svarR = lk.svarR; lj.slopeR = lk.slopeR; lj.xbarR = lk.xbarR;
         }
     }
+    if (hq == 0) TRLL(28);
     if constexpr (PAIRS) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // (the particles' lanes have written ok / cL / cR / vL / vR of their records)
       for (int i0 = 0; i0 < npair; i0 += 64) {
         const int i = i0 + ln;
-        PairIn x = x0;
-        int kk = kk0, kx = kx0;
-        if (i0 != 0 && i < npair) pair_load(i, x, kk, kx);
+        PairIn x = x0[hq];
+        int kk = kk0[hq], kx = kx0[hq];
+        if (i0 != 0 && i < npair) pair_load(nlist, i, x, kk, kx);
         if (i < npair) {
           LJob& lj = s_job[kk];
           const ChildX cx = child_values_x(S, lj.ok, lj.cL, lj.cR, x.axL, x.axN, x.pq, x.pv, x.z0, x.z1,
                                            leaf_sd_x(S, cn, par ^ 1, par, kx));  // same routine as k_ctrl
           lj.vLx[kx] = cx.vL;
           lj.vRx[kx] = cx.vR;
+          if (hq == 0 && i0 == 0) TRLL(29);
           // handed to the next slot's control kernel (Dev::finx): it needs exactly these
           if (blockIdx.x == 0) S.finx[((size_t)par * MAXP + lj.p) * KXr + kx] = FinX{cx.vL, cx.vR, cx.aL, cx.aR};
           if constexpr (CATF) {  // the child's part of the factorised softmax for this output (pgb_cat_side)
@@ -466,14 +517,11 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
         }
       }
     }
-    nlist += __popcll(m);
     }
-    if (tid == 0) s_n[0] = nlist;
   }
   TRL(38);
   __syncthreads();
   TRL(25);
-  unsigned sat = 0;
   const int nact = s_n[0];
   TRL(26);
   if (nact != 0) {  // (the passes; a slot without an active particle goes straight to the INIT part)
@@ -573,11 +621,11 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
         nid_nx = gload_u32_off(newl + dst_u, base32);
       };
       if (g0 < g1) fetch_labels(g0);
-      TRL(27);
+      TRLP(27);
       for (int g = g0; g < g1; ++g) {
         const LJob& lj = s_job[g];
         const uint32_t ids = ids_nx, nid = nid_nx;
-        if (g == g0 + 1) TRL(28);  // (the first particle of the item done: own rows loaded / computed with it)
+        if (g == g0 + 1) TRLP(28);  // (the first particle of the item done: own rows loaded / computed with it)
         if (g + 1 < g1) fetch_labels(g + 1);
         const uint32_t lab = uni((uint32_t)lj.label), nlab = uni((uint32_t)lj.new_label);
         // (compile-time K: the particle's leaf values in registers; run-time K: read from its LDS record where used.
@@ -893,7 +941,7 @@ void k_loglik(const Dev* __restrict__ Sp, int par, int nwg, const Cmd* __restric
         else passes(std::false_type{});
         if (dense) __builtin_amdgcn_wave_barrier();  // the next particle's list goes into the same storage
       }
-      TRL(29);
+      TRLP(29);
       __syncthreads();
       for (int t = tid; t < (g1 - g0) * 3; t += BT) {
         const int gi = t / 3, i = t % 3;

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="also per-workgroup first/last clock readings of the row pass")
     ap.add_argument("--lib", default=TRACE_SO, help="trace build to load / write")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--list", action="store_true", help="the library was built with -DPGB_TRACE_LIST: stamps 27..29 are inside k_loglik's job list")
     ap.add_argument("--deltas", action="store_true", help="also the p10 / p50 / p90 of the stage-to-stage differences of k_loglik's stamps")
     ap.add_argument("--ll", action="store_true", help="the library was built with -DPGB_STAMP_LL: the per-workgroup stamps are k_loglik's")
     a = ap.parse_args()
@@ -110,7 +111,7 @@ def main():
         v = v[np.isfinite(v) & (v < 200)]
         print(f"{name:28s} n={int(sel.sum()):5d}  " + " ".join(parts) + f"  | next k_ctrl {np.median(v):.2f} (mean {v.mean():.2f})")
         if a.deltas:  # distribution of the stage-to-stage differences of the likelihood pass (a median of offsets hides a two-humped stage)
-            seq = (24, 36, 37, 38, 25, 26, 39, 27, 29, 30, 31)
+            seq = (24, 36, 37, 27, 28, 29, 38, 25, 26, 39, 30, 31) if a.list else (24, 36, 37, 38, 25, 26, 39, 27, 29, 30, 31)
             out = []
             for i0, i1 in zip(seq[:-1], seq[1:]):
                 m = (t[sel, i0] > 0) & (t[sel, i1] > 0)
