@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Parity hunt on a GPU box: random configurations (tests/_cases.random_case) through the HIP library and
 the CPU oracle, bit-for-bit digests compared.
-usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS] [large] [compat]
-(large: n = 50k .. 1M, few trees; compat: the upstream-semantics switches on, PGB_COMPAT_* = 1 + seed % 3)"""
+usage: python tools/fuzz_hunt.py FIRST_SEED COUNT [SECONDS] [large] [compat] [mk]
+(large: n = 50k .. 1M, few trees; compat: the upstream-semantics switches on, PGB_COMPAT_* = 1 + seed % 3;
+mk: only the configurations with K-vector leaves -- the seeds of the others are skipped)"""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
 large = "large" in sys.argv[4:]
 compat_on = "compat" in sys.argv[4:]
+mk_only = "mk" in sys.argv[4:]
 hip, orc = default_backend(0), oracle_backend()
 t0, bad, done = time.time(), [], 0
 fam = {}
@@ -26,6 +28,8 @@ for seed in range(first, first + count):
     if time.time() - t0 > budget:
         break
     c = random_case(seed, large, compat=(1 + seed % 3) if compat_on else 0)
+    if mk_only and int(c["K"]) < 2:
+        continue
     g, o = digest(run_case(c, hip)), digest(run_case(c, orc))
     done += 1
     key = (c["family"], int(c["K"]), str(c.get("response", "constant")))

@@ -160,16 +160,18 @@ def main():
 
         def by_block(name, sel):
             idx = np.nonzero(sel)[0]
-            acc_d, acc_s, acc_e, cnt = np.zeros(1024), np.zeros(1024), np.zeros(1024), 0
+            acc_d, acc_s, acc_e, cnt, nbs = np.zeros(1024), np.zeros(1024), np.zeros(1024), 0, 0
             for i in idx:
                 st, en = sb[i, :, 0], sb[i, :, 1]
                 m = (st > 0) & (en > st)
-                if m.sum() < 1024 or abs(st[m].min() - t[i, 12]) > (400 if a.ll else 50):
+                if m.sum() < 256 or abs(st[m].min() - t[i, 12]) > (400 if a.ll else 50):
                     continue
-                t0 = st.min()
-                acc_d += en - st
-                acc_s += st - t0
-                acc_e += en - t0
+                nb = int(np.nonzero(m)[0].max()) + 1  # (the grid of the launch: the likelihood pass has fewer than 1024 workgroups)
+                t0 = st[m].min()
+                acc_d[:nb] += (en - st)[:nb]
+                acc_s[:nb] += (st - t0)[:nb]
+                acc_e[:nb] += (en - t0)[:nb]
+                nbs = max(nbs, nb)
                 cnt += 1
             if cnt == 0:
                 return
@@ -178,9 +180,13 @@ def main():
             print("  blocks 0..15 duration", np.round(d[:16], 2))
             print("  blocks 0..15 start   ", np.round(st_[:16], 2))
             for lo in (0, 64, 128, 256, 384, 512, 640, 768, 896):
-                hi = lo + (64 if lo < 128 else 128)
+                hi = min(lo + (64 if lo < 128 else 128), nbs)
+                if lo >= nbs:
+                    break
                 print(f"  blocks {lo:4d}..{hi - 1:4d}: start {st_[lo:hi].mean():.2f}  duration {d[lo:hi].mean():.2f} (max {d[lo:hi].max():.2f})  end {en_[lo:hi].mean():.2f} (max {en_[lo:hi].max():.2f})")
+            d, en_ = d[:nbs], en_[:nbs]
             print("  by blockIdx % 8: duration", np.round([d[k::8].mean() for k in range(8)], 2), "end", np.round([en_[k::8].max() for k in range(8)], 2))
+            print("  duration deciles over the blocks:", np.round(np.percentile(d, [0, 10, 25, 50, 75, 90, 100]), 2))
 
         def tails(name, sel, show_n=6):
             idx = np.nonzero(sel)[0]
