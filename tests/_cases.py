@@ -63,6 +63,13 @@ def make_case(name: str):
         X = rng.normal(size=(n, p))
         Y = (rng.random(n) < 1 / (1 + np.exp(-2 * X[:, 0] + X[:, 1]))).astype(float)
         c.update(m=4, P=100, steps=10, family="bernoulli_probit")
+    elif name == "categorical_k4_particles_100":  # K-vector leaves above 64 particles: both blocks of 64 have jobs whose
+        n, p, K = 3000, 6, 4                      # extension outputs the likelihood pass lists (one lane per pair) and hands on
+        X = rng.normal(size=(n, p))
+        F = np.stack([X[:, 0], -X[:, 0], 1.5 * X[:, 1], 0 * X[:, 0]])
+        pr = np.exp(F) / np.exp(F).sum(0)
+        Y = (rng.random(n)[None, :] > np.cumsum(pr, axis=0)).sum(0).clip(0, K - 1).astype(float)
+        c.update(m=4, P=100, steps=10, family="categorical", K=K)
     elif name == "duplicates":
         n, p = 4096, 3
         X = rng.integers(0, 3, (n, p)).astype(float)  # heavy ties, no jitter at this level
@@ -288,7 +295,7 @@ def make_case(name: str):
 
 
 CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tree_two_particles",
-         "max_particles", "particles_128", "particles_100_probit", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
+         "max_particles", "particles_128", "particles_100_probit", "categorical_k4_particles_100", "duplicates", "deep_trees", "onehot_fail_nan", "probit_cfg4_small",
          "logit_nan_onehot", "categorical_k3_reference", "categorical_k4_cfg5_small",
          "meanscale_k2_reference", "subset_rule", "categorical_k6_generic", "categorical_k12", "categorical_k16_linear", "linear_response", "mix_response", "poisson_counts", "negbin_counts", "quantile_asymlaplace", "robust_student_t", "poisson_exposure", "gamma_positive", "linear_poisson", "mix_probit",
          "meanscale_k2_linear", "categorical_k3_mix", "categorical_k3_offset",
