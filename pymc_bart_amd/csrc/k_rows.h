@@ -61,6 +61,20 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
   __shared__ int s_n[2];
   const Cmd* cmd = &cmds[par];
   const int kind = cmd->kind;
+#ifndef PGB_ROWS_JPRE
+#define PGB_ROWS_JPRE 1 /* experiment knob: 0 = the job records are requested where the list is made, behind the command word */
+#endif
+  // The job records of this lane's particles (wave 0: the particle list below) are requested WITH the command word:
+  // their addresses depend on `par` alone and the records exist for every index below MAXP.  Requested where the list
+  // is made they were a second round trip behind it in every workgroup of every launch (stamps 12 -> 13: 1.24 us at
+  // cfg2).  (k_ctrl and k_loglik start the same way.)
+  Job j_pre[MAXP / 64];
+  if constexpr (PGB_ROWS_JPRE != 0) {
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int hq = 0; hq < MAXP / 64; ++hq) j_pre[hq] = jobs_all[(size_t)par * MAXP + threadIdx.x + 64 * hq];
+    }
+  }
   TRR_BIND(S.ctrl[par ^ 1].slot_no - 1);  // (stamp 12: entry)
   // profiling: every workgroup leaves its first and last device-clock reading; the host takes
   // min(start) .. max(end) per launch -- the interval rocprofv3 reports for the dispatch
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
       Job j;
       j.active = 0;
       j.copy = 0;
-      if (q >= 1 && q < S.P) j = jobs[q];  // one round trip: the whole job
+      if (q >= 1 && q < S.P) j = PGB_ROWS_JPRE != 0 ? j_pre[hq] : jobs[q];  // (requested at the head of the kernel)
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
       if constexpr (F32 && !LIN) {

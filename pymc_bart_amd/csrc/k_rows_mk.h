@@ -18,7 +18,12 @@
 #define PGB_MK_WGS(KT) ((KT) == 4 ? 3 : 4) /* K = 4: 149 registers without a spill (3 per CU) beat 128 with eight spilled (4 per CU): 723 k against 687 k at cfg5 */
 #endif
 template <int KT, bool LIN, bool F32 = false>
-__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_rows_mk(const Dev* __restrict__ Sp, int par) {
+__global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_rows_mk(const Dev* __restrict__ Sp, int par,
+                                                                                            const Cmd* __restrict__ cmds,
+                                                                                            const Job* __restrict__ jobs_all) {
+  // cmds / jobs_all repeat S.cmd / S.jobs as kernel arguments (preloaded into SGPRs), as in k_rows: the command word
+  // and the job records are requested at once instead of behind a load of their pointers from the argument block S
+  // and behind one another (round 5: three dependent round trips at the head of every launch were one)
   const DevG& S = *reinterpret_cast<const DevG*>(Sp);
   const int K = KT > 0 ? KT : S.K, KX = K - 1;
   constexpr int TW = KT > 0 ? KT : 4;  // outputs per tile (= K for the compile-time instances: one tile)
@@ -28,8 +33,15 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
   __shared__ double s_lv[2][256][KB];
   __shared__ RJob s_job[MAXP];
   __shared__ int s_n[2];
-  const Cmd* cmd = &S.cmd[par];
+  const Cmd* cmd = &cmds[par];
   const int kind = cmd->kind;
+  Job j_pre[MAXP / 64];  // (wave 0: the particle list below)
+  if constexpr (PGB_ROWS_JPRE != 0) {
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int hq = 0; hq < MAXP / 64; ++hq) j_pre[hq] = jobs_all[(size_t)par * MAXP + threadIdx.x + 64 * hq];
+    }
+  }
   TRR_BIND(S.ctrl[par ^ 1].slot_no - 1);  // (stamp 12: entry; 13 jobs listed, 14 rows of the last item loaded, 15 items done)
   long long* pstamp = nullptr;            // profiling: first / last device-clock reading of every workgroup (see k_rows)
   if (S.prof_stamps != nullptr && threadIdx.x == 0 && blockIdx.x < PROF_BLOCKS && !PGB_STAMP_LL_ON) {
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
   };
 
   if (do_part) {
-    const Job* jobs = S.jobs + (size_t)par * MAXP;
+    const Job* jobs = jobs_all + (size_t)par * MAXP;
     if (tid < 64) {
       int nlist = 0;  // (lanes' particles tid, tid + 64, ...: one block of 64 after the other)
       bool plain = true;   // every particle with work splits the root of a fresh stump on a continuous column without NaNs
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
       Job j;
       j.active = 0;
       j.copy = 0;
-      if (q >= 1 && q < S.P) j = jobs[q];
+      if (q >= 1 && q < S.P) j = PGB_ROWS_JPRE != 0 ? j_pre[hq] : jobs[q];  // (requested at the head of the kernel)
       const bool has = (j.active | j.copy) != 0;
       const unsigned long long m = __ballot(has);
       {

@@ -818,19 +818,19 @@ static int enqueue_slots(pgb_handle* h, int count) {
 #undef CTRL_ARGS
 #define ROWS_ARGS dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs
     if (d.K > 1 && lin) {  // linear leaves: one instance for any K
-      LAUNCH_K(PK_ROWS, (k_rows_mk<0, true>), grows, dd, par);
+      LAUNCH_K(PK_ROWS, (k_rows_mk<0, true>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
     } else if (d.K == 2) {
-      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<2, false, true>), grows, dd, par);
-      else LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<2, false, true>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<2, false>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
     } else if (d.K == 3) {
-      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<3, false, true>), grows, dd, par);
-      else LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<3, false, true>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<3, false>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
     } else if (d.K == 4) {
-      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par);
-      else LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<4, false, true>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<4, false>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
     } else if (d.K > 1) {
-      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<0, false, true>), grows, dd, par);
-      else LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par);
+      if (d.XK16) LAUNCH_K(PK_ROWS, (k_rows_mk<0, false, true>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
+      else LAUNCH_K(PK_ROWS, (k_rows_mk<0, false>), grows, dd, par, (const Cmd*)d.cmd, (const Job*)d.jobs);
     } else {
       const bool nrm = h->s.family == PGB_FAMILY_NORMAL;
       if (lin && h->has_subset) {  // (a linear leaf regresses on whatever column its parent split on)
