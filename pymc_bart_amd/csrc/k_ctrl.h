@@ -480,11 +480,8 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
   //   set 0: round r of the current tree            (iter,     r, p)
   //   set 1: round 0 of the next tree to be updated (iter + 1, 0, p)
 #ifndef PGB_CTRL_FINX
-#define PGB_CTRL_FINX 1 /* experiment knob: 0 = waves 1..3 derive the extension outputs again (the round-4 form), 1 = Dev::finx read after the draws, 2 = requested before them */
+#define PGB_CTRL_FINX 1 /* 0 = waves 1..3 derive the extension outputs of K-vector leaves again (the round-4 form; A/B knob) */
 #endif
-  FinX fx_pre = {0.0, 0.0, 0, 0};  // (K-vector constant leaves: see the finish stage below)
-  if constexpr (MK && !LIN && PGB_CTRL_FINX == 2)
-    if (!begin && tid >= 64 && tid - 64 < P * KX) fx_pre = S.finx[(size_t)(par ^ 1) * MAXP * KX + (tid - 64)];
   if (tid >= 64 && tid < 192) {
     const int set = (tid >> 6) - 1, l = tid & 63;
     const pgb_u2 u = pgb_draw2(S.seed, set ? it + 1u : it, set ? 0u : (uint32_t)r, (uint32_t)p,
@@ -757,17 +754,12 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       // the counts and every output's sums, parent values and leaf noise: two dependent round trips of scattered
       // loads in front of the barrier below, 1.4 us after wave 0 was done at cfg5.  (Particles without a pending
       // split: stale entries, never read -- s_finx[anc] is consulted only when Fin::ok says there was one.)
-#ifndef PGB_CTRL_FINX_WAVES
-#define PGB_CTRL_FINX_WAVES 0xE /* experiment knob: the waves that copy (bit w = wave w) */
-#endif
-      constexpr int NCW = ((PGB_CTRL_FINX_WAVES >> 1) & 1) + ((PGB_CTRL_FINX_WAVES >> 2) & 1) + ((PGB_CTRL_FINX_WAVES >> 3) & 1);
-      const int wv = tid >> 6;
-      if (wv >= 1 && ((PGB_CTRL_FINX_WAVES >> wv) & 1)) {
-        // (rank of this wave among the copying ones)
-        const int rk = __builtin_popcount(PGB_CTRL_FINX_WAVES & ((1 << wv) - 1) & 0xE);
+      // (requested before the draws instead of behind them: no gain; wave 3 alone, whose draws are done early:
+      //  slower -- profiles/r05_experiments.md section 4)
+      if (tid >= 64) {
         const FinX* fx = S.finx + (size_t)(par ^ 1) * MAXP * KX;
-        for (int e = rk * 64 + (tid & 63); e < P * KX; e += NCW * 64) {
-          const FinX t = (PGB_CTRL_FINX == 2 && e == tid - 64) ? fx_pre : fx[e];
+        for (int e = tid - 64; e < P * KX; e += BT - 64) {
+          const FinX t = fx[e];
           ChildX& d = s_finx[e / KX][e % KX];
           d.vL = t.vL; d.vR = t.vR; d.aL = t.aL; d.aR = t.aR;
           d.sL = d.sR = 0.0;
