@@ -257,15 +257,24 @@ int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int6
 
 /* Checkpoint / resume of one chain (what pickling the reference's step method into a PyMC worker
  * process carries: reference SURVEY 8b "must be picklable"; tree hand-off bart.py:134-135).
- * The blob is an opaque image of the sampler state at an idle point (between asteps); it is
- * specific to the backend that wrote it.  To resume: pgb_create with the SAME settings,
- * pgb_set_data / pgb_set_response with the same data, then pgb_checkpoint_load; the chain then
- * continues bit-identically (the random numbers are addressed by (seed, iter, ...), so the image
- * carries no generator state beyond the iteration counter).  An image carries a layout version and is
- * refused by a build whose records differ.  Loading also clears a poisoned handle (see the callback). */
+ * The blob is the CHAIN IMAGE of include/pgbart_image.h: the state of the chain at an idle point (between
+ * asteps) in a layout that belongs to no backend -- sum_trees, the m accepted trees with every row's leaf label,
+ * the running-sd accumulators, the split weights, leaf_sd[K], iter, lower, the likelihood parameters, the counters.
+ * Any backend that implements this ABI continues a chain any other wrote, bit for bit: pgb_create with the
+ * SAME settings, pgb_set_data / pgb_set_response (/ pgb_set_offset) with the same data, then pgb_checkpoint_load
+ * (the random numbers are addressed by (seed, iter, ...), so the image carries no generator state beyond the
+ * iteration counter).  An image carries a layout version; a record that is truncated, inconsistent or written for
+ * other settings is refused with PGB_E_INVALID and a message.  Loading also clears a poisoned handle (see the
+ * callback); saving refuses one.  The size depends on the trees: ask pgb_checkpoint_size right before saving. */
 int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out);
 int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes);
 int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes);
+
+/* The revision of THIS header a library was built against (PGB_ABI_VERSION): bumped whenever a signature, a
+ * struct of this file or the chain image changes, so that a binding refuses a stale library instead of calling it
+ * with shifted arguments.  Replaces nothing in the reference (PyO3 checks its own module at import). */
+#define PGB_ABI_VERSION 6
+int32_t pgb_abi_version(void);
 
 #ifdef __cplusplus
 }

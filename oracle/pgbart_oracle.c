@@ -50,6 +50,7 @@
 #include <string.h>
 
 #include "pgbart.h"
+#include "pgbart_image.h"
 #include "pgbart_pack.h"
 #include "pgbart_spec.h"
 
@@ -65,6 +66,7 @@ static int fail(int code, const char* msg) {
 const char* pgb_last_error(void) { return g_err; }
 const char* pgb_backend_name(void) { return "oracle-cpu"; }
 int32_t pgb_max_particles(void) { return PGB_MAX_PARTICLES; }
+int32_t pgb_abi_version(void) { return PGB_ABI_VERSION; }
 
 typedef struct {
   int32_t var; /* -1 leaf */
@@ -1133,109 +1135,135 @@ int pgb_profile_kernel(pgb_handle* h, int32_t which, double* kernel_ms_out, int6
 }
 
 /* ------------------------------------------------------------------ checkpoint / resume
- * (same ABI as the HIP backend; the image layout is this backend's own) */
-typedef struct {
-  char magic[8];
-  char backend[16];
-  pgb_settings s;
-  int64_t payload_bytes;
-  int64_t rs_count, iter;
-  int32_t lower, n_last;
-  double leaf_sd, leaf_sdx[PGB_MAX_OUTPUTS - 1], inv_sigma2, lik_param2;
-  pgb_counters ctr;
-} ockpt;
-
-typedef struct { void* p; size_t bytes; } oblk;
-
-static int o_blocks(pgb_handle* h, oblk* b) {
-  const pgb_settings* s = &h->s;
-  size_t n = (size_t)s->n, K = (size_t)s->n_outputs, p = (size_t)s->p, m = (size_t)s->m;
-  int k = 0;
-  b[k++] = (oblk){h->st, sizeof(double) * n * K};
-  b[k++] = (oblk){h->rs_mean, sizeof(double) * n * K};
-  b[k++] = (oblk){h->rs_m2, sizeof(double) * n * K};
-  b[k++] = (oblk){h->trees, sizeof(otree) * m};
-  b[k++] = (oblk){h->lid, m * n};
-  b[k++] = (oblk){h->alpha_vec, sizeof(int64_t) * p};
-  b[k++] = (oblk){h->cdf, sizeof(int64_t) * p};
-  b[k++] = (oblk){h->vi, sizeof(int32_t) * p};
-  b[k++] = (oblk){h->last_ids, sizeof(int32_t) * m};
-  return k;
+ * The chain image of include/pgbart_image.h: the record every backend writes and reads.  This backend keeps its
+ * accepted trees as node tables + one label byte per (tree, row), which is what the image holds; the per-node
+ * sufficient statistics and row segments of a tree are particle state and do not outlive the update. */
+static int32_t o_total_nodes(const pgb_handle* h) {
+  int32_t N = 0;
+  for (int t = 0; t < h->s.m; ++t) N += h->trees[t].n_nodes;
+  return N;
 }
 
 int pgb_checkpoint_size(pgb_handle* h, int64_t* bytes_out) {
   if (!h || !bytes_out) return fail(PGB_E_INVALID, "null argument");
-  oblk b[16];
-  int nb = o_blocks(h, b);
-  int64_t tot = (int64_t)sizeof(ockpt);
-  for (int i = 0; i < nb; ++i) tot += (int64_t)b[i].bytes;
-  *bytes_out = tot;
+  *bytes_out = pgb_image_bytes(h->s.n, h->s.p, h->s.m, h->s.n_outputs, o_total_nodes(h));
   return PGB_OK;
 }
 
 int pgb_checkpoint_save(pgb_handle* h, void* host_buf, int64_t bytes) {
   if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
-  int64_t need;
-  pgb_checkpoint_size(h, &need);
+  if (h->cb_failed) return fail(PGB_E_STATE, "an earlier step of this sampler was abandoned half-way; restore a checkpoint");
+  const pgb_settings* s = &h->s;
+  const int64_t n = s->n;
+  const int K = s->n_outputs, m = s->m, p = s->p;
+  const int32_t N = o_total_nodes(h);
+  const int64_t need = pgb_image_bytes(n, p, m, K, N);
   if (bytes < need) return fail(PGB_E_INVALID, "checkpoint buffer too small");
-  ockpt hd;
-  memset(&hd, 0, sizeof hd);
-  memcpy(hd.magic, "PGBCKPT1", 8);
-  snprintf(hd.backend, sizeof hd.backend, "%s", pgb_backend_name());
-  hd.s = h->s;
-  hd.payload_bytes = need - (int64_t)sizeof hd;
-  hd.rs_count = h->rs_count;
+  pgb_image_header hd;
+  pgb_image_begin(host_buf, need, s, N, pgb_backend_name(), &hd);
   hd.iter = h->iter;
+  hd.rs_count = h->rs_count;
   hd.lower = h->lower;
-  hd.n_last = h->n_last;
-  hd.leaf_sd = h->leaf_sd;
-  memcpy(hd.leaf_sdx, h->leaf_sdx, sizeof hd.leaf_sdx);
-  hd.inv_sigma2 = h->inv_sigma2;
-  hd.lik_param2 = h->lik_param2;
+  hd.last_lower = h->n_last > 0 ? h->last_ids[0] : 0;
+  hd.last_n = h->n_last;
+  hd.leaf_sd[0] = h->leaf_sd;
+  for (int o = 1; o < K; ++o) hd.leaf_sd[o] = h->leaf_sdx[o - 1];
+  hd.lik_param[0] = h->inv_sigma2;
+  hd.lik_param[1] = h->lik_param2;
   hd.ctr = h->ctr;
   memcpy(host_buf, &hd, sizeof hd);
-  char* o = (char*)host_buf + sizeof hd;
-  oblk b[16];
-  int nb = o_blocks(h, b);
-  for (int i = 0; i < nb; ++i) {
-    memcpy(o, b[i].p, b[i].bytes);
-    o += b[i].bytes;
+  pgb_image_view v;
+  pgb_image_bind(host_buf, &hd, &v);
+  memcpy(v.sum_trees, h->st, sizeof(double) * (size_t)n * K);
+  memcpy(v.rs_mean, h->rs_mean, sizeof(double) * (size_t)n * K);
+  memcpy(v.rs_m2, h->rs_m2, sizeof(double) * (size_t)n * K);
+  memcpy(v.alpha, h->alpha_vec, sizeof(int64_t) * (size_t)p);
+  memcpy(v.cdf, h->cdf, sizeof(int64_t) * (size_t)p);
+  int32_t g = 0;
+  for (int t = 0; t < m; ++t) {
+    const otree* T = &h->trees[t];
+    v.node_off[t] = g;
+    for (int k = 0; k < T->n_nodes; ++k, ++g) {
+      const onode* z = &T->nd[k];
+      const int leaf = z->var < 0;
+      const int islin = leaf && s->response != PGB_RESPONSE_CONSTANT && z->svar >= 0;
+      v.var[g] = z->var;
+      v.left[g] = leaf ? -1 : z->left;
+      v.right[g] = leaf ? -1 : z->right;
+      v.depth[g] = z->depth;
+      v.label[g] = z->label;
+      v.svar[g] = islin ? z->svar : -1;
+      v.count[g] = z->cnt;
+      v.split[g] = leaf ? 0.0 : z->split;
+      v.xbar[g] = islin ? z->xbar : 0.0;
+      for (int o = 0; o < K; ++o) {
+        v.value[(size_t)g * K + o] = !leaf ? 0.0 : o ? z->valx[o - 1] : z->value;
+        v.slope[(size_t)g * K + o] = !islin ? 0.0 : o ? z->slopex[o - 1] : z->slope;
+      }
+    }
   }
+  v.node_off[m] = g;
+  memcpy(v.lid, h->lid, (size_t)m * (size_t)n);
   return PGB_OK;
 }
 
 int pgb_checkpoint_load(pgb_handle* h, const void* host_buf, int64_t bytes) {
   if (!h || !host_buf) return fail(PGB_E_INVALID, "null argument");
   if (!h->have_data || !h->have_y) return fail(PGB_E_INVALID, "set_data/set_response first");
-  if (bytes < (int64_t)sizeof(ockpt)) return fail(PGB_E_INVALID, "checkpoint truncated");
-  ockpt hd;
+  const char* why = pgb_image_check(host_buf, bytes, &h->s);
+  if (why) return fail(PGB_E_INVALID, why);
+  const pgb_settings* s = &h->s;
+  const int64_t n = s->n;
+  const int K = s->n_outputs, m = s->m, p = s->p;
+  pgb_image_header hd;
   memcpy(&hd, host_buf, sizeof hd);
-  if (memcmp(hd.magic, "PGBCKPT1", 8) != 0) return fail(PGB_E_INVALID, "not a pgbart checkpoint");
-  if (strncmp(hd.backend, pgb_backend_name(), sizeof hd.backend) != 0)
-    return fail(PGB_E_INVALID, "checkpoint was written by a different backend");
-  if (memcmp(&hd.s, &h->s, sizeof(pgb_settings)) != 0)
-    return fail(PGB_E_INVALID, "checkpoint settings differ from this sampler's settings");
-  int64_t need;
-  pgb_checkpoint_size(h, &need);
-  if (hd.payload_bytes != need - (int64_t)sizeof hd || bytes < need)
-    return fail(PGB_E_INVALID, "checkpoint layout does not match this build");
-  const char* o = (const char*)host_buf + sizeof hd;
-  oblk b[16];
-  int nb = o_blocks(h, b);
-  for (int i = 0; i < nb; ++i) {
-    memcpy(b[i].p, o, b[i].bytes);
-    o += b[i].bytes;
+  pgb_image_view v;
+  pgb_image_bind((void*)host_buf, &hd, &v);
+  memcpy(h->st, v.sum_trees, sizeof(double) * (size_t)n * K);
+  memcpy(h->rs_mean, v.rs_mean, sizeof(double) * (size_t)n * K);
+  memcpy(h->rs_m2, v.rs_m2, sizeof(double) * (size_t)n * K);
+  memcpy(h->alpha_vec, v.alpha, sizeof(int64_t) * (size_t)p);
+  memcpy(h->cdf, v.cdf, sizeof(int64_t) * (size_t)p);
+  for (int t = 0; t < m; ++t) {
+    otree* T = &h->trees[t];
+    const int32_t base = v.node_off[t], nn = v.node_off[t + 1] - base;
+    memset(T, 0, sizeof *T);
+    T->n_nodes = nn;
+    T->next_pop = nn;
+    for (int k = 0; k < nn; ++k) {
+      const int32_t g = base + k;
+      onode* z = &T->nd[k];
+      z->var = v.var[g];
+      z->left = v.left[g];
+      z->right = v.right[g];
+      z->depth = v.depth[g];
+      z->label = v.label[g];
+      z->split = v.split[g];
+      z->cnt = v.count[g];
+      z->svar = v.svar[g];
+      z->xbar = v.xbar[g];
+      z->value = v.value[(size_t)g * K];
+      z->slope = v.slope[(size_t)g * K];
+      for (int o = 1; o < K; ++o) {
+        z->valx[o - 1] = v.value[(size_t)g * K + o];
+        z->slopex[o - 1] = v.slope[(size_t)g * K + o];
+      }
+      if (z->var < 0) T->n_leaves += 1;
+    }
   }
+  memcpy(h->lid, v.lid, (size_t)m * (size_t)n);
   h->rs_count = hd.rs_count;
   h->iter = hd.iter;
   h->lower = hd.lower;
-  h->n_last = hd.n_last;
-  h->leaf_sd = hd.leaf_sd;
-  memcpy(h->leaf_sdx, hd.leaf_sdx, sizeof hd.leaf_sdx);
-  h->inv_sigma2 = hd.inv_sigma2;
-  h->lik_param2 = hd.lik_param2;
+  h->n_last = hd.last_n;
+  for (int i = 0; i < hd.last_n; ++i) h->last_ids[i] = hd.last_lower + i;
+  h->leaf_sd = hd.leaf_sd[0];
+  for (int o = 1; o < K; ++o) h->leaf_sdx[o - 1] = hd.leaf_sd[o];
+  h->inv_sigma2 = hd.lik_param[0];
+  h->lik_param2 = hd.lik_param[1];
   h->ctr = hd.ctr;
+  memset(h->vi, 0, sizeof(int32_t) * (size_t)p);
   h->cb_failed = 0;
   return PGB_OK;
 }

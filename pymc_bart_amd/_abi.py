@@ -20,6 +20,7 @@ MAX_DEPTH = 64
 MAX_PARTICLES = 128  # of the p128 build of the library; the default build takes 64 (PGBLibrary.max_particles)
 MAX_OUTPUTS = 16  # PGB_MAX_OUTPUTS (include/pgbart_spec.h)
 MAX_NODES = 255
+ABI_VERSION = 6  # PGB_ABI_VERSION of include/pgbart.h this binding was written against
 
 RULE_CONTINUOUS = 0
 RULE_ONEHOT = 1
@@ -82,6 +83,7 @@ SYMBOLS = (
     "pgb_checkpoint_size",
     "pgb_checkpoint_save",
     "pgb_checkpoint_load",
+    "pgb_abi_version",
 )
 
 
@@ -167,6 +169,16 @@ class PGBLibrary:
         self.path = path
         self.lib = C.CDLL(path)
         lib = self.lib
+        # a library built against another revision of include/pgbart.h would be called with shifted arguments
+        # (pgb_predict lost one between rounds 4 and 5, pgb_tree_arrays gained `rule`): refuse it by name
+        try:
+            have = int(lib.pgb_abi_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:
+            raise PGBError(f"{path} implements revision {have if have >= 0 else '< 6 (no pgb_abi_version)'} of "
+                           f"include/pgbart.h, this binding revision {ABI_VERSION}: rebuild it "
+                           "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         vp = C.c_void_p
         lib.pgb_last_error.restype = C.c_char_p
         lib.pgb_last_error.argtypes = []
@@ -204,6 +216,7 @@ class PGBLibrary:
             if name not in ("pgb_last_error", "pgb_backend_name"):
                 fn.restype = C.c_int
         lib.pgb_max_particles.argtypes = []
+        lib.pgb_abi_version.argtypes = []
 
     @property
     def backend_name(self) -> str:

@@ -153,6 +153,7 @@ static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
 extern "C" const char* pgb_last_error(void) { return g_err; }
 extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
 extern "C" int32_t pgb_max_particles(void) { return PGB_MAX_PARTICLES; }
+extern "C" int32_t pgb_abi_version(void) { return PGB_ABI_VERSION; }
 
 // The instance of k_loglik a sampler launches, chosen once: per number of outputs (loops unrolled for
 // K = 2, 3, 4), per family for single-output constant leaves (one family's code per instance).
@@ -1399,44 +1400,7 @@ extern "C" int pgb_export_trees_packed(pgb_handle* h, int32_t which, void* host_
   return rc;
 }
 
-extern "C" int pgb_get_state(pgb_handle* h, double* leaf_sd_out, int64_t* iter_out, int32_t* lower_out) {
-  if (!h) return fail(PGB_E_INVALID, "null handle");
-  JOIN_ASYNC(h);
-  Dev& d = h->d;
-  Ctrl c;
-  InitAcc ia[IA_SLOTS];
-  HIPCHK(hipMemcpyAsync(&c, &d.ctrl[h->slot & 1], sizeof c, hipMemcpyDeviceToHost, h->stream));
-  const size_t ia_read = (size_t)((h->slot & 1) ^ 1);  // the last slot's sums
-  HIPCHK(hipMemcpyAsync(ia, &d.initacc[ia_read * IA_SLOTS], sizeof ia, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  double leaf_sd = c.leaf_sd;
-  long long qstd = 0;
-  for (int k = 0; k < IA_SLOTS; ++k) qstd += ia[k].QSTD;
-  if (c.pend_leafsd) leaf_sd = pgb_tuned_leaf_sd(c.leaf_sd, c.pend_iter, qstd, d.sc.inv_c1, d.n);
-  if (leaf_sd_out) {
-    leaf_sd_out[0] = leaf_sd;
-    const int KX = d.K - 1;
-    if (KX > 0) {
-      std::vector<long long> ix((size_t)IA_SLOTS * 2 * KX);
-      HIPCHK(hipMemcpy(ix.data(), d.iax + (size_t)((h->slot & 1) ^ 1) * IA_SLOTS * 2 * KX,
-                       ix.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      double lsdx[2 * KXMAX];
-      HIPCHK(hipMemcpy(lsdx, d.lsdx, sizeof lsdx, hipMemcpyDeviceToHost));
-      for (int k = 0; k < KX; ++k) {
-        double v = lsdx[(h->slot & 1) * KXMAX + k];
-        if (c.pend_leafsd) {
-          long long q = 0;
-          for (int sl = 0; sl < IA_SLOTS; ++sl) q += ix[(size_t)sl * 2 * KX + KX + k];
-          v = pgb_tuned_leaf_sd(v, c.pend_iter, q, d.sc.inv_c1, d.n);
-        }
-        leaf_sd_out[k + 1] = v;
-      }
-    }
-  }
-  if (iter_out) *iter_out = c.iter;
-  if (lower_out) *lower_out = c.lower;
-  return PGB_OK;
-}
+// (pgb_get_state: pgb_checkpoint.h, next to the image that needs the same idle-state read)
 
 extern "C" int pgb_get_split_weights(pgb_handle* h, double* out) {
   if (!h || !out) return fail(PGB_E_INVALID, "null argument");

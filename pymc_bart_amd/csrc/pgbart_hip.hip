@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "pgbart.h"
+#include "pgbart_image.h"
 #include "pgbart_pack.h"
 #include "pgbart_spec.h"
 

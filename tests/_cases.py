@@ -310,7 +310,9 @@ CASES = ["cfg1_friedman", "nan_onehot_prior", "ragged_1025", "tiny_n3", "one_tre
 def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
     """Run the case on a backend; returns everything the two backends must agree on.
     ``checkpoint_at``: step indices before which the chain is checkpointed, its sampler destroyed
-    and a freshly built sampler restored from the image (must not change anything)."""
+    and a freshly built sampler restored from the image (must not change anything); a dict
+    ``{step: backend}`` moves the chain to ANOTHER backend there (the image belongs to none:
+    include/pgbart_image.h)."""
     X, Y = c["X"], c["Y"]
     p = X.shape[1]
     family = c.get("family", "normal")
@@ -330,6 +332,8 @@ def run_case(c, backend, record_every: int = 1, checkpoint_at=()):
         if it in checkpoint_at:
             blob = s.checkpoint()
             del s
+            if isinstance(checkpoint_at, dict):
+                backend = checkpoint_at[it]
             s = PySampler(st, X, Y, rules, prior, backend=backend)
             if c.get("offset") is not None:
                 s.set_offset(c["offset"])

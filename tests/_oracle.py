@@ -52,8 +52,8 @@ def build_oracle(force: bool = False) -> str:
     src = os.path.join(ORACLE_DIR, "pgbart_oracle.c")
     stale = (not os.path.exists(ORACLE_SO)) or any(
         os.path.getmtime(f) > os.path.getmtime(ORACLE_SO)
-        for f in (src, os.path.join(ROOT, "include", "pgbart.h"), os.path.join(ROOT, "include", "pgbart_pack.h"),
-                  os.path.join(ROOT, "include", "pgbart_spec.h"), os.path.join(ROOT, "include", "pgbart_lltab.h"))
+        for f in [src] + [os.path.join(ROOT, "include", h) for h in sorted(os.listdir(os.path.join(ROOT, "include")))
+                          if h.endswith(".h")]
     )
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B"])
