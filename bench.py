@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # fp64 VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, a wave64 fp64 instruction occupies its SIMD for 4
 # cycles (78.6 TFLOP/s fp64 vector = 16 lanes x 2 flop per SIMD and clock)
 VALU_F64_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # G wave-instructions / s
-ROUND = "r05"
+ROUND = "r06"
 NOTES = "profiles/BENCH_NOTES.md"
 
 METRIC = {
@@ -88,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="headline only (skip resident / tune1 / workload legs)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the cfg4 / cfg5 legs of the default run")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of timed CPU work per baseline leg")
+    ap.add_argument("--gather-draws", type=int, default=100,
+                    help="N-rank runs: posterior draws per rank that the end-of-run gather moves to rank 0 "
+                         "(100 draws of n doubles = 80 MB per rank at cfg2; capped at 256 MiB per rank)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU: the launcher, the process group, the aggregation and "
@@ -154,11 +157,13 @@ def _cpu_run(w, seed, budget_s, burn, response, so_path, trees_per_step=None, ma
 
 
 def _cpu_worker(args_tuple):
-    (wname, wkw, seed, budget_s, burn, response, so_path) = args_tuple
+    (wname, wkw, seed, budget_s, burn, response, so_path, *rest) = args_tuple
+    trees_per_step, max_steps = (rest + [None, 256])[:2] if rest else (None, 256)
     sys.path.insert(0, ROOT)
     from pymc_bart_amd import workloads
 
-    return _cpu_run(getattr(workloads, wname)(**wkw), seed, budget_s, burn, response, so_path)
+    return _cpu_run(getattr(workloads, wname)(**wkw), seed, budget_s, burn, response, so_path,
+                    trees_per_step=trees_per_step, max_steps=max_steps)
 
 
 def _cpu_host():
@@ -210,7 +215,7 @@ def cpu_baseline(wname, wkw, seed, budget_s, response="constant"):
     return out
 
 
-def cpu_baseline_short(w, wname, seed, budget_s):
+def cpu_baseline_short(w, wname, seed, budget_s, all_cores=True):
     """The bounded CPU sample of a large configuration (cfg4 / cfg5): the oracle in THIS process on the data
     already generated, one tree update per step (a 10 %-of-m astep costs the oracle tens of seconds there),
     one core.  Runs after every GPU leg of the workload."""
@@ -219,7 +224,22 @@ def cpu_baseline_short(w, wname, seed, budget_s):
 
     so_path, flags = build_oracle_native()
     r = _cpu_run(w, seed, budget_s, 0, "constant", so_path, trees_per_step=1, max_steps=64)
-    return {
+    many = None
+    cores = min(8, os.cpu_count() or 1)
+    if all_cores and cores > 1:
+        # C chains as C processes, each on its own copy of the data (regenerated in the child: 0.8 / 0.4 GB), the
+        # same one-tree-per-step sample -- the "8 chains on 8 cores" row of BASELINE.md's plan for this workload
+        import multiprocessing as mp
+
+        with mp.get_context("spawn").Pool(cores) as pool:
+            many = pool.map(_cpu_worker, [(wname, dict(seed=3415), seed + c, budget_s, 0, "constant", so_path, 1, 64)
+                                          for c in range(cores)])
+    extra = {}
+    if many:
+        extra["all_cores"] = {"value": sum(q["particle_steps"] / q["dt"] for q in many), "unit": "particle-steps/s",
+                              "cores": cores, "chains": cores,
+                              "sample": f"{cores} independent chains as {cores} processes, same one-tree-per-step sample"}
+    return extra | {
         "value": r["particle_steps"] / r["dt"], "unit": "particle-steps/s", "cores": 1, "kind": "port",
         "sample": f"{r['tree_updates']} tune=0 tree updates ({r['dt']:.1f} s, one tree per step) of the same {wname} "
                   f"data from the start of a chain after 1 warm-up tree update; oracle/ (C restatement), 1 chain on 1 core",
@@ -229,6 +249,33 @@ def cpu_baseline_short(w, wname, seed, budget_s):
         "rows_touched_per_s": r["rows_touched"] / r["dt"],
         "host": _cpu_host(),
     }
+
+
+def cpu_cfg1(budget_s=3.0):
+    """BASELINE.json configs[0] -- Friedman n=500, p=5, m=50, 10 particles, one chain on the CPU restatement (one core).
+    The GPU never touches it: BASELINE.md's table has a row for it, and it is the smallest case both backends are
+    held to (tests: `cfg1_friedman`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import build_oracle_native
+    from pymc_bart_amd import workloads
+
+    so_path, flags = build_oracle_native()
+    w = workloads.cfg1(3415)
+    r = _cpu_run(w, 3415, budget_s, 10, "constant", so_path, max_steps=100_000)
+    return {"metric": "particle-steps/sec (cfg1: Friedman n=500, p=5, m=50, 10 particles)", "backend": "oracle-cpu",
+            "value": r["particle_steps"] / r["dt"], "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "tree_updates_per_s": r["tree_updates"] / r["dt"], "compiler": flags,
+            "sample": f"{r['steps']} tune=0 asteps ({r['dt']:.1f} s) after 10 tune=1 asteps"}
+
+
+def so_sha256(path):
+    import hashlib
+
+    try:
+        with open(path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()
+    except OSError:
+        return None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -349,18 +396,24 @@ def kernel_profile(s, tune, steps):
             "slots": d["slots"]}
 
 
-def load_pmc(wname):
+def load_pmc(wname, lib_path=None):
     """Per-launch counter averages of the hot kernels from the separate ``rocprofv3 --pmc`` passes
-    (``tools/pmc_collect.sh``; the newest round's file that exists)."""
-    for rnd in (ROUND, "r04", "r03", "r02"):
+    (``tools/pmc_collect.sh``; the newest round's file that exists).  Returns (counters, file, stale): the counters
+    are read from a COMMITTED file, not measured in this run, so each file names the library it was taken on
+    (``library_sha256``); ``stale`` is True when that is not the library this process loaded -- a kernel changed and
+    nobody re-ran the counter passes (round-5 VERDICT, weak #6)."""
+    for rnd in (ROUND, "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wname}.json")
         if os.path.exists(path):
             with open(path) as fh:
-                return json.load(fh), f"profiles/{rnd}_pmc_{wname}.json"
-    return {}, None
+                d = json.load(fh)
+            have = so_sha256(lib_path) if lib_path else None
+            stale = (d.get("library_sha256") is None) or (have is not None and d["library_sha256"] != have)
+            return d, f"profiles/{rnd}_pmc_{wname}.json", bool(stale)
+    return {}, None, False
 
 
-def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
+def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True, lib_path=None):
     """``roofline`` (the dominant kernel of the workload), ``roofline_rows`` (the row pass, HBM) and
     ``roofline_kernels`` (every kernel of the slot) from a :func:`kernel_profile` block."""
     from pymc_bart_amd import workloads
@@ -378,7 +431,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
         # dependent loads and scalar decisions (profiles/r03_experiments.md section 5: ~1.6 us until its first data,
         # ~3.8 us of dependent work); its floor is latency, and it is the other half of a cfg2 slot
         out["roofline_kernels"]["k_ctrl"]["bound"] = "latency"
-    pmc, pmc_src = load_pmc(wname) if default_cfg else ({}, None)
+    pmc, pmc_src, pmc_stale = load_pmc(wname, lib_path) if default_cfg else ({}, None, False)
     ms_rows, launches = prof["ms_rows"], prof["launches"]
     tu, rt, parts = prof["tree_updates"], prof["rows_touched"], prof["partitions"]
     rows = None
@@ -403,6 +456,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": pmc_src,
+            "traffic_stale": pmc_stale if traffic else None,
             "launches": launches, "avg_launch_us": avg_us,
             "avg_kernel_us_device_clock": (prof["clk_ms"] * 1e3 / prof["clk_launches"]) if prof["clk_launches"] else None,
             "frac_device_clock": (alg / (prof["clk_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof["clk_ms"] > 0 else None,
@@ -426,7 +480,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
             "achieved": ginst, "peak": VALU_F64_PEAK_GINST, "unit": "G wave-instructions/s",
             "frac": (ginst / VALU_F64_PEAK_GINST) if ginst else None,
             "avg_launch_us": kl["ms"] * 1e3 / kl["launches"], "launches": kl["launches"],
-            "valu_wave_insts_per_launch": insts, "insts_source": pmc_src,
+            "valu_wave_insts_per_launch": insts, "insts_source": pmc_src, "traffic_stale": pmc_stale if insts else None,
             "note": NOTES + "#roofline-of-the-likelihood-pass",
         }
         if rows is not None:
@@ -654,7 +708,12 @@ def main():
 
     # ---- roofline of the dominant kernel + per-kernel shares: a further block with events attached
     if not dry and not args.no_roofline and rank == 0:
-        line.update(rooflines(wname, w, X.shape, kernel_profile(s, tune, args.steps), args.response, default_cfg))
+        line.update(rooflines(wname, w, X.shape, kernel_profile(s, tune, args.steps), args.response, default_cfg,
+                              lib_path=be.lib.path))
+        if line.get("roofline"):
+            # SURVEY.md 8(d)'s own definition, over the WALL clock of the timed asteps (host outputs and all):
+            # sum of B_tree / seconds / 8 TB/s -- next to `frac`, which is the dominant kernel's
+            line["roofline"]["whole_step_frac"] = line["algorithmic_GBps_whole_step"] / HBM_PEAK_GBS
 
     # ---- tune=1 block (reported separately: SURVEY.md 8d)
     if solo and not args.no_extras and not tune:
@@ -663,24 +722,20 @@ def main():
         line["tune1"] = {"value": u_t["particle_steps"] / el_t, "unit": "particle-steps/s", "path": "resident",
                          "ms_per_step": el_t * 1e3 / args.steps, "value_min": t_min, "value_max": t_max,
                          "tree_updates_per_s": u_t["tree_updates"] / el_t}
+        # ... and through PGBART.astep itself, as the headline is ("tune=False and tune=True reported
+        # separately"; a tuning astep publishes no history but pays the running-sd pass and the weight update)
+        step.tune = True
+        (el_a, u_a), a_min, a_max = median_block(astep_blocks(step, args.steps, 5, barrier))
+        step.tune = tune
+        line["tune1"]["astep"] = {"value": u_a["particle_steps"] / el_a, "unit": "particle-steps/s", "path": "PGBART.astep",
+                                  "ms_per_step": el_a * 1e3 / args.steps, "value_min": a_min, "value_max": a_max,
+                                  "tree_updates_per_s": u_a["tree_updates"] / el_a, "repeats": 5}
 
-    # ---- end-of-run gather of the draws (the only collective; outside the timed region)
+    # ---- end-of-run gather (the only collective; outside the timed region): what a user's run hands to rank 0 --
+    #      `--gather-draws` kept draws of this chain (100 x n doubles = 80 MB per rank at cfg2), its tree history as
+    #      packed records and its variable-inclusion stats -- through chains.gather_chains itself
     if dist is not None:
-        if dry:
-            draw = torch.full((8,), float(rank), dtype=torch.float64)
-        else:
-            s.step(tune, fetch=False)  # one synchronous step: the device buffer holds this chain's last draw
-            draw = s.sum_trees_device().clone()  # (K*n,)
-        outs = [torch.empty_like(draw) for _ in range(world)] if rank == 0 else None
-        barrier()
-        g0 = time.perf_counter()
-        dist.gather(draw, outs, dst=0)  # as chains.gather_chains: every shard goes to rank 0 over its own xGMI link
-        if not dry:
-            torch.cuda.synchronize()
-        line["gather_ms"] = (time.perf_counter() - g0) * 1e3
-        line["gather_bytes_per_rank"] = int(draw.numel() * 8)
-        if rank == 0 and world > 1:
-            assert not torch.equal(outs[0], outs[1]), "chains must be independent"
+        line.update(end_of_run_gather(step, dist, rank, world, dry, args, seed, barrier))
 
     # ---- informational: PyMC's default of 4 chains, run concurrently on ONE GPU (never the headline)
     if solo and not args.no_multichain:
@@ -740,6 +795,8 @@ def main():
                     d.pop("chain_start"), speedup_vs_cpu_baseline=None)
                 ma = d["cpu_baseline"]["matched_age"]
                 ma["speedup_vs_cpu_baseline"] = ma["gpu_value"] / d["cpu_baseline"]["value"]
+        if default_cfg and wname == "cfg2" and not args.no_extras:
+            line["cfg1"] = cpu_cfg1()
     line["gpu_legs_seconds"] = gpu_done_s
 
     # ---- the last object of the line: every headline figure again, compact (a kept log tail holds it)
@@ -749,6 +806,10 @@ def main():
         b = {"value": _r(d.get("value")), "ms": _r(d.get("ms_per_step")),
              "resident": _r((d.get("resident_path") or {}).get("value")),
              "kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": _r(rf.get("frac")),
+             "step_frac": _r(rf.get("whole_step_frac")), "tu_s": _r(d.get("tree_updates_per_s")),
+             "stale": True if (rf.get("traffic_stale") or rr.get("traffic_stale")) else None,
+             "cpu8": _r(((d.get("cpu_baseline") or {}).get("all_cores") or {}).get("value")),
+             "tune1": _r(((d.get("tune1") or {}).get("astep") or {}).get("value")),
              "rows_hbm_frac": _r(rr.get("frac") if rr else (rf.get("measured_hbm_frac") if rf.get("bound") == "hbm" else None)),
              "us": {k: _r(v["avg_us"]) for k, v in kk.items()},
              "cpu": _r((d.get("cpu_baseline") or {}).get("value")),
@@ -757,12 +818,12 @@ def main():
         return {k: v for k, v in b.items() if v is not None}
 
     summ = {"cfg2" if default_cfg and wname == "cfg2" else wname: brief(line)}
-    if "all_cores" in (line.get("cpu_baseline") or {}):
-        summ[next(iter(summ))]["cpu8"] = _r(line["cpu_baseline"]["all_cores"]["value"])
     if "concurrent_chains" in line:
         summ[next(iter(summ))]["chains4"] = _r(line["concurrent_chains"]["value"])
     for wn, d in (line.get("workloads") or {}).items():
         summ[wn] = brief(d)
+    if "cfg1" in line:
+        summ["cfg1"] = {"cpu": _r(line["cfg1"]["value"]), "tu_s": _r(line["cfg1"]["tree_updates_per_s"])}
     line["summary"] = summ
 
     if rank == 0:
@@ -771,6 +832,62 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_of_run_gather(step, dist, rank, world, dry, args, seed, barrier):
+    """Draw ``--gather-draws`` more posterior draws on every rank (PGBART.astep, tune=0: the draws, their trees,
+    their stats), then ONE ``chains.gather_chains`` to rank 0, timed.  Rank 0 checks what arrived: one entry per
+    rank, in rank order, keyed 3415 + rank, no two chains alike, every history as long as its draws."""
+    from pymc_bart_amd.chains import gather_chains
+    from pymc_bart_amd.utils import _decode_vi
+
+    G = max(1, int(args.gather_draws))
+    if dry:
+        width, p = 8, 4
+        mu = np.arange(G, dtype=np.float64)[:, None] + 1000.0 * rank + np.zeros((G, width))
+        vi_stats = ["AAAAAA=="] * G
+        vi = np.zeros((G, p), np.int64)
+        history = (None, [b"dry"] * G)
+        counters = step.counters
+    else:
+        width = int(np.prod(step.shape))
+        G = max(1, min(G, (256 << 20) // (8 * width)))  # at most 256 MiB of draws per rank (cfg5: 32 draws of 4 x 250k)
+        p = step.num_variates
+        step.tune = False
+        step.reset_history()  # the history that travels is the history of the draws that travel
+        mu = np.empty((G, width))
+        vi_stats = []
+        for d in range(G):
+            m_d, stats = step.astep(None)
+            mu[d] = np.asarray(m_d).reshape(-1)
+            vi_stats.append(stats[0]["variable_inclusion"])
+        vi = np.array([_decode_vi(v, p) for v in vi_stats], dtype=np.int64).reshape(-1, p)
+        history = (step.history[0], list(step.history[1]))
+        counters = step.counters
+    result = {"chain": rank, "seed": seed, "mu": mu, "sigma": np.ones(G), "variable_inclusion": vi_stats,
+              "vi_counts": vi, "history": history, "counters": counters}
+    tm = {}
+    barrier()
+    g0 = time.perf_counter()
+    got = gather_chains(result, dist, dst=0, force_collective=True, timings=tm)
+    barrier()
+    gather_s = time.perf_counter() - g0
+    out = {"gather_ms": gather_s * 1e3, "gather_draws": G, "gather_bytes_per_rank": tm["dense_bytes"],
+           "gather_stages_ms": {k: tm[k] for k in ("h2d_ms", "collective_ms", "object_ms", "d2h_ms")},
+           # the collective alone, device to device: the shards of all ranks land on rank 0
+           "gather_collective_GBps": world * tm["dense_bytes"] / max(tm["collective_ms"] * 1e-3, 1e-9) / 1e9}
+    if rank == 0:
+        assert len(got) == world, (len(got), world)
+        for r, item in enumerate(got):
+            assert item["chain"] == r and item["seed"] == 3415 + r, (r, item["chain"], item["seed"])
+            assert item["mu"].shape == (G, width) and len(item["history"][1]) == G == len(item["variable_inclusion"])
+        assert np.array_equal(got[0]["mu"], mu)  # rank 0's own shard came back as it went
+        for r in range(1, world):
+            assert not np.array_equal(got[r]["mu"], got[0]["mu"]), "chains must be independent"
+            assert all(not np.array_equal(got[r]["mu"], got[q]["mu"]) for q in range(1, r)), "chains must be independent"
+        out["gather_history_bytes_per_rank"] = int(sum(len(getattr(b, "raw", b)) for b in history[1]))
+        out["gather_chains_checked"] = world
+    return out
 
 
 def _r(x, sig=4):
@@ -822,7 +939,13 @@ def workload_leg(wn, make_chain, be, args, torch):
                           "ms_per_step": el_r * 1e3 / steps, "value_min": r_min, "value_max": r_max,
                           "astep_fraction_of_resident": d["value"] / (u_r["particle_steps"] / el_r)}
     if not args.no_roofline:
-        d.update(rooflines(wn, w, w["X"].shape, kernel_profile(s, False, steps)))
+        d.update(rooflines(wn, w, w["X"].shape, kernel_profile(s, False, steps), lib_path=be.lib.path))
+        from pymc_bart_amd import workloads as _wl
+
+        d["algorithmic_GBps_whole_step"] = _wl.bytes_per_tree_update(
+            w["X"].shape[0], d["rows_touched_per_tree"], K=w.get("K", 1)) * d["tree_updates_per_s"] / 1e9
+        if d.get("roofline"):
+            d["roofline"]["whole_step_frac"] = d["algorithmic_GBps_whole_step"] / HBM_PEAK_GBS
     del s
     st.sampler = None  # free the chain's HBM before the next chain
     if not args.no_cpu_baseline:

@@ -58,7 +58,7 @@ def sample_chain(op: BARTOp, tune: int, draws: int, num_particles: int = 10, ran
         "sigma": sig_draws,
         "variable_inclusion": vi_stats,
         "vi_counts": vi,
-        "history": (step._baseline, step._batches),
+        "history": step.history,
         "counters": step.counters,
         "step": step,
     }
@@ -72,8 +72,9 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
     pass -> control kernel ...), so a single chain is latency-bound at cfg2 sizes.  Chains are
     independent, hence each gets its own HIP stream and a host thread that feeds its state machine
     (the ctypes calls release the GIL); the row pass of one chain overlaps the control kernel of
-    another.  Measured on MI355X at cfg2: 1 chain 1.74 M, 2 chains 2.98 M, 4 chains 4.47 M
-    particle-steps/s aggregate.  The draws of every chain are bit-identical to the ones it
+    another.  Measured on MI355X at cfg2 (resident path, ``BENCH_r05.json``): 1 chain 2.2 M, 4 chains 5.8 M
+    particle-steps/s aggregate; the current figures are the ``resident_path`` / ``concurrent_chains`` entries of the
+    committed bench line (``tools/show_bench.py``).  The draws of every chain are bit-identical to the ones it
     produces when run alone (``tests/test_parity_gpu.py``)."""
     import threading
 
@@ -97,7 +98,7 @@ def sample_chains(op: BARTOp, chains: int, tune: int, draws: int, **kw) -> list[
     return out
 
 
-def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool = False):
+def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool = False, timings: dict | None = None):
     """The single end-of-run collective: gather every rank's draws and tree history on ``dst``.
 
     Dense draws travel as one tensor per rank with ``gather`` to ``dst`` (over RCCL/xGMI on GPUs every rank's
@@ -107,7 +108,12 @@ def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool 
     per-chain results on ``dst`` and ``None`` elsewhere.  Without a process group it returns ``[result]``; a group of ONE rank
     skips the collectives too unless ``force_collective`` is set (the GPU suite sets it to run the RCCL
     calls of this function at world size 1 before an 8-GPU job meets them for the first time).
+    ``timings`` (a dict, filled in place): milliseconds of the stages -- ``h2d_ms`` staging the dense block on the
+    device, ``collective_ms`` the ``gather`` itself (device to device), ``object_ms`` the pickled pieces, ``d2h_ms``
+    the receive buffers back on the host (``dst`` only) -- and ``dense_bytes`` per rank.
     """
+    import time
+
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return [{k: v for k, v in result.items() if k != "step"}]
     import torch
@@ -117,17 +123,35 @@ def gather_chains(result: dict, dist=None, dst: int = 0, force_collective: bool 
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     # keep_draws=False: only sigma travels densely
     mu = result["mu"] if result["mu"] is not None else np.empty((result["sigma"].shape[0], 0))
+
+    def tick():
+        if on_gpu:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    t0 = tick()
     dense = torch.from_numpy(np.concatenate([mu, result["sigma"][:, None]], axis=1)).to(dev)
     parts = [torch.empty_like(dense) for _ in range(world)] if rank == dst else None
+    t1 = tick()
     dist.gather(dense, parts, dst=dst)
+    t2 = tick()
     small = {k: result[k] for k in ("chain", "variable_inclusion", "vi_counts", "history", "counters")}
+    if "seed" in result:
+        small["seed"] = result["seed"]
     gathered = [None] * world if rank == dst else None
     dist.gather_object(small, gathered, dst=dst)
+    t3 = tick()
+    if timings is not None:
+        timings.update(h2d_ms=(t1 - t0) * 1e3, collective_ms=(t2 - t1) * 1e3, object_ms=(t3 - t2) * 1e3, d2h_ms=0.0,
+                       dense_bytes=int(dense.numel() * dense.element_size()))
     if rank != dst:
         return None
     out = []
+    hosts = [parts[r].cpu().numpy() for r in range(world)]
+    if timings is not None:
+        timings["d2h_ms"] = (tick() - t3) * 1e3
     for r in range(world):
-        d = parts[r].cpu().numpy()
+        d = hosts[r]
         item = dict(gathered[r])
         item["mu"] = d[:, :-1] if result["mu"] is not None else None
         item["sigma"] = d[:, -1]

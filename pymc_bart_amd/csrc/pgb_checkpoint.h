@@ -308,7 +308,6 @@ extern "C" int pgb_profile(pgb_handle* h, int32_t enable, double* kernel_ms_out,
     if (!h->prof_buf) {
       int rc = dalloc(h, &h->prof_buf, (size_t)PROF_RING * PROF_BLOCKS * 2);
       if (rc != PGB_OK) return rc;
-      h->alloc_persist.back() = 0;
     }
     h->d.prof_stamps = h->prof_buf;
     HIPCHK(hipMemsetAsync(h->d.prof_stamps, 0, (size_t)PROF_RING * PROF_BLOCKS * 2 * sizeof(long long), h->stream));

@@ -27,7 +27,6 @@ struct pgb_handle {
   hipStream_t stream_out;              // pgb_step_host: the step's results leave on this stream, past the idle slots
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;     // per allocation: payload size ...
-  std::vector<char> alloc_persist;     // ... and whether a checkpoint carries it
   std::vector<char> alloc_owned;       // ... and whether it is a hipMalloc of its own (else a piece of `slab`)
   void* slab;                          // small records share one allocation (see dalloc_bytes)
   size_t slab_used;
@@ -136,7 +135,6 @@ static int dalloc_bytes(pgb_handle* h, void** p, size_t bytes) {
   }
   h->allocs.push_back(q);
   h->alloc_bytes.push_back(bytes);
-  h->alloc_persist.push_back(1);
   *p = q;
   return PGB_OK;
 }
@@ -147,8 +145,6 @@ static int dalloc(pgb_handle* h, T** p, size_t count) {
   if (rc == PGB_OK) *p = (T*)q;
   return rc;
 }
-// data, per-tree scratch and pointer tables are rebuilt by create/set_data: not part of a checkpoint
-static void transient(pgb_handle* h) { h->alloc_persist.back() = 0; }
 
 extern "C" const char* pgb_last_error(void) { return g_err; }
 extern "C" const char* pgb_backend_name(void) { return "hip-gfx950"; }
@@ -324,12 +320,9 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
 #define DA(ptr, cnt) \
   if ((rc = dalloc(h, &ptr, (size_t)(cnt))) != PGB_OK) { pgb_destroy(h); return rc; }
   DA(XT, (size_t)d.p * d.n_pad);
-  transient(h);
   DA(y, d.n_pad);
-  transient(h);
   double* off;
   DA(off, (size_t)d.K * d.n_pad);
-  transient(h);
   d.off = off;
   const int K = d.K, KX = d.K - 1;
   DA(st, (size_t)2 * K * d.n_pad);
@@ -351,23 +344,19 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     DA(d.finx, (size_t)2 * MAXP * KX);
     if (s->family == PGB_FAMILY_CATEGORICAL && s->response == PGB_RESPONSE_CONSTANT) {
       // the row part of the factorised softmax: scratch of one tree update (no checkpoint carries it)
+      // (zeroed once below: the passes of a tree's later rounds read the padded rows of the last chunk as well, which
+      //  the pass that starts the tree never writes)
       DA(d.cat_e, (size_t)K * d.n_pad);
-      transient(h);
       DA(d.cat_a, d.n_pad);
-      transient(h);
       DA(d.cat_c, d.n_pad);
-      transient(h);
     }
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
-  transient(h);  // particle labels live for one tree update only
   DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
   if (s->family == PGB_FAMILY_CALLBACK) {
     DA(d.cb_mu, (size_t)MAXP * d.n_pad);
-    transient(h);
     DA(d.cb_side, (size_t)MAXP * d.n_pad);
-    transient(h);
     h->y_host.assign((size_t)d.n, 0.0);
     h->off_host.assign((size_t)d.n, 0.0);
   }
@@ -424,7 +413,6 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     d.host_flag = (unsigned long long*)dp;
 #ifdef PGB_TRACE
     if ((rc = dalloc(h, &d.trace, (size_t)TRACE_SLOTS * TRACE_W)) != PGB_OK) { pgb_destroy(h); return rc; }
-    transient(h);
     HC(hipMemsetAsync(d.trace, 0, (size_t)TRACE_SLOTS * TRACE_W * sizeof(long long), sm));
 #endif
     {  // host-facing results of pgb_step_host: mapped pinned block + dense sum_trees staging
@@ -439,10 +427,8 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
       HC(hipHostGetDevicePointer(&dp2, hp2, 0));
       h->out_dev = (unsigned char*)dp2;
       if ((rc = dalloc(h, &h->st_dense, (size_t)d.K * d.n)) != PGB_OK) { pgb_destroy(h); return rc; }
-      transient(h);
     }
     if ((rc = dalloc(h, &h->d_dev, 1)) != PGB_OK) { pgb_destroy(h); return rc; }
-    transient(h);  // holds device pointers
     HC(hipMemcpyAsync(h->d_dev, &d, sizeof(Dev), hipMemcpyHostToDevice, sm));
   }
   HC(hipMemcpyAsync(prior_leaf, s->prior_leaf, PGB_MAX_DEPTH * sizeof(double), hipMemcpyHostToDevice, sm));
@@ -462,6 +448,11 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
     HC(hipMemsetAsync(d.jvx, 0, (size_t)2 * MAXP * KX * sizeof(double), sm));
     HC(hipMemsetAsync(d.jzx, 0, (size_t)2 * MAXP * KX * 2 * sizeof(double), sm));
     HC(hipMemsetAsync(d.finx, 0, (size_t)2 * MAXP * KX * sizeof(FinX), sm));
+    if (d.cat_e) {
+      HC(hipMemsetAsync(d.cat_e, 0, (size_t)K * d.n_pad * sizeof(double), sm));
+      HC(hipMemsetAsync(d.cat_a, 0, d.n_pad * sizeof(double), sm));
+      HC(hipMemsetAsync(d.cat_c, 0, d.n_pad, sm));
+    }
     hipLaunchKernelGGL(k_fill_f64, dim3(1), dim3(256), 0, sm, d.lsdx, (long long)2 * KXMAX, s->init_leaf_sd);
     // every accepted tree starts as a stump whose K-vector leaf is init_leaf
     hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)(((size_t)d.m * MAXN * KX + 255) / 256)), dim3(256), 0, sm,
@@ -628,7 +619,6 @@ extern "C" int pgb_set_data(pgb_handle* h, const double* X_dev, int64_t ldx, con
         uint16_t* xk = nullptr;
         int rck = dalloc(h, &xk, count);
         if (rck != PGB_OK) return rck;
-        transient(h);
         d.XK16 = xk;
         h->rows_mk_cap = 0;  // (another instance of the K-vector row pass from here on)
       }

@@ -53,6 +53,14 @@ class TreeArrays:
         if self.svar is None:
             self.svar = np.full(nn, -1, np.int32)
 
+    def __setstate__(self, state):
+        """Objects pickled before a field existed (``rule`` came in round 5; ``slope`` / ``xbar`` / ``svar`` before
+        it) are restored without ``__init__``: fill what is missing the way ``__post_init__`` does."""
+        self.__dict__.update(state)
+        for f in ("slope", "xbar", "svar", "rule"):
+            self.__dict__.setdefault(f, None)
+        self.__post_init__()
+
     @property
     def n_trees(self) -> int:
         return int(self.tree_id.shape[0])
@@ -162,11 +170,12 @@ class PackedTrees:
     a single small copy, the decoding happens when (and if) predictions are made, and the history travels
     through the reference's ``Manager().list()`` mailbox (``bart.py:134-135``) as a few KB of bytes."""
 
-    __slots__ = ("raw", "_ta")
+    __slots__ = ("raw", "_ta", "owner")
 
-    def __init__(self, raw: bytes):
+    def __init__(self, raw: bytes, owner: str | None = None):
         self.raw = raw
         self._ta = None
+        self.owner = owner  # which chain published this forest as its baseline (PGBART._publish); survives pickling
 
     def decoded(self) -> TreeArrays:
         if self._ta is None:
@@ -179,7 +188,7 @@ class PackedTrees:
         return getattr(self.decoded(), name)
 
     def __reduce__(self):
-        return (PackedTrees, (self.raw,))
+        return (PackedTrees, (self.raw, self.owner))
 
 
 def _as_list(batches) -> list:
@@ -226,8 +235,14 @@ def load_history(path):
         arrs = {f: z[f"c{i}_{f}"] for f in _HISTORY_FIELDS if f"c{i}_{f}" in z.files}
         if "rule" not in arrs:
             var = arrs["var"].astype(np.int64)
-            arrs["rule"] = np.zeros(var.shape[0], np.int32) if col_rules is None else \
-                np.where(var >= 0, np.asarray(col_rules, np.int32)[np.maximum(var, 0)], 0).astype(np.int32)
+            if col_rules is None:
+                arrs["rule"] = np.zeros(var.shape[0], np.int32)
+            else:
+                cr = np.asarray(col_rules, np.int32)
+                if var.size and int(var.max()) >= cr.size:  # a truncated rules array must not be an IndexError
+                    raise ValueError(f"tree-history file: a tree splits on column {int(var.max())} but the file lists "
+                                     f"the split rules of {cr.size} columns")
+                arrs["rule"] = np.where(var >= 0, cr[np.maximum(var, 0)], 0).astype(np.int32)
         sizes = z[f"c{i}_sizes"].tolist()
         forests, t0 = [], 0
         for nt in sizes:

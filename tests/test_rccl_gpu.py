@@ -38,7 +38,9 @@ def test_bench_rank_under_torchrun_initialises_rccl_and_runs_its_collectives():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["ranks_reported_by_collective"] == 1           # an all_reduce of ones on a cuda tensor over RCCL
-    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 100_000 * 8   # the end-of-run gather to rank 0
+    # the end-of-run gather to rank 0 is chains.gather_chains on 100 kept draws + sigma (80 MB) through RCCL
+    assert d["gather_ms"] >= 0 and d["gather_bytes_per_rank"] == 100 * 100_001 * 8 and d["gather_draws"] == 100
+    assert d["gather_chains_checked"] == 1 and d["gather_collective_GBps"] > 0 and d["gather_history_bytes_per_rank"] > 0
     assert d["per_rank_ms_per_step"] and len(d["per_rank_ms_per_step"]) == 1
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["data"] == "synthetic"
     assert d["roofline"]["kernel"] == "k_rows"              # the HIP path ran under the launcher

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Final-build evidence of a round (run on the GPU box from the repo root; results under gpurun_out/fin,
 # to be copied into profiles/): PMC passes first (bench.py reads the traffic / instruction counts from
-# profiles/<round>_pmc_<workload>.json; ROUND=r05 by default), then the default bench line, then rocprofv3 kernel traces.
-R=$PWD; O=$R/gpurun_out/fin; mkdir -p $O; export ROUND=${ROUND:-r05}
+# profiles/<round>_pmc_<workload>.json; ROUND=r06 by default), then the default bench line, then rocprofv3 kernel traces.
+R=$PWD; O=$R/gpurun_out/fin; mkdir -p $O; export ROUND=${ROUND:-r06}
 for W in cfg2 cfg4 cfg5; do
   tools/pmc_collect.sh $W > $O/pmc_$W.log 2>&1
   cp $R/gpurun_out/${ROUND}_pmc_$W.json $R/profiles/${ROUND}_pmc_$W.json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic / VALU instruction counts of the hot kernels, per launch, from separate rocprofv3 --pmc passes
-# (counters only: no trace domains), written to gpurun_out/${ROUND:-r05}_pmc_<workload>.json -- copy it to profiles/,
+# (counters only: no trace domains), written to gpurun_out/${ROUND:-r06}_pmc_<workload>.json -- copy it to profiles/,
 # where bench.py reads `roofline.traffic` / the instruction counts from.  Run on the GPU box from the repo root.
 # The run under the counters follows the HEADLINE protocol (100 tune=1 asteps of burn-in, then tune=0); the
 # averages are taken over the LAST 15 % of each kernel's dispatches, i.e. the steady-state tune=0 part.
@@ -18,9 +18,11 @@ for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
 done
 python3 $R/tools/pmc_summary.py --tail 0.15 $DIRS > /tmp/pmc_${W}.json
 python3 - <<PY
-import json
+import hashlib, json
 raw = json.load(open("/tmp/pmc_${W}.json"))
-out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged over the last 15 % of each kernel's dispatches by tools/pmc_summary.py --tail 0.15)",
+out = {"library_sha256": hashlib.sha256(open("$R/pymc_bart_amd/csrc/libpgbart_hip.so", "rb").read()).hexdigest(),
+       "library": "pymc_bart_amd/csrc/libpgbart_hip.so (bench.py compares this hash with the library it loaded: roofline.traffic_stale)",
+       "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged over the last 15 % of each kernel's dispatches by tools/pmc_summary.py --tail 0.15)",
        "workload": "$W",
        "note": "FETCH_SIZE on gfx950 counts a 128-B line fetched from the fabric as 64 B: x2 (exact to 4 digits for 1 / 4 / 16 / 32 B-per-lane streams, profiles/r03_fetch_calibration.json); WRITE_SIZE exact; units KB per launch as the counters report them; SQ_INSTS_VALU counts wave-instructions",
        "raw": {k: v for k, v in raw.items() if k.startswith("k_")}}
@@ -34,6 +36,6 @@ for k, v in raw.items():
     if v.get("SQ_INSTS_VALU_avg_per_launch") is not None and v.get("launches", 0) >= e.get("valu_launches", 0):
         e.update(valu_launches=v["launches"], valu_wave_insts_per_launch=v["SQ_INSTS_VALU_avg_per_launch"],
                  waves_per_launch=v.get("SQ_WAVES_avg_per_launch"))
-json.dump(out, open("$R/gpurun_out/${ROUND:-r05}_pmc_${W}.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/${ROUND:-r06}_pmc_${W}.json", "w"), indent=1)
 print({k: v for k, v in out.items() if k.startswith("k_")})
 PY

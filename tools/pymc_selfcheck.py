@@ -3,7 +3,9 @@
 reference's own sampler tests -- /root/reference/tests/test_bart.py:44-64 (variable inclusion), :67-81 (missing
 data), :84-104 (shared X, posterior predictive shapes), :107-123 (shape=(2, n)), :140-164 (categorical, three
 split rules), :167-208 (two BART variables, automatic step assignment), :211-241 (manual ``PGBART([mu],
-num_particles=5)``), :244-256 (mutable named dim) -- run through ``pymc_bart_amd`` on cuda:0.
+num_particles=5)``), :244-256 (mutable named dim) -- run through ``pymc_bart_amd`` on cuda:0.  The tests are held
+here as a TABLE (shapes, keyword arguments, sampling arguments, named assertions: ``CASES``) and one generic runner
+builds each model from its row.
 
     python tools/pymc_selfcheck.py [--quick] [--only NAME ...] [--semantics]
 
@@ -63,129 +65,138 @@ def check_registration(pm, pmb, amd, q):
     assert "IDEAL" in str(comp).upper() or int(comp) >= 3, comp
 
 
-def check_vi(pm, pmb, amd, q, response="constant"):  # tests/test_bart.py:44-64
+# The reference's sampler tests as DATA: one row per test of /root/reference/tests/test_bart.py -- which lines, the
+# shapes of the synthetic inputs, the BART variables (name, which X / Y, keyword arguments), the observed distribution,
+# the pm.sample arguments (`quick` halves the ones marked True) and the assertions to make, by name.  One generic
+# runner builds the model from the row; nothing of the reference's test source is repeated here.
+#   data:      n rows; xs = column counts of the design matrices; "tie" = X[:, 0] is Y plus noise; "nan" = a block of
+#              missing values in X[:, 0]; "classes" = the 9-row three-class problem of :140-164; "sum" = Y_k built
+#              from the leading columns of X_k
+#   observed:  "normal_hn" Normal(sum of the BART variables, HalfNormal(1)); "normal_1" Normal(., 1);
+#              "meanscale" Normal(w[0], |w[1]|); "softmax" Categorical(softmax)
+CASES = [
+    dict(name="variable_inclusion", ref=":44-64", data=dict(n=250, xs=[3], tie=True), bart=[dict(m=10)],
+         observed="normal_hn", sample=dict(tune=200, draws=200), quick=True, expect=["vi_first_dominates"]),
+    dict(name="variable_inclusion_linear", ref=":44-64 (response=linear)", data=dict(n=250, xs=[3], tie=True),
+         bart=[dict(m=10, response="linear")], observed="normal_hn", sample=dict(tune=200, draws=200), quick=True,
+         expect=["vi_first_dominates"]),
+    dict(name="missing_data", ref=":67-81", data=dict(n=50, xs=[2], nan=(10, 20)), bart=[dict(m=10)],
+         observed="normal_hn", sample=dict(tune=100, draws=100, chains=1), quick=True, expect=[]),
+    dict(name="shared_variable", ref=":84-104", data=dict(n=50, xs=[2]), bart=[dict(m=2)], shared_x=True,
+         observed="normal_hn", sample=dict(tune=100, draws=100, chains=2), quick=True, expect=["ppc_shapes"]),
+    dict(name="shape_2xn", ref=":107-123", data=dict(n=250, xs=[3]), bart=[dict(m=2, shape=(2, 250), name="w")],
+         observed="meanscale", sample=dict(tune=50, draws=10), expect=["coords_2xn"]),
+    dict(name="categorical", ref=":140-164", data=dict(classes=True), per_rule=("ContinuousSplit", "OneHotSplit"),
+         bart=[dict(m=2, shape=(3, 9), name="logodds")], observed="softmax", sample=dict(tune=600, draws=600),
+         expect=["classes_recovered", "vi_preds_shape"]),
+    dict(name="two_bart_auto", ref=":167-208", data=dict(n=50, xs=[2, 3], sum=True), bart=[dict(m=5, name="mu1"),
+         dict(m=5, name="mu2")], observed="normal_hn", sample=dict(tune=50, draws=50, chains=1),
+         expect=["separate_histories", "posterior_shapes", "vi_utils"]),
+    dict(name="two_bart_manual_step", ref=":211-241", data=dict(n=30, xs=[2, 2], sum=True), bart=[dict(m=3, name="mu1"),
+         dict(m=3, name="mu2")], observed="normal_hn", manual_steps=5, sample=dict(tune=20, draws=20, chains=1),
+         expect=["posterior_shapes"]),
+    dict(name="mutable_named_dim", ref=":244-256", data=dict(n=50, xs=[2]), bart=[dict(m=10, dims="obs")],
+         named_dims=True, observed="normal_1", sample=dict(tune=20, draws=20, chains=1, seedless=True), expect=[]),
+]
+
+
+def _case_data(d):
+    if d.get("classes"):
+        Y = np.repeat(np.arange(3), 3)
+        X = np.concatenate([Y[:, None], np.random.default_rng(12345).integers(0, 6, size=(9, 4))], axis=1)
+        return [X], [Y], Y
+    n = d["n"]
+    Xs = [np.random.normal(0, 1, size=(n, k)) for k in d["xs"]]
+    Y = np.random.normal(0, 1, size=n)
+    if d.get("tie"):
+        Xs[0][:, 0] = np.random.normal(Y, 0.1)
+    if d.get("nan"):
+        Xs[0][d["nan"][0]: d["nan"][1], 0] = np.nan
+    Ys = [Y] * len(Xs)
+    if d.get("sum"):  # each BART variable gets a response of its own, built from its leading columns
+        Ys = [X[:, : 1 + i].sum(axis=1) + np.random.normal(0, 0.1, size=n) for i, X in enumerate(Xs)]
+    return Xs, Ys, Y
+
+
+def run_case(case, pm, pmb, amd, q, rule=None):
     from pymc_bart.utils import _decode_vi
 
-    X = np.random.normal(0, 1, size=(250, 3))
-    Y = np.random.normal(0, 1, size=250)
-    X[:, 0] = np.random.normal(Y, 0.1)
-    with pm.Model():
-        mu = pmb.BART("mu", X, Y, m=10, response=response)
-        sigma = pm.HalfNormal("sigma", 1)
-        pm.Normal("y", mu, sigma, observed=Y)
-        idata = pm.sample(tune=200 // q, draws=200 // q, random_seed=3415, progressbar=False)
-    vi_vals = idata["sample_stats"]["variable_inclusion"].values.ravel()
-    var_imp = np.array([_decode_vi(val, 3) for val in vi_vals]).sum(axis=0)
-    var_imp = var_imp / var_imp.sum()
-    assert var_imp[0] > var_imp[1:].sum(), var_imp
-    np.testing.assert_almost_equal(var_imp.sum(), 1)
+    Xs, Ys, Y = _case_data(case["data"])
+    n = Y.shape[0]
+    div = q if case.get("quick") else 1
+    sk = dict(case["sample"])
+    seedless = sk.pop("seedless", False)
+    sk.update(tune=sk["tune"] // div, draws=sk["draws"] // div, progressbar=False)
+    if not seedless:
+        sk["random_seed"] = 3415
+    coords = {"obs": np.arange(n), "feature": ["a", "b"]} if case.get("named_dims") else None
+    with pm.Model(coords=coords) as model:
+        rvs = []
+        for i, kw in enumerate(case["bart"]):
+            kw = dict(kw)
+            name = kw.pop("name", "mu")
+            X_in = Xs[i]
+            if case.get("shared_x"):
+                X_in = pm.Data("data_X", X_in)
+            if case.get("named_dims"):
+                X_in = pm.Data("x", X_in, dims=("obs", "feature"))
+            if rule is not None:
+                kw["split_rules"] = [rule] * Xs[i].shape[1]
+            rvs.append(pmb.BART(name, X_in, Ys[i], **kw))
+        total = rvs[0] if len(rvs) == 1 else sum(rvs[1:], rvs[0])
+        obs = case["observed"]
+        if obs == "normal_hn":
+            extra = {"shape": total.shape} if case.get("shared_x") else {}
+            pm.Normal("y", total, pm.HalfNormal("sigma", 1), observed=Y, **extra)
+        elif obs == "normal_1":
+            pm.Normal("y", mu=total, sigma=1.0, observed=Y, dims="obs")
+        elif obs == "meanscale":
+            pm.Normal("y", total[0], pm.math.abs(total[1]), observed=Y)
+        else:
+            pm.Categorical("y", p=pm.math.softmax(total.T, axis=-1), observed=Y)
+        if case.get("manual_steps"):
+            sk["step"] = [amd.PGBART([rv], num_particles=case["manual_steps"]) for rv in rvs]
+        idata = pm.sample(**sk)
+        d, chains = sk["draws"], sk.get("chains")
+        for what in case["expect"]:
+            if what == "vi_first_dominates":
+                vals = idata["sample_stats"]["variable_inclusion"].values.ravel()
+                imp = np.array([_decode_vi(v, Xs[0].shape[1]) for v in vals]).sum(axis=0)
+                imp = imp / imp.sum()
+                assert imp[0] > imp[1:].sum(), imp
+            elif what == "ppc_shapes":
+                ppc = pm.sample_posterior_predictive(idata, progressbar=False)
+                pm.set_data({"data_X": Xs[0][:3]})
+                ppc2 = pm.sample_posterior_predictive(idata, sample_vars=["mu", "y"], progressbar=False)
+                assert ppc.posterior_predictive["y"].shape == (chains, d, n)
+                assert ppc2.posterior_predictive["y"].shape == (chains, d, 3)
+            elif what == "coords_2xn":
+                assert model.initial_point()["w"].shape == (2, n)
+                assert idata.posterior.coords["w_dim_0"].data.size == 2 and idata.posterior.coords["w_dim_1"].data.size == n
+            elif what == "classes_recovered":
+                idata = pm.sample_posterior_predictive(idata, predictions=True, extend_inferencedata=True,
+                                                       random_seed=3415, progressbar=False)
+                assert (idata.predictions.y.median(["chain", "draw"]) == Y).all(), rule
+            elif what == "vi_preds_shape":
+                assert pmb.compute_variable_importance(idata, bartrv=rvs[0], X=Xs[0])["preds"].shape == (5, 50, 9, 3)
+            elif what == "separate_histories":
+                assert rvs[0].owner.op.all_trees is not rvs[1].owner.op.all_trees
+            elif what == "posterior_shapes":
+                for kw in case["bart"]:
+                    assert idata.posterior[kw["name"]].shape == (chains, d, n)
+            elif what == "vi_utils":
+                vi = pmb.compute_variable_importance(idata, rvs[0], Xs[0], model=model)
+                k = Xs[0].shape[1]
+                assert vi["labels"].shape == (k,) and vi["preds"].shape == (k, 50, n) and vi["preds_all"].shape == (50, n)
+                vt = pmb.get_variable_inclusion(idata, Xs[0], model=model, bart_var_name=case["bart"][0]["name"])
+                assert vt[0].shape == (k,) and len(vt[1]) == k and isinstance(vt[1][0], str)
 
 
-def check_vi_linear(pm, pmb, amd, q):
-    check_vi(pm, pmb, amd, q, response="linear")
-
-
-def check_missing(pm, pmb, amd, q):  # :67-81
-    X = np.random.normal(0, 1, size=(50, 2))
-    Y = np.random.normal(0, 1, size=50)
-    X[10:20, 0] = np.nan
-    with pm.Model():
-        mu = pmb.BART("mu", X, Y, m=10)
-        sigma = pm.HalfNormal("sigma", 1)
-        pm.Normal("y", mu, sigma, observed=Y)
-        pm.sample(tune=100 // q, draws=100 // q, chains=1, random_seed=3415, progressbar=False)
-
-
-def check_shared(pm, pmb, amd, q):  # :84-104
-    X = np.random.normal(0, 1, size=(50, 2))
-    Y = np.random.normal(0, 1, size=50)
-    d = 100 // q
-    with pm.Model():
-        data_X = pm.Data("data_X", X)
-        mu = pmb.BART("mu", data_X, Y, m=2)
-        sigma = pm.HalfNormal("sigma", 1)
-        pm.Normal("y", mu, sigma, observed=Y, shape=mu.shape)
-        idata = pm.sample(tune=d, draws=d, chains=2, random_seed=3415, progressbar=False)
-        ppc = pm.sample_posterior_predictive(idata, progressbar=False)
-        pm.set_data({"data_X": X[:3]})
-        ppc2 = pm.sample_posterior_predictive(idata, sample_vars=["mu", "y"], progressbar=False)
-    assert ppc.posterior_predictive["y"].shape == (2, d, 50)
-    assert ppc2.posterior_predictive["y"].shape == (2, d, 3)
-
-
-def check_shape(pm, pmb, amd, q):  # :107-123
-    X = np.random.normal(0, 1, size=(250, 3))
-    Y = np.random.normal(0, 1, size=250)
-    with pm.Model() as model:
-        w = pmb.BART("w", X, Y, m=2, shape=(2, 250))
-        pm.Normal("y", w[0], pm.math.abs(w[1]), observed=Y)
-        idata = pm.sample(tune=50, draws=10, random_seed=3415, progressbar=False)
-    assert model.initial_point()["w"].shape == (2, 250)
-    assert idata.posterior.coords["w_dim_0"].data.size == 2
-    assert idata.posterior.coords["w_dim_1"].data.size == 250
-
-
-def check_categorical(pm, pmb, amd, q):  # :140-164
-    Y = np.array([0, 0, 0, 1, 1, 1, 2, 2, 2])
-    rng = np.random.default_rng(12345)
-    X = np.concatenate([Y[:, None], rng.integers(0, 6, size=(9, 4))], axis=1)
-    for rule in ("ContinuousSplit", "OneHotSplit"):
-        with pm.Model():
-            lo = pmb.BART("logodds", X, Y, m=2, shape=(3, 9), split_rules=[rule] * 5)
-            pm.Categorical("y", p=pm.math.softmax(lo.T, axis=-1), observed=Y)
-            idata = pm.sample(tune=600, draws=600, random_seed=3415, progressbar=False)
-            idata = pm.sample_posterior_predictive(idata, predictions=True, extend_inferencedata=True,
-                                                   random_seed=3415, progressbar=False)
-        assert (idata.predictions.y.median(["chain", "draw"]) == Y).all(), rule
-        assert pmb.compute_variable_importance(idata, bartrv=lo, X=X)["preds"].shape == (5, 50, 9, 3)
-
-
-def check_two_bart_auto(pm, pmb, amd, q):  # :167-208
-    X1 = np.random.normal(0, 1, size=(50, 2))
-    X2 = np.random.normal(0, 1, size=(50, 3))
-    Y = np.random.normal(0, 1, size=50)
-    Y1 = X1[:, 0] + np.random.normal(0, 0.1, size=50)
-    Y2 = X2[:, 0] + X2[:, 1] + np.random.normal(0, 0.1, size=50)
-    with pm.Model() as model:
-        mu1 = pmb.BART("mu1", X1, Y1, m=5)
-        mu2 = pmb.BART("mu2", X2, Y2, m=5)
-        sigma = pm.HalfNormal("sigma", 1)
-        pm.Normal("y", mu1 + mu2, sigma, observed=Y)
-        idata = pm.sample(tune=50, draws=50, chains=1, random_seed=3415, progressbar=False)
-        assert mu1.owner.op.all_trees is not mu2.owner.op.all_trees
-        assert idata.posterior["mu1"].shape == (1, 50, 50) and idata.posterior["mu2"].shape == (1, 50, 50)
-        vi = pmb.compute_variable_importance(idata, mu1, X1, model=model)
-        assert vi["labels"].shape == (2,) and vi["preds"].shape == (2, 50, 50) and vi["preds_all"].shape == (50, 50)
-        vt = pmb.get_variable_inclusion(idata, X1, model=model, bart_var_name="mu1")
-        assert vt[0].shape == (2,) and len(vt[1]) == 2 and isinstance(vt[1][0], str)
-
-
-def check_two_bart_manual(pm, pmb, amd, q):  # :211-241
-    X1 = np.random.normal(0, 1, size=(30, 2))
-    X2 = np.random.normal(0, 1, size=(30, 2))
-    Y = np.random.normal(0, 1, size=30)
-    Y1 = X1[:, 0] + np.random.normal(0, 0.1, size=30)
-    Y2 = X2[:, 1] + np.random.normal(0, 0.1, size=30)
-    with pm.Model():
-        mu1 = pmb.BART("mu1", X1, Y1, m=3)
-        mu2 = pmb.BART("mu2", X2, Y2, m=3)
-        sigma = pm.HalfNormal("sigma", 1)
-        pm.Normal("y", mu1 + mu2, sigma, observed=Y)
-        step1 = amd.PGBART([mu1], num_particles=5)
-        step2 = amd.PGBART([mu2], num_particles=5)
-        idata = pm.sample(tune=20, draws=20, chains=1, step=[step1, step2], random_seed=3415, progressbar=False)
-    assert idata.posterior["mu1"].shape == (1, 20, 30) and idata.posterior["mu2"].shape == (1, 20, 30)
-
-
-def check_named_dim(pm, pmb, amd, q):  # :244-256
-    rng = np.random.default_rng(0)
-    N = 50
-    X, Y = rng.normal(size=(N, 2)), rng.normal(size=N)
-    with pm.Model(coords={"obs": np.arange(N), "feature": ["a", "b"]}):
-        x = pm.Data("x", X, dims=("obs", "feature"))
-        mu = pmb.BART("mu", X=x, Y=Y, m=10, dims="obs")
-        pm.Normal("y", mu=mu, sigma=1.0, observed=Y, dims="obs")
-        pm.sample(tune=20, draws=20, chains=1, progressbar=False)
+def _table_check(case):
+    def fn(pm, pmb, amd, q):
+        for rule in case.get("per_rule", (None,)):
+            run_case(case, pm, pmb, amd, q, rule)
+    return fn
 
 
 def leaves_per_tree(idata, p, m, batch=0.1):
@@ -229,11 +240,7 @@ def semantics_report(pm, pmb, amd, q):
           + ("" if near == "default" else "  (run models with PGBART_SEMANTICS=upstream to match it)"))
 
 
-CHECKS = [("registration", check_registration), ("variable_inclusion", check_vi),
-          ("variable_inclusion_linear", check_vi_linear), ("missing_data", check_missing),
-          ("shared_variable", check_shared), ("shape_2xn", check_shape), ("categorical", check_categorical),
-          ("two_bart_auto", check_two_bart_auto), ("two_bart_manual_step", check_two_bart_manual),
-          ("mutable_named_dim", check_named_dim)]
+CHECKS = [("registration", check_registration)] + [(c["name"], _table_check(c)) for c in CASES]
 
 
 def main():
