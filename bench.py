@@ -805,16 +805,16 @@ def main():
         kk = d.get("roofline_kernels") or {}
         b = {"value": _r(d.get("value")), "ms": _r(d.get("ms_per_step")),
              "resident": _r((d.get("resident_path") or {}).get("value")),
-             "kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": _r(rf.get("frac")),
+             "kernel": rf.get("kernel"), "frac": _r(rf.get("frac")),
              "step_frac": _r(rf.get("whole_step_frac")), "tu_s": _r(d.get("tree_updates_per_s")),
              "stale": True if (rf.get("traffic_stale") or rr.get("traffic_stale")) else None,
              "cpu8": _r(((d.get("cpu_baseline") or {}).get("all_cores") or {}).get("value")),
              "tune1": _r(((d.get("tune1") or {}).get("astep") or {}).get("value")),
-             "rows_hbm_frac": _r(rr.get("frac") if rr else (rf.get("measured_hbm_frac") if rf.get("bound") == "hbm" else None)),
+             "rows_hbm": _r(rr.get("frac") if rr else (rf.get("measured_hbm_frac") if rf.get("bound") == "hbm" else None)),
              "us": {k: _r(v["avg_us"]) for k, v in kk.items()},
              "cpu": _r((d.get("cpu_baseline") or {}).get("value")),
              "x_cpu": _r(d.get("speedup_vs_cpu_baseline")),
-             "x_cpu_same_age": _r(((d.get("cpu_baseline") or {}).get("matched_age") or {}).get("speedup_vs_cpu_baseline"))}
+             "x_same_age": _r(((d.get("cpu_baseline") or {}).get("matched_age") or {}).get("speedup_vs_cpu_baseline"))}
         return {k: v for k, v in b.items() if v is not None}
 
     summ = {"cfg2" if default_cfg and wname == "cfg2" else wname: brief(line)}

@@ -64,10 +64,13 @@ def run(budget=60.0, seed=1, backs=None):
             for s in S.values():
                 s.set_likelihood([sg])
         elif op == "ckpt":
-            for k, b in backs.items():
-                blob = S[k].checkpoint()
+            # the image belongs to no backend (include/pgbart_image.h): every other time the two chains swap images
+            blobs = {k: S[k].checkpoint() for k in backs}
+            cross = bool(rng.integers(0, 2)) and len(backs) == 2
+            names = list(backs)
+            for i, (k, b) in enumerate(backs.items()):
                 S[k] = PySampler(st, X, Y, rules, prior, backend=b)
-                S[k].restore(blob)
+                S[k].restore(blobs[names[1 - i]] if cross else blobs[k])
         else:
             for which in (0, 1):
                 assert S["hip"].export_trees(which).raw == S["oracle"].export_trees(which).raw, f"export {which} differs"
