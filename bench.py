@@ -268,14 +268,30 @@ def cpu_cfg1(budget_s=3.0):
             "sample": f"{r['steps']} tune=0 asteps ({r['dt']:.1f} s) after 10 tune=1 asteps"}
 
 
-def so_sha256(path):
+def kernel_source_sha256(root=None):
+    """Identity of the device code of this tree: sha256 over the sources the HIP library is built from
+    (pymc_bart_amd/csrc/*.hip, *.h, include/*.h) and the compiler flags.  (Not a hash of the .so: two hipcc builds of
+    the same sources differ in their bytes.)"""
+    import glob
     import hashlib
 
+    root = ROOT if root is None else root
+    files = sorted(glob.glob(os.path.join(root, "pymc_bart_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(root, "pymc_bart_amd", "csrc", "*.hip"))
+                   + glob.glob(os.path.join(root, "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
     try:
-        with open(path, "rb") as fh:
-            return hashlib.sha256(fh.read()).hexdigest()
-    except OSError:
-        return None
+        sys.path.insert(0, root)
+        import __graft_entry__ as g
+
+        h.update(" ".join(x for x in g.HIPCC_FLAGS if not x.startswith("-I")).encode())
+    except Exception:  # noqa: BLE001 - the flags are a refinement: the sources alone still identify a kernel change
+        pass
+    return h.hexdigest()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -396,24 +412,24 @@ def kernel_profile(s, tune, steps):
             "slots": d["slots"]}
 
 
-def load_pmc(wname, lib_path=None):
+def load_pmc(wname, current=None):
     """Per-launch counter averages of the hot kernels from the separate ``rocprofv3 --pmc`` passes
     (``tools/pmc_collect.sh``; the newest round's file that exists).  Returns (counters, file, stale): the counters
-    are read from a COMMITTED file, not measured in this run, so each file names the library it was taken on
-    (``library_sha256``); ``stale`` is True when that is not the library this process loaded -- a kernel changed and
-    nobody re-ran the counter passes (round-5 VERDICT, weak #6)."""
+    are read from a COMMITTED file, not measured in this run, so each file names the kernel sources it was taken on
+    (``kernel_source_sha256``); ``stale`` is True when those are not this tree's -- a kernel changed and
+    nobody re-ran the counter passes (round-5 VERDICT, weak #6).  ``current``: this tree's hash (tests pass one)."""
     for rnd in (ROUND, "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wname}.json")
         if os.path.exists(path):
             with open(path) as fh:
                 d = json.load(fh)
-            have = so_sha256(lib_path) if lib_path else None
-            stale = (d.get("library_sha256") is None) or (have is not None and d["library_sha256"] != have)
+            have = kernel_source_sha256() if current is None else current
+            stale = d.get("kernel_source_sha256") != have
             return d, f"profiles/{rnd}_pmc_{wname}.json", bool(stale)
     return {}, None, False
 
 
-def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True, lib_path=None):
+def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True):
     """``roofline`` (the dominant kernel of the workload), ``roofline_rows`` (the row pass, HBM) and
     ``roofline_kernels`` (every kernel of the slot) from a :func:`kernel_profile` block."""
     from pymc_bart_amd import workloads
@@ -431,7 +447,7 @@ def rooflines(wname, w, X_shape, prof, response="constant", default_cfg=True, li
         # dependent loads and scalar decisions (profiles/r03_experiments.md section 5: ~1.6 us until its first data,
         # ~3.8 us of dependent work); its floor is latency, and it is the other half of a cfg2 slot
         out["roofline_kernels"]["k_ctrl"]["bound"] = "latency"
-    pmc, pmc_src, pmc_stale = load_pmc(wname, lib_path) if default_cfg else ({}, None, False)
+    pmc, pmc_src, pmc_stale = load_pmc(wname) if default_cfg else ({}, None, False)
     ms_rows, launches = prof["ms_rows"], prof["launches"]
     tu, rt, parts = prof["tree_updates"], prof["rows_touched"], prof["partitions"]
     rows = None
@@ -708,8 +724,7 @@ def main():
 
     # ---- roofline of the dominant kernel + per-kernel shares: a further block with events attached
     if not dry and not args.no_roofline and rank == 0:
-        line.update(rooflines(wname, w, X.shape, kernel_profile(s, tune, args.steps), args.response, default_cfg,
-                              lib_path=be.lib.path))
+        line.update(rooflines(wname, w, X.shape, kernel_profile(s, tune, args.steps), args.response, default_cfg))
         if line.get("roofline"):
             # SURVEY.md 8(d)'s own definition, over the WALL clock of the timed asteps (host outputs and all):
             # sum of B_tree / seconds / 8 TB/s -- next to `frac`, which is the dominant kernel's
@@ -939,7 +954,7 @@ def workload_leg(wn, make_chain, be, args, torch):
                           "ms_per_step": el_r * 1e3 / steps, "value_min": r_min, "value_max": r_max,
                           "astep_fraction_of_resident": d["value"] / (u_r["particle_steps"] / el_r)}
     if not args.no_roofline:
-        d.update(rooflines(wn, w, w["X"].shape, kernel_profile(s, False, steps), lib_path=be.lib.path))
+        d.update(rooflines(wn, w, w["X"].shape, kernel_profile(s, False, steps)))
         from pymc_bart_amd import workloads as _wl
 
         d["algorithmic_GBps_whole_step"] = _wl.bytes_per_tree_update(

@@ -18,6 +18,10 @@ for w in cfg2 cfg4 cfg5; do
   tools/pmc_busy.sh gpurun_out/fin/${ROUND}_${w}_issue_wait.txt $A --no-roofline > /dev/null 2>&1
   tools/pmc_mix.sh gpurun_out/fin/${ROUND}_${w}_instruction_mix.txt $A --no-roofline > /dev/null 2>&1
 done
+python tools/image_timing.py > $O/${ROUND}_image_timing.json 2> /dev/null
+# one rank under the launcher: RCCL initialised, the end-of-run gather (100 draws = 80 MB) through the nccl backend
+python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-multichain > $O/${ROUND}_bench_rccl_world1.json 2> /dev/null
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1) > $O/${ROUND}_final_gpu_tests.txt
 python tools/occupancy_guard.py > $O/${ROUND}_occupancy.txt 2>&1
 python tools/latency_guard.py > $O/${ROUND}_latency_guard.txt 2>&1; echo "latency guard rc=$?" >> $O/${ROUND}_latency_guard.txt; tail -3 $O/${ROUND}_latency_guard.txt
 ls -la $O

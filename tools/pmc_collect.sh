@@ -18,10 +18,11 @@ for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
 done
 python3 $R/tools/pmc_summary.py --tail 0.15 $DIRS > /tmp/pmc_${W}.json
 python3 - <<PY
-import hashlib, json
+import importlib.util, json
+spec = importlib.util.spec_from_file_location("bench_mod", "$R/bench.py"); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 raw = json.load(open("/tmp/pmc_${W}.json"))
-out = {"library_sha256": hashlib.sha256(open("$R/pymc_bart_amd/csrc/libpgbart_hip.so", "rb").read()).hexdigest(),
-       "library": "pymc_bart_amd/csrc/libpgbart_hip.so (bench.py compares this hash with the library it loaded: roofline.traffic_stale)",
+out = {"kernel_source_sha256": bench.kernel_source_sha256(),
+       "kernel_source": "sha256 over pymc_bart_amd/csrc/*.hip, *.h, include/*.h and the hipcc flags (bench.kernel_source_sha256; bench.py compares it with the tree it runs from: roofline.traffic_stale)",
        "command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py $A   (one pass per counter C in FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, SQ_WAVES; averaged over the last 15 % of each kernel's dispatches by tools/pmc_summary.py --tail 0.15)",
        "workload": "$W",
        "note": "FETCH_SIZE on gfx950 counts a 128-B line fetched from the fabric as 64 B: x2 (exact to 4 digits for 1 / 4 / 16 / 32 B-per-lane streams, profiles/r03_fetch_calibration.json); WRITE_SIZE exact; units KB per launch as the counters report them; SQ_INSTS_VALU counts wave-instructions",
