@@ -212,12 +212,16 @@ struct SplitRow {
   int vkey;  // order key of the value (XK16), 0 without keys
   double v;
 };
+// V16: compile the sixteen-counts-in-registers path (below) in -- the KEYS instances of k_ctrl, i.e. the data sets
+// beyond the Infinity Cache, which are the ones with hundreds of chunks; the instance the small data sets launch
+// (cfg2: a latency kernel at its register edge) carries none of it.
+template <bool V16 = false>
 __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool subset_rule, int src_gen, int src_slot,
                                                      int ncnt, int ncc, int nlabel, const double* pre0,
                                                      const double* pre1, const uint16_t* xk16, long long* tr_rec = nullptr) {
   const double* xc = S.XT + (size_t)j * S.n_pad;
   const uint8_t* lid = src_slot >= 0 ? S.lid + ((size_t)src_gen * MAXP + src_slot) * S.n_pad : nullptr;
-  const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * S.nchunks : nullptr;
+  const uint16_t* ccr = ncc >= 0 ? S.cc + (size_t)ncc * (V16 ? S.cc_stride : S.nchunks) : nullptr;
   const uint16_t* kc = xk16 ? xk16 + (size_t)j * S.n_pad : nullptr;  // (xk16 = S.XK16 as a preloaded kernel argument)
   SplitRow out;
   out.found = 0;
@@ -226,12 +230,22 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
   // per-lane partial sums of the node's per-chunk row counts (independent of the retry); the counts of a
   // lane's chunks stay in registers (<= 4 chunks per lane, i.e. n <= 262144: one 8-byte load, no re-read
   // when the k-th row is located; longer columns walk the counts in memory)
-  const int per = (S.nchunks + 63) / 64;
+  // 257 .. 1024 chunks (n <= 1 048 576 rows: cfg4): a lane owns SIXTEEN chunks whatever n is, and their counts -- 32
+  // contiguous bytes of the row, 16-byte aligned because rows are padded to 8 counts (Dev::cc_stride) -- arrive in TWO
+  // 16-byte loads and stay in registers.  (The general path below walked them with sixteen 2-byte loads, and then
+  // found the chunk of the k-th row with a SECOND round trip -- the owning lane's counts, one per lane, and a scan:
+  // 1.4 + 0.4 us of k_ctrl's 7.7 at cfg4 against 0.6 us for the same stage at cfg2, in-kernel stamps.)
+#ifndef PGB_SEL_V16
+#define PGB_SEL_V16 1 /* experiment knob: 0 = the general path for every size (A/B) */
+#endif
+  const bool v16 = V16 && PGB_SEL_V16 != 0 && S.nchunks > 256 && S.nchunks <= 1024;  // (wave-uniform)
+  const int per = v16 ? 16 : (S.nchunks + 63) / 64;
   const int c0 = lane_id() * per;
   int c1 = c0 + per;
   if (c1 > S.nchunks) c1 = S.nchunks;
   int part = 0, pre = 0;
   unsigned cw[4] = {0u, 0u, 0u, 0u};  // counts of chunks c0 .. c0 + 3
+  uint32_t cp[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // v16: counts of chunks c0 .. c0 + 15, two per word
   const bool inreg = per <= 4;
   if (lid != nullptr) {
     if (inreg) {
@@ -239,6 +253,19 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
       for (int i = 0; i < 4; ++i)
         if (i < per && c0 + i < S.nchunks) cw[i] = ccr[c0 + i];
       part = (int)(cw[0] + cw[1] + cw[2] + cw[3]);
+    } else if (v16) {
+      // (counts beyond nchunks inside the padded row are 0: pgb_create zeroes the table and the row passes write
+      //  chunks < nchunks only; beyond the padded row nothing is read)
+      if (c0 + 8 <= S.cc_stride) {
+        const uint4 a = *(const uint4*)(ccr + c0);
+        cp[0] = a.x; cp[1] = a.y; cp[2] = a.z; cp[3] = a.w;
+      }
+      if (c0 + 16 <= S.cc_stride) {
+        const uint4 b = *(const uint4*)(ccr + c0 + 8);
+        cp[4] = b.x; cp[5] = b.y; cp[6] = b.z; cp[7] = b.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part += (int)((cp[i] & 0xFFFFu) + (cp[i] >> 16));
     } else {
       for (int cc = c0; cc < c1; ++cc) part += ccr[cc];
     }
@@ -265,6 +292,15 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
               kk -= (int)cw[i];
               ++cstar;
             }
+        } else if (v16) {  // the same walk over the lane's sixteen counts in registers
+#pragma unroll
+          for (int i = 0; i < 15; ++i) {
+            const int ci = (int)((i & 1) ? (cp[i >> 1] >> 16) : (cp[i >> 1] & 0xFFFFu));
+            if (kk >= ci && cstar == c0 + i) {
+              kk -= ci;
+              ++cstar;
+            }
+          }
         } else if (per > 64) {  // (more than 64 chunks per lane, n > 4M rows: walk the counts)
           while (kk >= ccr[cstar]) {
             kk -= ccr[cstar];
@@ -275,7 +311,7 @@ __device__ __forceinline__ SplitRow select_split_row(const DevG& S, int j, bool 
       const int ol = (int)__ffsll((long long)__ballot(own)) - 1;
       cstar = __builtin_amdgcn_readlane(cstar, ol);
       kk = __builtin_amdgcn_readlane(kk, ol);
-      if (!inreg && per <= 64) {
+      if (!inreg && !v16 && per <= 64) {
         // the owning lane's chunks, one per lane: a second scan instead of a serial walk of dependent loads
         // (at n = 1M a lane owns 16 chunks)
         const int cl = cstar + lane_id();
@@ -931,7 +967,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
       sr.v = 0.0;
       if (attempt) {
         TR(6);
-        sr = select_split_row(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
+        sr = select_split_row<KEYS>(S, jvar, jrule == PGB_RULE_SUBSET, f_gen, f_slot, nd.cnt, nd.cc_row, nd.label, s_pre[0],
                               s_pre1[0], KEYS ? xk16 : nullptr, TR_REC);
       }
       TR(7);
@@ -1342,7 +1378,7 @@ void k_ctrl(const Dev* __restrict__ Sp, int par, int nwg, Ctrl* __restrict__ ctr
     // runs on wave 0 only (no workgroup barriers)
     if (tid < 64) {
       TR(6);
-      const SplitRow sr = select_split_row(S, s_i[8 + set], s_i[10 + set] == PGB_RULE_SUBSET, job.src_gen, job.src_slot,
+      const SplitRow sr = select_split_row<KEYS>(S, s_i[8 + set], s_i[10 + set] == PGB_RULE_SUBSET, job.src_gen, job.src_slot,
                                            ncnt, ncc, nlabel, s_pre[set], s_pre1[set], KEYS ? xk16 : nullptr);
       if (tid == 0) {
         s_i[14] = sr.found;  // (not s_i[0]: waves 1..3 read s_i[0..1] after the resampling barrier and no later barrier orders them)

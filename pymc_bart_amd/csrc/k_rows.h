@@ -637,8 +637,8 @@ __global__ __launch_bounds__(BT, (NORMAL && !LIN) ? 3 : 2) void k_rows(const Dev
         Acc* a = &S.acc[((size_t)par * MAXP + rj.p) * ACC_PER + (chunk & (ACC_SLOTS - 1)) * ACC_STRIDE];
         if (i == 0) {
           const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
-          ccp[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
-          ccp[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+          ccp[(size_t)rj.ccL * (F32 ? S.cc_stride : S.nchunks) + chunk] = (uint16_t)cL;
+          ccp[(size_t)rj.ccR * (F32 ? S.cc_stride : S.nchunks) + chunk] = (uint16_t)cR;
           if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
         } else if (s != 0) {
           long long* dst = i == 1 ? &a->aL : i == 2 ? &a->bL : i == 3 ? &a->c2L : i == 4 ? &a->aN : i == 5 ? &a->bN : &a->c2N;

@@ -626,8 +626,8 @@ __global__ __launch_bounds__(BT, (KT >= 2 && !LIN) ? PGB_MK_WGS(KT) : 2) void k_
           long long* ax = S.accx + ((size_t)par * MAXP + rj.p) * AX_PER + (size_t)(chunk & (AX_SLOTS - 1)) * AX_REC;
           if (i == 0) {
             const int cL = (int)(s & 0xFFFFF), cR = (int)((s >> 20) & 0xFFFFF), cN = (int)(s >> 40);
-            S.cc[(size_t)rj.ccL * S.nchunks + chunk] = (uint16_t)cL;
-            S.cc[(size_t)rj.ccR * S.nchunks + chunk] = (uint16_t)cR;
+            S.cc[(size_t)rj.ccL * (F32 ? S.cc_stride : S.nchunks) + chunk] = (uint16_t)cL;
+            S.cc[(size_t)rj.ccR * (F32 ? S.cc_stride : S.nchunks) + chunk] = (uint16_t)cR;
             if (cL | cN) atomicAdd(&a->cnts, (unsigned long long)cL | ((unsigned long long)cN << 32));
           } else if (s != 0) {
             const int kk = (i - 1) % TW, k = k0 + kk;

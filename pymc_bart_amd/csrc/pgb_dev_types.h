@@ -182,7 +182,7 @@ struct DevT {  // kernel argument block (by value)
   dptr<G, double> rs_m2;
   dptr<G, uint8_t> tree_lid;  // [m][n_pad]
   dptr<G, uint8_t> lid;       // [NGEN][MAXP][n_pad]
-  dptr<G, uint16_t> cc;       // [CC_ROUNDS*MAXP*2][nchunks]
+  dptr<G, uint16_t> cc;       // [CC_ROUNDS*MAXP*2][nchunks], or [..][cc_stride] for the instances with order keys (see cc_stride)
   dptr<G, DTree> trees;       // [m]
   dptr<G, DPart> parts;       // [2][P]
   dptr<G, Job> jobs;          // [2][P]
@@ -244,6 +244,11 @@ struct DevT {  // kernel argument block (by value)
   dptr<G, long long> prof_stamps;
   dptr<G, unsigned long long> host_flag;  // pinned host word: number of completed asteps
   dptr<G, long long> trace;               // PGB_TRACE builds only: [TRACE_SLOTS][TRACE_W] wall_clock64 stamps
+  // Row stride of `cc` for the instances of the data sets with order keys (k_ctrl<.., KEYS>, k_rows<.., F32>,
+  // k_rows_mk<.., F32>): nchunks rounded up to 8 counts, so that a lane's sixteen counts are two aligned 16-byte loads
+  // (select_split_row<V16>).  Every other instance strides by nchunks, as before.  (At the END of the block: the
+  // instances that do not use it keep every offset -- and with it their register allocation -- as it was.)
+  int32_t cc_stride, pad_cc;
 };
 typedef DevT<false> Dev;   // as the host fills it in and the kernels receive it
 typedef DevT<true> DevG;   // as the kernels read it (see above)

@@ -268,6 +268,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   d.n = s->n;
   d.nchunks = (int)((s->n + CH - 1) / CH);
   d.n_pad = (long long)d.nchunks * CH;
+  d.cc_stride = (d.nchunks + 7) & ~7;
   d.p = s->p;
   d.m = s->m;
   d.P = s->num_particles;
@@ -353,7 +354,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
   }
   DA(tree_lid, (size_t)d.m * d.n_pad);
   DA(lid, (size_t)NGEN * MAXP * d.n_pad);
-  DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks);
+  DA(cc, (size_t)CC_ROUNDS * MAXP * 2 * d.cc_stride);
   if (s->family == PGB_FAMILY_CALLBACK) {
     DA(d.cb_mu, (size_t)MAXP * d.n_pad);
     DA(d.cb_side, (size_t)MAXP * d.n_pad);
@@ -459,7 +460,7 @@ extern "C" int pgb_create(const pgb_settings* s, void* stream, pgb_handle** out)
                        d.tvx, (long long)d.m * MAXN * KX, s->init_leaf);
   }
   HC(hipMemsetAsync(lid, PGB_ORPHAN, (size_t)NGEN * MAXP * d.n_pad, sm));
-  HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.nchunks * sizeof(uint16_t), sm));
+  HC(hipMemsetAsync(cc, 0, (size_t)CC_ROUNDS * MAXP * 2 * d.cc_stride * sizeof(uint16_t), sm));
   HC(hipMemsetAsync(d.parts, 0, 2 * MAXP * sizeof(DPart), sm));
   HC(hipMemsetAsync(d.jobs, 0, 2 * MAXP * sizeof(Job), sm));
   HC(hipMemsetAsync(d.acc, 0, 2 * MAXP * ACC_PER * sizeof(Acc), sm));
