@@ -114,6 +114,27 @@ class ChainImage:
     def leaf_sd(self) -> np.ndarray:
         return np.array(self.header.leaf_sd[: int(self.header.s.n_outputs)])
 
+    def forest(self, rules=None):
+        """The m accepted trees of the image as a :class:`~pymc_bart_amd.trees.TreeArrays` -- what
+        ``pgb_export_trees(h, 1, ...)`` returns for the chain the image was taken from, so a checkpoint can be
+        predicted from (``PosteriorSampler(forest, [[0 .. m-1]], m, K)``) without a sampler.  ``rules``: the
+        ``PGB_RULE_*`` of the p columns (the image holds the trees, not the model's split rules); ``None``: every
+        split is continuous."""
+        from .trees import TreeArrays
+
+        m = int(self.header.s.m)
+        var = np.array(self.var, np.int32)
+        if rules is None:
+            rule = np.zeros(var.shape[0], np.int32)
+        else:
+            rule = np.where(var >= 0, np.asarray(rules, np.int32)[np.maximum(var, 0)], 0).astype(np.int32)
+        return TreeArrays(n_outputs=int(self.header.s.n_outputs), tree_id=np.arange(m, dtype=np.int32),
+                          node_off=np.array(self.node_off, np.int32), var=var, split=np.array(self.split),
+                          left=np.array(self.left, np.int32), right=np.array(self.right, np.int32),
+                          count=np.array(self.count, np.int64), value=np.array(self.value),
+                          slope=np.array(self.slope), xbar=np.array(self.xbar), svar=np.array(self.svar, np.int32),
+                          rule=rule)
+
     def chain_fields(self) -> dict:
         """Everything two backends must agree on at the same point of a chain: all of the image except who wrote it
         and the backend-specific ``slots`` counter."""

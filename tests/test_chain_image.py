@@ -158,3 +158,26 @@ def test_binding_refuses_a_library_of_another_abi_revision(tmp_path):
     subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so2)])
     with pytest.raises(_abi.PGBError, match="no pgb_abi_version"):
         _abi.PGBLibrary(str(so2))
+
+
+def test_the_forest_of_an_image_predicts_like_the_sampler_it_came_from(oracle):
+    """`ChainImage.forest()` = `export_trees(1)` of the chain: a checkpoint can be predicted from without a sampler,
+    and its in-sample prediction is the image's own sum_trees (one-hot / subset splits included: the caller names the
+    columns' rules, the image holds trees)."""
+    from pymc_bart_amd.trees import PosteriorSampler
+
+    c = make_case("subset_rule")
+    s = _sampler(c, oracle)
+    for it in range(8):
+        s.step(it < 4)
+    img = ChainImage.parse(s.checkpoint())
+    f_img, f_smp = img.forest(rules=c["rules"]), s.export_trees(1)
+    for name in ("tree_id", "node_off", "var", "left", "right", "count", "split", "value", "rule"):
+        assert np.array_equal(getattr(f_img, name), getattr(f_smp, name)), name
+    m = c["m"]
+    ps = PosteriorSampler(f_img, np.arange(m, dtype=np.int32)[None, :], m, 1, backend=oracle)
+    # rows without a missing value in a split column predict exactly what the chain holds for them
+    X = c["X"]
+    ok = ~np.isnan(X).any(axis=1)
+    pred = ps.sample_posterior(X[ok], [0])[0, 0]
+    np.testing.assert_allclose(pred, img.sum_trees[0][ok], rtol=0, atol=1e-9)
