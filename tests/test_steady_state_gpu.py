@@ -208,18 +208,18 @@ def test_full_size_cfg2_parity_at_steady_state(hip, oracle):
 def test_full_size_cfg4_parity_at_steady_state(hip, oracle):
     """BASELINE.json configs[3]: n = 1M, p = 100, probit, m = 200, P = 40; 8 trees per astep so that the oracle's
     share (8 tree updates at ~2.5 s each) stays bounded: 250 tuning asteps (2 000 tree updates) on the GPU, then
-    one astep on both."""
+    one tuning and one draw astep on both."""
     w = workloads.cfg4(seed=3415)
     g, o = _pair(w, hip, oracle, m=200, num_particles=40, batch=(8, 8), family="bernoulli_probit")
-    img = _burn_in_then_compare(g, o, 250, [(True, 1)])
+    img = _burn_in_then_compare(g, o, 250, [(True, 1), (False, 1)])  # (tune=0 is what bench.py times)
     assert img.header.iter == 2000 and img.node_off[-1] > 3 * 200
 
 
 def test_full_size_cfg5_parity_at_steady_state(hip, oracle):
     """BASELINE.json configs[4]: K = 4 softmax, n = 250k, p = 200, m = 100, P = 40; 8 trees per astep (a sweep
     is 12 asteps of 8 trees and one of 4): 130 tuning asteps = ten sweeps = 1 000 tree updates on the GPU, then one
-    tuning astep on both."""
+    tuning and one draw astep on both."""
     w = workloads.cfg5(seed=3415)
     g, o = _pair(w, hip, oracle, m=100, num_particles=40, batch=(8, 8), family="categorical", n_outputs=4)
-    img = _burn_in_then_compare(g, o, 130, [(True, 1)])
+    img = _burn_in_then_compare(g, o, 130, [(True, 1), (False, 1)])  # (tune=0 is what bench.py times)
     assert img.header.iter == 1000 and img.node_off[-1] > 3 * 100
